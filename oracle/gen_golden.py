@@ -1,0 +1,64 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+    python -m oracle.gen_golden            # from the repo root; needs /root/reference
+
+The reference's Python is imported in place through `oracle/ref_shim.py`; nothing of it is copied.
+Fixtures hold expected OUTPUTS only (inputs/weights are rebuilt from tags, see oracle/detrand.py).
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+from . import fixtures, ref_shim, scenarios
+
+
+def reference_namespace():
+    resnet = ref_shim.load("core.model.backbone.resnet")
+    ns = types.SimpleNamespace()
+    for n in ("cifar_resnet32", "resnet18", "resnet32_V2", "CosineLinear", "SplitCosineLinear"):
+        setattr(ns, n, getattr(resnet, n))
+    ns.EWC = ref_shim.load("core.model.ewc").EWC
+    ns.LWF = ref_shim.load("core.model.lwf").LWF
+    ns.ICarl = ref_shim.load("core.model.icarl").ICarl
+    ns.LUCIR = ref_shim.load("core.model.lucir").LUCIR
+    ns.Finetune = ref_shim.load("core.model.finetune").Finetune
+    ns.LinearHerdingBuffer = ref_shim.load("core.model.buffer.linearherdingbuffer").LinearHerdingBuffer
+    return ns
+
+
+def main(out_dir=None):
+    torch.set_num_threads(8)
+    out_dir = out_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    ad = scenarios.PluginAdapter(reference_namespace(), "cpu")
+    jobs = {}
+    for arch in ("cifar_resnet32", "resnet32_V2", "resnet18"):
+        jobs[f"backbone_{arch}"] = lambda a=arch: scenarios.scenario_backbone(ad, a)
+    jobs["ewc"] = lambda: scenarios.scenario_ewc(ad)
+    jobs["lwf_resnet18"] = lambda: scenarios.scenario_lwf(ad)
+    jobs["lwf_cifar_resnet32"] = lambda: scenarios.scenario_lwf(ad, dict(arch="cifar_resnet32", feat_dim=64, bs=8))
+    jobs["lucir"] = lambda: scenarios.scenario_lucir(ad)
+
+    def icarl():
+        with tempfile.TemporaryDirectory() as d:
+            return scenarios.scenario_icarl(ad, d)
+    jobs["icarl"] = icarl
+    only = sys.argv[1:]
+    for name, fn in jobs.items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(0)
+        # fp64 run of the reference = the semantic ground truth (see fixtures.use_dtype)
+        with fixtures.use_dtype(torch.float64):
+            res = fn()
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **res)
+        print(f"{name}: {os.path.getsize(path)} bytes", {k: getattr(v, 'shape', None) for k, v in list(res.items())[:4]})
+
+
+if __name__ == "__main__":
+    main()

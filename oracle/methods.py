@@ -1,0 +1,409 @@
+"""CPU restatement of the in-scope continual-learning methods (TEST INFRASTRUCTURE, see oracle/__init__).
+
+Each class mirrors the observable behaviour of one reference plugin *as the reference Trainer drives
+it* (`core/trainer.py:563-614`): `model.train()` flips every sub-module -- including frozen teachers
+-- to train mode, so teacher BatchNorm uses batch statistics and its running stats drift
+(SURVEY.md section 8a quirks a10/a11/a12).  Backbones are the functional nets of `oracle/nets.py`.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import nets
+
+
+def _clone_dict(d, grad=False):
+    return {k: v.detach().clone().requires_grad_(grad and v.is_floating_point()) for k, v in d.items()}
+
+
+def linear_default_init(out_f, in_f, generator=None):
+    """nn.Linear default init: U(-1/sqrt(in), 1/sqrt(in)) for weight and bias."""
+    b = 1.0 / math.sqrt(in_f)
+    w = (torch.rand(out_f, in_f, generator=generator) * 2 - 1) * b
+    bias = (torch.rand(out_f, generator=generator) * 2 - 1) * b
+    return w, bias
+
+
+def kd_loss(pred, soft, T=2.0):
+    """`-(softmax(soft/T) * log_softmax(pred/T)).sum() / B`; reference lwf.py:75-78, icarl.py:198-206."""
+    lp = torch.log_softmax(pred / T, dim=1)
+    q = torch.softmax(soft / T, dim=1)
+    return -(q * lp).sum() / pred.shape[0]
+
+
+class Net:
+    """backbone + linear head ("Model" of ewc.py:43-57 / icarl.py:24-38)."""
+
+    def __init__(self, arch, P, Bf, head_w, head_b):
+        self.arch = arch
+        self.P = P            # backbone params (leaf tensors)
+        self.Bf = Bf          # BN buffers
+        self.head_w = head_w
+        self.head_b = head_b
+
+    def features(self, x, train):
+        return nets.forward(self.arch, self.P, self.Bf, x, train)
+
+    def logits(self, x, train):
+        return F.linear(self.features(x, train), self.head_w, self.head_b)
+
+    def named_parameters(self):
+        for k, v in self.P.items():
+            yield "backbone." + k, v
+        yield "classifier.weight", self.head_w
+        yield "classifier.bias", self.head_b
+
+    def parameters(self):
+        return [p for _, p in self.named_parameters()]
+
+    def clone(self, grad=True):
+        return Net(self.arch, _clone_dict(self.P, grad), _clone_dict(self.Bf),
+                   self.head_w.detach().clone().requires_grad_(grad),
+                   self.head_b.detach().clone().requires_grad_(grad))
+
+
+def _acc(logit, y):
+    pred = torch.argmax(logit, dim=1)
+    return pred, (pred == y).sum().item() / y.shape[0]
+
+
+# --------------------------------------------------------------------------------------------- EWC
+class EWC:
+    """reference core/model/ewc.py:59-229."""
+
+    def __init__(self, net, init_cls_num, inc_cls_num, lamda):
+        self.network = net                        # head has init_cls_num rows (ewc.py:63)
+        self.init_cls_num, self.inc_cls_num, self.lamda = init_cls_num, inc_cls_num, lamda
+        self.ref_param = {n: p.detach().clone() for n, p in net.named_parameters()}        # ewc.py:65-66
+        self.fisher = {n: torch.zeros_like(p) for n, p in net.named_parameters()}         # ewc.py:67-68
+        self.task_idx = 0
+
+    def before_task(self, task_idx, new_rows=None):
+        """Grow the head to init + task_idx*inc rows, old rows copied (ewc.py:71-80).
+        `new_rows` = (w, b) full-size tensors supplying the fresh rows (default nn.Linear init)."""
+        self.task_idx = task_idx
+        net = self.network
+        out_old = net.head_w.shape[0]
+        n_new = self.init_cls_num + task_idx * self.inc_cls_num
+        w, b = new_rows if new_rows is not None else linear_default_init(n_new, net.head_w.shape[1])
+        w = w.detach().clone(); b = b.detach().clone()
+        w[:out_old] = net.head_w.detach(); b[:out_old] = net.head_b.detach()
+        net.head_w = w.requires_grad_(True); net.head_b = b.requires_grad_(True)
+
+    def compute_ewc(self):
+        """sum_n sum F_n * (p_n[:len(ref_n)] - ref_n)^2 / 2   (ewc.py:221-225)."""
+        loss = 0
+        for n, p in self.network.named_parameters():
+            if n in self.fisher:
+                r = self.ref_param[n]
+                loss = loss + torch.sum(self.fisher[n] * (p[: len(r)] - r).pow(2)) / 2
+        return loss
+
+    def observe(self, x, y, train=True):
+        logit = self.network.logits(x, train)
+        if self.task_idx == 0:
+            loss = F.cross_entropy(logit, y)                                             # ewc.py:87
+        else:
+            old = self.network.head_w.shape[0] - self.inc_cls_num                        # ewc.py:92
+            loss = F.cross_entropy(logit[:, old:], y - old) + self.lamda * self.compute_ewc()   # ewc.py:99-100
+        pred, acc = _acc(logit, y)
+        return pred, acc, loss
+
+    def inference(self, x, y):
+        return _acc(self.network.logits(x, False), y)
+
+    def get_fisher(self, batches, batch_size):
+        """ewc.py:147-205: Fisher of the *batch-mean* gradient times len(y), BN in train mode,
+        divided by batch_size*len(loader)."""
+        fisher = {n: torch.zeros_like(p) for n, p in self.network.named_parameters()}
+        for x, y in batches:
+            for p in self.network.parameters():
+                p.grad = None
+            loss = F.cross_entropy(self.network.logits(x, True), y)
+            loss.backward()
+            for n, p in self.network.named_parameters():
+                if p.grad is not None:
+                    fisher[n] += p.grad.pow(2) * len(y)
+        num = batch_size * len(batches)
+        for p in self.network.parameters():
+            p.grad = None
+        return {n: f / num for n, f in fisher.items()}
+
+    def after_task(self, batches, batch_size):
+        """ewc.py:110-133 (ref snapshot BEFORE the Fisher pass; alpha merge even at task 0)."""
+        self.ref_param = {n: p.detach().clone() for n, p in self.network.named_parameters()}
+        new_fisher = self.get_fisher(batches, batch_size)
+        alpha = 1 - self.inc_cls_num / self.network.head_w.shape[0]
+        for n, p in self.fisher.items():
+            new_fisher[n][: len(p)] = alpha * p + (1 - alpha) * new_fisher[n][: len(p)]
+        self.fisher = new_fisher
+
+
+# --------------------------------------------------------------------------------------------- LwF
+class LWF:
+    """reference core/model/lwf.py:9-81 (lamda hard-coded 3, T=2, teacher BN follows `train`)."""
+
+    def __init__(self, net, init_cls_num, inc_cls_num):
+        self.network = net            # net.head_* plays `self.classifier` (lwf.py:13)
+        self.init_cls_num, self.inc_cls_num = init_cls_num, inc_cls_num
+        self.known, self.total = 0, 0
+        self.old = None               # frozen copy: old_backbone + old_fc
+        self.task_idx = 0
+
+    def before_task(self, task_idx, new_rows=None):
+        self.task_idx = task_idx
+        self.known = self.total
+        self.total = self.init_cls_num + task_idx * self.inc_cls_num       # lwf.py:44-45
+        net = self.network
+        old_w, old_b = net.head_w.detach().clone(), net.head_b.detach().clone()
+        w, b = new_rows if new_rows is not None else linear_default_init(self.total, net.head_w.shape[1])
+        w = w.detach().clone(); b = b.detach().clone()
+        n_old = old_w.shape[0]
+        w[:n_old] = old_w; b[:n_old] = old_b                                 # lwf.py:35-37
+        if task_idx != 0:
+            # old_fc = copy of the classifier BEFORE growth; old_backbone = copy of the backbone (lwf.py:33,49)
+            self.old = Net(net.arch, _clone_dict(net.P), _clone_dict(net.Bf), old_w, old_b)
+        net.head_w = w.requires_grad_(True); net.head_b = b.requires_grad_(True)
+
+    def observe(self, x, y, train=True):
+        logit = self.network.logits(x, train)
+        if self.task_idx == 0:
+            loss = F.cross_entropy(logit, y)
+        else:
+            k = self.known
+            loss_clf = F.cross_entropy(logit[:, k:], y - k)                 # lwf.py:61-62
+            with torch.no_grad():
+                soft = self.old.logits(x, train)                             # teacher in `train` mode: quirk a10
+            loss = 3 * kd_loss(logit[:, :k], soft, 2.0) + loss_clf           # lwf.py:63-65
+        pred, acc = _acc(logit, y)
+        return pred, acc, loss
+
+    def inference(self, x, y):
+        return _acc(self.network.logits(x, False), y)
+
+
+# ------------------------------------------------------------------------------------------- iCaRL
+class ICarl:
+    """reference core/model/icarl.py:42-287."""
+
+    def __init__(self, net, init_cls_num, inc_cls_num):
+        self.network = net            # head allocated with num_class rows up-front (icarl.py:56)
+        self.init_cls_num, self.inc_cls_num = init_cls_num, inc_cls_num
+        self.old_network = None
+        self.prev_cls_num = 0
+        self.accu_cls_num = 0
+        self.cur_task_id = 0
+        self.class_means = None
+
+    def before_task(self, task_idx):
+        if self.cur_task_id == 0:
+            self.accu_cls_num = self.init_cls_num
+        else:
+            self.accu_cls_num += self.inc_cls_num                            # icarl.py:158-163
+
+    def observe(self, x, y, train=True):
+        cur = self.network.logits(x, train)[:, : self.accu_cls_num]         # icarl.py:208
+        loss = F.cross_entropy(cur, y)
+        if self.cur_task_id > 0:
+            with torch.no_grad():                                            # grads into the teacher are discarded
+                old = self.old_network.logits(x, train)
+            loss = loss + kd_loss(cur[:, : self.prev_cls_num], old[:, : self.prev_cls_num], 2.0)
+        pred, acc = _acc(cur, y)
+        return pred, acc, loss
+
+    def after_task_model(self):
+        """icarl.py:169-176: snapshot teacher; buffer/herding handled by the caller."""
+        self.old_network = self.network.clone(grad=False)
+        self.prev_cls_num = self.accu_cls_num
+        self.cur_task_id += 1
+
+    def inference(self, x, y):
+        if self.class_means is not None and len(self.class_means) == self.accu_cls_num:
+            feats = self.network.features(x, False)
+            return _acc(-ncm_distance(feats, self.class_means), y)          # argmin distance
+        logits = self.network.logits(x, False)[:, : self.accu_cls_num]
+        return _acc(logits, y)
+
+
+def ncm_distance(feats, means):
+    """squared L2 between every feature and every class mean (icarl.py:124-138)."""
+    return (feats.unsqueeze(1) - means.unsqueeze(0)).pow(2).sum(2)
+
+
+def class_means_from_buffer(feats, labels):
+    """icarl.py:262-285: L2-normalise features, per-class mean, re-normalise."""
+    f = feats / feats.norm(dim=1).view(-1, 1)
+    out = []
+    for c in np.unique(labels.numpy()):
+        m = f[labels == int(c)].mean(0)
+        out.append(m / m.norm())
+    return torch.stack(out)
+
+
+def herding_select(feats, labels, samples_per_class):
+    """Greedy mean-matching on L2-normalised features; returns global indices
+    (buffer/linearherdingbuffer.py:124-163; selected row is 'removed' by +1e6)."""
+    f = feats / feats.norm(dim=1).view(-1, 1)
+    f = f.clone()
+    lab = labels.numpy()
+    result = []
+    for c in np.unique(lab):
+        ind = np.where(lab == c)[0]
+        cf = f[ind]
+        mean = cf.mean(0, keepdim=True)
+        run = torch.zeros_like(mean)
+        i = 0
+        while i < samples_per_class and i < cf.shape[0]:
+            cost = (mean - (cf + run) / (i + 1)).norm(2, 1)
+            j = cost.argmin().item()
+            result.append(int(j + ind[0]))
+            run += cf[j:j + 1]
+            cf[j] = cf[j] + 1e6
+            i += 1
+    return result
+
+
+# ------------------------------------------------------------------------------------------- LUCIR
+def cosine_linear(x, w, sigma=None):
+    """sigma * normalize(x) @ normalize(w)^T   (backbone/resnet.py:436-441)."""
+    out = F.linear(F.normalize(x, p=2, dim=1), F.normalize(w, p=2, dim=1))
+    return out if sigma is None else sigma * out
+
+
+class LUCIR:
+    """reference core/model/lucir.py:73-239, heads backbone/resnet.py:418-463."""
+
+    def __init__(self, arch, P, Bf, w0, sigma, init_cls_num, inc_cls_num, lamda, K, lw_mr, dist):
+        self.arch, self.P, self.Bf = arch, P, Bf
+        self.fc1_w = w0            # CosineLinear at task 0; SplitCosineLinear.fc1 later
+        self.fc2_w = None
+        self.sigma = sigma
+        self.init_cls_num, self.inc_cls_num = init_cls_num, inc_cls_num
+        self.lamda, self.K, self.lw_mr, self.dist = lamda, K, lw_mr, dist
+        self.ref = None
+        self.task_idx = 0
+        self.cur_lamda = lamda
+
+    def _weights(self):
+        return self.fc1_w if self.fc2_w is None else torch.cat([self.fc1_w, self.fc2_w], 0)
+
+    def scores_and_feats(self, x, train):
+        feats = nets.forward(self.arch, self.P, self.Bf, x, train)
+        s = cosine_linear(feats, self._weights())
+        return feats, s
+
+    def before_task(self, task_idx, class_feats=None):
+        """lucir.py:82-132.  `class_feats` = list (one per new class) of [n_i, D] eval-mode feature
+        tensors used to imprint fc2 (lucir.py:134-159)."""
+        self.task_idx = task_idx
+        if task_idx >= 1:
+            self.ref = dict(P=_clone_dict(self.P), Bf=_clone_dict(self.Bf), w=self._weights().detach().clone(),
+                            sigma=self.sigma.detach().clone())
+            old_w = self._weights().detach().clone()
+            n_old = old_w.shape[0]
+            self.cur_lamda = self.lamda * math.sqrt(n_old * 1.0 / self.inc_cls_num)
+            avg_norm = old_w.norm(dim=1, keepdim=True).mean(0).double()
+            self.fc1_w = old_w.clone().requires_grad_(True)
+            novel = torch.zeros(self.inc_cls_num, old_w.shape[1])
+            for j, cf in enumerate(class_feats):
+                nf = F.normalize(cf.double(), p=2, dim=1)
+                emb = nf.mean(0)
+                novel[j] = (F.normalize(emb, p=2, dim=0) * avg_norm).to(novel.dtype)
+            self.fc2_w = novel.requires_grad_(True)
+            self.num_old = n_old
+        else:
+            self.cur_lamda = self.lamda
+
+    def observe(self, x, y, train=True):
+        feats, s = self.scores_and_feats(x, train)
+        logit = self.sigma * s
+        if self.task_idx == 0:
+            loss = F.cross_entropy(logit, y)
+        else:
+            with torch.no_grad():
+                ref_feats = nets.forward(self.arch, self.ref["P"], self.ref["Bf"], x, train)
+            # CosineEmbeddingLoss(target=1) = mean(1 - cos)   lucir.py:182-183
+            loss = (1 - F.cosine_similarity(feats, ref_feats, dim=1)).mean() * self.cur_lamda
+            loss = loss + F.cross_entropy(logit, y)
+            gt = s.gather(1, y.view(-1, 1)).squeeze(1)
+            novel = s[:, self.num_old:].topk(self.K, dim=1)[0]
+            hard = y < self.num_old
+            if int(hard.sum()) > 0:
+                g = gt[hard].view(-1, 1).repeat(1, self.K)
+                n = novel[hard]
+                # MarginRankingLoss(margin=dist)(g, n, 1) = mean(max(0, -(g-n)+dist))   lucir.py:204-205
+                loss = loss + torch.clamp(-(g - n) + self.dist, min=0).mean() * self.lw_mr
+        pred, acc = _acc(logit, y)
+        return pred, acc, loss
+
+    def inference(self, x, y):
+        _, s = self.scores_and_feats(x, False)
+        return _acc(self.sigma * s, y)
+
+    def parameters(self):
+        ps = list(self.P.values()) + [self.fc1_w]
+        if self.fc2_w is not None:
+            ps.append(self.fc2_w)
+        ps.append(self.sigma)
+        return ps
+
+
+# ------------------------------------------------------------------------------------- optimisers
+class SGD:
+    """torch.optim.SGD semantics (trainer.py:159-166): d = g + wd*p; buf = m*buf + d (first step buf=d); p -= lr*buf.
+    Params whose grad is None are skipped."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        self.params = list(params)
+        self.lr, self.momentum, self.wd = lr, momentum, weight_decay
+        self.buf = [None] * len(self.params)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            d = p.grad + self.wd * p if self.wd != 0 else p.grad.clone()
+            if self.momentum != 0:
+                if self.buf[i] is None:
+                    self.buf[i] = d.clone()
+                else:
+                    self.buf[i].mul_(self.momentum).add_(d)
+                d = self.buf[i]
+            p.add_(d, alpha=-self.lr)
+
+
+class Adam:
+    """torch.optim.Adam (no amsgrad): m,v EMA, bias correction, p -= lr*mhat/(sqrt(vhat)+eps)."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps, self.wd = lr, betas[0], betas[1], eps, weight_decay
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            g = p.grad + self.wd * p if self.wd != 0 else p.grad
+            self.m[i].mul_(self.b1).add_(g, alpha=1 - self.b1)
+            self.v[i].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            bc1 = 1 - self.b1 ** self.t
+            bc2 = 1 - self.b2 ** self.t
+            denom = (self.v[i].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            p.addcdiv_(self.m[i], denom, value=-self.lr / bc1)

@@ -1,0 +1,537 @@
+"""Golden scenarios (TEST INFRASTRUCTURE, see oracle/__init__).
+
+One scenario = one deterministic script of plugin calls.  It is executed by
+
+* the REFERENCE  (`oracle/gen_golden.py`, build container only)  -> `tests/golden/*.npz`
+* the ORACLE     (`tests/test_oracle_golden.py`, CPU)            -> must match the fixtures
+* the PRODUCT    (`tests/test_parity_gpu.py`, MI355X)            -> must match within the bf16 tolerance
+
+Reference and product expose the same plugin surface (that is the drop-in boundary), so they share
+`PluginAdapter`; the oracle has its own functional API and uses `OracleAdapter`.
+"""
+import copy
+import os
+
+import numpy as np
+import torch
+
+from . import detrand
+from . import fixtures as fx
+from . import methods as om
+from . import nets
+
+
+# ----------------------------------------------------------------------------------- data helpers
+class ListLoader:
+    """Minimal loader: iterable of batch dicts + the attributes the reference reads
+    (`batch_size`, `__len__`, `dataset`, `num_workers`, `pin_memory`)."""
+
+    def __init__(self, batches, batch_size, dataset=None):
+        self.batches = batches
+        self.batch_size = batch_size
+        self.dataset = dataset
+        self.num_workers = 0
+        self.pin_memory = False
+
+    def __iter__(self):
+        for x, y in self.batches:
+            yield {"image": x, "label": y}
+
+    def __len__(self):
+        return len(self.batches)
+
+
+class PngDataset(torch.utils.data.Dataset):
+    """Class-folder style dataset over PNG files (reference layout docs/tutorials/en/data_module_en.md:15-39):
+    `images` are paths relative to data_root/mode, `trfms` maps a PIL image to a tensor."""
+
+    def __init__(self, data_root, mode, images, labels, trfms):
+        self.data_root, self.mode = data_root, mode
+        self.images, self.labels, self.trfms = list(images), list(labels), trfms
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        img = Image.open(os.path.join(self.data_root, self.mode, self.images[i])).convert("RGB")
+        return {"image": self.trfms(img), "label": int(self.labels[i])}
+
+
+def png_transform(img):
+    a = np.asarray(img, dtype=np.float32) / 255.0              # HWC
+    m = np.asarray(fx.CIFAR_MEAN, np.float32)
+    s = np.asarray(fx.CIFAR_STD, np.float32)
+    return fx._t(((a - m) / s).transpose(2, 0, 1).copy())
+
+
+def write_class_pngs(root, mode, tag, classes, per_class):
+    """-> (images, labels) with files root/mode/<cls>/<k>.png built from detrand data."""
+    from PIL import Image
+    images, labels = [], []
+    for c in classes:
+        d = os.path.join(root, mode, f"{c:03d}")
+        os.makedirs(d, exist_ok=True)
+        pat = detrand.uniform(f"{tag}/pattern{c}", (32, 32, 3), 0.0, 1.0)
+        raw = detrand.uniform(f"{tag}/c{c}", (per_class, 32, 32, 3), 0.0, 1.0)
+        for k in range(per_class):
+            a = np.clip((0.6 * raw[k] + 0.4 * pat) * 255.0, 0, 255).astype(np.uint8)
+            rel = os.path.join(f"{c:03d}", f"{k}.png")
+            Image.fromarray(a).save(os.path.join(root, mode, rel))
+            images.append(rel)
+            labels.append(int(c))
+    return images, labels
+
+
+# --------------------------------------------------------------------------------------- adapters
+class PluginAdapter:
+    """Drives classes with the LibContinual plugin surface found in `ns` (the reference's
+    `core.model` modules, or `libcontinual_amd.model`)."""
+
+    kind = "plugin"
+
+    def __init__(self, ns, device="cpu", sgd_factory=None):
+        self.ns, self.device = ns, device
+        self.sgd_factory = sgd_factory or (lambda params, **kw: torch.optim.SGD(params, **kw))
+
+    def backbone(self, arch, P, Bf):
+        if arch == "resnet18":
+            bb = self.ns.resnet18(num_classes=100, args={"dataset": "cifar100"})
+        else:
+            bb = getattr(self.ns, arch)()
+        sd = {k: v.clone() for k, v in P.items()}
+        sd.update({k: v.clone() for k, v in Bf.items()})
+        bb = bb.to(fx._DTYPE[0])
+        bb.load_state_dict(sd)
+        return bb.to(self.device)
+
+    def to_dev(self, t):
+        return t.to(self.device)
+
+    def batch(self, x, y):
+        return {"image": x, "label": y}
+
+
+class OracleAdapter:
+    kind = "oracle"
+    device = "cpu"
+
+
+# ------------------------------------------------------------------------------ scenario: backbone
+def scenario_backbone(adapter, arch, B=4):
+    """features / all parameter grads / running stats for one train-mode batch, then eval features."""
+    tag = f"bb/{arch}"
+    P, Bf = fx.det_backbone_state(arch, tag)
+    x = fx.det_images(tag + "/x", B)
+    _, feat_dim, _ = nets.arch(arch)
+    cw = fx._t(detrand.uniform(tag + "/cw", (B, feat_dim), -1, 1))
+    out = {}
+    if adapter.kind == "oracle":
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        Bb = {k: v.clone() for k, v in Bf.items()}
+        f = nets.forward(arch, Pg, Bb, x, True)
+        (f * cw).sum().backward()
+        grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+        bufs = Bb
+        fe = nets.forward(arch, Pg, Bb, x, False).detach()
+    else:
+        bb = adapter.backbone(arch, P, Bf)
+        bb.train()
+        f = bb(adapter.to_dev(x))["features"]
+        (f * adapter.to_dev(cw)).sum().backward()
+        grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros(p.shape)) for k, p in bb.named_parameters()}
+        bufs = {k: b.detach().cpu() for k, b in bb.named_buffers()}
+        bb.eval()
+        with torch.no_grad():
+            fe = bb(adapter.to_dev(x))["features"].detach().cpu()
+    out["features_train"] = f.detach().cpu().numpy()
+    out["features_eval"] = fe.numpy()
+    names, rows = fx.summarize(grads)
+    out["grad_names"] = np.asarray(names)
+    out["grad_rows"] = rows
+    first = nets.param_shapes(arch)[0][0]
+    out["grad_stem"] = grads[first].numpy()
+    bn_names = [n for n, _ in nets.buffer_shapes(arch) if "running" in n]
+    names_b, rows_b = fx.summarize({n: bufs[n] for n in bn_names})
+    out["buf_rows"] = rows_b
+    return out
+
+
+# ----------------------------------------------------------------------------------- scenario: EWC
+EWC_CFG = dict(arch="cifar_resnet32", feat_dim=64, init=6, inc=2, lamda=1000.0, bs=8,
+               lr=0.1, momentum=0.9, wd=5e-4)
+
+
+def scenario_ewc(adapter):
+    """task 0: 2 SGD steps; after_task (Fisher over 3 batches, last one ragged); task 1: 2 steps with
+    the penalty active.  Mirrors trainer.py:283-407 call order for method 'EWC'."""
+    c = EWC_CFG
+    tag = "ewc"
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    w0, b0 = fx.det_linear(tag + "/head0", c["init"], c["feat_dim"])
+    w1, b1 = fx.det_linear(tag + "/head1", c["init"] + c["inc"], c["feat_dim"])
+    t0 = [fx.det_batch(f"{tag}/t0/{i}", c["bs"], 0, c["init"]) for i in range(2)]
+    fb = [fx.det_batch(f"{tag}/fisher/{i}", c["bs"] if i < 2 else 5, 0, c["init"]) for i in range(3)]
+    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], c["init"], c["init"] + c["inc"]) for i in range(2)]
+    losses, preds, accs = [], [], []
+    if adapter.kind == "oracle":
+        net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()},
+                     {k: v.clone() for k, v in Bf.items()}, w0.clone().requires_grad_(True), b0.clone().requires_grad_(True))
+        m = om.EWC(net, c["init"], c["inc"], c["lamda"])
+
+        def run(batches):
+            opt = om.SGD(net.parameters(), c["lr"], c["momentum"], c["wd"])
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item()); preds.append(pred.numpy()); accs.append(acc)
+        m.before_task(0, new_rows=(w0, b0))
+        run(t0)
+        m.after_task(fb, c["bs"])
+        fisher0 = {k: v.clone() for k, v in m.fisher.items()}
+        m.before_task(1, new_rows=(w1, b1))
+        run(t1)
+        params = dict(net.named_parameters())
+        bufs = net.Bf
+        fisher = fisher0
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.EWC(bb, c["feat_dim"], 100, device=adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"],
+                   lamda=c["lamda"]).to(adapter.device)
+
+        def set_head(w, b, old):
+            with torch.no_grad():
+                m.network.classifier.weight.data[old:] = adapter.to_dev(w[old:])
+                m.network.classifier.bias.data[old:] = adapter.to_dev(b[old:])
+
+        def run(batches):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], momentum=c["momentum"], weight_decay=c["wd"])
+            m.train()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy()); accs.append(acc)
+        m.before_task(0, None, None, None)
+        set_head(w0, b0, 0)
+        # EWC.__init__ snapshots ref_param before we load the head; irrelevant at task 0 (penalty inactive)
+        run(t0)
+        m.after_task(0, None, ListLoader(fb, c["bs"]), None)
+        fisher = {k: v.detach().cpu().clone() for k, v in m.fisher.items()}
+        m.before_task(1, None, None, None)
+        set_head(w1, b1, c["init"])
+        run(t1)
+        params = {k: v.detach().cpu() for k, v in m.network.named_parameters()}
+        bufs = {k: v.detach().cpu() for k, v in m.network.backbone.named_buffers()}
+    out = dict(losses=np.asarray(losses, np.float64), preds=np.stack(preds), accs=np.asarray(accs, np.float64))
+    names, rows = fx.summarize(fisher)
+    out["fisher_names"], out["fisher_rows"] = np.asarray(names), rows
+    out["fisher_head_w"] = fisher["classifier.weight"].numpy()
+    out["fisher_bn1"] = fisher["backbone.bn_1.weight"].numpy()
+    names, rows = fx.summarize(params)
+    out["param_names"], out["param_rows"] = np.asarray(names), rows
+    out["head_w"] = params["classifier.weight"].detach().numpy()
+    out["rm_last"] = bufs["stage_3.4.bn_b.running_mean"].numpy()
+    return out
+
+
+# ----------------------------------------------------------------------------------- scenario: LwF
+LWF_CFG = dict(arch="resnet18", feat_dim=512, init=6, inc=2, bs=4, lr=0.1)
+
+
+def scenario_lwf(adapter, cfg=None):
+    """task 0: 1 step (CE); task 1: 2 steps with CE(new) + 3*KD(T=2) against the frozen copy whose BN is
+    (quirk a10) in train mode.  SGD lr .1 without momentum (config/lwf.yaml:14-17)."""
+    c = dict(LWF_CFG, **(cfg or {}))
+    tag = "lwf/" + c["arch"]
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    w0, b0 = fx.det_linear(tag + "/head0", c["init"], c["feat_dim"])
+    w1, b1 = fx.det_linear(tag + "/head1", c["init"] + c["inc"], c["feat_dim"])
+    t0 = [fx.det_batch(f"{tag}/t0/{i}", c["bs"], 0, c["init"]) for i in range(1)]
+    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], c["init"], c["init"] + c["inc"]) for i in range(2)]
+    losses, preds = [], []
+    if adapter.kind == "oracle":
+        net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()},
+                     {k: v.clone() for k, v in Bf.items()}, w0.clone().requires_grad_(True), b0.clone().requires_grad_(True))
+        m = om.LWF(net, c["init"], c["inc"])
+
+        def run(batches):
+            opt = om.SGD(net.parameters(), c["lr"])
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item()); preds.append(pred.numpy())
+        m.before_task(0, new_rows=(w0, b0)); run(t0)
+        m.before_task(1, new_rows=(w1, b1)); run(t1)
+        logits = net.logits(t1[0][0], False).detach()
+        teacher_rm = m.old.Bf[_last_bn(c["arch"]) + ".running_mean"]
+        params = dict(net.named_parameters())
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.LWF(bb, c["feat_dim"], 100, device=adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"]).to(adapter.device)
+
+        def set_head(w, b, old):
+            with torch.no_grad():
+                m.classifier.weight.data[old:] = adapter.to_dev(w[old:])
+                m.classifier.bias.data[old:] = adapter.to_dev(b[old:])
+
+        def run(batches):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"])
+            m.train()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
+        m.before_task(0, None, None, None); set_head(w0, b0, 0); run(t0)
+        m.before_task(1, None, None, None); set_head(w1, b1, c["init"]); run(t1)
+        m.eval()
+        with torch.no_grad():
+            logits = m.classifier(m.backbone(adapter.to_dev(t1[0][0]))["features"]).cpu()
+        teacher_rm = dict(m.old_backbone.named_buffers())[_last_bn(c["arch"]) + ".running_mean"].cpu()
+        params = {("backbone." + k): v.detach().cpu() for k, v in m.backbone.named_parameters()}
+        params["classifier.weight"] = m.classifier.weight.detach().cpu()
+        params["classifier.bias"] = m.classifier.bias.detach().cpu()
+    out = dict(losses=np.asarray(losses, np.float64), preds=np.stack(preds), logits_eval=logits.numpy(),
+               teacher_rm=teacher_rm.numpy())
+    names, rows = fx.summarize(params)
+    out["param_names"], out["param_rows"] = np.asarray(names), rows
+    return out
+
+
+def _last_bn(arch):
+    return nets.arch(arch)[0][-1].bn
+
+
+# --------------------------------------------------------------------------------- scenario: iCaRL
+ICARL_CFG = dict(arch="cifar_resnet32", feat_dim=64, init=4, inc=2, num_class=8, bs=8, lr=0.1, momentum=0.9,
+                 wd=5e-4, buffer_size=24, per_class=12)
+
+
+def scenario_icarl(adapter, tmpdir):
+    """task 0 (4 classes x 12 PNG images): 2 steps; after_task: teacher snapshot, herding into a
+    LinearHerdingBuffer(24) (6/class), class means; NCM inference; task 1: rehearsal union batches with
+    CE + KD; after_task again (buffer reduced to 4/class)."""
+    c = ICARL_CFG
+    tag = "icarl"
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    hw, hb = fx.det_linear(tag + "/head", c["num_class"], c["feat_dim"])
+    root = os.path.join(tmpdir, "icarl_data")
+    imgs0, labs0 = write_class_pngs(root, "train", tag, range(0, c["init"]), c["per_class"])
+    imgs1, labs1 = write_class_pngs(root, "train", tag, range(c["init"], c["init"] + c["inc"]), c["per_class"])
+    timgs, tlabs = write_class_pngs(root, "test", tag + "/test", range(0, c["init"] + c["inc"]), 4)
+
+    def load(images, labels, mode="train"):
+        ds = PngDataset(root, mode, images, labels, png_transform)
+        xs = torch.stack([ds[i]["image"] for i in range(len(ds))])
+        return xs, torch.tensor(labels, dtype=torch.long)
+
+    def batches_of(xs, ys, order):
+        out = []
+        for s in range(0, len(order), c["bs"]):
+            idx = torch.tensor(order[s:s + c["bs"]])
+            out.append((xs[idx], ys[idx]))
+        return out
+
+    x0, y0 = load(imgs0, labs0)
+    order0 = list(np.argsort(detrand.uniform(tag + "/perm0", (len(labs0),)))[: 2 * c["bs"]])
+    tx, ty = load(timgs, tlabs, "test")
+    res = {}
+    losses, preds = [], []
+    if adapter.kind == "oracle":
+        net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()},
+                     {k: v.clone() for k, v in Bf.items()}, hw.clone().requires_grad_(True), hb.clone().requires_grad_(True))
+        m = om.ICarl(net, c["init"], c["inc"])
+
+        def run(batches):
+            opt = om.SGD(net.parameters(), c["lr"], c["momentum"], c["wd"])
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item()); preds.append(pred.numpy())
+
+        buf_images, buf_labels = [], []
+
+        def after_task(images, labels, xs, ys, cur_classes):
+            nonlocal buf_images, buf_labels
+            m.old_network = net.clone(grad=False)
+            m.prev_cls_num = m.accu_cls_num
+            spc = c["buffer_size"] // m.accu_cls_num
+            if m.cur_task_id > 0:                      # reduce_old_data (linearherdingbuffer.py:55-75)
+                bi, bl = np.array(buf_images), np.array(buf_labels)
+                buf_images, buf_labels = [], []
+                for yy in np.unique(bl):
+                    sel = bl == yy
+                    buf_images.extend(bi[sel][:spc]); buf_labels.extend(bl[sel][:spc])
+            # herding over current-class samples only, in class order (linearherdingbuffer.py:83-100)
+            keep = [i for cc in cur_classes for i in range(len(labels)) if labels[i] == cc]
+            k_imgs = [images[i] for i in keep]; k_labs = [labels[i] for i in keep]
+            kx, ky = xs[torch.tensor(keep)], ys[torch.tensor(keep)]
+            with torch.no_grad():
+                feats = torch.cat([net.features(kx[s:s + 32], False) for s in range(0, len(keep), 32)])
+            chosen = om.herding_select(feats, ky, spc)
+            buf_images.extend([k_imgs[i] for i in chosen]); buf_labels.extend([int(k_labs[i]) for i in chosen])
+            bx, by = load(buf_images, buf_labels)
+            with torch.no_grad():
+                bf = torch.cat([net.features(bx[s:s + c["bs"]], False) for s in range(0, len(buf_labels), c["bs"])])
+            m.class_means = om.class_means_from_buffer(bf, by)
+            m.cur_task_id += 1
+            return chosen
+
+        m.before_task(0)
+        run(batches_of(x0, y0, order0))
+        chosen0 = after_task(imgs0, labs0, x0, y0, list(range(0, c["init"])))
+        res["chosen0"] = np.asarray(chosen0)
+        res["buffer_labels0"] = np.asarray(buf_labels)
+        res["class_means0"] = m.class_means.numpy().copy()
+        p, a = m.inference(tx[: 4 * c["init"]], ty[: 4 * c["init"]])
+        res["ncm_pred0"] = p.numpy()
+        m.before_task(1)
+        u_imgs, u_labs = imgs1 + list(buf_images), labs1 + list(buf_labels)     # trainer.py:305-312
+        ux, uy = load(u_imgs, u_labs)
+        order1 = list(np.argsort(detrand.uniform(tag + "/perm1", (len(u_labs),)))[: 2 * c["bs"]])
+        run(batches_of(ux, uy, order1))
+        chosen1 = after_task(u_imgs, u_labs, ux, uy, list(range(c["init"], c["init"] + c["inc"])))
+        res["chosen1"] = np.asarray(chosen1)
+        res["buffer_labels1"] = np.asarray(buf_labels)
+        res["class_means1"] = m.class_means.numpy().copy()
+        p, a = m.inference(tx, ty)
+        res["ncm_pred1"] = p.numpy()
+        params = dict(net.named_parameters())
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.ICarl(bb, c["feat_dim"], c["num_class"], device=adapter.device, init_cls_num=c["init"],
+                     inc_cls_num=c["inc"], task_num=2).to(adapter.device)
+        with torch.no_grad():
+            m.network.classifier.weight.data.copy_(adapter.to_dev(hw)); m.network.classifier.bias.data.copy_(adapter.to_dev(hb))
+        buffer = ns.LinearHerdingBuffer(c["buffer_size"], 64)
+
+        def run(batches):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], momentum=c["momentum"], weight_decay=c["wd"])
+            m.train()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
+
+        test_ds = PngDataset(root, "test", timgs, tlabs, png_transform)
+        test_loaders = [ListLoader([], c["bs"], test_ds)]
+        m.before_task(0, buffer, None, None)
+        run(batches_of(x0, y0, order0))
+        ds0 = PngDataset(root, "train", imgs0, labs0, png_transform)
+        m.after_task(0, buffer, ListLoader([], c["bs"], ds0), test_loaders)
+        res["chosen0"] = np.asarray([imgs0.index(p) for p in buffer.images])
+        res["buffer_labels0"] = np.asarray([int(v) for v in buffer.labels])
+        res["class_means0"] = m.class_means.detach().cpu().numpy().copy()
+        m.eval()
+        with torch.no_grad():
+            p, a = m.inference(adapter.batch(tx[: 4 * c["init"]], ty[: 4 * c["init"]]))
+        res["ncm_pred0"] = p.cpu().numpy()
+        m.before_task(1, buffer, None, None)
+        u_imgs, u_labs = imgs1 + list(buffer.images), labs1 + [int(v) for v in buffer.labels]
+        ux, uy = load(u_imgs, u_labs)
+        order1 = list(np.argsort(detrand.uniform(tag + "/perm1", (len(u_labs),)))[: 2 * c["bs"]])
+        run(batches_of(ux, uy, order1))
+        ds1 = PngDataset(root, "train", u_imgs, u_labs, png_transform)
+        m.after_task(1, buffer, ListLoader([], c["bs"], ds1), test_loaders)
+        new = list(buffer.images)[-(c["buffer_size"] // (c["init"] + c["inc"])) * c["inc"]:]
+        kept = [p_ for cc in range(c["init"], c["init"] + c["inc"]) for p_, l_ in zip(u_imgs, u_labs) if l_ == cc]
+        res["chosen1"] = np.asarray([kept.index(p_) for p_ in new])
+        res["buffer_labels1"] = np.asarray([int(v) for v in buffer.labels])
+        res["class_means1"] = m.class_means.detach().cpu().numpy().copy()
+        m.eval()
+        with torch.no_grad():
+            p, a = m.inference(adapter.batch(tx, ty))
+        res["ncm_pred1"] = p.cpu().numpy()
+        params = {k: v.detach().cpu() for k, v in m.network.named_parameters()}
+    res["losses"] = np.asarray(losses, np.float64)
+    res["preds"] = np.stack(preds)
+    names, rows = fx.summarize(params)
+    res["param_names"], res["param_rows"] = np.asarray(names), rows
+    return res
+
+
+# --------------------------------------------------------------------------------- scenario: LUCIR
+LUCIR_CFG = dict(arch="resnet32_V2", feat_dim=64, init=6, inc=2, bs=8, lr=0.1, momentum=0.9, wd=5e-4,
+                 lamda=5.0, K=2, lw_mr=1.0, dist=0.5, per_class=10)
+
+
+def scenario_lucir(adapter):
+    """task 0: 1 step (CE on the cosine head); before_task(1): teacher snapshot + fc2 imprint from
+    class-mean features; task 1: 2 steps with less-forget + CE + margin-ranking (batches mix old and new
+    labels), param groups per lucir.py:229-236."""
+    c = LUCIR_CFG
+    tag = "lucir"
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    b = 1.0 / np.sqrt(c["feat_dim"])
+    w0 = fx._t(detrand.uniform(tag + "/w0", (c["init"], c["feat_dim"]), -b, b))
+    t0 = [fx.det_batch(f"{tag}/t0/0", c["bs"], 0, c["init"])]
+    new_classes = list(range(c["init"], c["init"] + c["inc"]))
+    cls_x = {cc: fx.class_images(tag, cc, c["per_class"]) for cc in new_classes}
+    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], 0, c["init"] + c["inc"]) for i in range(2)]
+    losses, preds = [], []
+    res = {}
+    if adapter.kind == "oracle":
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        Bb = {k: v.clone() for k, v in Bf.items()}
+        m = om.LUCIR(c["arch"], Pg, Bb, w0.clone().requires_grad_(True), torch.ones(1, requires_grad=True),
+                     c["init"], c["inc"], c["lamda"], c["K"], c["lw_mr"], c["dist"])
+
+        def run(batches, groups):
+            opts = [om.SGD(ps, **kw) for ps, kw in groups]
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                for o in opts: o.zero_grad()
+                loss.backward()
+                for o in opts: o.step()
+                losses.append(loss.item()); preds.append(pred.numpy())
+        m.before_task(0)
+        run(t0, [(m.parameters(), dict(lr=c["lr"], momentum=c["momentum"], weight_decay=c["wd"]))])
+        with torch.no_grad():
+            cf = [nets.forward(c["arch"], Pg, Bb, cls_x[cc], False) for cc in new_classes]
+        m.before_task(1, class_feats=cf)
+        base = list(m.P.values()) + [m.fc2_w, m.sigma]
+        run(t1, [(base, dict(lr=0.1, momentum=c["momentum"], weight_decay=5e-4)),
+                 ([m.fc1_w], dict(lr=0.0, momentum=c["momentum"], weight_decay=0.0))])
+        res["fc2_imprint_norm"] = np.asarray([m.cur_lamda])
+        params = {("backbone." + k): v for k, v in m.P.items()}
+        params["classifier.fc1.weight"] = m.fc1_w; params["classifier.fc2.weight"] = m.fc2_w
+        params["classifier.sigma"] = m.sigma
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.LUCIR(bb, c["feat_dim"], 100, device=adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"],
+                     lamda=c["lamda"], K=c["K"], lw_mr=c["lw_mr"], dist=c["dist"]).to(adapter.device)
+        with torch.no_grad():
+            m.network.classifier.weight.data.copy_(adapter.to_dev(w0))
+
+        def run(batches):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], momentum=c["momentum"], weight_decay=c["wd"])
+            m.train()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
+        m.before_task(0, None, None, None)
+        run(t0)
+
+        class _DS(torch.utils.data.Dataset):
+            def __init__(s):
+                s.images = [(cc, k) for cc in new_classes for k in range(c["per_class"])]
+                s.labels = [cc for cc in new_classes for k in range(c["per_class"])]
+            def __len__(s): return len(s.labels)
+            def __getitem__(s, i):
+                im = s.images[i]
+                return {"image": cls_x[int(im[0])][int(im[1])], "label": int(s.labels[i])}
+        m.before_task(1, None, ListLoader([], c["bs"], _DS()), None)
+        res["fc2_imprint_norm"] = np.asarray([m.cur_lamda])
+        run(t1)
+        m.after_task(1, None, None, None)
+        params = {k: v.detach().cpu() for k, v in m.network.named_parameters()}
+    res["losses"] = np.asarray(losses, np.float64)
+    res["preds"] = np.stack(preds)
+    names, rows = fx.summarize(params)
+    res["param_names"], res["param_rows"] = np.asarray(names), rows
+    res["fc2_w"] = params["classifier.fc2.weight"].detach().numpy()
+    return res
