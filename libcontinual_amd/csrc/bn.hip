@@ -1,0 +1,407 @@
+// bn.hip -- BatchNorm2d (+ residual add + ReLU) forward / backward, global average pool, layout
+// conversion and conv-weight shadow preparation.  All HBM-bound streaming kernels: 16-byte (bf16x8)
+// or 32-byte (fp32x8) accesses per lane, coalesced along the NHWC channel axis, wavefront (64-lane)
+// reductions, per-block partials instead of atomics (deterministic).
+//
+// Reference semantics: nn.BatchNorm2d(momentum=0.1, eps=1e-5) + F.relu + residual add,
+// core/model/backbone/resnet.py:296-316; nn.AvgPool2d(8) / AdaptiveAvgPool2d(1), :160, :344.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- stats finalize
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int tiles, double invM, double unbias,
+                                                          int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* rm, float* rv, float momentum, float eps, float* mean_o,
+                                                          float* invstd_o, float* scale, float* shift) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < tiles; t += 64) {
+        s1 += (double)part[((size_t)t * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)t * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        double mean = s1 * invM;
+        double var = s2 * invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float istd = (float)(1.0 / sqrt(var + (double)eps));
+        float g = gamma[c], b = beta[c];
+        float sc = g * istd;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = istd;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+        if (rm != nullptr) {
+            rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+            rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * unbias);
+        }
+    }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                      float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float istd = 1.f / sqrtf(rv[c] + eps);
+    float sc = gamma[c] * istd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------------------------------- apply
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res,
+                                                       T* __restrict__ y, int64_t nchunks, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int c0 = (int)((i * 8) % C);
+        float v[8], r[8];
+        load8<T>(z + i * 8, v);
+        if (RES) load8<T>(res + i * 8, r);
+        const float4 s0 = *reinterpret_cast<const float4*>(scale + c0), s1 = *reinterpret_cast<const float4*>(scale + c0 + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(shift + c0), h1 = *reinterpret_cast<const float4*>(shift + c0 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = fmaf(v[e], sc[e], sh[e]);
+            if (RES) o += r[e];
+            if (RELU) o = fmaxf(o, 0.f);
+            v[e] = o;
+        }
+        store8<T>(y + i * 8, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward
+// pass 1: per-channel partial sums of g = dy*mask and g*xhat over a slab of rows.
+// thread layout: cpr = C/8 chunk columns per row, rpi = 256/cpr rows per iteration.
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                            const T* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ part,
+                                                            int64_t M, int C) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [256][16]
+    const int cpr = C >> 3;
+    const int rpi = 256 / cpr;
+    const int cc = threadIdx.x % cpr, ro = threadIdx.x / cpr;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (ro < rpi) {
+        float mu[8], is[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = mean[cc * 8 + e]; is[e] = invstd[cc * 8 + e]; }
+        for (int64_t r = (int64_t)blockIdx.x * rpi + ro; r < M; r += (int64_t)gridDim.x * rpi) {
+            const int64_t off = r * C + cc * 8;
+            float g[8], yy[8], zz[8];
+            load8<T>(dy + off, g);
+            load8<T>(z + off, zz);
+            if (RELU) load8<T>(y + off, yy);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gg = g[e];
+                if (RELU) gg = yy[e] > 0.f ? gg : 0.f;
+                a1[e] += gg;
+                a2[e] += gg * (zz[e] - mu[e]) * is[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = a1[e]; red[threadIdx.x * 16 + 8 + e] = a2[e]; }
+    __syncthreads();
+    // channel c, which w: sum over ro
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+        int which = idx / C, c = idx - which * C;
+        int col = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int q = 0; q < rpi; ++q) s += red[(q * cpr + col) * 16 + which * 8 + e];
+        part[((size_t)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int G, double invM, int C,
+                                                              float* dgamma, float* dbeta, float* coef) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < G; t += 64) {
+        s1 += (double)part[((size_t)t * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)t * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        dbeta[c] += (float)s1;
+        dgamma[c] += (float)s2;
+        coef[c] = (float)(s1 * invM);
+        coef[C + c] = (float)(s2 * invM);
+    }
+}
+
+// pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres (+)= g
+template <typename T, bool RELU, int DRES>   // DRES: 0 none, 1 write, 2 accumulate
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const T* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ coef, T* __restrict__ dz, T* __restrict__ dres,
+                                                           int64_t nchunks, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int c0 = (int)((i * 8) % C);
+        float g[8], yy[8], zz[8], o[8], rr[8];
+        load8<T>(dy + i * 8, g);
+        load8<T>(z + i * 8, zz);
+        if (RELU) load8<T>(y + i * 8, yy);
+        if (DRES == 2) load8<T>(dres + i * 8, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float gg = g[e];
+            if (RELU) gg = yy[e] > 0.f ? gg : 0.f;
+            const float is = invstd[c];
+            const float xh = (zz[e] - mean[c]) * is;
+            o[e] = gamma[c] * is * (gg - coef[c] - xh * coef[C + c]);
+            g[e] = gg;
+            if (DRES == 2) rr[e] += gg;
+        }
+        store8<T>(dz + i * 8, o);
+        if (DRES == 1) store8<T>(dres + i * 8, g);
+        if (DRES == 2) store8<T>(dres + i * 8, rr);
+    }
+}
+
+int bn_bwd_blocks(int64_t M, int C) {
+    int cpr = C >> 3;
+    int rpi = 256 / cpr;
+    int64_t g = (M + rpi - 1) / rpi;
+    // a few iterations per block; cap so the finalize reduction stays short
+    g = (g + 7) / 8;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int ew_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------ avg pool
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ a, float* __restrict__ feat, int N, int HW, int C) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * C) return;
+    int n = idx / C, c = idx - n * C;
+    const T* p = a + (size_t)n * HW * C + c;
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += Elem<T>::ld(p + (size_t)i * C);
+    feat[idx] = s / (float)HW;
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ da, int N, int HW, int C) {
+    const int64_t nchunks = (int64_t)N * HW * C / 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        int64_t e0 = i * 8;
+        int c0 = (int)(e0 % C);
+        int n = (int)(e0 / ((int64_t)HW * C));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dfeat[(size_t)n * C + c0 + e] * inv;
+        store8<T>(da + e0, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ layout converts
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int Cpad) {
+    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (int64_t)N * HW) return;
+    int n = (int)(pix / HW), hw = (int)(pix - (int64_t)n * HW);
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? x[((size_t)n * C + c0 + e) * HW + hw] : 0.f;
+        store8<T>(y + pix * Cpad + c0, v);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ y, float* __restrict__ x, int N, int C, int HW) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * C * HW) return;
+    int hw = (int)(idx % HW);
+    int64_t t = idx / HW;
+    int c = (int)(t % C);
+    int n = (int)(t / C);
+    x[idx] = Elem<T>::ld(y + ((size_t)n * HW + hw) * C + c);
+}
+
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int taps,
+                                   int Creal, int Cpad) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = (int64_t)K * taps * Cpad;
+    if (idx >= n) return;
+    int c = (int)(idx % Cpad);
+    int64_t t = idx / Cpad;
+    int tap = (int)(t % taps);
+    int k = (int)(t / taps);
+    float v = c < Creal ? w[((size_t)k * taps + tap) * Creal + c] : 0.f;
+    Elem<T>::st(wf + idx, v);
+    if (wd != nullptr) Elem<T>::st(wd + ((size_t)c * taps + tap) * K + k, v);
+}
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" int clhip_bn_stats_finalize(const float* part, int tiles, int64_t M, int C, const float* gamma, const float* beta,
+                                       float* rm, float* rv, float momentum, float eps, float* mean, float* invstd,
+                                       float* scale, float* shift, void* stream) {
+    CLHIP_CHECK_ARG(part && gamma && beta && mean && invstd && scale && shift && tiles > 0 && M > 0 && C > 0);
+    CLHIP_CHECK_ARG((rm == nullptr) == (rv == nullptr));
+    double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, tiles, 1.0 / (double)M,
+                       unbias, C, gamma, beta, rm, rv, momentum, eps, mean, invstd, scale, shift);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                    float* scale, float* shift, void* stream) {
+    CLHIP_CHECK_ARG(gamma && beta && rm && rv && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps,
+                       C, scale, shift);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+template <typename T>
+static int bn_apply_t(const void* z, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu,
+                      hipStream_t st) {
+    int64_t nch = M * C / 8;
+    dim3 g(ew_blocks(nch)), b(256);
+    const T* zz = (const T*)z; const T* rr = (const T*)res; T* yy = (T*)y;
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<T, true, true>), g, b, 0, st, zz, scale, shift, rr, yy, nch, C);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<T, true, false>), g, b, 0, st, zz, scale, shift, rr, yy, nch, C);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), g, b, 0, st, zz, scale, shift, rr, yy, nch, C);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), g, b, 0, st, zz, scale, shift, rr, yy, nch, C);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_bn_apply(const void* z, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C,
+                              int relu, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(z && scale && shift && y && M > 0 && C >= 8 && C % 8 == 0);
+    if (dtype == CLHIP_BF16) return bn_apply_t<bf16_t>(z, scale, shift, res, y, M, C, relu, (hipStream_t)stream);
+    if (dtype == CLHIP_F32) return bn_apply_t<float>(z, scale, shift, res, y, M, C, relu, (hipStream_t)stream);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+extern "C" size_t clhip_bn_bwd_ws_floats(int64_t M, int C) { return (size_t)bn_bwd_blocks(M, C) * 2 * C + 2 * (size_t)C; }
+
+template <typename T>
+static int bn_bwd_t(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
+                    float* dgamma, float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, float* ws,
+                    hipStream_t st) {
+    const int G = bn_bwd_blocks(M, C);
+    float* part = ws;
+    float* coef = ws + (size_t)G * 2 * C;
+    const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
+    size_t lds = 256 * 16 * sizeof(float);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, M, C);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, M, C);
+    CLHIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, G, 1.0 / (double)M, C, dgamma, dbeta, coef);
+    CLHIP_LAUNCH_CHECK();
+    int64_t nch = M * C / 8;
+    dim3 g(ew_blocks(nch)), b(256);
+    T* dzz = (T*)dz; T* dr = (T*)dres;
+    int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
+#define BWD_APPLY(R, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, D>), g, b, 0, st, dyy, yy, zz, mean, invstd, gamma, coef, dzz, dr, nch, C)
+    if (relu) { if (mode == 0) BWD_APPLY(true, 0); else if (mode == 1) BWD_APPLY(true, 1); else BWD_APPLY(true, 2); }
+    else { if (mode == 0) BWD_APPLY(false, 0); else if (mode == 1) BWD_APPLY(false, 1); else BWD_APPLY(false, 2); }
+#undef BWD_APPLY
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_bn_bwd(const void* dy, const void* y, const void* z, const float* mean, const float* invstd,
+                            const float* gamma, float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M,
+                            int C, int relu, float* ws, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dy && z && mean && invstd && gamma && dgamma && dbeta && dz && ws && M > 0);
+    CLHIP_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 2048);
+    CLHIP_CHECK_ARG(!relu || y);
+    if (dtype == CLHIP_BF16)
+        return bn_bwd_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, ws, (hipStream_t)stream);
+    if (dtype == CLHIP_F32)
+        return bn_bwd_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, ws, (hipStream_t)stream);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+extern "C" int clhip_avgpool_fwd(const void* a, float* feat, int N, int HW, int C, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(a && feat && N > 0 && HW > 0 && C > 0);
+    dim3 g((N * C + 255) / 256), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, (const bf16_t*)a, feat, N, HW, C);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((avgpool_fwd_kernel<float>), g, b, 0, (hipStream_t)stream, (const float*)a, feat, N, HW, C);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_avgpool_bwd(const float* dfeat, void* da, int N, int HW, int C, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dfeat && da && N > 0 && HW > 0 && C >= 8 && C % 8 == 0);
+    dim3 g(ew_blocks((int64_t)N * HW * C / 8)), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, dfeat, (bf16_t*)da, N, HW, C);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((avgpool_bwd_kernel<float>), g, b, 0, (hipStream_t)stream, dfeat, (float*)da, N, HW, C);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 8 == 0);
+    int64_t npix = (int64_t)N * H * W;
+    dim3 g((unsigned)((npix + 255) / 256)), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, x, (bf16_t*)y, N, C, H * W, Cpad);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), g, b, 0, (hipStream_t)stream, x, (float*)y, N, C, H * W, Cpad);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_nhwc_to_nchw(const void* y, float* x, int N, int C, int H, int W, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0);
+    int64_t n = (int64_t)N * C * H * W;
+    dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, (const bf16_t*)y, x, N, C, H * W);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), g, b, 0, (hipStream_t)stream, (const float*)y, x, N, C, H * W);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_conv_weight_prep(const float* w, void* w_fwd, void* w_dg, int K, int taps, int Creal, int Cpad, int dtype,
+                                      void* stream) {
+    CLHIP_CHECK_ARG(w && w_fwd && K > 0 && taps > 0 && Creal > 0 && Cpad >= Creal);
+    int64_t n = (int64_t)K * taps * Cpad;
+    dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((weight_prep_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, w, (bf16_t*)w_fwd, (bf16_t*)w_dg, K, taps, Creal, Cpad);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((weight_prep_kernel<float>), g, b, 0, (hipStream_t)stream, w, (float*)w_fwd, (float*)w_dg, K, taps, Creal, Cpad);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}

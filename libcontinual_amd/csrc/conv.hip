@@ -1,0 +1,511 @@
+// conv.hip -- convolution as implicit GEMM on the CDNA4 matrix cores (gfx950).
+//
+// Replaces nn.Conv2d forward / dgrad / wgrad of the reference ResNets
+// (core/model/backbone/resnet.py:17-24, 295-298, 337, 367).  Activations NHWC, weights K,R,S,C.
+//
+//   forward:  z[p][o]   = sum_{tap,c} x[p @ tap][c] * w[o][tap][c]          p = output pixel
+//   dgrad  :  dx[q][c]  = sum_{tap,o} dz[q @ tap^-1][o] * wd[c][tap][o]     q = input pixel
+//   wgrad  :  dw[o][tap][c] += sum_p dz[p][o] * x[p @ tap][c]
+//
+// forward and dgrad share one kernel: a GEMM whose "pixel" operand is gathered on the fly (im2col is
+// never materialised).  MFMA orientation: D[row = out channel][col = pixel], so a lane ends up with 4
+// consecutive channels of one pixel (one 8-byte store in bf16).  16x16x32 bf16 MFMA (or 8x 16x16x4
+// fp32 MFMA in the exact fp32 parity mode); fp32 accumulation.  The BatchNorm batch statistics are
+// reduced from the fp32 accumulators in the epilogue (per-tile partials, no atomics -> deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;   // K-step: 32 reduction elements = one bf16 MFMA
+
+struct ConvParams {
+    const void* src;   // gathered tensor [N, Hs, Ws, Cs]
+    const void* wt;    // [Cd][taps][Cs]
+    void* dst;         // [N, Hd, Wd, Cd]
+    float* stats;      // [tiles_m][2][Cd] or nullptr
+    int N, Hs, Ws, Cs, log2Cs, Hd, Wd, Cd, ksize, stride, pad, accumulate;
+    int M;             // N*Hd*Wd
+    int K;             // taps*Cs
+};
+
+template <typename T> struct Chunk;                       // 8 elements
+template <> struct Chunk<bf16_t> { uint4 a; };
+template <> struct Chunk<float> { uint4 a, b; };
+
+template <typename T> __device__ __forceinline__ Chunk<T> zero_chunk() {
+    Chunk<T> c;
+    if constexpr (sizeof(T) == 2) { c.a = make_uint4(0, 0, 0, 0); }
+    else { c.a = make_uint4(0, 0, 0, 0); c.b = make_uint4(0, 0, 0, 0); }
+    return c;
+}
+template <typename T> __device__ __forceinline__ Chunk<T> load_chunk(const T* p) {
+    Chunk<T> c;
+    if constexpr (sizeof(T) == 2) { c.a = *reinterpret_cast<const uint4*>(p); }
+    else { c.a = *reinterpret_cast<const uint4*>(p); c.b = *reinterpret_cast<const uint4*>(p + 4); }
+    return c;
+}
+
+// LDS tile: rows of BK elements.  bf16 rows are 64 B; the 16-B chunk index is XOR-swizzled with
+// ((row>>3)&1)<<1 so that every 16-lane service group of ds_read_b128 touches 16 distinct 16-B slots
+// of the 256-B bank row (derivation in DESIGN.md); fp32 rows (parity mode) are left linear.
+template <typename T> __device__ __forceinline__ int lds_off(int row, int chunk) {
+    if constexpr (sizeof(T) == 2) return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4);
+    else return row * 128 + (chunk << 5);
+}
+template <typename T> __device__ __forceinline__ void lds_store(char* base, int row, int chunk, const Chunk<T>& c) {
+    char* p = base + lds_off<T>(row, chunk);
+    if constexpr (sizeof(T) == 2) { *reinterpret_cast<uint4*>(p) = c.a; }
+    else { *reinterpret_cast<uint4*>(p) = c.a; *reinterpret_cast<uint4*>(p + 16) = c.b; }
+}
+template <typename T> __device__ __forceinline__ Chunk<T> lds_load(const char* base, int row, int chunk) {
+    const char* p = base + lds_off<T>(row, chunk);
+    Chunk<T> c;
+    if constexpr (sizeof(T) == 2) { c.a = *reinterpret_cast<const uint4*>(p); }
+    else { c.a = *reinterpret_cast<const uint4*>(p); c.b = *reinterpret_cast<const uint4*>(p + 16); }
+    return c;
+}
+
+// acc += W-frag (rows = out channels) x X-frag (cols = pixels) over 32 reduction elements
+template <typename T> __device__ __forceinline__ f32x4 mma32(const Chunk<T>& wf, const Chunk<T>& xf, f32x4 acc) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8_t a = __builtin_bit_cast(bf16x8_t, wf.a);
+        bf16x8_t b = __builtin_bit_cast(bf16x8_t, xf.a);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    } else {
+        // lane group g owns reduction elements 8g..8g+7; MFMA j consumes element j of every group:
+        // any consistent assignment of reduction indices to (lane group, MFMA) is valid for a sum.
+        const float* a = reinterpret_cast<const float*>(&wf);
+        const float* b = reinterpret_cast<const float*>(&xf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+        return acc;
+    }
+}
+
+// MODE 0: forward gather  (hs = hd*stride + r - pad)
+// MODE 1: dgrad gather    (hs = (hd + pad - r)/stride when divisible)
+template <typename T, int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    constexpr int MT = BM / 64;            // 16-pixel tiles per wave (4 waves split the BM pixels)
+    constexpr int NT = BN / 16;            // 16-channel tiles
+    constexpr int AROWS = BM / 64;         // A-tile rows staged per thread
+    constexpr int BROWS = (BN + 63) / 64;  // B-tile rows staged per thread
+    constexpr int ROWB = BK * sizeof(T);
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB + 4 * BN * 2 * sizeof(float)];
+    char* As = smem;
+    char* Bs = smem + BM * ROWB;
+    float* red = reinterpret_cast<float*>(smem + (BM + BN) * ROWB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T* __restrict__ src = static_cast<const T*>(p.src);
+    const T* __restrict__ wt = static_cast<const T*>(p.wt);
+
+    // ---- per-thread staging coordinates (fixed for the whole K loop)
+    const int ca = tid & 3;                 // chunk column within the 32-wide K step
+    int a_base[AROWS], a_h0[AROWS], a_w0[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        int pix = m0 + (tid >> 2) + 64 * i;
+        if (pix < p.M) {
+            int wd = pix % p.Wd;
+            int t = pix / p.Wd;
+            int hd = t % p.Hd;
+            int n = t / p.Hd;
+            a_base[i] = n * p.Hs * p.Ws;
+            if (MODE == 0) { a_h0[i] = hd * p.stride - p.pad; a_w0[i] = wd * p.stride - p.pad; }
+            else { a_h0[i] = hd + p.pad; a_w0[i] = wd + p.pad; }
+        } else {
+            a_base[i] = -1; a_h0[i] = 0; a_w0[i] = 0;
+        }
+    }
+
+    Chunk<T> ra[AROWS], rb[BROWS];
+    auto gload = [&](int kstep) {
+        const int kk = kstep * BK + ca * 8;
+        const bool kvalid = kk < p.K;
+        const int tap = kk >> p.log2Cs;
+        const int cs = kk & (p.Cs - 1);
+        const int r = (p.ksize == 3) ? tap / 3 : 0;
+        const int s = (p.ksize == 3) ? tap - 3 * r : 0;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            bool ok = kvalid && a_base[i] >= 0;
+            int hs, ws;
+            if (MODE == 0) {
+                hs = a_h0[i] + r; ws = a_w0[i] + s;
+            } else {
+                int th = a_h0[i] - r, tw = a_w0[i] - s;
+                ok = ok && th >= 0 && tw >= 0;
+                if (p.stride == 1) { hs = th; ws = tw; }
+                else { ok = ok && (th % p.stride == 0) && (tw % p.stride == 0); hs = th / p.stride; ws = tw / p.stride; }
+            }
+            ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+            if (ok) ra[i] = load_chunk<T>(src + ((size_t)(a_base[i] + hs * p.Ws + ws) * p.Cs + cs));
+            else ra[i] = zero_chunk<T>();
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int row = (tid >> 2) + 64 * i;
+            int o = n0 + row;
+            if (row < BN && o < p.Cd && kvalid) rb[i] = load_chunk<T>(wt + ((size_t)o * p.K + kk));
+            else rb[i] = zero_chunk<T>();
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) lds_store<T>(As, (tid >> 2) + 64 * i, ca, ra[i]);
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int row = (tid >> 2) + 64 * i;
+            if (row < BN) lds_store<T>(Bs, row, ca, rb[i]);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int fr = lane & 15, fg = lane >> 4;
+    gload(0);
+    sstore();
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        if (k + 1 < nk) gload(k + 1);          // global loads in flight while the MFMAs run
+        Chunk<T> xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[i] = lds_load<T>(As, wave * (BM / 4) + i * 16 + fr, fg);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = lds_load<T>(Bs, j * 16 + fr, fg);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mma32<T>(wf[j], xf[i], acc[i][j]);
+        __syncthreads();
+        if (k + 1 < nk) {
+            sstore();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[row = channel fg*4+e][col = pixel fr]
+    T* __restrict__ dst = static_cast<T*>(p.dst);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = m0 + wave * (BM / 4) + i * 16 + fr;
+        if (pix < p.M) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int o = n0 + j * 16 + fg * 4;
+                if (o < p.Cd) {
+                    T* q = dst + (size_t)pix * p.Cd + o;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (p.accumulate) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(q + e);
+                    }
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 u;
+                        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(q) = u;
+                    } else {
+                        *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+        // per-channel sum / sum of squares over this tile's pixels (rows beyond M hold exact zeros)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (fr == 0) {
+                    int c = j * 16 + fg * 4 + e;
+                    red[(wave * 2 + 0) * BN + c] = s1;
+                    red[(wave * 2 + 1) * BN + c] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            int which = tid / BN, c = tid - which * BN;
+            float t = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] + red[(2 * 2 + which) * BN + c] +
+                      red[(3 * 2 + which) * BN + c];
+            if (n0 + c < p.Cd) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + c] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+struct WgradParams {
+    const void* x;    // [N,H,W,C]
+    const void* dz;   // [N,Ho,Wo,K]
+    float* dw;        // [K][taps][Creal] fp32, atomically accumulated
+    int N, H, W, C, log2C, Creal, Ho, Wo, K, ksize, stride, pad;
+    int M;            // N*Ho*Wo
+    int J;            // taps*C
+    int pix_per_split;
+};
+
+// Fragment of the TRANSPOSED LDS tile: tile is [32 pixels][64 channels] (row = pixel); the MFMA
+// operand wants, for channel column `col`, the 8 pixels 8g..8g+7 of lane group g.
+template <typename T, bool TR>
+__device__ __forceinline__ Chunk<T> lds_load_transposed(const char* tile, int col0, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    Chunk<T> c;
+    if constexpr (sizeof(T) == 2) {
+        constexpr int ROWB = 64 * 2;
+        if constexpr (TR) {
+            // ds_read_b64_tr_b16: the 16 lanes of a group fetch a [4 pixels][16 channels] block (lane i:
+            // pixel i>>2, channels 4*(i&3)..+3) and receive it transposed (lane i: channel i, 4 pixels).
+            const char* a0 = tile + (fg * 8 + (fr >> 2)) * ROWB + (col0 + (fr & 3) * 4) * 2;
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
+            uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+            c.a = make_uint4(l.x, l.y, h.x, h.y);
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t e0 = *reinterpret_cast<const uint16_t*>(tile + (fg * 8 + 2 * j) * ROWB + (col0 + fr) * 2);
+                uint32_t e1 = *reinterpret_cast<const uint16_t*>(tile + (fg * 8 + 2 * j + 1) * ROWB + (col0 + fr) * 2);
+                w[j] = e0 | (e1 << 16);
+            }
+            c.a = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        constexpr int ROWB = 64 * 4;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(tile + (fg * 8 + j) * ROWB + (col0 + fr) * 4);
+        c.a = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+        c.b = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+    }
+    return c;
+}
+
+// grid: x = J tiles (64 (tap,c) columns), y = K tiles (64 out channels), z = pixel splits
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int ROWB = 64 * sizeof(T);
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * ROWB];
+    char* Zs = smem;                 // [32 pixels][64 out channels]
+    char* Xs = smem + 32 * ROWB;     // [32 pixels][64 (tap,c) columns]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    const T* __restrict__ x = static_cast<const T*>(p.x);
+    const T* __restrict__ dz = static_cast<const T*>(p.dz);
+
+    const int row = tid >> 3, ch = tid & 7;          // staging: one 8-element chunk per thread per tile
+    // (tap, c) of this thread's X chunk is fixed over the pixel loop
+    const int jx = j0 + ch * 8;
+    const bool jvalid = jx < p.J;
+    const int tap = jx >> p.log2C;
+    const int cx = jx & (p.C - 1);
+    const int r = (p.ksize == 3) ? tap / 3 : 0;
+    const int s = (p.ksize == 3) ? tap - 3 * r : 0;
+    const bool ovalid = (o0 + ch * 8) < p.K;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Chunk<T> rz, rx;
+    auto gload = [&](int pb) {
+        int pix = pb + row;
+        bool pv = pix < pend;
+        rz = (pv && ovalid) ? load_chunk<T>(dz + ((size_t)pix * p.K + o0 + ch * 8)) : zero_chunk<T>();
+        bool ok = pv && jvalid;
+        size_t off = 0;
+        if (ok) {
+            int wo = pix % p.Wo;
+            int t = pix / p.Wo;
+            int ho = t % p.Ho;
+            int n = t / p.Ho;
+            int hs = ho * p.stride - p.pad + r, ws = wo * p.stride - p.pad + s;
+            ok = (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+            off = ((size_t)(n * p.H + hs) * p.W + ws) * p.C + cx;
+        }
+        rx = ok ? load_chunk<T>(x + off) : zero_chunk<T>();
+    };
+    auto sstore = [&]() {
+        char* zq = Zs + row * ROWB + ch * 8 * sizeof(T);
+        char* xq = Xs + row * ROWB + ch * 8 * sizeof(T);
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(zq) = rz.a;
+            *reinterpret_cast<uint4*>(xq) = rx.a;
+        } else {
+            *reinterpret_cast<uint4*>(zq) = rz.a; *reinterpret_cast<uint4*>(zq + 16) = rz.b;
+            *reinterpret_cast<uint4*>(xq) = rx.a; *reinterpret_cast<uint4*>(xq + 16) = rx.b;
+        }
+    };
+
+    if (pbeg < pend) {
+        gload(pbeg);
+        sstore();
+        __syncthreads();
+        for (int pb = pbeg; pb < pend; pb += 32) {
+            const bool more = pb + 32 < pend;
+            if (more) gload(pb + 32);
+            Chunk<T> zf = lds_load_transposed<T, TR>(Zs, wave * 16, lane);   // rows = 16 out channels of this wave
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Chunk<T> xf = lds_load_transposed<T, TR>(Xs, j * 16, lane);  // cols = 16 (tap,c) columns
+                acc[j] = mma32<T>(zf, xf, acc[j]);
+            }
+            __syncthreads();
+            if (more) {
+                sstore();
+                __syncthreads();
+            }
+        }
+    }
+
+    // D[row = out channel fg*4+e][col = (tap,c) column fr]
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int jj = j0 + j * 16 + fr;
+        if (jj >= p.J) continue;
+        int tp = jj >> p.log2C, c = jj & (p.C - 1);
+        if (c >= p.Creal) continue;
+        int taps = p.ksize * p.ksize;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int o = o0 + wave * 16 + fg * 4 + e;
+            if (o < p.K) atomicAdd(p.dw + ((size_t)o * taps + tp) * p.Creal + c, acc[j][e]);
+        }
+    }
+}
+
+template <typename T, int MODE>
+int launch_igemm(const ConvParams& p, hipStream_t st) {
+    const int Cd = p.Cd;
+    int BN = Cd >= 128 ? 128 : (Cd >= 64 ? 64 : (Cd >= 32 ? 32 : 16));
+    int gy = (Cd + BN - 1) / BN;
+    bool small = ((int64_t)((p.M + 127) / 128) * gy) < 512;
+    int BM = small ? 64 : 128;
+    dim3 grid((p.M + BM - 1) / BM, gy);
+#define LAUNCH(bm, bn) hipLaunchKernelGGL((conv_igemm_kernel<T, bm, bn, MODE>), grid, dim3(256), 0, st, p)
+    if (BM == 128) {
+        if (BN == 128) LAUNCH(128, 128); else if (BN == 64) LAUNCH(128, 64); else if (BN == 32) LAUNCH(128, 32); else LAUNCH(128, 16);
+    } else {
+        if (BN == 128) LAUNCH(64, 128); else if (BN == 64) LAUNCH(64, 64); else if (BN == 32) LAUNCH(64, 32); else LAUNCH(64, 16);
+    }
+#undef LAUNCH
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+int fwd_tile_m(int M, int Cd) {
+    int BN = Cd >= 128 ? 128 : (Cd >= 64 ? 64 : (Cd >= 32 ? 32 : 16));
+    int gy = (Cd + BN - 1) / BN;
+    bool small = ((int64_t)((M + 127) / 128) * gy) < 512;
+    return small ? 64 : 128;
+}
+
+int check_conv(int N, int H, int W, int C, int K, int ksize, int stride, int pad) {
+    CLHIP_CHECK_ARG(N > 0 && H > 0 && W > 0);
+    CLHIP_CHECK_ARG(ksize == 1 || ksize == 3);
+    CLHIP_CHECK_ARG(stride >= 1 && pad >= 0);
+    CLHIP_CHECK_ARG(C >= 8 && ilog2_exact(C) >= 0);     // channel counts are powers of two (pad the stem to 8)
+    CLHIP_CHECK_ARG(K >= 16 && K % 16 == 0);
+    CLHIP_CHECK_ARG((int64_t)N * H * W * (C > K ? C : K) < (int64_t)1 << 31);
+    return CLHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize, int stride, int pad) {
+    int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    int M = N * Ho * Wo;
+    int bm = fwd_tile_m(M, K);
+    return (M + bm - 1) / bm;
+}
+
+extern "C" int clhip_conv_fwd(const void* x, const void* w_fwd, void* z, float* stat_partials, int N, int H, int W, int C,
+                              int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(x && w_fwd && z);
+    ConvParams p;
+    p.src = x; p.wt = w_fwd; p.dst = z; p.stats = stat_partials;
+    p.N = N; p.Hs = H; p.Ws = W; p.Cs = C; p.log2Cs = ilog2_exact(C);
+    p.Hd = (H + 2 * pad - ksize) / stride + 1; p.Wd = (W + 2 * pad - ksize) / stride + 1; p.Cd = K;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = 0;
+    p.M = N * p.Hd * p.Wd; p.K = ksize * ksize * C;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == CLHIP_BF16) return launch_igemm<bf16_t, 0>(p, st);
+    if (dtype == CLHIP_F32) return launch_igemm<float, 0>(p, st);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C,
+                                int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(dz && w_dg && dx);
+    CLHIP_CHECK_ARG(C % 16 == 0);
+    ConvParams p;
+    p.src = dz; p.wt = w_dg; p.dst = dx; p.stats = nullptr;
+    p.N = N; p.Hs = (H + 2 * pad - ksize) / stride + 1; p.Ws = (W + 2 * pad - ksize) / stride + 1; p.Cs = K;
+    p.log2Cs = ilog2_exact(K);
+    CLHIP_CHECK_ARG(p.log2Cs >= 0);
+    p.Hd = H; p.Wd = W; p.Cd = C;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
+    p.M = N * H * W; p.K = ksize * ksize * K;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == CLHIP_BF16) return launch_igemm<bf16_t, 1>(p, st);
+    if (dtype == CLHIP_F32) return launch_igemm<float, 1>(p, st);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K,
+                                int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(x && dz && dw && Creal >= 1 && Creal <= C);
+    WgradParams p;
+    p.x = x; p.dz = dz; p.dw = dw;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.log2C = ilog2_exact(C); p.Creal = Creal;
+    p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
+    p.K = K; p.ksize = ksize; p.stride = stride; p.pad = pad;
+    p.M = N * p.Ho * p.Wo; p.J = ksize * ksize * C;
+    int gx = (p.J + 63) / 64, gy = (K + 63) / 64;
+    int tiles = gx * gy;
+    int max_splits = (p.M + 127) / 128;                 // at least 4 K-steps per block
+    int splits = (2048 + tiles - 1) / tiles;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int pps = (p.M + splits - 1) / splits;
+    pps = (pps + 31) / 32 * 32;
+    splits = (p.M + pps - 1) / pps;
+    p.pix_per_split = pps;
+    dim3 grid(gx, gy, splits);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static const bool no_tr = getenv("CLHIP_WGRAD_NO_TR") != nullptr;
+    if (dtype == CLHIP_BF16) {
+        if (no_tr) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
+    } else if (dtype == CLHIP_F32) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<float, false>), grid, dim3(256), 0, st, p);
+    } else {
+        CLHIP_CHECK_ARG(!"dtype");
+    }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}

@@ -1,0 +1,457 @@
+// head.hip -- classifier heads and the continual-learning loss terms, fp32.
+//
+//   linear / cosine-linear heads   (ewc.py:50, lwf.py:29-40, icarl.py:31; backbone/resnet.py:418-463)
+//   cross entropy on a column slice with label offset + argmax + correct count (ewc.py:87-108, lwf.py:61-62)
+//   distillation KD (T=2)          (lwf.py:75-78, icarl.py:198-206)
+//   LUCIR less-forget cosine embedding and top-K margin ranking (lucir.py:182-205)
+//   iCaRL nearest-class-mean and herding selection (icarl.py:122-152, buffer/linearherdingbuffer.py:140-161)
+//
+// These are tiny (B x <=100 logits); each is one launch with one wavefront per row and fuses forward
+// value, gradient, prediction and accuracy so the step needs no host synchronisation.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------- linear
+// one wave per batch row: x row cached in registers (D <= 64*16), loop over outputs
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ out, int B, int D, int O) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float xr[16];
+    const int nd = (D + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xr[i] = (i < nd && i * 64 + lane < D) ? x[(size_t)row * D + i * 64 + lane] : 0.f;
+    for (int o = 0; o < O; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nd && i * 64 + lane < D) s = fmaf(xr[i], w[(size_t)o * D + i * 64 + lane], s);
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)row * O + o] = s + (b ? b[o] : 0.f);
+    }
+}
+
+// dx[b][d] = sum_o dout[b][o] w[o][d]
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dx, int B, int D,
+                                     int O, int acc) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    int b = idx / D, d = idx - b * D;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(dout[(size_t)b * O + o], w[(size_t)o * D + d], s);
+    dx[idx] = acc ? dx[idx] + s : s;
+}
+// dw[o][d] = sum_b dout[b][o] x[b][d] ; db[o] = sum_b dout[b][o]
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dw,
+                                     float* __restrict__ db, int B, int D, int O, int acc) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * D) return;
+    int o = idx / D, d = idx - o * D;
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float g = dout[(size_t)b * O + o];
+        s = fmaf(g, x[(size_t)b * D + d], s);
+        sb += g;
+    }
+    dw[idx] = acc ? dw[idx] + s : s;
+    if (db != nullptr && d == 0) db[o] = acc ? db[o] + sb : sb;
+}
+
+// ---------------------------------------------------------------------------- CE on a column slice
+__global__ __launch_bounds__(256) void ce_slice_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B,
+                                                       int O, int lo, int hi, int pred_hi, float weight, float* loss_out,
+                                                       float* __restrict__ dlogits, int grad_acc, int64_t* pred, int32_t* correct) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* lr = logits + (size_t)row * O;
+    const int y = (int)labels[row];
+    // argmax over [0, pred_hi): first maximal index, as torch.argmax
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < pred_hi; c += 64) { float v = lr[c]; if (v > bv) { bv = v; bi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    // softmax over the slice
+    float mx = -INFINITY;
+    for (int c = lo + lane; c < hi; c += 64) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lo + lane; c < hi; c += 64) se += expf(lr[c] - mx);
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    if (dlogits != nullptr) {
+        float* dr = dlogits + (size_t)row * O;
+        const float sc = weight / (float)B;
+        for (int c = lane; c < O; c += 64) {
+            float g = 0.f;
+            if (c >= lo && c < hi) g = sc * (expf(lr[c] - lse) - (c == y ? 1.f : 0.f));
+            if (grad_acc) { if (c >= lo && c < hi) dr[c] += g; }
+            else dr[c] = g;
+        }
+    }
+    if (lane == 0) {
+        float li = (y >= lo && y < hi) ? (lse - lr[y]) : 0.f;
+        atomicAdd(loss_out, weight * li / (float)B);
+        if (pred) pred[row] = bi;
+        if (correct && bi == y) atomicAdd(correct, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- KD
+__global__ __launch_bounds__(256) void kd_kernel(const float* __restrict__ pred, int ps, const float* __restrict__ soft, int ss, int B,
+                                                 int k, float invT, float weight, float* loss_out, float* __restrict__ dpred, int grad_acc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* pr = pred + (size_t)row * ps;
+    const float* sr = soft + (size_t)row * ss;
+    float mp = -INFINITY, mq = -INFINITY;
+    for (int c = lane; c < k; c += 64) { mp = fmaxf(mp, pr[c] * invT); mq = fmaxf(mq, sr[c] * invT); }
+    mp = wave_max(mp); mq = wave_max(mq);
+    float sp = 0.f, sq = 0.f;
+    for (int c = lane; c < k; c += 64) { sp += expf(pr[c] * invT - mp); sq += expf(sr[c] * invT - mq); }
+    sp = wave_sum(sp); sq = wave_sum(sq);
+    const float lsep = mp + logf(sp);
+    float li = 0.f;
+    const float sc = weight * invT / (float)B;
+    for (int c = lane; c < k; c += 64) {
+        float q = expf(sr[c] * invT - mq) / sq;
+        float lp = pr[c] * invT - lsep;
+        li -= q * lp;
+        if (dpred != nullptr) {
+            float g = sc * (expf(lp) - q);
+            float* d = dpred + (size_t)row * ps + c;
+            *d = grad_acc ? *d + g : g;
+        }
+    }
+    li = wave_sum(li);
+    if (lane == 0) atomicAdd(loss_out, weight * li / (float)B);
+}
+
+// -------------------------------------------------------------------------------- cosine linear
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ x, float* __restrict__ nrm, int R, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { float v = x[(size_t)row * D + d]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    if (lane == 0) nrm[row] = fmaxf(sqrtf(s), 1e-12f);     // F.normalize eps
+}
+__global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ xn, const float* __restrict__ wn,
+                                                         float* __restrict__ out, int B, int D, int O) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    for (int o = 0; o < O; ++o) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s = fmaf(x[(size_t)row * D + d], w[(size_t)o * D + d], s);
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)row * O + o] = s / (xn[row] * wn[o]);
+    }
+}
+// dx[b][d] = sum_o dout[b,o] * (wh[o][d] - s[b,o]*xh[b][d]) / xn[b]
+__global__ void cosine_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ out,
+                                     const float* __restrict__ xn, const float* __restrict__ wn, const float* __restrict__ dout,
+                                     float* __restrict__ dx, int B, int D, int O, int acc) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    int b = idx / D, d = idx - b * D;
+    float xh = x[idx] / xn[b];
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) {
+        float g = dout[(size_t)b * O + o];
+        s += g * (w[(size_t)o * D + d] / wn[o] - out[(size_t)b * O + o] * xh);
+    }
+    s /= xn[b];
+    dx[idx] = acc ? dx[idx] + s : s;
+}
+__global__ void cosine_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ out,
+                                     const float* __restrict__ xn, const float* __restrict__ wn, const float* __restrict__ dout,
+                                     float* __restrict__ dw, int B, int D, int O, int acc) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * D) return;
+    int o = idx / D, d = idx - o * D;
+    float wh = w[idx] / wn[o];
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float g = dout[(size_t)b * O + o];
+        s += g * (x[(size_t)b * D + d] / xn[b] - out[(size_t)b * O + o] * wh);
+    }
+    s /= wn[o];
+    dw[idx] = acc ? dw[idx] + s : s;
+}
+
+// nn.CosineEmbeddingLoss(target=1): mean_b (1 - cos(a_b, b_b)), cos = a.b / sqrt((|a|^2+eps)(|b|^2+eps)), eps=1e-8
+__global__ __launch_bounds__(256) void cos_embed_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int D,
+                                                        float weight, float* loss_out, float* __restrict__ da, int grad_acc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* ar = a + (size_t)row * D;
+    const float* br = b + (size_t)row * D;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int d = lane; d < D; d += 64) { float u = ar[d], v = br[d]; ab = fmaf(u, v, ab); aa = fmaf(u, u, aa); bb = fmaf(v, v, bb); }
+    ab = wave_sum(ab); aa = wave_sum(aa) + 1e-8f; bb = wave_sum(bb) + 1e-8f;
+    const float den = sqrtf(aa * bb);
+    const float cs = ab / den;
+    if (da != nullptr) {
+        const float sc = -weight / (float)B;
+        for (int d = lane; d < D; d += 64) {
+            float g = sc * (br[d] / den - cs * ar[d] / aa);
+            float* q = da + (size_t)row * D + d;
+            *q = grad_acc ? *q + g : g;
+        }
+    }
+    if (lane == 0) atomicAdd(loss_out, weight * (1.f - cs) / (float)B);
+}
+
+// lucir.py:187-205.  one wave per row; rows with label >= num_old contribute nothing.
+// loss = weight * sum_{hard rows} sum_{k<K} max(0, margin - gt + novel_k) / (hard_num*K)
+// two launches: count (host-free: count kernel writes hard_count) then loss.
+__global__ void count_hard_kernel(const int64_t* __restrict__ labels, int B, int num_old, int32_t* hard_count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B && labels[i] < num_old) atomicAdd(hard_count, 1);
+}
+__global__ __launch_bounds__(256) void margin_rank_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels, int B,
+                                                          int O, int num_old, int K, float margin, float weight,
+                                                          const int32_t* __restrict__ hard_count, float* loss_out,
+                                                          float* __restrict__ ds, int grad_acc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int hn = *hard_count;
+    const int y = (int)labels[row];
+    float* dr = ds ? ds + (size_t)row * O : nullptr;
+    const bool hard = (y < num_old) && hn > 0;
+    int sel[8];                 // chosen novel columns whose hinge is active (wave-uniform), -1 otherwise
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sel[k] = -1;
+    float li = 0.f, dgt = 0.f, sc = 0.f;
+    if (hard) {
+        const float* sr = scores + (size_t)row * O;
+        const float gt = sr[y];
+        sc = weight / (float)(hn * K);
+        unsigned long long taken = 0ull;   // one bit per column slot owned by this lane
+        // top-K novel scores by repeated wave arg-max (K = 2 in the shipped config); ties -> lower index
+        for (int k = 0; k < K; ++k) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            int slot = 0;
+            for (int c = num_old + lane; c < O; c += 64, ++slot) {
+                if ((taken >> slot) & 1ull) continue;
+                float v = sr[c];
+                if (v > bv) { bv = v; bi = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bi == 0x7fffffff) break;
+            if (((bi - num_old) & 63) == lane) taken |= 1ull << ((bi - num_old) >> 6);
+            float h = margin - gt + bv;
+            if (h > 0.f) { li += h; dgt -= sc; sel[k] = bi; }
+        }
+    }
+    if (dr) {   // every column written exactly once by its owner lane
+        for (int c = lane; c < O; c += 64) {
+            float g = 0.f;
+            if (hard) {
+                if (c == y) g += dgt;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (sel[k] == c) g += sc;
+            }
+            if (grad_acc) { if (g != 0.f) dr[c] += g; }
+            else dr[c] = g;
+        }
+    }
+    if (hard && lane == 0) atomicAdd(loss_out, sc * li);
+}
+
+// out[r] = x[r] / max(||x[r]||, eps)
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { float v = x[(size_t)row * D + d]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    const float inv = 1.f / sqrtf(s);
+    for (int d = lane; d < D; d += 64) out[(size_t)row * D + d] = x[(size_t)row * D + d] * inv;
+}
+
+// ------------------------------------------------------------------------------------------ NCM
+__global__ __launch_bounds__(256) void ncm_kernel(const float* __restrict__ f, const float* __restrict__ means, int B, int M, int D,
+                                                  int64_t* pred) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float bv = INFINITY; int bi = 0;
+    for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) { float t = f[(size_t)row * D + d] - means[(size_t)m * D + d]; s = fmaf(t, t, s); }
+        s = wave_sum(s);
+        if (s < bv) { bv = s; bi = m; }     // first minimal index, as torch.argmin
+    }
+    if (lane == 0) pred[row] = bi;
+}
+
+// herding: single block; ws = [mu(D) | run(D) | taken(n)]
+__global__ __launch_bounds__(256) void herding_kernel(const float* __restrict__ f, int n, int D, int m, int32_t* chosen, float* ws) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    float* mu = ws; float* run = ws + D; float* taken = ws + 2 * D;
+    const int tid = threadIdx.x;
+    for (int d = tid; d < D; d += 256) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += f[(size_t)i * D + d];
+        mu[d] = s / (float)n;
+        run[d] = 0.f;
+    }
+    for (int i = tid; i < n; i += 256) taken[i] = 0.f;
+    __syncthreads();
+    for (int k = 0; k < m && k < n; ++k) {
+        float bv = INFINITY; int bi = 0x7fffffff;
+        const float inv = 1.f / (float)(k + 1);
+        for (int i = tid; i < n; i += 256) {
+            float s = 0.f;
+            // a selected row is "removed" by +1e6 on every coordinate (linearherdingbuffer.py:160)
+            const float off = taken[i] * 1e6f;
+            for (int d = 0; d < D; ++d) { float t = mu[d] - (f[(size_t)i * D + d] + off + run[d]) * inv; s = fmaf(t, t, s); }
+            if (s < bv) { bv = s; bi = i; }
+        }
+        sv[tid] = bv; si[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                float ov = sv[tid + o]; int oi = si[tid + o];
+                if (ov < sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const int best = si[0];
+        if (tid == 0) { chosen[k] = best; }
+        for (int d = tid; d < D; d += 256) run[d] += f[(size_t)best * D + d] + taken[best] * 1e6f;
+        __syncthreads();
+        if (tid == 0) taken[best] += 1.f;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+static int zero_scalar(void* p, size_t bytes, hipStream_t st) {
+    if (hipMemsetAsync(p, 0, bytes, st) != hipSuccess) { clhip_set_error("hipMemsetAsync failed"); return CLHIP_EHIP; }
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_linear_fwd(const float* x, const float* w, const float* b, float* out, int B, int D, int O, void* stream) {
+    CLHIP_CHECK_ARG(x && w && out && B > 0 && D > 0 && D <= 1024 && O > 0);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, x, w, b, out, B, D, O);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_linear_bwd(const float* x, const float* w, const float* dout, float* dx, float* dw, float* db, int B, int D,
+                                int O, int accumulate, void* stream) {
+    CLHIP_CHECK_ARG(x && w && dout && dw && B > 0 && D > 0 && O > 0);
+    if (dx) {
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST, dout, w, dx, B, D, O, 0);
+        CLHIP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((O * D + 255) / 256), dim3(256), 0, ST, dout, x, dw, db, B, D, O, accumulate);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_ce_slice(const float* logits, const int64_t* labels, int B, int O, int lo, int hi, int pred_hi, float weight,
+                              float* loss_out, int loss_accumulate, float* dlogits, int grad_accumulate, int64_t* pred,
+                              int32_t* correct, void* stream) {
+    CLHIP_CHECK_ARG(logits && labels && loss_out && B > 0 && O > 0 && lo >= 0 && hi > lo && hi <= O && pred_hi > 0 && pred_hi <= O);
+    if (!loss_accumulate) { if (int e = zero_scalar(loss_out, 4, ST)) return e; }
+    if (correct) { if (int e = zero_scalar(correct, 4, ST)) return e; }
+    hipLaunchKernelGGL(ce_slice_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, labels, B, O, lo, hi, pred_hi, weight, loss_out,
+                       dlogits, grad_accumulate, pred, correct);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_kd_loss(const float* pred, int pred_stride, const float* soft, int soft_stride, int B, int k, float T,
+                             float weight, float* loss_out, int loss_accumulate, float* dpred, int grad_accumulate, void* stream) {
+    CLHIP_CHECK_ARG(pred && soft && loss_out && B > 0 && k > 0 && pred_stride >= k && soft_stride >= k && T > 0.f);
+    if (!loss_accumulate) { if (int e = zero_scalar(loss_out, 4, ST)) return e; }
+    hipLaunchKernelGGL(kd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, pred, pred_stride, soft, soft_stride, B, k, 1.f / T, weight,
+                       loss_out, dpred, grad_accumulate);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_cosine_linear_fwd(const float* x, const float* w, float* out, float* xnorm, float* wnorm, int B, int D, int O,
+                                       void* stream) {
+    CLHIP_CHECK_ARG(x && w && out && xnorm && wnorm && B > 0 && D > 0 && O > 0);
+    hipLaunchKernelGGL(row_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, x, xnorm, B, D);
+    hipLaunchKernelGGL(row_norm_kernel, dim3((O + 3) / 4), dim3(256), 0, ST, w, wnorm, O, D);
+    hipLaunchKernelGGL(cosine_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, x, w, xnorm, wnorm, out, B, D, O);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_cosine_linear_bwd(const float* x, const float* w, const float* out, const float* xnorm, const float* wnorm,
+                                       const float* dout, float* dx, float* dw, int B, int D, int O, int accumulate, void* stream) {
+    CLHIP_CHECK_ARG(x && w && out && xnorm && wnorm && dout && B > 0 && D > 0 && O > 0);
+    if (dx) hipLaunchKernelGGL(cosine_bwd_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST, x, w, out, xnorm, wnorm, dout, dx, B, D, O, 0);
+    if (dw) hipLaunchKernelGGL(cosine_bwd_dw_kernel, dim3((O * D + 255) / 256), dim3(256), 0, ST, x, w, out, xnorm, wnorm, dout, dw, B, D, O, accumulate);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_cos_embed_loss(const float* a, const float* b, int B, int D, float weight, float* loss_out, int loss_accumulate,
+                                    float* da, int grad_accumulate, void* stream) {
+    CLHIP_CHECK_ARG(a && b && loss_out && B > 0 && D > 0);
+    if (!loss_accumulate) { if (int e = zero_scalar(loss_out, 4, ST)) return e; }
+    hipLaunchKernelGGL(cos_embed_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, a, b, B, D, weight, loss_out, da, grad_accumulate);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_margin_rank_loss(const float* scores, const int64_t* labels, int B, int O, int num_old, int K, float margin,
+                                      float weight, float* loss_out, int loss_accumulate, float* dscores, int grad_accumulate,
+                                      int32_t* hard_count, void* stream) {
+    CLHIP_CHECK_ARG(scores && labels && loss_out && hard_count && B > 0 && O > num_old && num_old > 0 && K >= 1 && K <= O - num_old);
+    CLHIP_CHECK_ARG(O - num_old <= 64 * 64 && K <= 8);
+    if (!loss_accumulate) { if (int e = zero_scalar(loss_out, 4, ST)) return e; }
+    if (int e = zero_scalar(hard_count, 4, ST)) return e;
+    hipLaunchKernelGGL(count_hard_kernel, dim3((B + 255) / 256), dim3(256), 0, ST, labels, B, num_old, hard_count);
+    hipLaunchKernelGGL(margin_rank_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, scores, labels, B, O, num_old, K, margin, weight,
+                       hard_count, loss_out, dscores, grad_accumulate);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_ncm_classify(const float* feats, const float* means, int B, int M, int D, int64_t* pred, void* stream) {
+    CLHIP_CHECK_ARG(feats && means && pred && B > 0 && M > 0 && D > 0);
+    hipLaunchKernelGGL(ncm_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, feats, means, B, M, D, pred);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_herding_select(const float* feats, int n, int D, int m, int32_t* chosen, float* ws, void* stream) {
+    CLHIP_CHECK_ARG(feats && chosen && ws && n > 0 && D > 0 && m > 0);
+    hipLaunchKernelGGL(herding_kernel, dim3(1), dim3(256), 0, ST, feats, n, D, m, chosen, ws);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_l2_normalize_rows(const float* x, float* out, int R, int D, void* stream) {
+    CLHIP_CHECK_ARG(x && out && R > 0 && D > 0);
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, x, out, R, D);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}

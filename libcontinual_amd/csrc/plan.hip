@@ -1,0 +1,215 @@
+// plan.hip -- static execution plan for a ResNet backbone: a list of (conv -> BatchNorm -> +residual ->
+// ReLU) units followed by a global average pool.  One C call runs the whole forward (or backward):
+// no per-op host dispatch, no autograd graph, fixed workspace offsets (hipGraph-capturable: nothing
+// here allocates or synchronises).  Replaces CifarResNet.forward / ResNet._forward_impl /
+// modified_ResNet.forward (core/model/backbone/resnet.py:381-395, 215-223, 549-560) and the autograd
+// backward the reference trainer triggers with loss.backward() (core/trainer.py:604).
+#include <vector>
+#include <new>
+
+#include "common.h"
+
+namespace {
+constexpr float kBnMomentum = 0.1f;   // nn.BatchNorm2d defaults used by every reference ResNet
+constexpr float kBnEps = 1e-5f;
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Act {
+    int H, W, C;
+    size_t y_off;    // activation (bytes into workspace)
+    size_t dy_off;   // its gradient
+    size_t bytes;
+};
+
+struct Unit {
+    clhip_unit_desc d;
+    int cin_pad;
+    int H, W, Ho, Wo;
+    int64_t M;
+    int tiles;
+    size_t z_off;
+    size_t sh_fwd, sh_dg;          // byte offsets in the shadow buffer
+    size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
+    int dx_acc, dres_acc;
+};
+}  // namespace
+
+struct clhip_plan {
+    int N, H, W, Cin, Cin_pad, dtype, esize;
+    std::vector<Unit> units;
+    std::vector<Act> acts;
+    size_t ws_bytes, shadow_bytes;
+    size_t dz_off;           // scratch for the pre-BN gradient
+    size_t f_base;           // byte offset of the fp32 region
+    size_t f_part, f_bnws;   // float offsets: conv stat partials, bn backward scratch
+    int feat_dim;
+};
+
+extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_units, int N, int H, int W, int Cin, int dtype) {
+    if (!units || n_units <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (dtype != CLHIP_BF16 && dtype != CLHIP_F32)) {
+        clhip_set_error("clhip_plan_create: invalid argument");
+        return nullptr;
+    }
+    clhip_plan* p = new (std::nothrow) clhip_plan();
+    if (!p) { clhip_set_error("out of host memory"); return nullptr; }
+    p->N = N; p->H = H; p->W = W; p->Cin = Cin; p->dtype = dtype; p->esize = dtype == CLHIP_BF16 ? 2 : 4;
+    p->Cin_pad = (Cin + 7) / 8 * 8;
+    if (ilog2_exact(p->Cin_pad) < 0) { int c = 8; while (c < Cin) c <<= 1; p->Cin_pad = c; }
+    size_t off = 0, sh = 0;
+    Act a0{H, W, p->Cin_pad, 0, 0, (size_t)N * H * W * p->Cin_pad * p->esize};
+    a0.y_off = off; off = align_up(off + a0.bytes);
+    p->acts.push_back(a0);
+    size_t max_z = 0, max_part = 0, max_bnws = 0, nfloat = 0;
+    for (int i = 0; i < n_units; ++i) {
+        Unit u{};
+        u.d = units[i];
+        if (u.d.src < 0 || u.d.src > i || u.d.res > i || (u.d.ksize != 1 && u.d.ksize != 3) || u.d.stride < 1 || u.d.cout % 16) {
+            clhip_set_error("clhip_plan_create: bad unit %d", i);
+            delete p;
+            return nullptr;
+        }
+        const Act& s = p->acts[u.d.src];
+        u.cin_pad = s.C;
+        if ((u.d.src == 0 && u.d.cin != Cin) || (u.d.src != 0 && u.d.cin != s.C)) {
+            clhip_set_error("clhip_plan_create: unit %d channel mismatch", i);
+            delete p;
+            return nullptr;
+        }
+        u.H = s.H; u.W = s.W;
+        u.Ho = (s.H + 2 * u.d.pad - u.d.ksize) / u.d.stride + 1;
+        u.Wo = (s.W + 2 * u.d.pad - u.d.ksize) / u.d.stride + 1;
+        u.M = (int64_t)N * u.Ho * u.Wo;
+        u.tiles = clhip_conv_fwd_tiles(N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad);
+        if (u.d.res >= 0) {
+            const Act& r = p->acts[u.d.res];
+            if (r.H != u.Ho || r.W != u.Wo || r.C != u.d.cout) {
+                clhip_set_error("clhip_plan_create: unit %d residual shape mismatch", i);
+                delete p;
+                return nullptr;
+            }
+        }
+        size_t bytes = (size_t)u.M * u.d.cout * p->esize;
+        u.z_off = off; off = align_up(off + bytes);
+        Act a{u.Ho, u.Wo, u.d.cout, off, 0, bytes};
+        off = align_up(off + bytes);
+        p->acts.push_back(a);
+        size_t wbytes = (size_t)u.d.cout * u.d.ksize * u.d.ksize * u.cin_pad * p->esize;
+        u.sh_fwd = sh; sh = align_up(sh + wbytes);
+        u.sh_dg = sh; sh = align_up(sh + wbytes);
+        u.f_mean = nfloat; u.f_invstd = nfloat + u.d.cout; u.f_scale = nfloat + 2 * (size_t)u.d.cout; u.f_shift = nfloat + 3 * (size_t)u.d.cout;
+        nfloat += 4 * (size_t)u.d.cout;
+        if (bytes > max_z) max_z = bytes;
+        size_t part = (size_t)u.tiles * 2 * u.d.cout;
+        if (part > max_part) max_part = part;
+        size_t bw = clhip_bn_bwd_ws_floats(u.M, u.d.cout);
+        if (bw > max_bnws) max_bnws = bw;
+        p->units.push_back(u);
+    }
+    for (size_t i = 1; i < p->acts.size(); ++i) { p->acts[i].dy_off = off; off = align_up(off + p->acts[i].bytes); }
+    p->dz_off = off; off = align_up(off + max_z);
+    p->f_base = off;
+    nfloat = (nfloat + 63) / 64 * 64;
+    p->f_part = nfloat; nfloat += (max_part + 63) / 64 * 64;
+    p->f_bnws = nfloat; nfloat += (max_bnws + 63) / 64 * 64;
+    off = align_up(off + nfloat * sizeof(float));
+    p->ws_bytes = off;
+    p->shadow_bytes = sh;
+    p->feat_dim = p->units.back().d.cout;
+    // gradient write/accumulate flags: simulate the reverse sweep
+    std::vector<char> written(p->acts.size(), 0);
+    written.back() = 1;   // pool backward writes the last activation's gradient
+    for (int i = n_units - 1; i >= 0; --i) {
+        Unit& u = p->units[i];
+        if (u.d.res >= 0) { u.dres_acc = written[u.d.res]; written[u.d.res] = 1; }
+        if (u.d.src != 0) { u.dx_acc = written[u.d.src]; written[u.d.src] = 1; }
+    }
+    return p;
+}
+
+extern "C" void clhip_plan_destroy(clhip_plan* p) { delete p; }
+extern "C" size_t clhip_plan_workspace_bytes(const clhip_plan* p) { return p ? p->ws_bytes : 0; }
+extern "C" size_t clhip_plan_shadow_bytes(const clhip_plan* p) { return p ? p->shadow_bytes : 0; }
+extern "C" int clhip_plan_feat_dim(const clhip_plan* p) { return p ? p->feat_dim : 0; }
+
+#define TRY(call)            \
+    do {                     \
+        int e_ = (call);     \
+        if (e_) return e_;   \
+    } while (0)
+
+extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void* shadow, void* stream) {
+    CLHIP_CHECK_ARG(p && params && shadow);
+    char* sh = static_cast<char*>(shadow);
+    for (const Unit& u : p->units) {
+        bool need_dg = u.d.src != 0;
+        TRY(clhip_conv_weight_prep(params + u.d.w_off, sh + u.sh_fwd, need_dg ? sh + u.sh_dg : nullptr, u.d.cout,
+                                   u.d.ksize * u.d.ksize, u.d.cin, u.cin_pad, p->dtype, stream));
+    }
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* params, float* bn_stats, const void* shadow,
+                                  void* workspace, float* feat, int training, void* stream) {
+    CLHIP_CHECK_ARG(p && x && params && bn_stats && shadow && workspace && feat);
+    char* ws = static_cast<char*>(workspace);
+    const char* sh = static_cast<const char*>(shadow);
+    float* fr = reinterpret_cast<float*>(ws + p->f_base);
+    TRY(clhip_nchw_to_nhwc(x, ws + p->acts[0].y_off, p->N, p->Cin, p->H, p->W, p->Cin_pad, p->dtype, stream));
+    for (size_t i = 0; i < p->units.size(); ++i) {
+        const Unit& u = p->units[i];
+        const Act& src = p->acts[u.d.src];
+        const Act& dst = p->acts[i + 1];
+        float* part = training ? fr + p->f_part : nullptr;
+        TRY(clhip_conv_fwd(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, part, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
+                           u.d.stride, u.d.pad, p->dtype, stream));
+        if (training) {
+            TRY(clhip_bn_stats_finalize(part, u.tiles, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
+                                        bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean,
+                                        fr + u.f_invstd, fr + u.f_scale, fr + u.f_shift, stream));
+        } else {
+            TRY(clhip_bn_eval_affine(params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off,
+                                     kBnEps, u.d.cout, fr + u.f_scale, fr + u.f_shift, stream));
+        }
+        const void* res = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
+        TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, res, ws + dst.y_off, u.M, u.d.cout, u.d.relu, p->dtype, stream));
+    }
+    const Act& last = p->acts.back();
+    TRY(clhip_avgpool_fwd(ws + last.y_off, feat, p->N, last.H * last.W, last.C, p->dtype, stream));
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_plan_backward(clhip_plan* p, const float* dfeat, const float* params, const void* shadow, void* workspace,
+                                   float* grads, void* stream) {
+    CLHIP_CHECK_ARG(p && dfeat && params && shadow && workspace && grads);
+    char* ws = static_cast<char*>(workspace);
+    const char* sh = static_cast<const char*>(shadow);
+    float* fr = reinterpret_cast<float*>(ws + p->f_base);
+    const Act& last = p->acts.back();
+    TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
+    for (int i = (int)p->units.size() - 1; i >= 0; --i) {
+        const Unit& u = p->units[i];
+        const Act& src = p->acts[u.d.src];
+        const Act& dst = p->acts[i + 1];
+        void* dres = u.d.res >= 0 ? ws + p->acts[u.d.res].dy_off : nullptr;
+        TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
+                         grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                         fr + p->f_bnws, p->dtype, stream));
+        TRY(clhip_conv_wgrad(ws + src.y_off, ws + p->dz_off, grads + u.d.w_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
+                             u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+        if (u.d.src != 0) {
+            TRY(clhip_conv_dgrad(ws + p->dz_off, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,
+                                 u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+        }
+    }
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_plan_read_act(clhip_plan* p, const void* workspace, int idx, int which, float* out_nchw, void* stream) {
+    CLHIP_CHECK_ARG(p && workspace && out_nchw && idx >= 0 && idx < (int)p->acts.size() && which >= 0 && which <= 2);
+    CLHIP_CHECK_ARG(!(idx == 0 && which != 0));
+    const char* ws = static_cast<const char*>(workspace);
+    const Act& a = p->acts[idx];
+    const char* src = which == 0 ? ws + a.y_off : (which == 1 ? ws + p->units[idx - 1].z_off : ws + a.dy_off);
+    return clhip_nhwc_to_nchw(src, out_nchw, p->N, a.C, a.H, a.W, p->dtype, stream);
+}

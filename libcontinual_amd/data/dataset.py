@@ -1,0 +1,111 @@
+"""Per-task datasets / loaders (reference core/data/dataset.py:20-99, 232-303, core/data/dataloader.py:76-129).
+
+`SingleDataset` reads a class-folder image tree (data_root/{train,test}/<class>/<image>), the reference's
+on-disk format (docs/tutorials/en/data_module_en.md:15-39); `images` are paths relative to data_root/mode
+and `labels` ints, both plain lists so the trainer's rehearsal merge (core/trainer.py:305-312) and the
+herding buffer can edit them.  `ArrayDataset` is the same interface over in-memory uint8 arrays (synthetic
+data, tests).  Batches are dicts {"image": FloatTensor[B,3,H,W], "label": LongTensor[B]}.
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import transforms as T
+
+
+class SingleDataset(Dataset):
+    def __init__(self, data_root, mode, cls_map, trfms, start_idx=0, end_idx=0, init=True):
+        self.data_root, self.mode, self.cls_map, self.trfms = data_root, mode, cls_map, trfms
+        self.images, self.labels, self.labels_name = [], [], []
+        if init:
+            for label in range(start_idx, end_idx):
+                name = cls_map[label]
+                self.labels_name.append(name)
+                d = os.path.join(data_root, mode, name)
+                for f in sorted(os.listdir(d)):
+                    self.images.append(os.path.join(name, f))
+                    self.labels.append(label)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        img = Image.open(os.path.join(self.data_root, self.mode, self.images[idx])).convert("RGB")
+        return {"image": self.trfms(img), "label": int(self.labels[idx])}
+
+
+class ArrayDataset(Dataset):
+    """`store` is a uint8 array [N,H,W,3]; `images` holds indices into it."""
+
+    def __init__(self, store, images, labels, trfms, mode="train"):
+        self.store, self.trfms, self.mode, self.data_root = store, trfms, mode, None
+        self.images, self.labels = list(images), list(labels)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, idx):
+        return {"image": self.trfms(self.store[int(self.images[idx])]), "label": int(self.labels[idx])}
+
+
+class ContinualDatasets:
+    """task t covers labels [start_t, end_t): 0..init for t=0, then inc per task (dataset.py:81-92).
+    train: get_loader(t) -> the task's loader; test: the list of loaders of tasks 0..t (dataset.py:94-99)."""
+
+    def __init__(self, mode, task_num, init_cls_num, inc_cls_num, make_dataset, batch_size, num_workers=0, cls_map=None):
+        self.mode, self.task_num, self.cls_map = mode, task_num, cls_map
+        self.dataloaders = []
+        for i in range(task_num):
+            s = 0 if i == 0 else init_cls_num + (i - 1) * inc_cls_num
+            e = s + (init_cls_num if i == 0 else inc_cls_num)
+            self.dataloaders.append(DataLoader(make_dataset(s, e), shuffle=True, batch_size=batch_size, drop_last=False,
+                                               num_workers=num_workers, pin_memory=False))
+
+    def get_loader(self, task_idx):
+        assert 0 <= task_idx < self.task_num
+        return self.dataloaders[task_idx] if self.mode == "train" else self.dataloaders[: task_idx + 1]
+
+
+def get_dataloader(config, mode, cls_map=None):
+    """class order: `class_order` key if present else np.random.permutation (seeded by init_seed ->
+    the seed-1993 PyCIL order), reference dataloader.py:113-122"""
+    data_root = config["data_root"]
+    if "train_trfms" in config or "test_trfms" in config:
+        raise NotImplementedError("YAML-declared transforms are outside the hot-path scope")
+    trfms = T.cifar_resnet_transform(mode)
+    bs = config.get(f"{mode}_batch_size", config["batch_size"])
+    if config["dataset"] == "synthetic":
+        return synthetic_datasets(config, mode, trfms, bs)
+    if cls_map is None:
+        cls_list = sorted(os.listdir(os.path.join(data_root, mode)))
+        perm = config["class_order"] if "class_order" in config else np.random.permutation(len(cls_list))
+        cls_map = {label: cls_list[ori] for label, ori in enumerate(perm)}
+    mk = lambda s, e: SingleDataset(data_root, mode, cls_map, trfms, s, e)
+    return ContinualDatasets(mode, config["task_num"], config["init_cls_num"], config["inc_cls_num"], mk, bs,
+                             config["num_workers"], cls_map)
+
+
+def synthetic_store(n_classes, per_class, size, seed):
+    """class-conditional random images: a fixed random pattern per class blended with noise"""
+    g = np.random.RandomState(seed)
+    pats = g.rand(n_classes, size, size, 3)
+    imgs = np.empty((n_classes * per_class, size, size, 3), np.uint8)
+    labels = np.repeat(np.arange(n_classes), per_class)
+    for c in range(n_classes):
+        noise = g.rand(per_class, size, size, 3)
+        imgs[c * per_class:(c + 1) * per_class] = np.clip((0.5 * pats[c] + 0.5 * noise) * 255, 0, 255).astype(np.uint8)
+    return imgs, labels
+
+
+def synthetic_datasets(config, mode, trfms, bs):
+    n_cls = config["init_cls_num"] + (config["task_num"] - 1) * config["inc_cls_num"]
+    per = config.get("synthetic_per_class", 20) if mode == "train" else config.get("synthetic_test_per_class", 5)
+    store, labels = synthetic_store(n_cls, per, config["image_size"], config["seed"] + (0 if mode == "train" else 1))
+
+    def mk(s, e):
+        idx = [i for i in range(len(labels)) if s <= labels[i] < e]
+        return ArrayDataset(store, idx, [int(labels[i]) for i in idx], trfms, mode)
+    return ContinualDatasets(mode, config["task_num"], config["init_cls_num"], config["inc_cls_num"], mk, bs, 0, None)

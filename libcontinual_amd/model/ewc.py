@@ -1,0 +1,217 @@
+"""EWC plugin (reference core/model/ewc.py:43-229) on the HIP hot path.
+
+Same constructor, hooks, `fisher` / `ref_param` dicts (keys = `network.named_parameters()` names) and
+quirks as the reference: Fisher of the *batch-mean* gradient scaled by
+len(y), divisor batch_size*len(loader), BatchNorm in train mode during the Fisher pass, ref snapshot before
+the Fisher pass, alpha merge applied even after task 0, head slice `p[:len(ref)]`.
+
+MI355X design: the backbone's Fisher / reference parameters are single flat fp32 buffers aligned with the
+backbone's flat parameter buffer, so the penalty is ONE streaming reduction (clhip_ewc_penalty) instead
+of ~300 tiny torch kernels per step (ewc.py:221-225), its gradient ONE fused axpy into the flat gradient
+buffer (clhip_ewc_grad), and the Fisher accumulation ONE launch per batch (clhip_fisher_accum).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import call
+from .finetune import Finetune
+from .heads import HipLinear
+
+
+class Model(nn.Module):
+    """backbone + linear classifier (reference ewc.py:43-57)"""
+
+    def __init__(self, backbone, feat_dim, num_class):
+        super().__init__()
+        self.backbone = backbone
+        self.feat_dim = feat_dim
+        self.num_class = num_class
+        self.classifier = HipLinear(feat_dim, num_class)
+
+    def forward(self, x):
+        return self.get_logits(x)
+
+    def get_logits(self, x):
+        return self.classifier(self.backbone(x)["features"])
+
+
+class _EwcLossFn(torch.autograd.Function):
+    """CE(logits[:, lo:], y - lo) + lamda * sum F (p - p*)^2 / 2 as ONE autograd node: the forward runs
+    ce_slice + ewc_penalty (backbone flat buffer, head-weight and head-bias prefixes) into one scalar; the
+    backward scales dlogits and adds lamda*F*(p - p*) straight into the gradient buffers."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, lo, owner, anchor, head_w, head_b, aux):
+        st = torch.cuda.current_stream().cuda_stream
+        logits = logits.contiguous()
+        B, O = logits.shape
+        labels = labels.to(torch.int64).contiguous()
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        dlog = torch.empty_like(logits)
+        pred = torch.empty(B, device=logits.device, dtype=torch.int64)
+        correct = torch.empty(1, device=logits.device, dtype=torch.int32)
+        call("clhip_ce_slice", logits.data_ptr(), labels.data_ptr(), B, O, lo, O, O, 1.0, loss.data_ptr(), 0, dlog.data_ptr(), 0,
+             pred.data_ptr(), correct.data_ptr(), st)
+        flat, _ = owner.network.backbone.flat_parameters()
+        lam = float(owner.lamda)
+        ops.ewc_penalty(flat, owner._ref_flat, owner._fisher_flat, lam, loss, True)
+        nw, nb = owner._ref_head_w.numel(), owner._ref_head_b.numel()
+        ops.ewc_penalty(head_w.detach().reshape(-1)[:nw], owner._ref_head_w.reshape(-1), owner._fisher_head_w.reshape(-1), lam, loss, True)
+        ops.ewc_penalty(head_b.detach()[:nb], owner._ref_head_b, owner._fisher_head_b, lam, loss, True)
+        aux.pred, aux.correct, aux.batch = pred, correct, B
+        ctx.owner = owner
+        ctx.save_for_backward(dlog, head_w, head_b)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        dlog, head_w, head_b = ctx.saved_tensors
+        owner = ctx.owner
+        gout = gout.reshape(1).float().contiguous()
+        st = torch.cuda.current_stream().cuda_stream
+        dl = torch.empty_like(dlog)
+        call("clhip_scale_dev", dlog.data_ptr(), dl.data_ptr(), dlog.numel(), 1.0, gout.data_ptr(), st)
+        bb = owner.network.backbone
+        flat, gflat = bb.flat_parameters()
+        lam = float(owner.lamda)
+        ops.ewc_grad(flat, owner._ref_flat, owner._fisher_flat, gflat, lam, gout)
+        bb.attach_grads()
+        gw = torch.zeros_like(head_w)
+        gb = torch.zeros_like(head_b)
+        nw, nb = owner._ref_head_w.numel(), owner._ref_head_b.numel()
+        ops.ewc_grad(head_w.detach().reshape(-1)[:nw], owner._ref_head_w.reshape(-1), owner._fisher_head_w.reshape(-1),
+                     gw.view(-1)[:nw], lam, gout)
+        ops.ewc_grad(head_b.detach()[:nb], owner._ref_head_b, owner._fisher_head_b, gb[:nb], lam, gout)
+        return dl, None, None, None, None, gw, gb, None
+
+
+class EWC(Finetune):
+    def __init__(self, backbone, feat_dim, num_class, **kwargs):
+        super().__init__(backbone, feat_dim, num_class, **kwargs)
+        self.kwargs = kwargs
+        self.network = Model(self.backbone, feat_dim, kwargs["init_cls_num"])
+        self.lamda = self.kwargs["lamda"]
+        self.task_idx = 0
+        self._ref_flat = self._fisher_flat = None
+        self._ref_head_w = self._ref_head_b = self._fisher_head_w = self._fisher_head_b = None
+
+    # -- name -> tensor views, the reference's public attributes (ewc.py:65-68)
+    def _named_views(self, flat, hw, hb):
+        bb = self.network.backbone
+        out = {}
+        for (nm, shp, off, is_conv) in bb._layout:
+            out["backbone." + nm] = bb._view(flat, shp, off, is_conv)
+        out["classifier.weight"] = hw
+        out["classifier.bias"] = hb
+        return out
+
+    @property
+    def fisher(self):
+        self._ensure_state()
+        return self._named_views(self._fisher_flat, self._fisher_head_w, self._fisher_head_b)
+
+    @property
+    def ref_param(self):
+        self._ensure_state()
+        return self._named_views(self._ref_flat, self._ref_head_w, self._ref_head_b)
+
+    def _ensure_state(self):
+        bb = self.network.backbone
+        flat, _ = bb.flat_parameters()
+        if self._ref_flat is None or self._ref_flat.device != flat.device:
+            cls = self.network.classifier
+            self._ref_flat = flat.detach().clone()
+            self._fisher_flat = torch.zeros_like(flat)
+            self._ref_head_w = cls.weight.detach().clone()
+            self._ref_head_b = cls.bias.detach().clone()
+            self._fisher_head_w = torch.zeros_like(self._ref_head_w)
+            self._fisher_head_b = torch.zeros_like(self._ref_head_b)
+
+    def before_task(self, task_idx, buffer, train_loader, test_loaders):
+        """grow the head to init + task_idx*inc outputs, old rows copied (ewc.py:71-80)"""
+        self.task_idx = task_idx
+        old = self.network.classifier
+        new_fc = HipLinear(old.in_features, self.kwargs["init_cls_num"] + task_idx * self.kwargs["inc_cls_num"])
+        new_fc = new_fc.to(old.weight.device)
+        with torch.no_grad():
+            new_fc.weight.data[: old.out_features] = old.weight.data
+            new_fc.bias.data[: old.out_features] = old.bias.data
+        self.network.classifier = new_fc
+        self.network.to(self.device)
+
+    def observe(self, data):
+        x, y = self._xy(data)
+        logit = self.network(x)
+        aux = ops.LossAux()
+        if self.task_idx == 0:
+            loss = ops.classify_loss(logit, y, aux=aux)
+        else:
+            self._ensure_state()
+            old_classes = self.network.classifier.out_features - self.kwargs["inc_cls_num"]
+            cls = self.network.classifier
+            loss = _EwcLossFn.apply(logit, y, old_classes, self, self.network.backbone._params[0], cls.weight, cls.bias, aux)
+        self._last_aux = aux
+        return aux.pred, aux.acc(), loss
+
+    def compute_ewc(self):
+        """value of sum_n sum F_n (p_n[:len(ref_n)] - ref_n)^2 / 2 (no grad; ewc.py:207-225)"""
+        self._ensure_state()
+        flat, _ = self.network.backbone.flat_parameters()
+        out = torch.empty(1, device=flat.device, dtype=torch.float32)
+        cls = self.network.classifier
+        nw, nb = self._ref_head_w.numel(), self._ref_head_b.numel()
+        ops.ewc_penalty(flat, self._ref_flat, self._fisher_flat, 1.0, out, False)
+        ops.ewc_penalty(cls.weight.detach().reshape(-1)[:nw], self._ref_head_w.reshape(-1), self._fisher_head_w.reshape(-1), 1.0, out, True)
+        ops.ewc_penalty(cls.bias.detach()[:nb], self._ref_head_b, self._fisher_head_b, 1.0, out, True)
+        return out.view(())
+
+    def inference(self, data):
+        x, y = self._xy(data)
+        logit = self.network(x)
+        pred, correct = ops.predict(logit, y)
+        return pred, correct.item() / x.size(0)
+
+    def getFisher(self, train_loader):
+        """one pass over the task's loader: CE(all logits) -> backward -> fisher += grad^2 * len(y);
+        / (batch_size*len(loader))  (ewc.py:147-205).  Returns (flat, head_w, head_b) Fisher tensors."""
+        net = self.network
+        bb, cls = net.backbone, net.classifier
+        flat, gflat = bb.flat_parameters()
+        f_flat = torch.zeros_like(flat)
+        f_w = torch.zeros_like(cls.weight)
+        f_b = torch.zeros_like(cls.bias)
+        net.train()                                     # BN uses (and updates) batch statistics: quirk a9(iii)
+        num_samples = train_loader.batch_size * len(train_loader)
+        for data in train_loader:
+            x, y = self._xy(data)
+            for p in net.parameters():
+                p.grad = None
+            loss = ops.classify_loss(net(x), y)
+            loss.backward()
+            s = float(len(y)) / float(num_samples)
+            ops.fisher_accum(f_flat, gflat, s)
+            ops.fisher_accum(f_w.view(-1), cls.weight.grad.contiguous().view(-1), s)
+            ops.fisher_accum(f_b, cls.bias.grad.contiguous(), s)
+        for p in net.parameters():
+            p.grad = None
+        return f_flat, f_w, f_b
+
+    def after_task(self, task_idx, buffer, train_loader, test_loaders):
+        """ewc.py:110-133"""
+        self._ensure_state()
+        bb, cls = self.network.backbone, self.network.classifier
+        flat, _ = bb.flat_parameters()
+        ref_flat = flat.detach().clone()                # snapshot BEFORE the Fisher pass (quirk a9(vi))
+        ref_w, ref_b = cls.weight.detach().clone(), cls.bias.detach().clone()
+        nf, nw, nb = self.getFisher(train_loader)
+        alpha = 1 - self.kwargs["inc_cls_num"] / cls.out_features
+        ops.fisher_merge(nf, self._fisher_flat, alpha)
+        ow, ob = self._fisher_head_w, self._fisher_head_b
+        ops.fisher_merge(nw.view(-1)[: ow.numel()], ow.reshape(-1), alpha)
+        ops.fisher_merge(nb[: ob.numel()], ob, alpha)
+        self._fisher_flat, self._fisher_head_w, self._fisher_head_b = nf, nw, nb
+        self._ref_flat, self._ref_head_w, self._ref_head_b = ref_flat, ref_w, ref_b
+
+    def get_parameters(self, config):
+        return [{"params": self.network.parameters()}]

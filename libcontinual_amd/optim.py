@@ -1,0 +1,134 @@
+"""Fused optimizers on libclhip (replace torch.optim.SGD / Adam constructed at core/trainer.py:159-166).
+
+`SGD` / `Adam` here are torch.optim.Optimizer subclasses (so every LR scheduler keeps working and YAML
+`optimizer.name: SGD` resolves to them through the trainer), with torch.optim semantics: params whose
+grad is None are skipped, per-group lr / momentum / weight_decay.  The difference is the launch count:
+all parameters of a HipResNet live in one flat buffer, so a group that holds a whole backbone is updated
+with ONE kernel over the flat range (clhip_sgd_step / clhip_adam_step); any other parameter (heads) is
+one launch per tensor.  `grad_scale` folds the data-parallel 1/world_size (or a clip factor) into the step.
+"""
+import torch
+
+from . import ops
+from ._lib import require_gpu
+
+
+def _owner_of(p):
+    ref = getattr(p, "_clhip_owner", None)
+    return ref() if ref is not None else None
+
+
+def _tag_backbones(params):
+    """find HipResNet owners of the parameters (set lazily by walking `_clhip_owner` tags)"""
+    owners = {}
+    for p in params:
+        o = _owner_of(p)
+        if o is not None:
+            owners.setdefault(id(o), (o, []))[1].append(p)
+    return owners
+
+
+class _FusedBase(torch.optim.Optimizer):
+    grad_scale = 1.0
+
+    def _split(self, group):
+        """-> (list of (owner) whose full parameter set is in this group with live flat grads, leftover params)"""
+        params = [p for p in group["params"]]
+        owners = _tag_backbones(params)
+        whole, covered = [], set()
+        for oid, (o, ps) in owners.items():
+            if len(ps) == len(o._params) and all(p.grad is not None for p in o._params) and o._gflat is not None:
+                ok = all(p.grad.data_ptr() == o._gflat.data_ptr() + 4 * o._layout[i][2] for i, p in enumerate(o._params))
+                if ok:
+                    whole.append(o)
+                    covered.update(id(p) for p in ps)
+        rest = [p for p in params if id(p) not in covered and p.grad is not None]
+        return whole, rest
+
+    @staticmethod
+    def _dense(p):
+        """(tensor whose memory is the parameter's elements in storage order)"""
+        if p.is_contiguous():
+            return p.data.view(-1)
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
+            return p.data.permute(0, 2, 3, 1).reshape(-1)      # view: K,R,S,C memory order
+        raise RuntimeError("parameter is neither contiguous nor channels_last")
+
+    @staticmethod
+    def _dense_like(p, g):
+        if g.is_contiguous() and p.is_contiguous():
+            return g.view(-1)
+        if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last) and p.is_contiguous(memory_format=torch.channels_last):
+            return g.permute(0, 2, 3, 1).reshape(-1)
+        # layouts differ: bring the gradient into the parameter's memory order
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
+            return g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1)
+        return g.contiguous().view(-1)
+
+
+class SGD(_FusedBase):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
+        if dampening != 0 or nesterov:
+            raise NotImplementedError("dampening / nesterov are not used by the reference configs")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
+            whole, rest = self._split(group)
+            for o in whole:
+                flat, gflat = o._flat, o._gflat
+                require_gpu(flat)
+                st = self.state[o._params[0]]
+                buf = None
+                if mom != 0:
+                    buf = st.get("flat_momentum")
+                    if buf is None or buf.data_ptr() == 0 or buf.numel() != flat.numel() or buf.device != flat.device:
+                        buf = torch.zeros_like(flat)
+                        st["flat_momentum"] = buf
+                ops.sgd_step(flat, gflat, buf, lr, mom, wd, self.grad_scale)
+                o.mark_params_modified()
+            for p in rest:
+                require_gpu(p)
+                st = self.state[p]
+                pd = self._dense(p)
+                gd = self._dense_like(p, p.grad)
+                buf = None
+                if mom != 0:
+                    buf = st.get("momentum_buffer")
+                    if buf is None:
+                        buf = torch.zeros(pd.numel(), device=p.device, dtype=torch.float32)
+                        st["momentum_buffer"] = buf
+                ops.sgd_step(pd, gd, buf, lr, mom, wd, self.grad_scale)
+                o = _owner_of(p)
+                if o is not None:
+                    o.mark_params_modified()
+        return None
+
+
+class Adam(_FusedBase):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
+            whole, rest = self._split(group)
+            items = [(o._params[0], o._flat, o._gflat, o) for o in whole]
+            items += [(p, self._dense(p), self._dense_like(p, p.grad), _owner_of(p)) for p in rest]
+            for key, pd, gd, o in items:
+                require_gpu(pd)
+                st = self.state[key]
+                if "step" not in st or st["exp_avg"].numel() != pd.numel():
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros(pd.numel(), device=pd.device, dtype=torch.float32)
+                    st["exp_avg_sq"] = torch.zeros(pd.numel(), device=pd.device, dtype=torch.float32)
+                st["step"] += 1
+                ops.adam_step(pd, gd, st["exp_avg"], st["exp_avg_sq"], lr, b1, b2, eps, wd, self.grad_scale, st["step"])
+                if o is not None:
+                    o.mark_params_modified()
+        return None

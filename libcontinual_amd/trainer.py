@@ -1,0 +1,326 @@
+"""Trainer: task loop -> epoch loop -> batch loop, with the reference's hook order and special cases for
+the in-scope methods (core/trainer.py:26-720).
+
+Reproduced exactly: `before_task` -> fresh optimizer + scheduler every task
+(:294) -> rehearsal merge by dataset concatenation and reshuffle (:305-322) -> per epoch
+`model.train()` on the WHOLE plugin (:575), `init_seed(seed + epoch)` (:584), observe / zero_grad / backward /
+step (:602-606), scheduler.step per epoch (:404) -> `after_task` -> trainer-side buffer update by `strategy`
+(:410-418) -> `testing_times` evaluations, accuracy table, forgetting, BWT (:457-526); the
+`(epoch+1) == inc_epoch` validation quirk (:362); `int(acc * B)` correct-count reconstruction (:645).
+
+Different by design (MI355X-first): no per-step host sync -- loss / accuracy stay on the device as
+`ops.Deferred` and are read once per epoch; optimizers named SGD / Adam resolve to the fused libclhip
+ones; `n_gpu > 1` is real data parallelism (one process per GPU, launched by torchrun; gradient all-reduce of
+the flat buffers over RCCL, see parallel.py) instead of the reference's asserted-off scaffold (:37-40).
+"""
+import copy
+import os
+import sys
+from time import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import ops, parallel
+from . import scheduler as sched
+from .utils import AverageMeter, compute_bwt, compute_frgt, count_all_parameters, count_parameters, get_instance, init_seed
+
+_OBSERVE_DOES_BACKWARD = ("L2P",)      # core/trainer.py:593-596 (subset on the hot path)
+
+
+def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=None, device=None):
+    """The per-batch hot path (core/trainer.py:585-612): observe -> zero_grad -> backward -> [grad all-reduce]
+    -> step -> meters.  Shared by Trainer._train and bench.py so that the benchmark times exactly what
+    training runs.  Loss / accuracy stay on the device (ops.Deferred): no host sync inside the loop."""
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    with ops.deferred_metrics(on_gpu):
+        for b, batch in enumerate(batches):
+            batch["batch_id"] = b
+            if method_name in _OBSERVE_DOES_BACKWARD:
+                optimizer.zero_grad()
+                output, acc, loss = model.observe(batch)
+            else:
+                output, acc, loss = model.observe(batch)
+                optimizer.zero_grad()
+                loss.backward()
+            if reducer is not None:
+                reducer.reduce(model)
+            optimizer.step()
+            if meter is not None:
+                meter.update("acc1", 100 * acc)
+                meter.update("loss", loss.detach() if on_gpu else loss.item())
+
+
+class Trainer:
+    def __init__(self, rank, config, model_namespace=None, optim_namespace=None, dataloaders=None, log=print):
+        self.rank = rank
+        self.config = config
+        self.log = log if rank == 0 else (lambda *a, **k: None)
+        if model_namespace is None:
+            from . import model as model_namespace
+        if optim_namespace is None:
+            from . import optim as optim_namespace
+        self.arch, self.optim_ns = model_namespace, optim_namespace
+        self.distribute = config["n_gpu"] > 1
+        self.device = self._init_device(config)
+        if self.distribute:
+            self.rank, self.world = parallel.init_distributed(self.device.type == "cuda")
+        else:
+            self.world = 1
+        self.reducer = parallel.GradientReducer() if self.distribute else None
+        self.init_cls_num, self.inc_cls_num, self.task_num = config["init_cls_num"], config["inc_cls_num"], config["task_num"]
+        self.model = self._init_model(config)
+        if dataloaders is not None:
+            self.train_loader, self.test_loader = dataloaders
+        else:
+            self.train_loader, self.test_loader = self._init_dataloader(config)
+        self.buffer = get_instance(self.arch, "buffer", config)
+        self.task_idx = 0
+        self.init_epoch, self.inc_epoch, self.optimizer, self.scheduler = self._init_optim(config)
+        self.train_meter = AverageMeter("train", ["batch_time", "data_time", "calc_time", "loss", "acc1"])
+        self.test_meter = AverageMeter("test", ["batch_time", "data_time", "calc_time", "acc1"])
+        self.val_per_epoch = config["val_per_epoch"]
+        self.hook_trace = []          # (event, task, epoch) -- used by the parity tests of the call order
+
+    # ------------------------------------------------------------------------------------ set-up
+    def _init_device(self, config):
+        init_seed(config["seed"], config["deterministic"])
+        if config.get("device") == "cpu" or not torch.cuda.is_available():
+            if config.get("device") != "cpu":
+                raise RuntimeError("no HIP device visible; libcontinual_amd has no CPU path (set device: cpu only for "
+                                   "host-logic tests with your own CPU plugin)")
+            return torch.device("cpu")
+        ids = config.get("device_ids", "auto")
+        local = int(os.environ.get("LOCAL_RANK", self.rank))
+        if isinstance(ids, (list, tuple)):
+            idx = ids[local]
+        elif isinstance(ids, int) and not self.distribute:
+            idx = ids
+        else:
+            idx = local
+        dev = torch.device(f"cuda:{idx}")
+        torch.cuda.set_device(dev)
+        return dev
+
+    def _init_model(self, config):
+        try:
+            backbone = get_instance(self.arch, "backbone", config, **{"device": self.device})
+        except TypeError:
+            backbone = get_instance(self.arch, "backbone", config)
+        model = get_instance(self.arch, "classifier", config, **{"device": self.device, "backbone": backbone}).to(self.device)
+        if self.distribute:
+            parallel.broadcast_module_state(model)
+        return model
+
+    def _init_dataloader(self, config):
+        from .data import get_dataloader
+        train = get_dataloader(config, "train")
+        test = get_dataloader(config, "test", cls_map=train.cls_map)
+        return train, test
+
+    def _shard_loader(self, loader):
+        """per-rank loader: DistributedSampler(shuffle) + batch_size // n_gpu (core/trainer.py:229-241)"""
+        if not self.distribute:
+            return loader
+        sampler = torch.utils.data.distributed.DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.rank, shuffle=True)
+        return DataLoader(loader.dataset, sampler=sampler, batch_size=max(1, loader.batch_size // self.world),
+                          num_workers=loader.num_workers, drop_last=loader.drop_last)
+
+    def _init_optim(self, config):
+        init_epoch = config["init_epoch"] if "init_epoch" in config else config["epoch"]
+        key = "init_optimizer" if (self.task_idx == 0 and "init_optimizer" in config) else "optimizer"
+        ns = self.optim_ns if hasattr(self.optim_ns, config[key]["name"]) else torch.optim
+        optimizer = get_instance(ns, key, config, params=self.model.get_parameters(config))
+        if self.distribute and hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = 1.0 / self.world
+        name = config["lr_scheduler"]["name"]
+        kw = config["lr_scheduler"].get("kwargs") or {}
+        if name == "CosineSchedule":
+            scheduler = sched.CosineSchedule(optimizer, K=kw["K"])
+        elif name == "PatienceSchedule":
+            scheduler = sched.PatienceSchedule(optimizer, patience=kw["patience"], factor=kw["factor"])
+        elif name == "Constant":
+            scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda e: 1)
+        elif name == "CosineAnnealingWarmUp":
+            t_max = len(self.train_loader.get_loader(self.task_idx)) * (init_epoch if self.task_idx == 0 else config["epoch"])
+            scheduler = sched.CosineAnnealingWarmUp(optimizer, kw["warmup_length"], t_max)
+        else:
+            scheduler = get_instance(torch.optim.lr_scheduler, "lr_scheduler", config, optimizer=optimizer)
+        return init_epoch, config["epoch"], optimizer, scheduler
+
+    # ---------------------------------------------------------------------------------- main loop
+    def train_loop(self):
+        t_begin = time()
+        method_name = self.config["classifier"]["name"]
+        testing_times = self.config["testing_times"]
+        T = self.task_num
+        batch_last_acc_list, task_last_acc_list = np.zeros(T), np.zeros(T)
+        best_batch_last_acc_list, best_task_last_acc_list = np.zeros(T), np.zeros(T)
+        acc_table = np.zeros((T, T))
+        bwt_list, frgt_list = [], []
+        model = self.model
+        for task_idx in range(T):
+            self.task_idx = task_idx
+            self.log(f"================Task {task_idx} Start!================")
+            if hasattr(model, "before_task"):
+                self.hook_trace.append(("before_task", task_idx, -1))
+                model.before_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))
+            self.log(f"Trainable Parameters for Task {task_idx} : {count_parameters(model)} / {count_all_parameters(model)}")
+            _, _, self.optimizer, self.scheduler = self._init_optim(self.config)
+            dataloader = self.train_loader.get_loader(task_idx)
+            from .model.buffer import LinearBuffer, LinearHerdingBuffer
+            if isinstance(self.buffer, (LinearBuffer, LinearHerdingBuffer)) and self.buffer.buffer_size > 0 and task_idx > 0:
+                ds = dataloader.dataset                               # rehearsal union at dataset level (:305-322)
+                if isinstance(ds.images, list):
+                    ds.images.extend(self.buffer.images)
+                    ds.labels.extend(self.buffer.labels)
+                elif isinstance(ds.images, np.ndarray):
+                    ds.images = np.concatenate((ds.images, self.buffer.images), axis=0)
+                    ds.labels = np.concatenate((ds.labels, self.buffer.labels), axis=0)
+                else:
+                    assert 0
+                dataloader = DataLoader(ds, shuffle=True, batch_size=self.config["batch_size"], drop_last=False,
+                                        num_workers=self.config["num_workers"])
+            dataloader = self._shard_loader(dataloader)
+            self.log(f"================Task {task_idx} Training!================")
+            self.log(f"The training samples number : {len(dataloader.dataset)}")
+            best_batch_last_acc, best_task_last_acc = 0.0, 0.0
+            best_bwt, best_frgt = float("-inf"), float("inf")
+            n_epoch = self.init_epoch if task_idx == 0 else self.inc_epoch
+            for epoch_idx in range(n_epoch):
+                t0 = time()
+                if self.distribute and hasattr(dataloader.sampler, "set_epoch"):
+                    dataloader.sampler.set_epoch(epoch_idx)
+                meter = self._train(epoch_idx, dataloader)
+                acc1, loss = meter.avg("acc1"), meter.avg("loss")
+                if self.distribute:
+                    acc1 = self.reducer.mean_scalar(acc1, self.device)
+                    loss = self.reducer.mean_scalar(loss, self.device)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize()
+                dt = time() - t0
+                n_img = len(dataloader.dataset)
+                self.log(f"Epoch [{epoch_idx}/{n_epoch}] Learning Rate {self.scheduler.get_last_lr()}\t|\tLoss: {loss:.4f} "
+                         f"\tAverage Acc: {acc1:.2f} \t{n_img / dt:.0f} img/s")
+                self.last_epoch_stats = dict(task=task_idx, epoch=epoch_idx, loss=loss, acc1=acc1, images_per_sec=n_img / dt)
+                if (epoch_idx + 1) % self.val_per_epoch == 0 or (epoch_idx + 1) == self.inc_epoch:
+                    test_acc = self._validate(task_idx)
+                    batch_last_acc, per_task_acc = test_acc["avg_acc"], test_acc["per_task_acc"]
+                    best_batch_last_acc = max(batch_last_acc, best_batch_last_acc)
+                    task_last_acc = np.mean(per_task_acc)
+                    best_task_last_acc = max(task_last_acc, best_task_last_acc)
+                    frgt, bwt = compute_frgt(acc_table, per_task_acc, task_idx), compute_bwt(acc_table, per_task_acc, task_idx)
+                    best_frgt, best_bwt = min(frgt, best_frgt), max(bwt, best_bwt)
+                    self.log(f" * [Batch] Last Average Acc: {batch_last_acc:.2f} (Best: {best_batch_last_acc:.2f})")
+                    self.log(f" * Per-Task Acc: {per_task_acc}")
+                if self.config["lr_scheduler"]["name"] == "PatienceSchedule":
+                    self.scheduler.step(meter.avg("loss"))
+                    if self.scheduler.get_last_lr() < self.config["lr_scheduler"]["kwargs"]["stopping_lr"]:
+                        break
+                else:
+                    self.scheduler.step()
+            if hasattr(model, "after_task"):
+                self.hook_trace.append(("after_task", task_idx, -1))
+                model.after_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))
+            # trainer-side buffer update (:410-418)
+            self.buffer.total_classes += self.init_cls_num if task_idx == 0 else self.inc_cls_num
+            if self.buffer.buffer_size > 0:
+                from .model.buffer import herding_update, random_update
+                if self.buffer.strategy == "herding":
+                    herding_update(self.train_loader.get_loader(task_idx).dataset, self.buffer, model.backbone, self.device)
+                elif self.buffer.strategy == "random":
+                    random_update(self.train_loader.get_loader(task_idx).dataset, self.buffer)
+            for test_idx in range(testing_times):
+                test_acc = self._validate(task_idx)
+                batch_last_acc, per_task_acc = test_acc["avg_acc"], test_acc["per_task_acc"]
+                best_batch_last_acc = max(batch_last_acc, best_batch_last_acc)
+                task_last_acc = np.mean(per_task_acc)
+                best_task_last_acc = max(task_last_acc, best_task_last_acc)
+                batch_last_acc_list[task_idx] += batch_last_acc
+                task_last_acc_list[task_idx] += task_last_acc
+                acc_table[task_idx][: task_idx + 1] += np.array(per_task_acc)
+            best_batch_last_acc_list[task_idx] = best_batch_last_acc
+            best_task_last_acc_list[task_idx] = best_task_last_acc
+            batch_last_acc_list[task_idx] /= testing_times
+            task_last_acc_list[task_idx] /= testing_times
+            acc_table[task_idx] /= testing_times
+            batch_last_acc, task_last_acc = batch_last_acc_list[task_idx], task_last_acc_list[task_idx]
+            frgt, bwt = compute_frgt(acc_table, acc_table[task_idx], task_idx), compute_bwt(acc_table, acc_table[task_idx], task_idx)
+            if task_idx > 1:
+                frgt_list.append(frgt)
+                bwt_list.append(bwt)
+            self.log(f"================Result of Task {task_idx} Testing!================")
+            self.log(f" * [Batch] Last Average Acc: {batch_last_acc:.2f} (Best: {best_batch_last_acc:.2f})")
+            self.log(f" * [Task] Last Average Acc: {task_last_acc:.2f} (Best: {best_task_last_acc:.2f})")
+            self.log(f" * Forgetting: {frgt:.3f}  Backward Transfer: {bwt:.2f}")
+            self.log(f" * Per-Task Acc: {acc_table[task_idx][:task_idx + 1]}")
+        result = dict(
+            batch_last_acc=float(batch_last_acc), task_last_acc=float(task_last_acc),
+            batch_ovr_avg_acc=float(np.mean(batch_last_acc_list)),
+            task_ovr_avg_acc=float(np.sum(np.sum(acc_table[: task_idx + 1], axis=1) / np.arange(1, task_idx + 2)) / (task_idx + 1)),
+            ovr_bwt=float(np.mean(bwt_list)) if bwt_list else float("-inf"),
+            ovr_frgt=float(np.mean(frgt_list)) if frgt_list else float("inf"),
+            acc_table=acc_table, time=time() - t_begin)
+        self.log(f"================Overall Result of {self.task_num} Tasks!================")
+        self.log(f" * [Batch] Last Average Acc: {result['batch_last_acc']:.2f}   Overall Avg Acc: {result['batch_ovr_avg_acc']:.2f}")
+        self.log(f" * Time Costs : {result['time']:.2f} sec")
+        return result
+
+    def _train(self, epoch_idx, dataloader):
+        """the hot loop (core/trainer.py:563-614)"""
+        model = self.model
+        model.train()                      # whole plugin, teachers included (quirk a10/a11/a12)
+        meter = copy.deepcopy(self.train_meter)
+        meter.reset()
+        init_seed(self.config["seed"] + epoch_idx, self.config["deterministic"])
+        self.hook_trace.append(("train_epoch", self.task_idx, epoch_idx))
+        train_steps(model, self.optimizer, dataloader, self.reducer, self.config["classifier"]["name"], meter, self.device)
+        return meter
+
+    def _validate(self, task_idx):
+        """core/trainer.py:616-720 (testing_per_task branch and merged branch)"""
+        dataloaders = self.test_loader.get_loader(task_idx)
+        model = self.model
+        model.eval()
+        self.hook_trace.append(("validate", task_idx, -1))
+        per_task_acc, count_all, correct_all = [], 0, 0
+        with torch.no_grad():
+            if self.config["testing_per_task"]:
+                for t, dl in enumerate(dataloaders):
+                    correct_task, count_task = 0, 0
+                    for batch in dl:
+                        if self.config["setting"] == "task-aware":
+                            output, acc = model.inference(batch, task_id=t)
+                        else:
+                            output, acc = model.inference(batch)
+                        correct_task += int(acc * batch["label"].shape[0])
+                        count_task += batch["label"].shape[0]
+                    correct_all += correct_task
+                    count_all += count_task
+                    per_task_acc.append(round(correct_task * 100 / count_task, 2))
+            else:
+                datasets = [dl.dataset for dl in dataloaders]
+                merged = copy.deepcopy(datasets[0])
+                merged.images = np.concatenate([ds.images for ds in datasets], axis=0)
+                merged.labels = np.concatenate([ds.labels for ds in datasets], axis=0)
+                loader = DataLoader(merged, shuffle=True, batch_size=self.config["batch_size"], drop_last=False,
+                                    num_workers=self.config["num_workers"])
+                bounds, s = [], 0
+                for t in range(task_idx + 1):
+                    n = self.init_cls_num if t == 0 else self.inc_cls_num
+                    bounds.append((s, s + n))
+                    s += n
+                cb, nb = np.zeros(task_idx + 1, dtype=int), np.zeros(task_idx + 1, dtype=int)
+                for batch in loader:
+                    output, acc = model.inference(batch)
+                    preds, labels = output.cpu().numpy(), batch["label"].cpu().numpy()
+                    correct_all += int(np.sum(preds == labels))
+                    count_all += len(labels)
+                    for t, (a, e) in enumerate(bounds):
+                        m = (labels >= a) & (labels < e)
+                        if np.any(m):
+                            cb[t] += np.sum(preds[m] == labels[m])
+                            nb[t] += np.sum(m)
+                per_task_acc = [round(c * 100 / n, 2) if n > 0 else 0 for c, n in zip(cb, nb)]
+        return {"avg_acc": round(correct_all * 100 / count_all, 2), "per_task_acc": per_task_acc}

@@ -1,0 +1,107 @@
+"""Host utilities with the reference's semantics (core/utils/utils.py): `get_instance` reflection (:77-92),
+`init_seed` (:56-75), accuracy-table metrics `compute_bwt` / `compute_frgt` (:202-232), parameter counters.
+`AverageMeter` keeps the reference's interface but is plain Python floats (no pandas writes in the step loop,
+SURVEY.md section 3.3)."""
+import os
+import random
+
+import numpy as np
+import torch
+
+
+class AverageMeter:
+    def __init__(self, name, keys, writer=None):
+        self.name, self.keys, self.writer = name, list(keys), writer
+        self.reset()
+
+    def reset(self):
+        self._last = {k: 0.0 for k in self.keys}
+        self._total = {k: 0.0 for k in self.keys}
+        self._count = {k: 0 for k in self.keys}
+        self._pending = {}
+
+    def update(self, key, value, n=1):
+        """`value` may be a device-resident scalar (ops.Deferred or 0-dim tensor): it is queued and only
+        read back when an average is requested (one sync per epoch instead of 2-3 per step)."""
+        if hasattr(value, "tensor") or torch.is_tensor(value):
+            self._pending.setdefault(key, []).append((value, n))
+        else:
+            self._last[key] = value
+            self._total[key] += value * n
+        self._count[key] += n
+
+    def _flush(self, key):
+        pend = self._pending.pop(key, None)
+        if not pend:
+            return
+        ts, ws = [], []
+        for v, n in pend:
+            if torch.is_tensor(v):
+                ts.append(v.detach().reshape(()).float()); ws.append(float(n))
+            else:
+                ts.append(v.tensor.detach().reshape(()).float()); ws.append(float(v.scale) * n)
+        vals = torch.stack(ts).cpu().double() * torch.tensor(ws, dtype=torch.float64)
+        self._total[key] += float(vals.sum())
+        self._last[key] = float(vals[-1]) / (pend[-1][1] or 1)
+
+    def avg(self, key):
+        self._flush(key)
+        return self._total[key] / self._count[key] if self._count[key] else 0.0
+
+    def result(self):
+        return {k: self.avg(k) for k in self.keys}
+
+    def last(self, key):
+        self._flush(key)
+        return self._last[key]
+
+    def total(self, key):
+        self._flush(key)
+        return self._total[key]
+
+
+def init_seed(seed=0, deterministic=False):
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+    # (cudnn flags of the reference have no counterpart: libclhip kernels are deterministic except for
+    #  the fp32 atomic accumulation order of the weight gradients)
+
+
+def get_instance(module, name, config, **kwargs):
+    """getattr(module, config[name]['name'])(**kwargs, **config[name]['kwargs'])"""
+    if config[name].get("kwargs") is not None:
+        kwargs.update(config[name]["kwargs"])
+    return getattr(module, config[name]["name"])(**kwargs)
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def count_all_parameters(model):
+    return sum(p.numel() for p in model.parameters())
+
+
+def compute_bwt(acc_table, curr_acc, task_idx):
+    """backward transfer, formula of core/utils/utils.py:202-221"""
+    if task_idx > 1:
+        bwt = 0.0
+        for i in range(2, task_idx):
+            for j in range(i - 1):
+                bwt += acc_table[i, j] - acc_table[j, j]
+        for j in range(task_idx - 1):
+            bwt += curr_acc[j] - acc_table[j, j]
+        return (bwt * 2) / (task_idx * (task_idx + 1))
+    return 0.0
+
+
+def compute_frgt(acc_table, curr_acc, task_idx):
+    """forgetting, formula of core/utils/utils.py:224-232"""
+    if task_idx > 1:
+        return sum(np.diag(acc_table)[: task_idx - 1] - np.asarray(curr_acc)[: task_idx + 1][:-2]) / task_idx
+    return 0.0

@@ -1,0 +1,382 @@
+"""Kernel-level parity on a real MI355X: every libclhip entry point against the CPU oracle (plain torch
+fp32/fp64 CPU ops = the same arithmetic the reference runs) on seeded inputs.
+
+bf16 mode: operands are rounded to bf16 first and the oracle is evaluated in fp64 on the ROUNDED operands,
+so the only admissible differences are fp32 accumulation order and the final bf16 rounding of the output
+(relative 2^-8 of the output magnitude).  f32 mode: rtol 2e-4 (fp32 accumulation order only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from libcontinual_amd import _lib          # noqa: E402
+from libcontinual_amd._lib import call     # noqa: E402
+
+DEV = "cuda"
+DT = {"bf16": (_lib.BF16, torch.bfloat16), "f32": (_lib.F32, torch.float32)}
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def to_nhwc(x, tdt, cpad=None):
+    """CPU NCHW fp32 -> device NHWC in `tdt`, channels zero-padded"""
+    n, c, h, w = x.shape
+    cpad = cpad or c
+    y = torch.zeros(n, h, w, cpad)
+    y[..., :c] = x.permute(0, 2, 3, 1)
+    return y.to(tdt).to(DEV).contiguous()
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def quant(x, tdt):
+    return x.to(tdt).float()
+
+
+def tol(mode, ref):
+    scale = float(ref.abs().max()) + 1e-30
+    return (2 ** -7) * scale if mode == "bf16" else 2e-4 * scale
+
+
+CONV_CASES = [
+    # N, H, W, C, K, k, stride, pad
+    (2, 8, 8, 16, 16, 3, 1, 1),
+    (2, 8, 8, 16, 32, 3, 2, 1),
+    (2, 8, 8, 16, 32, 1, 2, 0),
+    (3, 5, 7, 32, 48, 3, 1, 1),        # ragged spatial size, K not a power of two
+    (2, 6, 6, 64, 128, 3, 1, 1),
+    (1, 4, 4, 256, 512, 3, 2, 1),
+    (4, 16, 16, 3, 16, 3, 1, 1),       # stem: 3 channels padded to 8
+    (2, 9, 9, 128, 256, 1, 2, 0),
+    (64, 32, 32, 16, 16, 3, 1, 1),     # M = 65536 -> the 128-row tile path
+    (1, 1, 1, 16, 16, 3, 1, 1),        # single pixel
+]
+
+
+def conv_setup(case, mode, seed=0):
+    N, H, W, C, K, k, s, p = case
+    code, tdt = DT[mode]
+    cpad = max(8, C)
+    x = quant(rnd((N, C, H, W), seed), tdt)
+    w = quant(rnd((K, C, k, k), seed + 1, 1.0 / (C * k * k) ** 0.5), tdt)
+    xd = to_nhwc(x, tdt, cpad)
+    wk = torch.zeros(K, k, k, cpad)
+    wk[..., :C] = w.permute(0, 2, 3, 1)
+    wfd = wk.to(tdt).to(DEV).contiguous()
+    return x, w, xd, wfd, code, tdt, cpad
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_and_stats(case, mode):
+    N, H, W, C, K, k, s, p = case
+    x, w, xd, wfd, code, tdt, cpad = conv_setup(case, mode)
+    ref = F.conv2d(x.double(), w.double(), None, s, p)
+    Ho, Wo = ref.shape[2:]
+    z = torch.empty(N, Ho, Wo, K, dtype=tdt, device=DEV)
+    tiles = _lib.lib().clhip_conv_fwd_tiles(N, H, W, cpad, K, k, s, p)
+    part = torch.full((tiles, 2, K), float("nan"), device=DEV)
+    call("clhip_conv_fwd", xd.data_ptr(), wfd.data_ptr(), z.data_ptr(), part.data_ptr(), N, H, W, cpad, K, k, s, p, code, st())
+    got = from_nhwc(z)
+    assert (got.double() - ref).abs().max() <= tol(mode, ref)
+    # BatchNorm statistics from the fp32 accumulators: per-channel sum / sum of squares
+    s1, s2 = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
+    r1, r2 = ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))
+    assert (s1 - r1).abs().max() <= 1e-4 * (ref.abs().sum(dim=(0, 2, 3)).max() + 1e-30)
+    assert (s2 - r2).abs().max() <= 1e-4 * (r2.max() + 1e-30)
+    # eval mode: no statistics requested
+    z2 = torch.empty_like(z)
+    call("clhip_conv_fwd", xd.data_ptr(), wfd.data_ptr(), z2.data_ptr(), None, N, H, W, cpad, K, k, s, p, code, st())
+    assert torch.equal(z2, z)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] >= 16 and (c[4] & (c[4] - 1)) == 0])
+def test_conv_dgrad(case, mode):
+    N, H, W, C, K, k, s, p = case
+    code, tdt = DT[mode]
+    w = quant(rnd((K, C, k, k), 5, 1.0 / (K * k * k) ** 0.5), tdt)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz = quant(rnd((N, K, Ho, Wo), 6), tdt)
+    xr = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w.double(), None, s, p).backward(dz.double())
+    ref = xr.grad
+    wdg = w.permute(1, 2, 3, 0).contiguous().to(tdt).to(DEV)        # [C][R][S][K]
+    dzd = to_nhwc(dz, tdt)
+    dx = torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+    call("clhip_conv_dgrad", dzd.data_ptr(), wdg.data_ptr(), dx.data_ptr(), 0, N, H, W, C, K, k, s, p, code, st())
+    got = from_nhwc(dx)
+    assert (got.double() - ref).abs().max() <= tol(mode, ref)
+    # accumulate flag: dx += result
+    base = quant(rnd((N, C, H, W), 7), tdt)
+    dx2 = to_nhwc(base, tdt)
+    call("clhip_conv_dgrad", dzd.data_ptr(), wdg.data_ptr(), dx2.data_ptr(), 1, N, H, W, C, K, k, s, p, code, st())
+    ref2 = ref + base.double()
+    assert (from_nhwc(dx2).double() - ref2).abs().max() <= tol(mode, ref2) * 1.5
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(case, mode):
+    N, H, W, C, K, k, s, p = case
+    x, w, xd, wfd, code, tdt, cpad = conv_setup(case, mode, seed=11)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz = quant(rnd((N, K, Ho, Wo), 12), tdt)
+    wr = w.double().clone().requires_grad_(True)
+    F.conv2d(x.double(), wr, None, s, p).backward(dz.double())
+    ref = wr.grad                                           # [K,C,k,k]
+    dzd = to_nhwc(dz, tdt)
+    dw = torch.zeros(K, k, k, C, device=DEV)                # K,R,S,Creal fp32
+    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), N, H, W, cpad, C, K, k, s, p, code, st())
+    got = dw.cpu().permute(0, 3, 1, 2).double()
+    t = 2e-4 * float(ref.abs().max()) + 1e-6               # fp32 accumulation of exactly representable products
+    assert (got - ref).abs().max() <= t
+    # accumulation into existing content (+=)
+    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), N, H, W, cpad, C, K, k, s, p, code, st())
+    assert (dw.cpu().permute(0, 3, 1, 2).double() - 2 * ref).abs().max() <= 2 * t
+
+
+def test_weight_prep_and_layout_converts():
+    K, C, k = 32, 3, 3
+    w = rnd((K, C, k, k), 3)
+    wm = w.permute(0, 2, 3, 1).contiguous().to(DEV)          # master layout K,R,S,C
+    for mode, (code, tdt) in DT.items():
+        wf = torch.empty(K, k * k, 8, dtype=tdt, device=DEV)
+        wd = torch.empty(8, k * k, K, dtype=tdt, device=DEV)
+        call("clhip_conv_weight_prep", wm.data_ptr(), wf.data_ptr(), wd.data_ptr(), K, k * k, C, 8, code, st())
+        ref = torch.zeros(K, k * k, 8)
+        ref[..., :C] = w.permute(0, 2, 3, 1).reshape(K, k * k, C)
+        assert torch.equal(wf.float().cpu(), ref.to(tdt).float())
+        assert torch.equal(wd.float().cpu(), ref.permute(2, 1, 0).to(tdt).float())
+        x = rnd((3, 3, 5, 6), 4)
+        y = torch.empty(3, 5, 6, 8, dtype=tdt, device=DEV)
+        call("clhip_nchw_to_nhwc", x.to(DEV).data_ptr(), y.data_ptr(), 3, 3, 5, 6, 8, code, st())
+        assert torch.equal(y.float().cpu()[..., :3], x.permute(0, 2, 3, 1).to(tdt).float())
+        assert float(y.float().abs().cpu()[..., 3:].max()) == 0.0
+        back = torch.empty(3, 8, 5, 6, device=DEV)
+        call("clhip_nhwc_to_nchw", y.data_ptr(), back.data_ptr(), 3, 8, 5, 6, code, st())
+        assert torch.equal(back.cpu()[:, :3], x.to(tdt).float())
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(4, 8, 8, 16), (3, 5, 5, 64), (2, 4, 4, 512), (64, 16, 16, 32)])
+@pytest.mark.parametrize("relu,res", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_batchnorm_fwd_bwd(shape, mode, relu, res):
+    N, H, W, C = shape
+    code, tdt = DT[mode]
+    M = N * H * W
+    z = quant(rnd((N, C, H, W), 20, 2.0) + 0.3, tdt)
+    r = quant(rnd((N, C, H, W), 21), tdt) if res else None
+    gamma, beta = rnd((C,), 22) * 0.5 + 1.0, rnd((C,), 23) * 0.2
+    rm0, rv0 = rnd((C,), 24) * 0.1, rnd((C,), 25).abs() + 0.5
+    dy = quant(rnd((N, C, H, W), 26), tdt)
+    # device: statistics partials as the conv epilogue would produce them (exact sums of z)
+    zd = to_nhwc(z, tdt)
+    z2 = z.double().permute(0, 2, 3, 1).reshape(M, C)
+    tiles = 3
+    part = torch.zeros(tiles, 2, C, dtype=torch.float64)
+    for t, ch in enumerate(torch.chunk(z2, tiles, 0)):
+        part[t, 0], part[t, 1] = ch.sum(0), (ch * ch).sum(0)
+    part = part.float().to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    rmd, rvd = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+    call("clhip_bn_stats_finalize", part.data_ptr(), tiles, M, C, gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
+         0.1, 1e-5, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st())
+    rd = to_nhwc(r, tdt) if res else None
+    yd = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+    call("clhip_bn_apply", zd.data_ptr(), scale.data_ptr(), shift.data_ptr(), rd.data_ptr() if res else None, yd.data_ptr(), M, C,
+         relu, code, st())
+    # oracle (fp64): nn.BatchNorm2d train semantics.  The ReLU mask is taken from the device's stored y so
+    # that elements within rounding distance of 0 cannot flip the comparison.
+    zr = z.double().clone().requires_grad_(True)
+    g64, b64 = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    y = F.batch_norm(zr, rm, rv, g64, b64, True, 0.1, 1e-5)
+    if res:
+        rr = r.double().clone().requires_grad_(True)
+        y = y + rr
+    ypre = y.detach().clone()
+    if relu:
+        y = y * (from_nhwc(yd) > 0).double()
+    y.backward(dy.double())
+    assert torch.allclose(rmd.cpu().double(), rm, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rvd.cpu().double(), rv, rtol=1e-4, atol=1e-6)
+    yref = F.relu(ypre) if relu else ypre
+    assert (from_nhwc(yd).double() - yref).abs().max() <= tol(mode, yref)
+    # backward
+    dyd = to_nhwc(dy, tdt)
+    ws = torch.empty(_lib.lib().clhip_bn_bwd_ws_floats(M, C), device=DEV)
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+    dres = torch.empty(N, H, W, C, dtype=tdt, device=DEV) if res else None
+    call("clhip_bn_bwd", dyd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+         dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), dres.data_ptr() if res else None, 0, M, C, relu, ws.data_ptr(), code, st())
+    gz = zr.grad
+    assert (from_nhwc(dz).double() - gz).abs().max() <= tol(mode, gz) * 2
+    assert (dgamma.cpu().double() - g64.grad).abs().max() <= 2e-3 * (g64.grad.abs().max() + 1e-9) + 1e-4
+    assert (dbeta.cpu().double() - b64.grad).abs().max() <= 2e-3 * (b64.grad.abs().max() + 1e-9) + 1e-4
+    if res:
+        assert (from_nhwc(dres).double() - rr.grad).abs().max() <= tol(mode, rr.grad)
+        # accumulate variant
+        call("clhip_bn_bwd", dyd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
+             dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), dres.data_ptr(), 1, M, C, relu, ws.data_ptr(), code, st())
+        assert (from_nhwc(dres).double() - 2 * rr.grad).abs().max() <= tol(mode, rr.grad) * 3
+    # eval-mode affine
+    call("clhip_bn_eval_affine", gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, C, scale.data_ptr(),
+         shift.data_ptr(), st())
+    ye = F.batch_norm(z.double(), rmd.cpu().double(), rvd.cpu().double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    call("clhip_bn_apply", zd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, yd.data_ptr(), M, C, 0, code, st())
+    assert (from_nhwc(yd).double() - ye).abs().max() <= tol(mode, ye)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_avgpool(mode):
+    code, tdt = DT[mode]
+    a = quant(rnd((5, 64, 8, 8), 30), tdt)
+    ad = to_nhwc(a, tdt)
+    feat = torch.empty(5, 64, device=DEV)
+    call("clhip_avgpool_fwd", ad.data_ptr(), feat.data_ptr(), 5, 64, 64, code, st())
+    assert torch.allclose(feat.cpu(), a.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+    df = rnd((5, 64), 31)
+    da = torch.empty(5, 8, 8, 64, dtype=tdt, device=DEV)
+    call("clhip_avgpool_bwd", df.to(DEV).data_ptr(), da.data_ptr(), 5, 64, 64, code, st())
+    ref = (df / 64)[:, :, None, None].expand(5, 64, 8, 8)
+    assert (from_nhwc(da) - ref).abs().max() <= tol(mode, ref)
+
+
+# ------------------------------------------------------------------------------------ heads / losses
+def test_linear_and_losses():
+    from libcontinual_amd import ops
+    B, D, O = 37, 512, 55
+    x = rnd((B, D), 40).to(DEV).requires_grad_(True)
+    w = (rnd((O, D), 41) * 0.05).to(DEV).requires_grad_(True)
+    b = (rnd((O,), 42) * 0.1).to(DEV).requires_grad_(True)
+    y = torch.from_numpy(np.random.RandomState(0).randint(50, 55, B)).to(DEV)
+    soft = (rnd((B, 50), 43) * 3).to(DEV)
+    logits = ops.linear(x, w, b)
+    aux = ops.LossAux()
+    loss = ops.classify_loss(logits, y, lo=50, hi=55, w_ce=1.0, teacher=soft, k=50, T=2.0, w_kd=3.0, aux=aux)
+    (loss * 1.7).backward()
+    xc, wc, bc = (t.detach().cpu().double().requires_grad_(True) for t in (x, w, b))
+    lg = F.linear(xc, wc, bc)
+    ce = F.cross_entropy(lg[:, 50:], y.cpu() - 50)
+    lp = torch.log_softmax(lg[:, :50] / 2, dim=1)
+    q = torch.softmax(soft.cpu().double() / 2, dim=1)
+    kd = -(q * lp).sum() / B
+    ref = ce + 3 * kd
+    (ref * 1.7).backward()
+    assert torch.allclose(logits.detach().cpu().double(), lg.detach(), rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    for got, want in ((x.grad, xc.grad), (w.grad, wc.grad), (b.grad, bc.grad)):
+        assert (got.cpu().double() - want).abs().max() <= 1e-4 * want.abs().max() + 1e-7
+    assert torch.equal(aux.pred.cpu(), lg.argmax(1))
+    assert aux.correct.item() == int((lg.argmax(1) == y.cpu()).sum())
+    # plain CE over all columns, and predict()
+    loss2 = ops.classify_loss(logits.detach(), y)
+    assert abs(loss2.item() - F.cross_entropy(lg.detach(), y.cpu()).item()) < 1e-4
+    pred, correct = ops.predict(logits.detach(), y, pred_hi=52)
+    assert torch.equal(pred.cpu(), lg.detach()[:, :52].argmax(1))
+
+
+def test_lucir_head_and_losses():
+    from libcontinual_amd import ops
+    B, D, O, nold, K = 24, 64, 12, 9, 2
+    x = rnd((B, D), 50).to(DEV).requires_grad_(True)
+    w = rnd((O, D), 51).to(DEV).requires_grad_(True)
+    sigma = torch.tensor([1.3], device=DEV, requires_grad=True)
+    ref_f = rnd((B, D), 52).to(DEV)
+    y = torch.from_numpy(np.random.RandomState(1).randint(0, O, B)).to(DEV)
+    s = ops.cosine_linear(x, w)
+    logit = ops.sigma_scale(s, sigma)
+    loss = ops.classify_loss(logit, y) + ops.cos_embed_loss(x, ref_f, 15.81) + ops.margin_rank_loss(s, y, nold, K, 0.5, 1.0)
+    loss.backward()
+    xc, wc, sc = (t.detach().cpu().double().requires_grad_(True) for t in (x, w, sigma))
+    s_ref = F.linear(F.normalize(xc, dim=1), F.normalize(wc, dim=1))
+    lg = sc * s_ref
+    yc = y.cpu()
+    l_ref = F.cross_entropy(lg, yc) + torch.nn.CosineEmbeddingLoss()(xc, ref_f.cpu().double(), torch.ones(B, dtype=torch.float64)) * 15.81
+    gt = s_ref.gather(1, yc.view(-1, 1)).squeeze(1)
+    nov = s_ref[:, nold:].topk(K, dim=1)[0]
+    hard = yc < nold
+    if int(hard.sum()) > 0:
+        g = gt[hard].view(-1, 1).repeat(1, K)
+        l_ref = l_ref + torch.nn.MarginRankingLoss(margin=0.5)(g.view(-1, 1), nov[hard].view(-1, 1), torch.ones(int(hard.sum()) * K, 1, dtype=torch.float64))
+    l_ref.backward()
+    assert torch.allclose(s.detach().cpu().double(), s_ref.detach(), rtol=1e-4, atol=1e-6)
+    assert abs(loss.item() - l_ref.item()) < 2e-4 * abs(l_ref.item())
+    for got, want in ((x.grad, xc.grad), (w.grad, wc.grad), (sigma.grad, sc.grad)):
+        assert (got.cpu().double() - want).abs().max() <= 2e-4 * want.abs().max() + 1e-7
+
+
+def test_flat_elementwise_family():
+    from libcontinual_amd import ops
+    n = 100003
+    p, ref, f, g = (rnd((n,), 60 + i).to(DEV) for i in range(4))
+    f = f.abs()
+    out = torch.empty(1, device=DEV)
+    ops.ewc_penalty(p, ref, f, 1000.0, out, False)
+    want = 1000.0 * (f.double() * (p.double() - ref.double()) ** 2).sum() / 2
+    assert abs(out.item() - want.item()) < 1e-4 * want.item()
+    ops.ewc_penalty(p[1:], ref[1:], f[1:], 1.0, out, True)         # misaligned pointers + accumulate
+    want2 = want + (f[1:].double() * (p[1:].double() - ref[1:].double()) ** 2).sum() / 2
+    assert abs(out.item() - want2.item()) < 1e-4 * want2.item()
+    g0 = g.clone()
+    sc = torch.tensor([0.5], device=DEV)
+    ops.ewc_grad(p, ref, f, g, 1000.0, sc)
+    assert torch.allclose(g, g0 + 500.0 * f * (p - ref), rtol=1e-5, atol=1e-5)
+    fi = torch.zeros(n, device=DEV)
+    ops.fisher_accum(fi, g0, 32.0 / 96.0)
+    assert torch.allclose(fi, g0 * g0 * (32.0 / 96.0), rtol=1e-6)
+    old = f.clone()
+    ops.fisher_merge(fi, old, 0.9)
+    assert torch.allclose(fi, 0.9 * old + 0.1 * g0 * g0 * (32.0 / 96.0), rtol=1e-5, atol=1e-7)
+    # SGD (momentum, wd) for 3 steps vs torch.optim.SGD, and Adam
+    for kind in ("sgd", "sgd_plain", "adam"):
+        pt = rnd((n,), 70).to(DEV)
+        pr = pt.clone().cpu().double().requires_grad_(True)
+        if kind == "adam":
+            opt = torch.optim.Adam([pr], lr=1.875e-3)
+            m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        else:
+            mom = 0.9 if kind == "sgd" else 0.0
+            opt = torch.optim.SGD([pr], lr=0.1, momentum=mom, weight_decay=5e-4 if kind == "sgd" else 0.0)
+            buf = torch.zeros(n, device=DEV) if mom else None
+        for step in range(1, 4):
+            gr = rnd((n,), 80 + step).to(DEV)
+            pr.grad = gr.cpu().double()
+            opt.step()
+            if kind == "adam":
+                ops.adam_step(pt, gr, m, v, 1.875e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, step)
+            else:
+                ops.sgd_step(pt, gr, buf, 0.1, mom, 5e-4 if kind == "sgd" else 0.0)
+        assert torch.allclose(pt.cpu().double(), pr.detach(), rtol=1e-4, atol=1e-5), kind
+    nrm = torch.empty(1, device=DEV)
+    ops.sq_norm(g0, nrm)
+    assert abs(nrm.item() - float((g0.double() ** 2).sum())) < 1e-4 * nrm.item()
+
+
+def test_ncm_and_herding_match_reference_math():
+    from libcontinual_amd import ops
+    from oracle import methods as om
+    feats = rnd((40, 64), 90) + 0.5
+    lab = torch.zeros(40, dtype=torch.long)
+    chosen_ref = om.herding_select(feats.clone(), lab, 12)
+    fn = ops.l2_normalize_rows(feats.to(DEV))
+    assert torch.allclose(fn.cpu(), feats / feats.norm(dim=1, keepdim=True), rtol=1e-5, atol=1e-6)
+    chosen = ops.herding_select(fn, 12).cpu().tolist()
+    assert chosen == chosen_ref
+    means = rnd((7, 64), 91)
+    pred = ops.ncm_classify(feats.to(DEV), means.to(DEV)).cpu()
+    assert torch.equal(pred, om.ncm_distance(feats, means).argmin(1))
