@@ -1,0 +1,222 @@
+"""bench.py -- images/sec of the hot path on N GPUs of one node (driver contract in the task statement).
+
+Workload (BASELINE.json configs[1]): LwF, ResNet-18 with the CIFAR stem, CIFAR-100 B50-5x10, bf16, task-0
+epoch step = forward + fused CE + backward + fused SGD on a synthetic batch already resident in HBM
+([B,3,32,32] fp32 normalised images, labels in [0,50)).  One "step" = one pass of the inner loop
+(`libcontinual_amd.trainer.train_steps`, the same function the Trainer runs) over one batch.
+N > 1: one process per GPU (torchrun), per-GPU batch fixed (weak scaling), one all-reduce of the flat gradient
+buffer over RCCL per step, 1/world folded into the SGD kernel.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, timed live with HIP events) and
+`cpu_baseline` (the CPU oracle of the same step on the host cores, bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_FWD_PER_IMG = {"resnet18": 1.1108e9, "cifar_resnet32": 0.13825e9}     # 2*MAC, SURVEY.md section 8(d)
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--workload", default="lwf_resnet18_b50_task0",
+                    choices=["lwf_resnet18_b50_task0", "lwf_resnet18_b50_task1", "icarl_resnet32_b50_task1", "ewc_resnet32_b50_task1"])
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_method(workload, dtype, dev):
+    """plugin + optimizer in the state of the named task (task>=1: teacher / Fisher active)"""
+    import libcontinual_amd.model as M
+    from libcontinual_amd import optim
+    if workload.startswith("lwf_resnet18"):
+        bb = M.resnet18(args={"dataset": "cifar100"}, dtype=dtype)
+        m = M.LWF(bb, 512, 100, device=dev, init_cls_num=50, inc_cls_num=5).to(dev)
+        m.before_task(0, None, None, None)
+        lo, hi = 0, 50
+        if workload.endswith("task1"):
+            m.before_task(1, None, None, None)
+            lo, hi = 50, 55
+        opt = optim.SGD(m.get_parameters({}), lr=0.1)                      # config/lwf.yaml:14-17
+        arch, teacher = "resnet18", workload.endswith("task1")
+    elif workload.startswith("icarl_resnet32"):
+        bb = M.cifar_resnet32(dtype=dtype)
+        m = M.ICarl(bb, 64, 100, device=dev, init_cls_num=50, inc_cls_num=5, task_num=11).to(dev)
+        m.before_task(0, None, None, None)
+        import copy
+        m.old_network = copy.deepcopy(m.network).eval()
+        m.prev_cls_num, m.cur_task_id = 50, 1
+        m.before_task(1, None, None, None)
+        lo, hi = 0, 55
+        opt = optim.SGD(m.get_parameters({}), lr=0.1, momentum=0.9, weight_decay=5e-4)
+        arch, teacher = "cifar_resnet32", True
+    else:
+        bb = M.cifar_resnet32(dtype=dtype)
+        m = M.EWC(bb, 64, 100, device=dev, init_cls_num=50, inc_cls_num=5, lamda=1000).to(dev)
+        m.before_task(0, None, None, None)
+        m._ensure_state()
+        m._fisher_flat.fill_(1e-4)
+        m.before_task(1, None, None, None)
+        lo, hi = 50, 55
+        opt = optim.SGD(m.get_parameters({}), lr=0.1, momentum=0.9, weight_decay=5e-4)
+        arch, teacher = "cifar_resnet32", False
+    return m, opt, arch, teacher, (lo, hi)
+
+
+def synthetic_batch(B, lo, hi, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, 32, 32, generator=g)
+    mean = torch.tensor([0.5071, 0.4866, 0.4409]).view(1, 3, 1, 1)
+    std = torch.tensor([0.2675, 0.2565, 0.2761]).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    y = torch.randint(lo, hi, (B,), generator=g)
+    return {"image": x.to(dev), "label": y.to(dev)}
+
+
+def cpu_baseline(workload, steps, batch):
+    """the CPU oracle (torch CPU fp32, all host cores) running the same step; bounded sample"""
+    from oracle import methods as om, nets
+    arch = "resnet18" if "resnet18" in workload else "cifar_resnet32"
+    torch.manual_seed(0)
+    P = {k: v.requires_grad_(True) for k, v in nets.init_params(arch).items()}
+    Bf = nets.init_buffers(arch)
+    fd = nets.arch(arch)[1]
+    w, b = om.linear_default_init(50, fd)
+    net = om.Net(arch, P, Bf, w.requires_grad_(True), b.requires_grad_(True))
+    m = om.LWF(net, 50, 5)
+    m.before_task(0, (w, b))
+    opt = om.SGD(net.parameters(), 0.1)
+    bt = synthetic_batch(batch, 0, 50, 1, "cpu")
+    x, y = bt["image"], bt["label"]
+
+    def step():
+        _, _, loss = m.observe(x, y, True)
+        opt.zero_grad(); loss.backward(); opt.step()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=batch * steps / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle), 1 warm-up")
+
+
+def dominant_kernel_roofline(dev, dtype, B):
+    """time the dominant kernel family of the ResNet-18 step -- the 3x3 stride-1 implicit-GEMM conv
+    forward at the layer1 shape [B,32,32,64]->64 -- with HIP events on the launch stream and price it
+    against the bf16 MFMA peak; algorithmic FLOPs = 2 * M * (9*Cin) * Cout per launch."""
+    from libcontinual_amd import _lib
+    code = _lib.BF16 if dtype == "bf16" else _lib.F32
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    N, H, W, C, K = B, 32, 32, 64, 64
+    x = torch.randn(N, H, W, C, device=dev).to(tdt)
+    w = (torch.randn(K, 9, C, device=dev) * 0.05).to(tdt)
+    z = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+    tiles = _lib.lib().clhip_conv_fwd_tiles(N, H, W, C, K, 3, 1, 1)
+    part = torch.empty(tiles, 2, K, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    run = lambda: _lib.call("clhip_conv_fwd", x.data_ptr(), w.data_ptr(), z.data_ptr(), part.data_ptr(), N, H, W, C, K, 3, 1, 1, code, st)
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * N * H * W * 9 * C * K
+    alg_bytes = (N * H * W * C + N * H * W * K) * (2 if dtype == "bf16" else 4) + w.numel() * w.element_size()
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="conv_igemm_kernel<bf16,128,64,fwd> @ [B,32,32,64]x[64,3,3,64]", achieved=ach,
+                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=None,
+                launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
+                hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    import torch.distributed as dist
+    from libcontinual_amd import parallel
+    from libcontinual_amd.trainer import train_steps
+    from libcontinual_amd.utils import AverageMeter
+    reducer = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        parallel.init_distributed(True)
+        reducer = parallel.GradientReducer()
+    torch.manual_seed(1993)
+    model, opt, arch, teacher, (lo, hi) = build_method(a.workload, a.dtype, dev)
+    if world > 1:
+        parallel.broadcast_module_state(model)
+        opt.grad_scale = 1.0 / world
+    model.train()
+    batches = [synthetic_batch(a.batch, lo, hi, 100 + rank * 7 + i, dev) for i in range(4)]
+    name = type(model).__name__
+    meter = AverageMeter("train", ["loss", "acc1"])
+
+    def run(n):
+        train_steps(model, opt, (batches[i % len(batches)] for i in range(n)), reducer, name, meter, dev)
+
+    run(a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_avg = meter.avg("loss")
+    if rank != 0:
+        return
+    ips = world * a.batch * a.steps / dt
+    fwd = FLOP_FWD_PER_IMG[arch]
+    step_flops_per_img = 3 * fwd + (fwd if teacher else 0.0)
+    out = {
+        "metric": "images/sec/node (task-0 epoch), CIFAR-100 B50-5x10" if a.workload.endswith("task0") else "images/sec/node (task>=1 step), CIFAR-100 B50-5x10",
+        "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": a.workload, "method": name, "backbone": arch, "per_gpu_batch": a.batch, "global_batch": a.batch * world,
+                   "image": "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused SGD", "final_loss": loss_avg},
+        "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
+        "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
+    }
+    out["roofline"] = dominant_kernel_roofline(dev, a.dtype, a.batch)
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps, 128)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ import torch.nn as nn
 from ... import _lib
 from ..._lib import call, require_gpu
 
-__all__ = ["HipResNet", "cifar_resnet20", "cifar_resnet32", "resnet18", "resnet34", "resnet32_V2",
+__all__ = ["HipResNet", "_Scratch", "_ScratchMixin", "cifar_resnet20", "cifar_resnet32", "resnet18", "resnet34", "resnet32_V2",
            "CosineLinear", "SplitCosineLinear"]
 
 
@@ -503,12 +503,33 @@ def resnet34(pretrained=False, progress=True, **kwargs):
 
 
 # ------------------------------------------------------------------------------------ cosine heads
-class CosineLinear(nn.Module):
+class _Scratch:
+    """per-forward tensors (autograd-attached) that must not follow the module through deepcopy/pickle"""
+
+    def __deepcopy__(self, memo):
+        return _Scratch()
+
+    def __getstate__(self):
+        return {}
+
+
+class _ScratchMixin:
+    @property
+    def last_scores(self):
+        return self._scratch.scores
+
+    @property
+    def last_features(self):
+        return self._scratch.features
+
+
+class CosineLinear(_ScratchMixin, nn.Module):
     """sigma * normalize(x) @ normalize(W)^T  (reference resnet.py:418-441) on libclhip kernels."""
 
     def __init__(self, in_features, out_features, sigma=True):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
+        self._scratch = _Scratch()
         self.weight = nn.Parameter(torch.empty(out_features, in_features))
         if sigma:
             self.sigma = nn.Parameter(torch.empty(1))
@@ -525,19 +546,20 @@ class CosineLinear(nn.Module):
     def forward(self, input):
         from ... import ops
         out = ops.cosine_linear(input, self.weight)
-        self.last_scores = out                     # pre-sigma scores (what the reference's forward hooks capture)
+        self._scratch.scores = out                 # pre-sigma scores (what the reference's forward hooks capture)
         if self.sigma is not None:
             out = ops.sigma_scale(out, self.sigma)
         return out
 
 
-class SplitCosineLinear(nn.Module):
+class SplitCosineLinear(_ScratchMixin, nn.Module):
     """fc1 (old classes) and fc2 (new classes) concatenated, then sigma (reference resnet.py:443-463)."""
 
     def __init__(self, in_features, out_features1, out_features2, sigma=True):
         super().__init__()
         self.in_features = in_features
         self.out_features = out_features1 + out_features2
+        self._scratch = _Scratch()
         self.fc1 = CosineLinear(in_features, out_features1, False)
         self.fc2 = CosineLinear(in_features, out_features2, False)
         if sigma:
@@ -551,7 +573,7 @@ class SplitCosineLinear(nn.Module):
         # one cosine kernel over the stacked weight rows == cat(fc1(x), fc2(x)); torch.cat only moves data
         w = torch.cat((self.fc1.weight, self.fc2.weight), dim=0)
         out = ops.cosine_linear(x, w)
-        self.last_scores = out
+        self._scratch.scores = out
         if self.sigma is not None:
             out = ops.sigma_scale(out, self.sigma)
         return out

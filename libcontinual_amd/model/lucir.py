@@ -17,13 +17,14 @@ import torch.nn as nn
 from torch.utils.data import DataLoader
 
 from .. import ops
-from .backbone.resnet import CosineLinear, SplitCosineLinear
+from .backbone.resnet import CosineLinear, SplitCosineLinear, _Scratch, _ScratchMixin
 from .finetune import Finetune
 
 
-class Model(nn.Module):
+class Model(_ScratchMixin, nn.Module):
     def __init__(self, backbone, feat_dim, num_class):
         super().__init__()
+        self._scratch = _Scratch()
         self.backbone = backbone
         self.feat_dim = feat_dim
         self.num_class = num_class
@@ -33,8 +34,8 @@ class Model(nn.Module):
         return self.get_logits(x)
 
     def get_logits(self, x):
-        self.last_features = self.backbone(x)["features"]
-        return self.classifier(self.last_features)
+        self._scratch.features = self.backbone(x)["features"]
+        return self.classifier(self._scratch.features)
 
 
 class LUCIR(Finetune):
