@@ -64,13 +64,16 @@ int clhip_conv_weight_prep(const float* w, void* w_fwd, void* w_dg, int K, int t
  *       partial sums for train-mode BatchNorm: float[tiles][2][K] (sum, sum of squares of the fp32
  *       accumulators), tiles = clhip_conv_fwd_tiles(); *not* atomics -> deterministic.
  * dgrad: dx[N,H,W,C] (+)= conv^T(dz[N,Ho,Wo,K], w_dg);  accumulate!=0 adds to the existing dx.
- * wgrad: dw[K][taps][Creal] += sum_pixels dz * x   (fp32, atomically accumulated: zero it first).    */
+ * wgrad: dw[K][taps][Creal] += sum_pixels dz * x   (fp32).  `ws` (nullable) is scratch of
+ *        clhip_conv_wgrad_ws_bytes() bytes: with it the 3x3/s1 kernel writes per-split partial blocks and reduces
+ *        them in a fixed order (bitwise reproducible); without it partial sums are combined with fp32 atomics. */
 int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize, int stride, int pad);
 int clhip_conv_fwd(const void* x, const void* w_fwd, void* z, float* stat_partials, int N, int H, int W, int C, int K,
                    int ksize, int stride, int pad, int dtype, void* stream);
 int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C, int K,
                      int ksize, int stride, int pad, int dtype, void* stream);
-int clhip_conv_wgrad(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K, int ksize,
+size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* ws, int N, int H, int W, int C, int Creal, int K, int ksize,
                      int stride, int pad, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

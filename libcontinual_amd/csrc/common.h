@@ -39,6 +39,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-e
     return (bf16_t)(u >> 16);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16x2 (lo in bits 0..15) with the hardware round-to-nearest-even convert (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 // Element traits: T = bf16_t (storage uint16) or float.  A "chunk" is 8 consecutive elements.
 template <typename T> struct Elem;
 template <> struct Elem<bf16_t> {
@@ -70,10 +78,7 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

@@ -12,6 +12,8 @@
 // consecutive channels of one pixel (one 8-byte store in bf16).  16x16x32 bf16 MFMA (or 8x 16x16x4
 // fp32 MFMA in the exact fp32 parity mode); fp32 accumulation.  The BatchNorm batch statistics are
 // reduced from the fp32 accumulators in the epilogue (per-tile partials, no atomics -> deterministic).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     }
                     if constexpr (sizeof(T) == 2) {
                         uint2 u;
-                        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        u.x = pack_bf16x2(v[0], v[1]);
+                        u.y = pack_bf16x2(v[2], v[3]);
                         *reinterpret_cast<uint2*>(q) = u;
                     } else {
                         *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
@@ -431,9 +433,40 @@ int check_conv(int N, int H, int W, int C, int K, int ksize, int stride, int pad
 
 }  // namespace
 
+// conv2.hip
+int clhip_conv2_tiles_m(int M, int Cd);
+int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                       int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st);
+int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
+                        int pad, int dtype, hipStream_t st);
+bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
+int clhip_conv3_tiles_m(int M, int Cd);
+int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, int N, int H, int W, int Cs, int Cd, int accumulate,
+                       int mode, hipStream_t st);
+bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st);
+size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K);
+static bool use_v3() {
+    static const bool v = getenv("CLHIP_NO_CONV3") == nullptr;    // A/B switch: halo kernel for 3x3 stride-1 layers
+    return v;
+}
+static bool use_v1() {
+    static const bool v = getenv("CLHIP_CONV_V1") != nullptr;     // A/B switch: first-generation kernel
+    return v;
+}
+
 extern "C" int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize, int stride, int pad) {
     int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     int M = N * Ho * Wo;
+    // NB: the plan sizes the statistics scratch with this; dtype is not known here, so report the larger count
+    if (!use_v1()) {
+        int t2 = clhip_conv2_tiles_m(M, K);
+        if (use_v3() && clhip_conv3_supported(H, W, C, K, ksize, stride, pad, CLHIP_BF16)) {
+            int t3 = clhip_conv3_tiles_m(M, K);
+            return t3 > t2 ? t3 : t2;
+        }
+        return t2;
+    }
     int bm = fwd_tile_m(M, K);
     return (M + bm - 1) / bm;
 }
@@ -449,6 +482,22 @@ extern "C" int clhip_conv_fwd(const void* x, const void* w_fwd, void* z, float* 
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = 0;
     p.M = N * p.Hd * p.Wd; p.K = ksize * ksize * C;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
+    if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, C, K, ksize, stride, pad, dtype)) {
+        // the caller's partial buffer may hold more tiles than this kernel writes: zero the tail rows
+        int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
+        int tiles_used = clhip_conv3_tiles_m(p.M, K);
+        if (stat_partials && tiles_alloc > tiles_used)
+            hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
+        return clhip_conv3_launch(x, w_fwd, z, stat_partials, N, H, W, C, K, 0, 0, st);
+    }
+    if (!use_v1()) {
+        int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
+        int tiles_used = clhip_conv2_tiles_m(p.M, K);
+        if (stat_partials && tiles_alloc > tiles_used)
+            hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
+        return clhip_conv2_launch(x, w_fwd, z, stat_partials, N, H, W, C, p.Hd, p.Wd, K, ksize, stride, pad, 0, 0, dtype, st);
+    }
     if (dtype == CLHIP_BF16) return launch_igemm<bf16_t, 0>(p, st);
     if (dtype == CLHIP_F32) return launch_igemm<float, 0>(p, st);
     CLHIP_CHECK_ARG(!"dtype");
@@ -469,13 +518,22 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.M = N * H * W; p.K = ksize * ksize * K;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
+    if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv3_launch(dz, w_dg, dx, nullptr, N, H, W, K, C, accumulate, 1, st);
+    if (!use_v1()) return clhip_conv2_launch(dz, w_dg, dx, nullptr, N, p.Hs, p.Ws, K, H, W, C, ksize, stride, pad, accumulate, 1, dtype, st);
     if (dtype == CLHIP_BF16) return launch_igemm<bf16_t, 1>(p, st);
     if (dtype == CLHIP_F32) return launch_igemm<float, 1>(p, st);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }
 
-extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K,
+extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad3_ws_bytes(N, H, W, C, K);
+    return 0;
+}
+
+extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* ws, int N, int H, int W, int C, int Creal, int K,
                                 int ksize, int stride, int pad, int dtype, void* stream) {
     if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
     CLHIP_CHECK_ARG(x && dz && dw && Creal >= 1 && Creal <= C);
@@ -497,6 +555,10 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, int N,
     p.pix_per_split = pps;
     dim3 grid(gx, gy, splits);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
+    if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
+        return clhip_wgrad3_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, Creal, K, st);
+    if (!use_v1()) return clhip_wgrad2_launch(x, dz, dw, N, H, W, C, Creal, K, ksize, stride, pad, dtype, st);
     static const bool no_tr = getenv("CLHIP_WGRAD_NO_TR") != nullptr;
     if (dtype == CLHIP_BF16) {
         if (no_tr) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, p);

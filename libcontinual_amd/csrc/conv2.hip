@@ -1,0 +1,552 @@
+// conv2.hip -- second-generation implicit-GEMM convolution (forward + dgrad) for gfx950.
+//
+// Same math and orientation as conv.hip (D[row = out channel][col = pixel], 16x16x32 bf16 MFMA, fp32
+// accumulate, BN statistics in the epilogue) but restructured around what the rocprofv3 trace of the
+// first version showed (profiles/r01_*): 8 MFMAs per wave between two barriers left the matrix pipe idle
+// ~85 % of the time.  Changes:
+//   * K-step 64 (one 3x3 tap of a 64-channel layer per step), 2 MFMA sub-steps per step;
+//   * per-wave tile up to 64 pixels x 64 channels (16 accumulator tiles, 8 ds_read_b128 per 16 MFMAs);
+//   * LDS double buffering with register prefetch: global loads for step k+1 are issued before the MFMAs
+//     of step k and written to the other LDS buffer afterwards -> ONE barrier per K-step;
+//   * 128-byte LDS rows with the XOR swizzle chunk ^= (row & 7): every 16-lane service group of
+//     ds_read_b128 hits 16 distinct 16-byte slots of the 256-byte bank row (conflict-free), and the
+//     staging writes of 8 consecutive lanes fill one whole row.
+//   * workgroup shapes chosen per layer so that >= 2 workgroups per CU exist even for the 4x4 / 8x8 layers.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BK2 = 64;
+
+struct ConvParams2 {
+    const void* src;
+    const void* wt;
+    void* dst;
+    float* stats;
+    int N, Hs, Ws, Cs, log2Cs, Hd, Wd, Cd, ksize, stride, pad, accumulate;
+    int M, K;
+};
+
+template <typename T> struct Chunk2;
+template <> struct Chunk2<bf16_t> { uint4 a; };
+template <> struct Chunk2<float> { uint4 a, b; };
+
+template <typename T> __device__ __forceinline__ Chunk2<T> zero2() {
+    Chunk2<T> c;
+    if constexpr (sizeof(T) == 2) { c.a = make_uint4(0, 0, 0, 0); }
+    else { c.a = make_uint4(0, 0, 0, 0); c.b = make_uint4(0, 0, 0, 0); }
+    return c;
+}
+template <typename T> __device__ __forceinline__ Chunk2<T> gload2(const T* p) {
+    Chunk2<T> c;
+    if constexpr (sizeof(T) == 2) { c.a = *reinterpret_cast<const uint4*>(p); }
+    else { c.a = *reinterpret_cast<const uint4*>(p); c.b = *reinterpret_cast<const uint4*>(p + 4); }
+    return c;
+}
+// row pitch: 8 chunks.  bf16: 128 B rows, swizzled.  fp32 (parity mode): 256 B rows, linear.
+template <typename T> __device__ __forceinline__ int lds_off2(int row, int chunk) {
+    if constexpr (sizeof(T) == 2) return row * 128 + ((chunk ^ (row & 7)) << 4);
+    else return row * 256 + (chunk << 5);
+}
+template <typename T> __device__ __forceinline__ void lds_st2(char* base, int row, int chunk, const Chunk2<T>& c) {
+    char* p = base + lds_off2<T>(row, chunk);
+    if constexpr (sizeof(T) == 2) { *reinterpret_cast<uint4*>(p) = c.a; }
+    else { *reinterpret_cast<uint4*>(p) = c.a; *reinterpret_cast<uint4*>(p + 16) = c.b; }
+}
+template <typename T> __device__ __forceinline__ Chunk2<T> lds_ld2(const char* base, int row, int chunk) {
+    const char* p = base + lds_off2<T>(row, chunk);
+    Chunk2<T> c;
+    if constexpr (sizeof(T) == 2) { c.a = *reinterpret_cast<const uint4*>(p); }
+    else { c.a = *reinterpret_cast<const uint4*>(p); c.b = *reinterpret_cast<const uint4*>(p + 16); }
+    return c;
+}
+template <typename T> __device__ __forceinline__ f32x4 mma2(const Chunk2<T>& wf, const Chunk2<T>& xf, f32x4 acc) {
+    if constexpr (sizeof(T) == 2) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf.a), __builtin_bit_cast(bf16x8_t, xf.a), acc, 0, 0, 0);
+    } else {
+        const float* a = reinterpret_cast<const float*>(&wf);
+        const float* b = reinterpret_cast<const float*>(&xf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+        return acc;
+    }
+}
+
+// WM x WN waves (WM*WN == 4); each wave owns MT 16-pixel tiles x NT 16-channel tiles.
+template <typename T, int WM, int WN, int MT, int NT, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int ROWB = BK2 * sizeof(T);
+    constexpr int AROWS = (BM + 31) / 32, BROWS = (BN + 31) / 32;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 stages; the stats scratch aliases stage 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T* __restrict__ src = static_cast<const T*>(p.src);
+    const T* __restrict__ wt = static_cast<const T*>(p.wt);
+
+    const int ca = tid & 7, rbase = tid >> 3;
+    // Per staged pixel row: element offset of its (tap 0, channel 0) source element and a 9-bit mask of the taps
+    // whose source pixel exists.  For the forward gather (any stride) and the stride-1 dgrad gather the source
+    // offset is row_const + tap_const, so a K-step costs one bit test and one add per 16-byte load instead of
+    // re-deriving coordinates (the first version spent ~12 VALU instructions per MFMA on that).
+    constexpr bool LINEAR = true;
+    const bool lin = (MODE == 0) || (p.stride == 1);
+    long long a_off[AROWS];
+    unsigned a_mask[AROWS];
+    int a_h0[AROWS], a_w0[AROWS], a_base[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        int row = rbase + 32 * i;
+        int pix = m0 + row;
+        a_off[i] = 0; a_mask[i] = 0; a_h0[i] = 0; a_w0[i] = 0; a_base[i] = -1;
+        if (row < BM && pix < p.M) {
+            int wd = pix % p.Wd;
+            int t = pix / p.Wd;
+            int hd = t % p.Hd;
+            int n = t / p.Hd;
+            a_base[i] = n * p.Hs * p.Ws;
+            int h0, w0, dir;
+            if (MODE == 0) { h0 = hd * p.stride - p.pad; w0 = wd * p.stride - p.pad; dir = 1; }
+            else { h0 = hd + p.pad; w0 = wd + p.pad; dir = -1; }
+            a_h0[i] = h0; a_w0[i] = w0;
+            if (lin) {
+                a_off[i] = ((long long)a_base[i] + (long long)h0 * p.Ws + w0) * p.Cs;
+                unsigned m = 0;
+                for (int r = 0; r < p.ksize; ++r)
+                    for (int s2 = 0; s2 < p.ksize; ++s2) {
+                        int hs = h0 + dir * r, ws = w0 + dir * s2;
+                        if ((unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws) m |= 1u << (r * p.ksize + s2);
+                    }
+                a_mask[i] = m;
+            }
+        }
+    }
+    (void)LINEAR;
+    long long b_off[BROWS];
+    bool b_ok[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        int row = rbase + 32 * i;
+        int o = n0 + row;
+        b_ok[i] = row < BN && o < p.Cd;
+        b_off[i] = (long long)o * p.K;
+    }
+    Chunk2<T> ra[AROWS], rb[BROWS];
+    auto gload = [&](int kstep) {
+        const int kk = kstep * BK2 + ca * 8;
+        const bool kvalid = kk < p.K;
+        const int tap = kk >> p.log2Cs;
+        const int cs = kk & (p.Cs - 1);
+        const int r = (p.ksize == 3) ? tap / 3 : 0;
+        const int s = (p.ksize == 3) ? tap - 3 * r : 0;
+        if (lin) {
+            const int dir = (MODE == 0) ? 1 : -1;
+            const long long toff = (long long)dir * (r * p.Ws + s) * p.Cs + cs;     // thread-uniform for this K-step
+            const unsigned bit = kvalid ? (1u << tap) : 0u;
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) ra[i] = (a_mask[i] & bit) ? gload2<T>(src + (a_off[i] + toff)) : zero2<T>();
+        } else {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                bool ok = kvalid && a_base[i] >= 0;
+                int th = a_h0[i] - r, tw = a_w0[i] - s;
+                ok = ok && th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0);
+                int hs = th / p.stride, ws = tw / p.stride;
+                ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+                ra[i] = ok ? gload2<T>(src + ((size_t)(a_base[i] + hs * p.Ws + ws) * p.Cs + cs)) : zero2<T>();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) rb[i] = (b_ok[i] && kvalid) ? gload2<T>(wt + (b_off[i] + kk)) : zero2<T>();
+    };
+    auto sstore = [&](int stage) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            int row = rbase + 32 * i;
+            if (row < BM) lds_st2<T>(As, row, ca, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int row = rbase + 32 * i;
+            if (row < BN) lds_st2<T>(Bs, row, ca, rb[i]);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK2 - 1) / BK2;
+    const int fr = lane & 15, fg = lane >> 4;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        const bool more = k + 1 < nk;
+        if (more) gload(k + 1);
+        const char* As = smem + (k & 1) * STAGE;
+        const char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Chunk2<T> xf[MT], wf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[i] = lds_ld2<T>(As, (wm * MT + i) * 16 + fr, ks * 4 + fg);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = lds_ld2<T>(Bs, (wn * NT + j) * 16 + fr, ks * 4 + fg);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mma2<T>(wf[j], xf[i], acc[i][j]);
+        }
+        if (more) sstore((k + 1) & 1);
+        __syncthreads();
+    }
+
+    T* __restrict__ dst = static_cast<T*>(p.dst);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = m0 + (wm * MT + i) * 16 + fr;
+        if (pix < p.M) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int o = n0 + (wn * NT + j) * 16 + fg * 4;
+                if (o < p.Cd) {
+                    T* q = dst + (size_t)pix * p.Cd + o;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (p.accumulate) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(q + e);
+                    }
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 u;
+                        u.x = pack_bf16x2(v[0], v[1]);
+                        u.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(q) = u;
+                    } else {
+                        *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN]; all LDS reads of the K loop are behind the last barrier
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (fr == 0) {
+                    int c = (wn * NT + j) * 16 + fg * 4 + e;
+                    red[(wm * 2 + 0) * BN + c] = s1;
+                    red[(wm * 2 + 1) * BN + c] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += 256) {
+            int which = idx / BN, c = idx - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
+            if (n0 + c < p.Cd) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + c] = t;
+        }
+    }
+}
+
+struct TileCfg { int bm, bn; };
+
+// candidate shapes, largest pixel tile first for each channel width
+TileCfg pick_tile(int M, int Cd) {
+    int bn = Cd >= 128 ? 128 : (Cd >= 64 ? 64 : (Cd >= 32 ? 32 : 16));
+    int gy = (Cd + bn - 1) / bn;
+    int cands128[2] = {128, 64};
+    int cands[3] = {256, 128, 64};
+    const int* c = bn == 128 ? cands128 : cands;
+    int n = bn == 128 ? 2 : 3;
+    for (int i = 0; i < n; ++i) {
+        int64_t wgs = (int64_t)((M + c[i] - 1) / c[i]) * gy;
+        if (wgs >= 512 || i == n - 1) return TileCfg{c[i], bn};
+    }
+    return TileCfg{64, bn};
+}
+
+template <typename T, int WM, int WN, int MT, int NT, int MODE>
+int launch_cfg(const ConvParams2& p, hipStream_t st) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * BK2 * sizeof(T);
+    static bool attr_set = false;
+    auto kern = conv_igemm2_kernel<T, WM, WN, MT, NT, MODE>;
+    if (!attr_set && lds > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.Cd + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+template <typename T, int MODE>
+int launch2(const ConvParams2& p, hipStream_t st) {
+    TileCfg t = pick_tile(p.M, p.Cd);
+    // <WM, WN, MT, NT>
+    if (t.bn == 128) {
+        if (t.bm == 128) return launch_cfg<T, 2, 2, 4, 4, MODE>(p, st);
+        return launch_cfg<T, 1, 4, 4, 2, MODE>(p, st);                   // 64 x 128
+    }
+    if (t.bn == 64) {
+        if (t.bm == 256) return launch_cfg<T, 4, 1, 4, 4, MODE>(p, st);
+        if (t.bm == 128) return launch_cfg<T, 4, 1, 2, 4, MODE>(p, st);
+        return launch_cfg<T, 4, 1, 1, 4, MODE>(p, st);
+    }
+    if (t.bn == 32) {
+        if (t.bm == 256) return launch_cfg<T, 4, 1, 4, 2, MODE>(p, st);
+        if (t.bm == 128) return launch_cfg<T, 4, 1, 2, 2, MODE>(p, st);
+        return launch_cfg<T, 4, 1, 1, 2, MODE>(p, st);
+    }
+    if (t.bm == 256) return launch_cfg<T, 4, 1, 4, 1, MODE>(p, st);
+    if (t.bm == 128) return launch_cfg<T, 4, 1, 2, 1, MODE>(p, st);
+    return launch_cfg<T, 4, 1, 1, 1, MODE>(p, st);
+}
+
+}  // namespace
+
+// entry points used by conv.hip's C ABI functions
+int clhip_conv2_tiles_m(int M, int Cd) { return (M + pick_tile(M, Cd).bm - 1) / pick_tile(M, Cd).bm; }
+
+int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                       int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st) {
+    ConvParams2 p;
+    p.src = src; p.wt = wt; p.dst = dst; p.stats = stats;
+    p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.log2Cs = ilog2_exact(Cs); p.Hd = Hd; p.Wd = Wd; p.Cd = Cd;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
+    p.M = N * Hd * Wd; p.K = ksize * ksize * Cs;
+    if (dtype == CLHIP_BF16) return mode == 0 ? launch2<bf16_t, 0>(p, st) : launch2<bf16_t, 1>(p, st);
+    return mode == 0 ? launch2<float, 0>(p, st) : launch2<float, 1>(p, st);
+}
+
+// =============================================================================================== wgrad v2
+// dw[o][tap][c] += sum_p dz[p][o] * x[p @ tap][c].   GEMM with the PIXEL axis as reduction: both operands
+// are stored pixel-major ([pixel][channel], as they sit in HBM), and the MFMA wants 8 consecutive
+// reduction elements per lane -> fragments are read with the gfx950 LDS transpose read
+// (ds_read_b64_tr_b16).  Workgroup tile BO out-channels x 128 (tap,c) columns, 64 pixels per K-step,
+// double-buffered LDS, split over the pixel axis (grid.z) with fp32 atomics into the gradient buffer.
+namespace {
+
+struct WgradParams2 {
+    const void* x; const void* dz; float* dw;
+    int N, H, W, C, log2C, Creal, Ho, Wo, lgHo, lgWo, K, ksize, stride, pad;
+    int M, J, pix_per_split, debug;
+};
+
+template <typename T>
+__device__ __forceinline__ Chunk2<T> lds_ld_tr(const char* tile, int pitch, int pix0, int col0, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    Chunk2<T> c;
+    if constexpr (sizeof(T) == 2) {
+        const char* a0 = tile + (pix0 + fg * 8 + (fr >> 2)) * pitch + (col0 + (fr & 3) * 4) * 2;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+        uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+        c.a = make_uint4(l.x, l.y, h.x, h.y);
+    } else {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(tile + (pix0 + fg * 8 + j) * pitch + (col0 + fr) * 4);
+        c.a = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+        c.b = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+    }
+    return c;
+}
+
+// WO x WJ waves; each wave MT out-channel tiles x NT column tiles.  BJ = WJ*NT*16 must be 128.
+template <typename T, int WO, int WJ, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradParams2 p) {
+    constexpr int BO = WO * MT * 16, BJ = WJ * NT * 16;
+    static_assert(BJ == 128, "column tile is 128");
+    constexpr int ZPITCH = BO * sizeof(T), XPITCH = BJ * sizeof(T);
+    constexpr int STAGE = 64 * (ZPITCH + XPITCH);
+    constexpr int ZCPR = BO / 8;                  // chunks per Z row
+    constexpr int ZRPP = 256 / ZCPR;              // Z rows per pass
+    constexpr int ZPASS = (64 + ZRPP - 1) / ZRPP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo_ = wave / WJ, wj = wave % WJ;
+    const int j0 = blockIdx.x * BJ, o0 = blockIdx.y * BO;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.M, pbeg + p.pix_per_split);
+    const T* __restrict__ x = static_cast<const T*>(p.x);
+    const T* __restrict__ dz = static_cast<const T*>(p.dz);
+
+    // X staging: chunk column fixed per thread -> (tap, c) fixed
+    const int cj = tid & 15, xrow = tid >> 4;
+    const int jx = j0 + cj * 8;
+    const bool jvalid = jx < p.J;
+    const int tap = jx >> p.log2C;
+    const int cx = jx & (p.C - 1);
+    const int r = (p.ksize == 3) ? tap / 3 : 0;
+    const int s = (p.ksize == 3) ? tap - 3 * r : 0;
+    const int cz = tid % ZCPR, zrow = tid / ZCPR;
+    const bool ovalid = (o0 + cz * 8) < p.K;
+
+    Chunk2<T> rx[4], rz[ZPASS];
+    auto gload = [&](int pb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int pix = pb + xrow + 16 * i;
+            bool ok = jvalid && pix < pend;
+            size_t off = 0;
+            if (ok) {
+                int wo, ho, n;
+                if (p.lgWo >= 0 && p.lgHo >= 0) { wo = pix & (p.Wo - 1); int t = pix >> p.lgWo; ho = t & (p.Ho - 1); n = t >> p.lgHo; }
+                else { wo = pix % p.Wo; int t = pix / p.Wo; ho = t % p.Ho; n = t / p.Ho; }
+                int hs = ho * p.stride - p.pad + r, ws = wo * p.stride - p.pad + s;
+                ok = (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+                off = ((size_t)(n * p.H + hs) * p.W + ws) * p.C + cx;
+            }
+            rx[i] = ok ? gload2<T>(x + off) : zero2<T>();
+        }
+#pragma unroll
+        for (int i = 0; i < ZPASS; ++i) {
+            int row = zrow + ZRPP * i;
+            int pix = pb + row;
+            rz[i] = (row < 64 && pix < pend && ovalid) ? gload2<T>(dz + ((size_t)pix * p.K + o0 + cz * 8)) : zero2<T>();
+        }
+    };
+    auto sstore = [&](int stage) {
+        char* Zs = smem + stage * STAGE;
+        char* Xs = Zs + 64 * ZPITCH;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char* q = Xs + (xrow + 16 * i) * XPITCH + cj * 8 * sizeof(T);
+            if constexpr (sizeof(T) == 2) { *reinterpret_cast<uint4*>(q) = rx[i].a; }
+            else { *reinterpret_cast<uint4*>(q) = rx[i].a; *reinterpret_cast<uint4*>(q + 16) = rx[i].b; }
+        }
+#pragma unroll
+        for (int i = 0; i < ZPASS; ++i) {
+            int row = zrow + ZRPP * i;
+            if (row < 64) {
+                char* q = Zs + row * ZPITCH + cz * 8 * sizeof(T);
+                if constexpr (sizeof(T) == 2) { *reinterpret_cast<uint4*>(q) = rz[i].a; }
+                else { *reinterpret_cast<uint4*>(q) = rz[i].a; *reinterpret_cast<uint4*>(q + 16) = rz[i].b; }
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (pbeg < pend) {
+        gload(pbeg);
+        sstore(0);
+        __syncthreads();
+        int st = 0;
+        for (int pb = pbeg; pb < pend; pb += 64, st ^= 1) {
+            const bool more = pb + 64 < pend;
+            if (more) gload(pb + 64);
+            const char* Zs = smem + st * STAGE;
+            const char* Xs = Zs + 64 * ZPITCH;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Chunk2<T> zf[MT], xf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) zf[i] = lds_ld_tr<T>(Zs, ZPITCH, ks * 32, (wo_ * MT + i) * 16, lane);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) xf[j] = lds_ld_tr<T>(Xs, XPITCH, ks * 32, (wj * NT + j) * 16, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) if (!(p.debug & 2)) acc[i][j] = mma2<T>(zf[i], xf[j], acc[i][j]);
+            }
+            if (more) sstore(st ^ 1);
+            __syncthreads();
+        }
+    }
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int taps = p.ksize * p.ksize;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int jj = j0 + (wj * NT + j) * 16 + fr;
+        if (jj >= p.J) continue;
+        int tp = jj >> p.log2C, c = jj & (p.C - 1);
+        if (c >= p.Creal) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int o = o0 + (wo_ * MT + i) * 16 + fg * 4 + e;
+                if (o < p.K && !(p.debug & 8)) atomicAdd(p.dw + ((size_t)o * taps + tp) * p.Creal + c, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+template <typename T, int WO, int WJ, int MT, int NT>
+int launch_wgrad_cfg(WgradParams2& p, hipStream_t st) {
+    constexpr int BO = WO * MT * 16, BJ = 128;
+    constexpr size_t lds = 2 * 64 * (size_t)(BO + BJ) * sizeof(T);
+    static bool attr_set = false;
+    auto kern = conv_wgrad2_kernel<T, WO, WJ, MT, NT>;
+    if (!attr_set && lds > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    int gx = (p.J + BJ - 1) / BJ, gy = (p.K + BO - 1) / BO;
+    int tiles = gx * gy;
+    int max_splits = (p.M + 255) / 256;            // >= 4 K-steps per workgroup
+    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 1536;
+    static const int dbg = getenv("CLHIP_WGRAD_DEBUG") ? atoi(getenv("CLHIP_WGRAD_DEBUG")) : 0;
+    p.debug = dbg;
+    int splits = (target + tiles - 1) / tiles;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int pps = (p.M + splits - 1) / splits;
+    pps = (pps + 63) / 64 * 64;
+    splits = (p.M + pps - 1) / pps;
+    p.pix_per_split = pps;
+    hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+template <typename T>
+int launch_wgrad2(WgradParams2& p, hipStream_t st) {
+    if (p.K >= 128) return launch_wgrad_cfg<T, 2, 2, 4, 4>(p, st);     // 128 x 128
+    if (p.K >= 64) return launch_wgrad_cfg<T, 1, 4, 4, 2>(p, st);      //  64 x 128
+    if (p.K >= 32) return launch_wgrad_cfg<T, 1, 4, 2, 2>(p, st);      //  32 x 128
+    return launch_wgrad_cfg<T, 1, 4, 1, 2>(p, st);                     //  16 x 128
+}
+
+}  // namespace
+
+int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
+                        int pad, int dtype, hipStream_t st) {
+    WgradParams2 p;
+    p.x = x; p.dz = dz; p.dw = dw;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.log2C = ilog2_exact(C); p.Creal = Creal;
+    p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
+    p.lgHo = ilog2_exact(p.Ho); p.lgWo = ilog2_exact(p.Wo);
+    p.K = K; p.ksize = ksize; p.stride = stride; p.pad = pad;
+    p.M = N * p.Ho * p.Wo; p.J = ksize * ksize * C;
+    if (dtype == CLHIP_BF16) return launch_wgrad2<bf16_t>(p, st);
+    return launch_wgrad2<float>(p, st);
+}

@@ -1,0 +1,560 @@
+// conv3.hip -- "halo" convolution for 3x3 / stride 1 / pad 1 layers (forward and dgrad), bf16, gfx950.
+//
+// Why: the PMC passes on the generic implicit-GEMM kernel (profiles/r01_pmc_conv2_*.txt) show it is bound by
+// the global->LDS path (~37 GB/s per CU, L2 hit rate 85 %): every one of the 9 filter taps re-gathers the same
+// input pixels, so a 256x64 tile moves 40 KB per 2.1 MFLOP (51 FLOP/B).  MI355X has 160 KB of LDS per CU, enough
+// to keep the whole input patch of a tile resident: here a workgroup loads the patch
+//     pixels [m0 - W - 1, m0 + BM + W + 1) x 64 channels            (one contiguous, fully coalesced range)
+// ONCE per 64-channel chunk and all 9 taps read their MFMA operand from it at a shifted LDS address
+// (q = p + (W+1) + dh*W + dw); out-of-image taps are zeroed per lane with a precomputed 9-bit mask, so no
+// padding is materialised and tiles may span image boundaries.  Only the weights of the current tap
+// (BN x 64, 8-16 KB) are streamed per step.  Bytes moved per FLOP drop ~3x (165-205 FLOP/B).
+//
+// Orientation, MFMA shape, swizzle, epilogue (bf16 store + BatchNorm partial statistics) as in conv2.hip.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct Conv3Params {
+    const bf16_t* src;   // [N,H,W,Cs]   (forward: x ; dgrad: dz)
+    const bf16_t* wt;    // [Cd][9][Cs]
+    bf16_t* dst;         // [N,H,W,Cd]
+    float* stats;
+    int N, H, W, Cs, Cd, accumulate;
+    int M;               // N*H*W
+    int np;              // patch pixels = BM + 2W + 2
+    int patch_bytes;     // np*128 rounded up to 256
+    int nbuf;            // patch buffers (2 when Cs > 64)
+    int debug;           // perf experiments only (CLHIP_CONV3_DEBUG): 1 = skip weight streaming, 2 = skip MFMA
+};
+
+__device__ __forceinline__ uint4 ldsq(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// LDS rows are 64 bf16 (128 B) padded to a 160-byte pitch.  With 36+4 dwords per row the three lane
+// sub-groups a ds_read_b128 is serviced in ({0-3,12-15} at chunk c, {20-27} at chunk c+1) land on 16 distinct
+// 16-byte slots for ANY starting row, so tap-shifted reads need no per-read swizzle arithmetic: the address of
+// a fragment is  base + shift*160  (one add per fragment per tap).  The kernel is instruction-issue bound
+// (a wave issues at most one instruction every ~4 cycles; profiles/r01_pmc_conv3_*.txt), so every VALU
+// instruction removed from the tap loop is worth ~1/8 of an MFMA.
+constexpr int PITCH = 160;
+
+// WM x WN waves, each wave 64 pixels x 64 channels.  MODE 0 forward (dh = r-1), MODE 1 dgrad (dh = 1-r).
+template <int WM, int WN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
+    constexpr int BM = WM * 64, BN = WN * 64, NTH = WM * WN * 64;
+    constexpr int WROWS = (BN * 8 + NTH - 1) / NTH;           // weight chunks per thread per tap
+    constexpr int PMAX = ((BM + 66) * 8 + NTH - 1) / NTH;     // patch chunks per thread (W <= 32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch0 = smem;                                      // np rows + 1 zero row
+    char* wst0 = smem + p.patch_bytes;                        // 2 weight stages of BN rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int W = p.W, H = p.H, Cs = p.Cs, K = 9 * Cs;
+    const int nchunk = Cs >> 6;
+    const int halo = W + 1;
+
+    // ---- per-lane tap masks and LDS base addresses of the 4 pixel fragments of this wave
+    unsigned tmask[4];
+    int xaddr[4];
+    const int zaddr = p.np * PITCH + fg * 16;               // zero row: out-of-image taps read from here
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = wm * 64 + i * 16 + fr;               // tile-relative output pixel
+        const int g = m0 + pl;
+        unsigned m = 0;
+        if (g < p.M) {
+            const int w = g % W, h = (g / W) % H;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t - 3 * r;
+                const int dh = MODE == 0 ? r - 1 : 1 - r, dw = MODE == 0 ? s - 1 : 1 - s;
+                if ((unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) m |= 1u << t;
+            }
+        }
+        tmask[i] = m;
+        xaddr[i] = (pl + halo) * PITCH + fg * 16;
+    }
+    int waddr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) waddr[j] = (wn * 64 + j * 16 + fr) * PITCH + fg * 16;
+
+    // ---- staging (register-parked global loads -> LDS)
+    uint4 pw[WROWS];
+    const bf16_t* wsrc[WROWS];
+    int wdst[WROWS];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+        const int idx = tid + i * NTH;
+        const int row = idx >> 3, ch = idx & 7;
+        const int o = n0 + row;
+        wsrc[i] = (row < BN && o < p.Cd) ? p.wt + ((size_t)o * K + ch * 8) : nullptr;
+        wdst[i] = row < BN ? row * PITCH + ch * 16 : -1;
+    }
+    auto wload = [&](int koff) {     // koff = tap*Cs + c*64
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) pw[i] = wsrc[i] ? *reinterpret_cast<const uint4*>(wsrc[i] + koff) : make_uint4(0, 0, 0, 0);
+    };
+    auto wstore = [&](int stage) {
+        char* ws = wst0 + stage * (BN * PITCH);
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i)
+            if (wdst[i] >= 0) *reinterpret_cast<uint4*>(ws + wdst[i]) = pw[i];
+    };
+    uint4 pp[PMAX];
+    const int np8 = p.np * 8;
+    auto pload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int idx = tid + i * NTH;
+            const int q = idx >> 3, ch = idx & 7;
+            const long long g = (long long)m0 - halo + q;
+            pp[i] = (idx < np8 && g >= 0 && g < p.M && !(p.debug & 4)) ? *reinterpret_cast<const uint4*>(p.src + ((size_t)g * Cs + c * 64 + ch * 8))
+                                                                        : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto pstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int idx = tid + i * NTH;
+            const int q = idx >> 3, ch = idx & 7;
+            if (idx < np8) *reinterpret_cast<uint4*>(patch0 + q * PITCH + ch * 16) = pp[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: zero row, patch of chunk 0, weights of (chunk 0, tap 0)
+    if (tid < 10) *reinterpret_cast<uint4*>(patch0 + p.np * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);
+    pload(0);
+    wload(0);
+    pstore();
+    wstore(0);
+    __syncthreads();
+
+    int step = 0;
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            const bool last = (c == nchunk - 1) && (tap == 8);
+            if (!last && !(p.debug & 1)) wload(tap == 8 ? (c + 1) * 64 : (tap + 1) * Cs + c * 64);
+            if (tap == 5 && c + 1 < nchunk) pload(c + 1);
+            const char* ws = wst0 + (step & 1) * (BN * PITCH);
+            constexpr int R = 0;
+            (void)R;
+            const int r = tap / 3, s = tap - 3 * r;
+            const int shift = (MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s)) * PITCH;
+            int xa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[i] = (tmask[i] & (1u << tap)) ? xaddr[i] + shift : zaddr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xf[4], wf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = ldsq(patch0 + xa[i] + ks * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = ldsq(ws + waddr[j] + ks * 64);
+                if (!(p.debug & 2))
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]),
+                                                                           __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+            }
+            if (tap == 8 && c + 1 < nchunk) {
+                __syncthreads();                    // every wave is done with this chunk's patch
+                pstore();
+            }
+            if (!last && !(p.debug & 1)) wstore((step + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue.  Accumulators hold D[row = channel fg*4+e][col = pixel fr]; they are staged through LDS as a
+    //      [BM pixels][BN channels] bf16 image so that the global stores are full 16-byte-per-lane row segments.
+    {
+        char* ot = smem;
+        constexpr int OPITCH = BN * 2 + 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pl = wm * 64 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = wn * 64 + j * 16 + fg * 4;
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (p.accumulate) {                          // dx += result: add in fp32, round once
+                    const int pix = m0 + pl, o = n0 + cl;
+                    if (pix < p.M && o < p.Cd) {
+                        const uint2 old = *reinterpret_cast<const uint2*>(p.dst + (size_t)pix * p.Cd + o);
+                        v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+                        v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+                    }
+                }
+                uint2 u;
+                u.x = pack_bf16x2(v0, v1);
+                u.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(ot + pl * OPITCH + cl * 2) = u;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;                        // 16-byte chunks per pixel row of the tile
+        for (int idx = tid; idx < BM * CPR; idx += NTH) {
+            const int pl = idx / CPR, ch = idx - pl * CPR;
+            const int pix = m0 + pl, o = n0 + ch * 8;
+            if (pix < p.M && o < p.Cd && !(p.debug & 8))
+                *reinterpret_cast<uint4*>(p.dst + (size_t)pix * p.Cd + o) = *reinterpret_cast<const uint4*>(ot + pl * OPITCH + ch * 16);
+        }
+        __syncthreads();
+    }
+    if (p.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);        // [WM][2][BN]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (fr == 0) {
+                    const int cc = wn * 64 + j * 16 + fg * 4 + e;
+                    red[(wm * 2 + 0) * BN + cc] = s1;
+                    red[(wm * 2 + 1) * BN + cc] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += NTH) {
+            const int which = idx / BN, cc = idx - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) t += red[(w2 * 2 + which) * BN + cc];
+            if (n0 + cc < p.Cd) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + cc] = t;
+        }
+    }
+}
+
+template <int WM, int WN, int MODE>
+int launch3(Conv3Params& p, hipStream_t st) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    p.np = BM + 2 * p.W + 2;
+    p.patch_bytes = ((p.np + 1) * PITCH + 255) / 256 * 256;       // + the zero row
+    p.nbuf = 1;
+    size_t lds = (size_t)p.patch_bytes + 2 * (size_t)BN * PITCH;
+    size_t olds = (size_t)BM * (BN * 2 + 16);
+    if (olds > lds) lds = olds;
+    auto kern = conv3_kernel<WM, WN, MODE>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            clhip_set_error("conv3: cannot reserve %zu bytes of LDS", lds);
+            return CLHIP_EHIP;
+        }
+        attr_lds = lds;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.Cd + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+struct Cfg3 { int wm, wn; };
+Cfg3 pick3(int M, int Cd) {
+    // 4-wave workgroups of ~57 KB LDS: two of them share a CU, so one workgroup's patch load / output store
+    // overlaps the other's MFMA phase (a single 8-wave workgroup per CU ran load -> compute -> store serially).
+    if (Cd < 128) {
+        if ((int64_t)(M + 255) / 256 >= 384) return Cfg3{4, 1};
+        return Cfg3{2, 1};
+    }
+    int gy = (Cd + 127) / 128;
+    if ((int64_t)((M + 127) / 128) * gy >= 384) return Cfg3{2, 2};
+    return Cfg3{1, 2};
+}
+
+}  // namespace
+
+bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
+    return dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && (Cs % 64) == 0 && (Cd % 64) == 0 && W <= 32 && W >= 2 && H >= 1;
+}
+
+int clhip_conv3_tiles_m(int M, int Cd) { return (M + pick3(M, Cd).wm * 64 - 1) / (pick3(M, Cd).wm * 64); }
+
+int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, int N, int H, int W, int Cs, int Cd, int accumulate,
+                       int mode, hipStream_t st) {
+    Conv3Params p;
+    p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
+    p.stats = stats; p.N = N; p.H = H; p.W = W; p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;
+    static const int dbg = getenv("CLHIP_CONV3_DEBUG") ? atoi(getenv("CLHIP_CONV3_DEBUG")) : 0;
+    p.debug = dbg;
+    Cfg3 c = pick3(p.M, Cd);
+#define L3(a, b) (mode == 0 ? launch3<a, b, 0>(p, st) : launch3<a, b, 1>(p, st))
+    if (c.wn == 1) {
+        if (c.wm == 8) return L3(8, 1);
+        if (c.wm == 4) return L3(4, 1);
+        return L3(2, 1);
+    }
+    if (c.wm == 4) return L3(4, 2);
+    if (c.wm == 2) return L3(2, 2);
+    return L3(1, 2);
+#undef L3
+}
+
+// =============================================================================================== wgrad3
+// dw[o][tap][c] += sum_p dz[p][o] * x[p @ tap][c] for 3x3 / stride 1 / pad 1 layers.
+//
+// The first two generations spent their time outside the matrix pipe (profiles/r01_wgrad_ablation.txt: 61 of
+// 112 us with the MFMAs removed, 46 us in fp32 atomics).  This version is built around three MI355X facts:
+//  * LDS is big enough to hold a zero-PADDED copy of the input rows a 64-pixel step touches
+//    ((R+2) x (W+2) pixels x 64 channels), so all 9 taps read the same resident patch at a constant address
+//    offset (dh*(W+2)+dw) and image borders need no masking at all;
+//  * ds_read_b64_tr_b16 delivers the pixel-major tiles transposed, i.e. directly as MFMA operands whose
+//    reduction index is the pixel;
+//  * one workgroup owns a 64(out) x 64(in) x 9(tap) block of dW in 72 accumulator tiles (8 waves x 18) and
+//    walks a long pixel range, so the fp32 atomics at the end are amortised over >= 16 steps
+//    (grid = ~1 workgroup per CU instead of ~6 short ones).
+namespace {
+
+struct Wgrad3Params {
+    const bf16_t* x;    // [N,H,W,C]
+    const bf16_t* dz;   // [N,H,W,K]
+    float* dw;          // [K][9][Creal]
+    float* slab;        // [splits][K][9][C] fp32 partials (deterministic path) or nullptr (atomics into dw)
+    int N, H, W, C, Creal, K, M;
+    int R, nimg;        // a 64-pixel step = nimg images x R rows x W cols
+    int steps_per_split;
+    int npatch;         // nimg*(R+2)*(W+2)
+};
+
+constexpr int P3 = 144;      // LDS pitch of a 64-channel (128 B) row: 4 consecutive rows fall in disjoint bank ranges
+
+// two transposing 8-byte reads -> 8 reduction elements; `second` = byte distance of reduction elements k+4..k+7
+__device__ __forceinline__ uint4 tr8(const char* base, int addr, int second) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr + second));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int oh = wave >> 2, ct = wave & 3;            // wave -> (32-row half of the out-channel tile, 16-channel column)
+    const int fr = lane & 15, fg = lane >> 4;
+    const int c0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const int W = p.W, H = p.H, PW = W + 2, R = p.R;
+    const int zbytes = 64 * P3, xbytes = p.npatch * P3;
+    const int stage_bytes = (zbytes + xbytes + 255) / 256 * 256;
+    const int s_beg = blockIdx.z * p.steps_per_split;
+    const int total_steps = (p.M + 63) / 64;
+    const int s_end = min(total_steps, s_beg + p.steps_per_split);
+
+    // ---- fragment addresses.  Reduction element k of a step is pixel (img, row, col) = (k/(R*W), (k%(R*W))/W, k%W).
+    //      Lane (fr, fg) feeds k = ks*32 + fg*8 + {0..7}; a transposing read fetches 4 consecutive k (same image row).
+    int zaddr[2], xaddr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int k = ks * 32 + fg * 8 + (fr >> 2);
+        zaddr[ks] = k * P3 + (oh * 32 + (fr & 3) * 4) * 2;
+        const int img = k / (R * W), rem = k - img * (R * W), rr = rem / W, cc = rem - rr * W;
+        // NB the "+4" second read of tr8 addresses pixel k+4: same row, 4 columns further -> +4 patch pixels
+        xaddr[ks] = ((img * (R + 2) + rr + 1) * PW + cc + 1) * P3 + (ct * 16 + (fr & 3) * 4) * 2;
+    }
+
+    // pixels k+4..k+7 sit 4 columns further in the same patch row, except for 4-pixel-wide images (next row)
+    const int xsecond = (W >= 8 ? 4 : PW) * P3;
+
+    // ---- staging assignments (fixed per thread)
+    // dz tile: 64 pixels x 8 chunks = 512 chunks -> one per thread
+    const int zk = tid >> 3, zch = tid & 7;
+    // patch: npatch pixels x 8 chunks, up to 3 per thread
+    int pp_pix[3], pp_img[3], pp_row[3], pp_col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int idx = tid + i * 512;
+        const int pix = idx >> 3;
+        pp_pix[i] = pix < p.npatch ? pix : -1;
+        const int per = (R + 2) * PW;
+        const int img = pix / per, rem = pix - img * per;
+        pp_img[i] = img; pp_row[i] = rem / PW - 1; pp_col[i] = rem % PW - 1;
+    }
+    const int pch = tid & 7;
+    uint4 rz, rx[3];
+    auto gload = [&](int s) {
+        const int p0 = s * 64;
+        const int pz = p0 + zk;
+        rz = pz < p.M ? *reinterpret_cast<const uint4*>(p.dz + ((size_t)pz * p.K + o0 + zch * 8)) : make_uint4(0, 0, 0, 0);
+        const int n0 = p0 / (W * H), h0 = (p0 / W) % H;       // first image / first row of this step
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bool ok = pp_pix[i] >= 0;
+            const int n = n0 + pp_img[i], h = h0 + pp_row[i], w = pp_col[i];
+            ok = ok && n < p.N && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            rx[i] = ok ? *reinterpret_cast<const uint4*>(p.x + (((size_t)n * H + h) * W + w) * p.C + c0 + pch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&](int stage) {
+        char* zs = smem + stage * stage_bytes;
+        char* xs = zs + zbytes;
+        *reinterpret_cast<uint4*>(zs + zk * P3 + zch * 16) = rz;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (pp_pix[i] >= 0) *reinterpret_cast<uint4*>(xs + pp_pix[i] * P3 + pch * 16) = rx[i];
+    };
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (s_beg < s_end) {
+        gload(s_beg);
+        sstore(0);
+        __syncthreads();
+        int st = 0;
+        for (int s = s_beg; s < s_end; ++s, st ^= 1) {
+            const bool more = s + 1 < s_end;
+            if (more) gload(s + 1);
+            const char* zs = smem + st * stage_bytes;
+            const char* xs = zs + zbytes;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 zf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) zf[i] = tr8(zs, zaddr[ks] + i * 32, 4 * P3);      // out-channel tiles oh*32 + i*16
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int r = t / 3, sx = t - 3 * r;
+                    const uint4 xf = tr8(xs, xaddr[ks] + ((r - 1) * PW + (sx - 1)) * P3, xsecond);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf[i]),
+                                                                           __builtin_bit_cast(bf16x8_t, xf), acc[i][t], 0, 0, 0);
+                }
+            }
+            if (more) sstore(st ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // D[row = out channel fg*4+e][col = in channel fr]
+    const int c = c0 + ct * 16 + fr;
+    if (p.slab != nullptr) {
+        // deterministic path: plain stores of this split's partial block; wgrad3_reduce_kernel sums the splits
+        float* out = p.slab + (size_t)blockIdx.z * p.K * 9 * p.C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = o0 + oh * 32 + i * 16 + fg * 4 + e;
+                    out[((size_t)o * 9 + t) * p.C + c] = acc[i][t][e];
+                }
+    } else if (c < p.Creal) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = o0 + oh * 32 + i * 16 + fg * 4 + e;
+                    if (o < p.K) atomicAdd(p.dw + ((size_t)o * 9 + t) * p.Creal + c, acc[i][t][e]);
+                }
+    }
+}
+
+// dw[i] += sum_s slab[s][i] in a fixed order (bitwise reproducible weight gradients).  blockIdx.y splits the
+// split range into 4 groups whose partial sums are combined through LDS, 8 independent loads in flight per lane.
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int splits) {
+    __shared__ float4 part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const int per = (splits + 3) / 4;
+        const int s0 = grp * per, s1 = min(splits, s0 + per);
+        const float4* base = reinterpret_cast<const float4*>(slab) + i;
+        int s = s0;
+        for (; s + 8 <= s1; s += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(s + u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; s < s1; ++s) { const float4 v = base[(size_t)s * n4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    }
+    part[grp][lane] = a;
+    __syncthreads();
+    if (grp == 0 && i < n4) {
+        float4 d = reinterpret_cast<const float4*>(dw)[i];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const float4 v = part[g][lane]; d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w; }
+        reinterpret_cast<float4*>(dw)[i] = d;
+    }
+}
+
+}  // namespace
+
+bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    if (!(dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C % 64 == 0 && K % 64 == 0 && Creal == C)) return false;
+    if (W < 4 || W > 32 || (W & 3)) return false;
+    int hw = H * W;
+    if (hw >= 64) return (64 % W == 0) && (H % (64 / W) == 0);
+    return 64 % hw == 0;
+}
+
+static void wgrad3_geometry(int N, int H, int W, int C, int K, Wgrad3Params& p, int& splits) {
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.M = N * H * W;
+    int hw = H * W;
+    if (hw >= 64) { p.nimg = 1; p.R = 64 / W; } else { p.nimg = 64 / hw; p.R = H; }
+    p.npatch = p.nimg * (p.R + 2) * (W + 2);
+    int tiles = (C / 64) * (K / 64);
+    int total_steps = (p.M + 63) / 64;
+    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 256;
+    splits = (target + tiles - 1) / tiles;
+    int max_splits = (total_steps + 7) / 8;              // >= 8 steps per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (total_steps + splits - 1) / splits;
+    splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
+}
+
+size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K) {
+    Wgrad3Params p; int splits;
+    wgrad3_geometry(N, H, W, C, K, p, splits);
+    return (size_t)splits * K * 9 * C * sizeof(float);
+}
+
+int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st) {
+    Wgrad3Params p; int splits;
+    wgrad3_geometry(N, H, W, C, K, p, splits);
+    p.x = static_cast<const bf16_t*>(x); p.dz = static_cast<const bf16_t*>(dz); p.dw = dw; p.slab = ws; p.Creal = Creal;
+    if (p.npatch > 192) { clhip_set_error("wgrad3: patch too large"); return CLHIP_EINVAL; }
+    size_t stage = ((size_t)64 * P3 + (size_t)p.npatch * P3 + 255) / 256 * 256;
+    size_t lds = 2 * stage;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(C / 64, K / 64, splits), dim3(512), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    if (ws != nullptr) {
+        int64_t n4 = (int64_t)K * 9 * C / 4;
+        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, ws, dw, n4, splits);
+        CLHIP_LAUNCH_CHECK();
+    }
+    return CLHIP_OK;
+}

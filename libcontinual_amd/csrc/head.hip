@@ -13,23 +13,33 @@
 namespace {
 
 // ------------------------------------------------------------------------------------- linear
-// one wave per batch row: x row cached in registers (D <= 64*16), loop over outputs
+// out[b][o] = x[b] . w[o] + bias[o]: one wave per (b, 4 outputs); the x row chunk is reused from registers
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ out, int B, int D, int O) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
-    float xr[16];
-    const int nd = (D + 63) / 64;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int og = (O + 3) / 4;
+    if (gw >= B * og) return;
+    const int row = gw / og, o0 = (gw - row * og) * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = lane * 4; d < D; d += 256) {
+        const int rem = D - d;
+        float xv[4];
+        if (rem >= 4) { float4 t = *reinterpret_cast<const float4*>(x + (size_t)row * D + d); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; }
+        else { for (int e = 0; e < 4; ++e) xv[e] = e < rem ? x[(size_t)row * D + d + e] : 0.f; }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xr[i] = (i < nd && i * 64 + lane < D) ? x[(size_t)row * D + i * 64 + lane] : 0.f;
-    for (int o = 0; o < O; ++o) {
-        float s = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            if (o0 + j < O) {
+                const float* wr = w + (size_t)(o0 + j) * D + d;
+                if (rem >= 4) { float4 t = *reinterpret_cast<const float4*>(wr); s[j] += xv[0] * t.x + xv[1] * t.y + xv[2] * t.z + xv[3] * t.w; }
+                else { for (int e = 0; e < rem; ++e) s[j] = fmaf(xv[e], wr[e], s[j]); }
+            }
+        }
+    }
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i < nd && i * 64 + lane < D) s = fmaf(xr[i], w[(size_t)o * D + i * 64 + lane], s);
-        s = wave_sum(s);
-        if (lane == 0) out[(size_t)row * O + o] = s + (b ? b[o] : 0.f);
+    for (int j = 0; j < 4; ++j) {
+        float t = wave_sum(s[j]);
+        if (lane == 0 && o0 + j < O) out[(size_t)row * O + o0 + j] = t + (b ? b[o0 + j] : 0.f);
     }
 }
 
@@ -43,20 +53,22 @@ __global__ void linear_bwd_dx_kernel(const float* __restrict__ dout, const float
     for (int o = 0; o < O; ++o) s = fmaf(dout[(size_t)b * O + o], w[(size_t)o * D + d], s);
     dx[idx] = acc ? dx[idx] + s : s;
 }
-// dw[o][d] = sum_b dout[b][o] x[b][d] ; db[o] = sum_b dout[b][o]
+// dw[o][d] (+)= sum_b dout[b][o] x[b][d] ; db[o] (+)= sum_b dout[b][o].  grid.y splits the batch; partial sums
+// are combined with fp32 atomics (dw / db zeroed by the launcher unless accumulating).
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dw,
-                                     float* __restrict__ db, int B, int D, int O, int acc) {
+                                     float* __restrict__ db, int B, int D, int O, int bchunk) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= O * D) return;
     int o = idx / D, d = idx - o * D;
+    int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
     float s = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < b1; ++b) {
         float g = dout[(size_t)b * O + o];
         s = fmaf(g, x[(size_t)b * D + d], s);
         sb += g;
     }
-    dw[idx] = acc ? dw[idx] + s : s;
-    if (db != nullptr && d == 0) db[o] = acc ? db[o] + sb : sb;
+    atomicAdd(dw + idx, s);
+    if (db != nullptr && d == 0) atomicAdd(db + o, sb);
 }
 
 // ---------------------------------------------------------------------------- CE on a column slice
@@ -353,8 +365,10 @@ static int zero_scalar(void* p, size_t bytes, hipStream_t st) {
 }
 
 extern "C" int clhip_linear_fwd(const float* x, const float* w, const float* b, float* out, int B, int D, int O, void* stream) {
-    CLHIP_CHECK_ARG(x && w && out && B > 0 && D > 0 && D <= 1024 && O > 0);
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, x, w, b, out, B, D, O);
+    CLHIP_CHECK_ARG(x && w && out && B > 0 && D > 0 && O > 0);
+    CLHIP_CHECK_ARG(D % 4 == 0 || D < 4 || true);
+    int waves = B * ((O + 3) / 4);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, ST, x, w, b, out, B, D, O);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -366,7 +380,13 @@ extern "C" int clhip_linear_bwd(const float* x, const float* w, const float* dou
         hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST, dout, w, dx, B, D, O, 0);
         CLHIP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((O * D + 255) / 256), dim3(256), 0, ST, dout, x, dw, db, B, D, O, accumulate);
+    if (!accumulate) {
+        if (int e = zero_scalar(dw, sizeof(float) * (size_t)O * D, ST)) return e;
+        if (db) { if (int e = zero_scalar(db, sizeof(float) * (size_t)O, ST)) return e; }
+    }
+    int splits = B >= 64 ? 8 : 1;
+    int bchunk = (B + splits - 1) / splits;
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((O * D + 255) / 256, splits), dim3(256), 0, ST, dout, x, dw, db, B, D, O, bchunk);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

@@ -43,6 +43,7 @@ struct clhip_plan {
     size_t dz_off;           // scratch for the pre-BN gradient
     size_t f_base;           // byte offset of the fp32 region
     size_t f_part, f_bnws;   // float offsets: conv stat partials, bn backward scratch
+    size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
     int feat_dim;
 };
 
@@ -60,7 +61,7 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     Act a0{H, W, p->Cin_pad, 0, 0, (size_t)N * H * W * p->Cin_pad * p->esize};
     a0.y_off = off; off = align_up(off + a0.bytes);
     p->acts.push_back(a0);
-    size_t max_z = 0, max_part = 0, max_bnws = 0, nfloat = 0;
+    size_t max_z = 0, max_part = 0, max_bnws = 0, nfloat = 0, max_wg = 0;
     for (int i = 0; i < n_units; ++i) {
         Unit u{};
         u.d = units[i];
@@ -104,10 +105,13 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
         if (part > max_part) max_part = part;
         size_t bw = clhip_bn_bwd_ws_floats(u.M, u.d.cout);
         if (bw > max_bnws) max_bnws = bw;
+        size_t wg = clhip_conv_wgrad_ws_bytes(N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, dtype);
+        if (wg > max_wg) max_wg = wg;
         p->units.push_back(u);
     }
     for (size_t i = 1; i < p->acts.size(); ++i) { p->acts[i].dy_off = off; off = align_up(off + p->acts[i].bytes); }
     p->dz_off = off; off = align_up(off + max_z);
+    p->wg_off = off; off = align_up(off + max_wg);
     p->f_base = off;
     nfloat = (nfloat + 63) / 64 * 64;
     p->f_part = nfloat; nfloat += (max_part + 63) / 64 * 64;
@@ -195,7 +199,7 @@ extern "C" int clhip_plan_backward(clhip_plan* p, const float* dfeat, const floa
         TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
                          grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
                          fr + p->f_bnws, p->dtype, stream));
-        TRY(clhip_conv_wgrad(ws + src.y_off, ws + p->dz_off, grads + u.d.w_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
+        TRY(clhip_conv_wgrad(ws + src.y_off, ws + p->dz_off, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         if (u.d.src != 0) {
             TRY(clhip_conv_dgrad(ws + p->dz_off, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,

@@ -61,6 +61,15 @@ CONV_CASES = [
     (2, 9, 9, 128, 256, 1, 2, 0),
     (64, 32, 32, 16, 16, 3, 1, 1),     # M = 65536 -> the 128-row tile path
     (1, 1, 1, 16, 16, 3, 1, 1),        # single pixel
+    # shapes served by the halo kernel (conv3.hip: 3x3 s1, channels multiple of 64), incl. ragged tiles,
+    # tiles spanning several images and every workgroup shape it picks
+    (8, 32, 32, 64, 64, 3, 1, 1),
+    (3, 16, 16, 128, 128, 3, 1, 1),
+    (5, 8, 8, 256, 256, 3, 1, 1),
+    (7, 4, 4, 512, 512, 3, 1, 1),
+    (2, 7, 5, 64, 64, 3, 1, 1),
+    (130, 32, 32, 64, 64, 3, 1, 1),    # 512-pixel tiles (8 waves), ragged last tile
+    (70, 16, 16, 128, 256, 3, 1, 1),   # 256x128 tiles
 ]
 
 
@@ -138,13 +147,20 @@ def test_conv_wgrad(case, mode):
     ref = wr.grad                                           # [K,C,k,k]
     dzd = to_nhwc(dz, tdt)
     dw = torch.zeros(K, k, k, C, device=DEV)                # K,R,S,Creal fp32
-    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), N, H, W, cpad, C, K, k, s, p, code, st())
+    wsb = _lib.lib().clhip_conv_wgrad_ws_bytes(N, H, W, cpad, C, K, k, s, p, code)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), None, N, H, W, cpad, C, K, k, s, p, code, st())   # atomics path
     got = dw.cpu().permute(0, 3, 1, 2).double()
     t = 2e-4 * float(ref.abs().max()) + 1e-6               # fp32 accumulation of exactly representable products
     assert (got - ref).abs().max() <= t
-    # accumulation into existing content (+=)
-    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), N, H, W, cpad, C, K, k, s, p, code, st())
+    # accumulation into existing content (+=), through the deterministic partial-block path when there is one
+    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), ws.data_ptr() if wsb else None, N, H, W, cpad, C, K, k, s, p, code, st())
     assert (dw.cpu().permute(0, 3, 1, 2).double() - 2 * ref).abs().max() <= 2 * t
+    if wsb:   # bitwise reproducible
+        d1, d2 = torch.zeros_like(dw), torch.zeros_like(dw)
+        for d in (d1, d2):
+            call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), d.data_ptr(), ws.data_ptr(), N, H, W, cpad, C, K, k, s, p, code, st())
+        assert torch.equal(d1, d2)
 
 
 def test_weight_prep_and_layout_converts():
