@@ -75,7 +75,7 @@ def get_dataloader(config, mode, cls_map=None):
     data_root = config["data_root"]
     if "train_trfms" in config or "test_trfms" in config:
         raise NotImplementedError("YAML-declared transforms are outside the hot-path scope")
-    trfms = T.cifar_resnet_transform(mode)
+    trfms = T.cifar_resnet_transform(mode, config.get("image_size", 32))
     bs = config.get(f"{mode}_batch_size", config["batch_size"])
     if config["dataset"] == "synthetic":
         return synthetic_datasets(config, mode, trfms, bs)

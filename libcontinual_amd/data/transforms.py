@@ -77,8 +77,8 @@ class Normalize:
         return (t - self.mean) / self.std
 
 
-def cifar_resnet_transform(mode):
+def cifar_resnet_transform(mode, size=32):
     common = [ToTensor(), Normalize(CIFAR_MEAN, CIFAR_STD)]
     if mode == "train":
-        return Compose([RandomCrop(32, padding=4), RandomHorizontalFlip(), ColorJitter(brightness=63 / 255), *common])
+        return Compose([RandomCrop(size, padding=4), RandomHorizontalFlip(), ColorJitter(brightness=63 / 255), *common])
     return Compose(common)

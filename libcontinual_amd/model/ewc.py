@@ -93,8 +93,13 @@ class EWC(Finetune):
         self.network = Model(self.backbone, feat_dim, kwargs["init_cls_num"])
         self.lamda = self.kwargs["lamda"]
         self.task_idx = 0
-        self._ref_flat = self._fisher_flat = None
-        self._ref_head_w = self._ref_head_b = self._fisher_head_w = self._fisher_head_b = None
+        # snapshot at construction, like the reference (ewc.py:65-68): head entries have init_cls_num rows
+        flat, _ = self.network.backbone.flat_parameters()
+        cls = self.network.classifier
+        self._ref_flat = flat.detach().clone()
+        self._fisher_flat = torch.zeros_like(flat)
+        self._ref_head_w, self._ref_head_b = cls.weight.detach().clone(), cls.bias.detach().clone()
+        self._fisher_head_w, self._fisher_head_b = torch.zeros_like(self._ref_head_w), torch.zeros_like(self._ref_head_b)
 
     # -- name -> tensor views, the reference's public attributes (ewc.py:65-68)
     def _named_views(self, flat, hw, hb):
@@ -117,16 +122,11 @@ class EWC(Finetune):
         return self._named_views(self._ref_flat, self._ref_head_w, self._ref_head_b)
 
     def _ensure_state(self):
-        bb = self.network.backbone
-        flat, _ = bb.flat_parameters()
-        if self._ref_flat is None or self._ref_flat.device != flat.device:
-            cls = self.network.classifier
-            self._ref_flat = flat.detach().clone()
-            self._fisher_flat = torch.zeros_like(flat)
-            self._ref_head_w = cls.weight.detach().clone()
-            self._ref_head_b = cls.bias.detach().clone()
-            self._fisher_head_w = torch.zeros_like(self._ref_head_w)
-            self._fisher_head_b = torch.zeros_like(self._ref_head_b)
+        """the Fisher / reference tensors follow the network to its device (they are plain attributes, not buffers)"""
+        flat, _ = self.network.backbone.flat_parameters()
+        if self._ref_flat.device != flat.device:
+            for n in ("_ref_flat", "_fisher_flat", "_ref_head_w", "_ref_head_b", "_fisher_head_w", "_fisher_head_b"):
+                setattr(self, n, getattr(self, n).to(flat.device))
 
     def before_task(self, task_idx, buffer, train_loader, test_loaders):
         """grow the head to init + task_idx*inc outputs, old rows copied (ewc.py:71-80)"""

@@ -1,0 +1,65 @@
+"""Data-parallel path on CPU with gloo, world_size 2 (the GPU path uses the same code over RCCL): one all-reduce per
+flat gradient buffer + one packed bucket for the head; 1/world folded into the optimizer; identical terms added
+on every rank (EWC) come out exact; parameters broadcast from rank 0."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import libcontinual_amd.model as M
+    from libcontinual_amd import parallel
+    parallel.init_distributed(device_is_cuda=False)
+    torch.manual_seed(100 + rank)                   # different init per rank on purpose
+    bb = M.cifar_resnet32()
+    head = torch.nn.Linear(64, 10)
+    net = torch.nn.ModuleDict({"backbone": bb, "classifier": head})
+    parallel.broadcast_module_state(net)
+    flat, gflat = bb.flat_parameters()
+    ref = flat.clone()
+    # every rank fabricates its local gradient: g_r = (r+1) * pattern  (+ a rank-independent "EWC" term)
+    pattern = torch.arange(flat.numel(), dtype=torch.float32) % 7 - 3
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    bb.attach_grads()
+    head.weight.grad = torch.full_like(head.weight, float(rank + 1))
+    head.bias.grad = torch.full_like(head.bias, 2.0 * (rank + 1))
+    red = parallel.GradientReducer()
+    red.reduce(net)
+    scale = 1.0 / world
+    want = (sum(r + 1 for r in range(world)) * pattern + 5.0 * world) * scale
+    ok = torch.allclose(gflat * scale, want) and torch.allclose(head.weight.grad * scale, torch.full_like(head.weight, 1.5)) \
+        and torch.allclose(head.bias.grad * scale, torch.full_like(head.bias, 3.0))
+    # gradients are still the views the optimizer reads
+    ok = ok and bb._params[0].grad.data_ptr() == gflat.data_ptr()
+    gathered = [torch.zeros_like(ref) for _ in range(world)]
+    dist.all_gather(gathered, ref)
+    ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)          # broadcast made the ranks identical
+    m = red.mean_scalar(float(rank), "cpu")
+    ok = ok and abs(m - 0.5) < 1e-12
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,168 @@
+"""CPU-only tests of the host side: C-ABI library loads and exports every declared symbol (no compute calls
+without a GPU), config loader semantics, registry, flat-parameter plumbing of the backbone, buffers, metrics,
+schedulers, and that the product refuses to run on CPU (no fallback)."""
+import copy
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import libcontinual_amd.model as M
+from libcontinual_amd import _lib, optim, ops
+from libcontinual_amd.config import Config
+from libcontinual_amd.utils import AverageMeter, compute_bwt, compute_frgt, get_instance
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    syms = _lib.header_symbols()
+    assert len(syms) >= 45
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(_lib._PROTOS) == set(syms), set(_lib._PROTOS) ^ set(syms)
+    assert _lib.lib().clhip_version() >= 100
+    # no device needed for pure host queries
+    assert _lib.lib().clhip_conv_fwd_tiles(256, 32, 32, 64, 64, 3, 1, 1) > 0
+    assert _lib.lib().clhip_bn_bwd_ws_floats(1024, 64) > 0
+
+
+def test_invalid_arguments_return_error_codes_not_exceptions():
+    L = _lib.lib()
+    rc = L.clhip_conv_fwd(None, None, None, None, 1, 4, 4, 16, 16, 3, 1, 1, 0, None)
+    assert rc == -1 and b"invalid argument" in L.clhip_last_error()
+    rc = L.clhip_conv_fwd(1, 1, 1, None, 1, 4, 4, 12, 16, 3, 1, 1, 0, None)      # 12 channels: not a power of two
+    assert rc == -1
+    with pytest.raises(_lib.ClhipError):
+        _lib.call("clhip_sgd_step", None, None, None, 10, 0.1, 0.0, 0.0, 1.0, None, None, 0.0, None)
+
+
+def test_no_cpu_fallback():
+    bb = M.cifar_resnet32()
+    with pytest.raises(_lib.ClhipError):
+        bb(torch.zeros(2, 3, 32, 32))
+    with pytest.raises(_lib.ClhipError):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), None)
+    with pytest.raises(_lib.ClhipError):
+        o = optim.SGD([torch.nn.Parameter(torch.zeros(4))], lr=0.1)
+        o.param_groups[0]["params"][0].grad = torch.zeros(4)
+        o.step()
+
+
+@pytest.mark.parametrize("name,nparam,ntensors", [("cifar_resnet32", 466256, 99), ("resnet18", 11179092, 62), ("resnet32_V2", 466256, 99)])
+def test_backbone_surface_matches_reference(name, nparam, ntensors):
+    """names / shapes / order of parameters and buffers == the reference's, via the oracle spec"""
+    from oracle import nets
+    bb = getattr(M, name)(args={"dataset": "cifar100"}) if name == "resnet18" else getattr(M, name)()
+    got = [(n, tuple(p.shape)) for n, p in bb.named_parameters()]
+    want = [(n, tuple(s)) for n, s in nets.param_shapes(name)]
+    assert sorted(got) == sorted(want)
+    assert sum(p.numel() for p in bb.parameters()) == nparam and len(got) == ntensors
+    assert sorted((n, tuple(b.shape)) for n, b in bb.named_buffers()) == sorted((n, tuple(s)) for n, s in nets.buffer_shapes(name))
+    # reference state_dicts load unchanged; conv weights live K,R,S,C in memory
+    P, Bf = nets.init_params(name), nets.init_buffers(name)
+    bb.load_state_dict({**P, **Bf})
+    for n, p in bb.named_parameters():
+        assert torch.equal(p.detach(), P[n])
+    w = dict(bb.named_parameters())[want[0][0]]
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    assert bb._ensure_flat(torch.device("cpu")) is False          # still packed after the load
+    # deepcopy (teachers) re-packs lazily and does not share storage, plans or workspaces
+    t = copy.deepcopy(bb)
+    assert t._ensure_flat(torch.device("cpu")) is True
+    assert torch.equal(t._flat, bb._flat) and t._flat.data_ptr() != bb._flat.data_ptr()
+    assert t._handle is not bb._handle and t._params[0]._clhip_owner() is t
+    # .data assignment breaks the view; the next use re-packs and keeps the new value
+    w.data = torch.ones_like(w)
+    assert bb._ensure_flat(torch.device("cpu")) is True and float(bb._flat[: w.numel()].min()) == 1.0
+
+
+def test_registry_and_method_construction():
+    cfg = {"backbone": {"name": "resnet18", "kwargs": {"num_classes": 100, "args": {"dataset": "cifar100"}}},
+           "classifier": {"name": "LWF", "kwargs": {"num_class": 100, "feat_dim": 512, "init_cls_num": 50, "inc_cls_num": 5}},
+           "buffer": {"name": "LinearBuffer", "kwargs": {"buffer_size": 0, "batch_size": 128, "strategy": "herding"}}}
+    bb = get_instance(M, "backbone", cfg)
+    m = get_instance(M, "classifier", cfg, device="cpu", backbone=bb)
+    for hook in ("observe", "inference", "before_task", "after_task", "get_parameters"):
+        assert callable(getattr(m, hook))
+    m.before_task(0, None, None, None)
+    assert m.classifier.out_features == 50
+    m.before_task(1, None, None, None)
+    assert m.classifier.out_features == 55 and m.old_fc.out_features == 50 and m.known_cls_num == 50
+    assert not any(p.requires_grad for p in m.old_backbone.parameters())
+    m.train()
+    assert m.old_backbone.training            # quirk a10: the trainer's model.train() un-freezes the teacher's BN
+    buf = get_instance(M, "buffer", cfg)
+    assert buf.buffer_size == 0 and buf.strategy == "herding" and buf.is_empty()
+    e = M.EWC(M.cifar_resnet32(), 64, 100, device="cpu", init_cls_num=50, inc_cls_num=5, lamda=1000)
+    e.before_task(1, None, None, None)
+    assert e.network.classifier.out_features == 55
+    assert set(e.fisher) == {n for n, _ in e.network.named_parameters()} and e.fisher["classifier.weight"].shape == (50, 64)
+    lu = M.LUCIR(M.resnet32_V2(), 64, 100, device="cpu", init_cls_num=50, inc_cls_num=5, lamda=5, K=2, lw_mr=1, dist=0.5)
+    lu.task_idx = 1
+    lu.network.classifier = M.SplitCosineLinear(64, 50, 5)
+    groups = lu.get_parameters({})
+    assert groups[1]["lr"] == 0 and groups[0]["lr"] == 0.1 and groups[0]["weight_decay"] == 5e-4
+
+
+def test_config_loader_semantics(tmp_path, monkeypatch):
+    (tmp_path / "config" / "headers").mkdir(parents=True)
+    (tmp_path / "config" / "headers" / "model.yaml").write_text("epoch: 7\nbatch_size: 11\n")
+    (tmp_path / "my.yaml").write_text("includes:\n  - headers/model.yaml\nbatch_size: 32\noptimizer:\n  name: SGD\n  kwargs:\n    lr: 0.1\n"
+                                      "    weight_decay: 5e-4\nclassifier:\n  name: EWC\n  kwargs:\n    lamda: 1000\n")
+    monkeypatch.chdir(tmp_path)
+    c = Config(str(tmp_path / "my.yaml")).get_config_dict()
+    assert c["epoch"] == 7                       # from ./config/ include
+    assert c["batch_size"] == 32                 # the file's own keys override its includes
+    assert c["optimizer"]["kwargs"]["weight_decay"] == 5e-4 and isinstance(c["optimizer"]["kwargs"]["weight_decay"], float)
+    assert c["testing_times"] == 10 and c["seed"] == 1993       # defaults from the packaged headers
+    assert "buffer" not in c          # ./config/headers/model.yaml (cwd-relative, config.py:78-80) shadows the packaged one
+    assert "includes" not in c
+    # the shipped B50-5x10 configs of this repo parse and name resolvable classes
+    for f in sorted(os.listdir(os.path.join(ROOT, "config"))):
+        if f.endswith(".yaml"):
+            monkeypatch.chdir(ROOT)
+            cc = Config(os.path.join(ROOT, "config", f)).get_config_dict()
+            assert hasattr(M, cc["backbone"]["name"]) and hasattr(M, cc["classifier"]["name"]) and hasattr(M, cc["buffer"]["name"])
+            assert cc["init_cls_num"] + (cc["task_num"] - 1) * cc["inc_cls_num"] == 100
+
+
+def test_metrics_and_meter():
+    acc = np.array([[80.0, 0, 0], [70.0, 75.0, 0], [60.0, 65.0, 90.0]])
+    assert compute_bwt(acc, acc[2], 2) == pytest.approx(((60 - 80) * 2) / (2 * 3))
+    assert compute_frgt(acc, acc[2], 2) == pytest.approx((80 - 60) / 2)
+    m = AverageMeter("t", ["loss", "acc1"])
+    m.update("loss", 2.0); m.update("loss", 4.0)
+    m.update("acc1", ops.Deferred(torch.tensor(3), 100.0 / 4))          # device-resident value, resolved lazily
+    m.update("acc1", torch.tensor(25.0))
+    assert m.avg("loss") == 3.0 and m.avg("acc1") == pytest.approx(50.0)
+
+
+def test_schedulers():
+    from libcontinual_amd.scheduler import CosineAnnealingWarmUp, CosineSchedule, PatienceSchedule
+    import math
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    o = torch.optim.SGD(p, lr=0.1)
+    s = CosineSchedule(o, K=20)
+    s.step(); s.step()
+    assert o.param_groups[0]["lr"] == pytest.approx(0.1 * math.cos(99 * math.pi * 2 / (200 * 19)))
+    o = torch.optim.SGD(p, lr=0.1)
+    s = CosineAnnealingWarmUp(o, 2, 10)
+    assert o.param_groups[0]["lr"] == pytest.approx(0.05)
+    s.step(); s.step()
+    assert o.param_groups[0]["lr"] == pytest.approx(0.1 * 0.5 * (1 + math.cos(math.pi * 2 / 10)))
+    o = torch.optim.SGD(p, lr=0.1)
+    s = PatienceSchedule(o, patience=2, factor=2)
+    for l in (1.0, 1.0, 1.0):
+        s.step(l)
+    assert o.param_groups[0]["lr"] == pytest.approx(0.05)
+
+
+def test_herding_buffer_bookkeeping():
+    b = M.LinearHerdingBuffer(20, 64)
+    b.add_data([f"a{i}" for i in range(10)] + [f"b{i}" for i in range(10)], [0] * 10 + [1] * 10)
+    b.reduce_old_data(1, 4)              # 20 // 4 = 5 per class, first-k kept
+    assert b.labels == [0] * 5 + [1] * 5 and b.images[:2] == ["a0", "a1"] and b.images[5] == "b0"
