@@ -243,23 +243,246 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv3g: same patch scheme, but the per-tap WEIGHT tiles are streamed by LDS-DMA (global_load_lds_dwordx4,
+// no staging registers) into a 4-deep ring, 3 taps ahead of the MFMAs.  Motivation (profiles/r01_*): on the
+// 8x8 / 4x4 layers there is only ~1 wave per SIMD, so nothing hides the ~1-2 us weight-load round trip when the
+// prefetch distance is one tap (~0.25 us of MFMAs); register prefetch at distance 3 would cost 48+ VGPRs.
+// The DMA writes lane-linearly (1 KB per wave-instruction = 8 rows of 128 B), so the weight ring uses 128-byte
+// rows with the XOR swizzle applied to the per-lane SOURCE address and, pre-computed once, to the read address.
+// Waits are counted (s_waitcnt vmcnt(N)) + raw s_barrier: __syncthreads() would drain the DMA queue.
+template <int WM, int WN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
+    constexpr int BM = WM * 64, BN = WN * 64, NTH = WM * WN * 64, NW = NTH / 64;
+    constexpr int NST = 4;
+    constexpr int WINST = (BN / 8) / NW;                      // DMA instructions per wave per tap
+    static_assert((BN / 8) % NW == 0, "row groups must divide among the waves");
+    constexpr int PMAX = ((BM + 66) * 8 + NTH - 1) / NTH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch0 = smem;
+    char* wst0 = smem + p.patch_bytes;                        // NST stages of BN x 128 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int W = p.W, H = p.H, Cs = p.Cs, K = 9 * Cs;
+    const int nchunk = Cs >> 6;
+    const int halo = W + 1;
+    const int nsteps = nchunk * 9;
+
+    unsigned tmask[4];
+    int xaddr[4];
+    const int zaddr = p.np * PITCH + fg * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = wm * 64 + i * 16 + fr;
+        const int g = m0 + pl;
+        unsigned m = 0;
+        if (g < p.M) {
+            const int w = g % W, h = (g / W) % H;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t - 3 * r;
+                const int dh = MODE == 0 ? r - 1 : 1 - r, dw = MODE == 0 ? s - 1 : 1 - s;
+                if ((unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) m |= 1u << t;
+            }
+        }
+        tmask[i] = m;
+        xaddr[i] = (pl + halo) * PITCH + fg * 16;
+    }
+    int waddr[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wn * 64 + j * 16 + fr;
+            waddr[j][ks] = row * 128 + (((ks * 4 + fg) ^ (row & 7)) << 4);
+        }
+    // DMA source pointers: instruction i of this wave fills rows [8g, 8g+8) of the stage, g = wave*WINST + i;
+    // lane l lands at row 8g + (l>>3), 16-byte slot (l&7), which must hold logical chunk (l&7) ^ (row&7).
+    const bf16_t* wsrc[WINST];
+#pragma unroll
+    for (int i = 0; i < WINST; ++i) {
+        const int g = wave * WINST + i;
+        const int row = g * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        const int o = n0 + row < p.Cd ? n0 + row : p.Cd - 1;    // rows past Cd (never stored) read a valid address
+        wsrc[i] = p.wt + ((size_t)o * K + chunk * 8);
+    }
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    auto wdma = [&](int step) {          // stream the weights of K-step `step` into ring slot step % NST
+        const int c = step / 9, tap = step - 9 * c;
+        const int koff = tap * Cs + c * 64;
+        char* ws = wst0 + (step & (NST - 1)) * (BN * 128) + wave * WINST * 1024;
+#pragma unroll
+        for (int i = 0; i < WINST; ++i)
+            __builtin_amdgcn_global_load_lds((gvoid*)(wsrc[i] + koff), (lvoid*)(ws + i * 1024), 16, 0, 0);
+    };
+
+    uint4 pp[PMAX];
+    const int np8 = p.np * 8;
+    auto pload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int idx = tid + i * NTH;
+            const int q = idx >> 3, ch = idx & 7;
+            const long long g = (long long)m0 - halo + q;
+            pp[i] = (idx < np8 && g >= 0 && g < p.M) ? *reinterpret_cast<const uint4*>(p.src + ((size_t)g * Cs + c * 64 + ch * 8))
+                                                      : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto pstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int idx = tid + i * NTH;
+            const int q = idx >> 3, ch = idx & 7;
+            if (idx < np8) *reinterpret_cast<uint4*>(patch0 + q * PITCH + ch * 16) = pp[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: patch of chunk 0 (register path), weights of steps 0..2 (DMA)
+    if (tid < 10) *reinterpret_cast<uint4*>(patch0 + p.np * PITCH + tid * 16) = make_uint4(0, 0, 0, 0);
+    pload(0);
+    pstore();                                    // compiler waits for the patch loads here (vmcnt(0)): nothing else in flight yet
+    wdma(0);
+    if (nsteps > 1) wdma(1);
+    if (nsteps > 2) wdma(2);
+    // wait until step 0's weights have landed: at most the 2 younger steps may be outstanding
+    if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WINST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int step = 0;
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            if (step + 3 < nsteps) wdma(step + 3);           // slot (step+3)%4 was last read at step-1: free since the last barrier
+            if (tap == 5 && c + 1 < nchunk) pload(c + 1);
+            const char* ws = wst0 + (step & (NST - 1)) * (BN * 128);
+            const int r = tap / 3, s = tap - 3 * r;
+            const int shift = (MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s)) * PITCH;
+            int xa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[i] = (tmask[i] & (1u << tap)) ? xaddr[i] + shift : zaddr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xf[4], wf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = ldsq(patch0 + xa[i] + ks * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = ldsq(ws + waddr[j][ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]),
+                                                                           __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+            }
+            if (tap == 8 && c + 1 < nchunk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();            // every wave is done reading this chunk's patch
+                pstore();                                // (waits for the parked patch loads and, in order, everything older)
+            }
+            // next step's weights must have landed; the two younger DMA batches may stay in flight.
+            // (in-order completion: waiting for "<= 2 batches outstanding" retires step+1's batch and anything older)
+            if (step + 3 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WINST) : "memory");
+            else if (step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WINST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    {
+        char* ot = smem;
+        constexpr int OPITCH = BN * 2 + 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pl = wm * 64 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = wn * 64 + j * 16 + fg * 4;
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (p.accumulate) {
+                    const int pix = m0 + pl, o = n0 + cl;
+                    if (pix < p.M && o < p.Cd) {
+                        const uint2 old = *reinterpret_cast<const uint2*>(p.dst + (size_t)pix * p.Cd + o);
+                        v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+                        v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+                    }
+                }
+                uint2 u;
+                u.x = pack_bf16x2(v0, v1);
+                u.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(ot + pl * OPITCH + cl * 2) = u;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        for (int idx = tid; idx < BM * CPR; idx += NTH) {
+            const int pl = idx / CPR, ch = idx - pl * CPR;
+            const int pix = m0 + pl, o = n0 + ch * 8;
+            if (pix < p.M && o < p.Cd)
+                *reinterpret_cast<uint4*>(p.dst + (size_t)pix * p.Cd + o) = *reinterpret_cast<const uint4*>(ot + pl * OPITCH + ch * 16);
+        }
+        __syncthreads();
+    }
+    if (p.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (fr == 0) {
+                    const int cc = wn * 64 + j * 16 + fg * 4 + e;
+                    red[(wm * 2 + 0) * BN + cc] = s1;
+                    red[(wm * 2 + 1) * BN + cc] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += NTH) {
+            const int which = idx / BN, cc = idx - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) t += red[(w2 * 2 + which) * BN + cc];
+            if (n0 + cc < p.Cd) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + cc] = t;
+        }
+    }
+}
+
 template <int WM, int WN, int MODE>
 int launch3(Conv3Params& p, hipStream_t st) {
     constexpr int BM = WM * 64, BN = WN * 64;
     p.np = BM + 2 * p.W + 2;
     p.patch_bytes = ((p.np + 1) * PITCH + 255) / 256 * 256;       // + the zero row
     p.nbuf = 1;
-    size_t lds = (size_t)p.patch_bytes + 2 * (size_t)BN * PITCH;
+    static const int gmode = getenv("CLHIP_CONV3G") ? atoi(getenv("CLHIP_CONV3G")) : 0;     // 0: register-staged weights everywhere
+    const bool use_g = gmode == 2 || (gmode == 1 && p.M <= 32768);   // LDS-DMA weight ring: correct, not faster yet (r01 profiles) -> opt-in
+    size_t lds = (size_t)p.patch_bytes + (use_g ? 4 * (size_t)BN * 128 : 2 * (size_t)BN * PITCH);
     size_t olds = (size_t)BM * (BN * 2 + 16);
     if (olds > lds) lds = olds;
-    auto kern = conv3_kernel<WM, WN, MODE>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    auto kern = use_g ? conv3g_kernel<WM, WN, MODE> : conv3_kernel<WM, WN, MODE>;
+    static size_t attr_lds[2] = {0, 0};
+    if (lds > attr_lds[use_g]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             clhip_set_error("conv3: cannot reserve %zu bytes of LDS", lds);
             return CLHIP_EHIP;
         }
-        attr_lds = lds;
+        attr_lds[use_g] = lds;
     }
     dim3 grid((p.M + BM - 1) / BM, (p.Cd + BN - 1) / BN);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, p);
@@ -269,6 +492,8 @@ int launch3(Conv3Params& p, hipStream_t st) {
 
 struct Cfg3 { int wm, wn; };
 Cfg3 pick3(int M, int Cd) {
+    static const char* ov = getenv("CLHIP_CONV3_CFG");       // tuning override "wm,wn"
+    if (ov) { int a = 0, b = 0; if (sscanf(ov, "%d,%d", &a, &b) == 2 && (b == 1 || (b == 2 && Cd >= 128))) return Cfg3{a, b}; }
     // 4-wave workgroups of ~57 KB LDS: two of them share a CU, so one workgroup's patch load / output store
     // overlaps the other's MFMA phase (a single 8-wave workgroup per CU ran load -> compute -> store serially).
     if (Cd < 128) {
@@ -277,7 +502,10 @@ Cfg3 pick3(int M, int Cd) {
     }
     int gy = (Cd + 127) / 128;
     if ((int64_t)((M + 127) / 128) * gy >= 384) return Cfg3{2, 2};
-    return Cfg3{1, 2};
+    // small images (8x8, 4x4): the per-tap weight tile dominates the staging work, so favour many pixels x 64
+    // channels per workgroup (measured on 256x{8x8x256, 4x4x512}: (4,1) 33/54 us vs (1,2) 43/69 us, r01 profiles)
+    if ((int64_t)((M + 255) / 256) * ((Cd + 63) / 64) >= 96) return Cfg3{4, 1};
+    return Cfg3{2, 1};
 }
 
 }  // namespace

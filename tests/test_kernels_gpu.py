@@ -70,6 +70,10 @@ CONV_CASES = [
     (2, 7, 5, 64, 64, 3, 1, 1),
     (130, 32, 32, 64, 64, 3, 1, 1),    # 512-pixel tiles (8 waves), ragged last tile
     (70, 16, 16, 128, 256, 3, 1, 1),   # 256x128 tiles
+    # stride-2 3x3: dgrad runs as 4 parity classes visiting only the contributing taps (conv2.hip)
+    (4, 16, 16, 64, 128, 3, 2, 1),
+    (33, 32, 32, 64, 128, 3, 2, 1),
+    (3, 9, 9, 64, 128, 3, 2, 1),       # odd image size -> generic path
 ]
 
 
