@@ -124,9 +124,10 @@ class EWC(Finetune):
     def _ensure_state(self):
         """the Fisher / reference tensors follow the network to its device (they are plain attributes, not buffers)"""
         flat, _ = self.network.backbone.flat_parameters()
-        if self._ref_flat.device != flat.device:
-            for n in ("_ref_flat", "_fisher_flat", "_ref_head_w", "_ref_head_b", "_fisher_head_w", "_fisher_head_b"):
-                setattr(self, n, getattr(self, n).to(flat.device))
+        for n in ("_ref_flat", "_fisher_flat", "_ref_head_w", "_ref_head_b", "_fisher_head_w", "_fisher_head_b"):
+            t = getattr(self, n)
+            if t.device != flat.device:
+                setattr(self, n, t.to(flat.device))
 
     def before_task(self, task_idx, buffer, train_loader, test_loaders):
         """grow the head to init + task_idx*inc outputs, old rows copied (ewc.py:71-80)"""

@@ -18,6 +18,19 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def _dev(*ts):
+    """all tensors handed to a kernel must live on the same HIP device (a host pointer would fault the GPU)"""
+    d = None
+    for t in ts:
+        if t is None:
+            continue
+        require_gpu(t)
+        if d is None:
+            d = t.device
+        elif t.device != d:
+            raise _lib.ClhipError(f"tensors on different devices: {d} vs {t.device}")
+
+
 def _f32c(t):
     require_gpu(t)
     if t.dtype != torch.float32:
@@ -279,36 +292,44 @@ def margin_rank_loss(scores, labels, num_old, K, margin, weight=1.0):
 
 # ------------------------------------------------------------------------------- flat-buffer family
 def ewc_penalty(p, ref, fisher, weight, loss_out, accumulate):
+    _dev(p, ref, fisher, loss_out)
     call("clhip_ewc_penalty", _ptr(p), _ptr(ref), _ptr(fisher), p.numel(), float(weight), _ptr(loss_out), int(accumulate), _st())
 
 
 def ewc_grad(p, ref, fisher, g, weight, dev_scale=None):
+    _dev(p, ref, fisher, g, dev_scale)
     call("clhip_ewc_grad", _ptr(p), _ptr(ref), _ptr(fisher), _ptr(g), p.numel(), float(weight), _ptr(dev_scale), _st())
 
 
 def fisher_accum(fisher, g, scale):
+    _dev(fisher, g)
     call("clhip_fisher_accum", _ptr(fisher), _ptr(g), fisher.numel(), float(scale), _st())
 
 
 def fisher_merge(new_f, old_f, alpha):
+    _dev(new_f, old_f)
     call("clhip_fisher_merge", _ptr(new_f), _ptr(old_f), old_f.numel(), float(alpha), _st())
 
 
 def sgd_step(p, g, mom, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0, ewc_ref=None, ewc_fisher=None, ewc_weight=0.0):
+    _dev(p, g, mom, ewc_ref, ewc_fisher)
     call("clhip_sgd_step", _ptr(p), _ptr(g), _ptr(mom), p.numel(), float(lr), float(momentum), float(weight_decay),
          float(grad_scale), _ptr(ewc_ref), _ptr(ewc_fisher), float(ewc_weight), _st())
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    _dev(p, g, m, v)
     call("clhip_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
          float(weight_decay), float(grad_scale), int(step), _st())
 
 
 def sq_norm(g, out, accumulate=False):
+    _dev(g, out)
     call("clhip_sq_norm", _ptr(g), g.numel(), _ptr(out), int(accumulate), _st())
 
 
 def scale_(g, s):
+    _dev(g)
     call("clhip_scale", _ptr(g), g.numel(), float(s), _st())
 
 
