@@ -88,22 +88,30 @@ def get_dataloader(config, mode, cls_map=None):
                              config["num_workers"], cls_map)
 
 
-def synthetic_store(n_classes, per_class, size, seed):
-    """class-conditional random images: a fixed random pattern per class blended with noise"""
-    g = np.random.RandomState(seed)
-    pats = g.rand(n_classes, size, size, 3)
+def synthetic_store(n_classes, per_class, size, seed, split=0):
+    """class-conditional random images: a class colour times a class-specific oriented grating (so that the
+    classes survive the random crop / flip augmentation; shared by the train and test splits), blended with
+    per-image noise and a per-image random phase (different per split)"""
+    gc = np.random.RandomState(seed)
+    colour = gc.rand(n_classes, 3)
+    freq = gc.uniform(-4.0, 4.0, size=(n_classes, 2))
+    g = np.random.RandomState(seed + 7919 * (split + 1))
+    yy, xx = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
     imgs = np.empty((n_classes * per_class, size, size, 3), np.uint8)
     labels = np.repeat(np.arange(n_classes), per_class)
     for c in range(n_classes):
+        phase = g.uniform(0, 2 * np.pi, size=(per_class, 1, 1))
+        wave = 0.5 + 0.5 * np.sin(2 * np.pi * (freq[c, 0] * xx + freq[c, 1] * yy)[None] / size + phase)
         noise = g.rand(per_class, size, size, 3)
-        imgs[c * per_class:(c + 1) * per_class] = np.clip((0.5 * pats[c] + 0.5 * noise) * 255, 0, 255).astype(np.uint8)
+        img = 0.6 * wave[..., None] * colour[c] + 0.4 * noise
+        imgs[c * per_class:(c + 1) * per_class] = np.clip(img * 255, 0, 255).astype(np.uint8)
     return imgs, labels
 
 
 def synthetic_datasets(config, mode, trfms, bs):
     n_cls = config["init_cls_num"] + (config["task_num"] - 1) * config["inc_cls_num"]
     per = config.get("synthetic_per_class", 20) if mode == "train" else config.get("synthetic_test_per_class", 5)
-    store, labels = synthetic_store(n_cls, per, config["image_size"], config["seed"] + (0 if mode == "train" else 1))
+    store, labels = synthetic_store(n_cls, per, config["image_size"], config["seed"], 0 if mode == "train" else 1)
 
     def mk(s, e):
         idx = [i for i in range(len(labels)) if s <= labels[i] < e]
