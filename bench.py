@@ -144,8 +144,18 @@ def dominant_kernel_roofline(dev, dtype, B):
     flops = 2.0 * N * H * W * 9 * C * K
     alg_bytes = (N * H * W * C + N * H * W * K) * (2 if dtype == "bf16" else 4) + w.numel() * w.element_size()
     ach = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="conv_igemm_kernel<bf16,128,64,fwd> @ [B,32,32,64]x[64,3,3,64]", achieved=ach,
-                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=None,
+    # HBM traffic per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/roofline_pmc.sh) of this same kernel / shape,
+    # committed under profiles/; null if no matching measurement is on disk
+    traffic, src = None, None
+    pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_roofline_pmc.json")
+    if os.path.exists(pj):
+        with open(pj) as f:
+            m = json.load(f)
+        if m.get("shape") == [N, H, W, C, K, 3, 1] and m.get("dtype") == dtype:
+            traffic, src = m["traffic_bytes_per_launch"], "profiles/r01_roofline_pmc.json (rocprofv3 --pmc, separate passes)"
+    kname = "conv3_kernel<4,1,0>" if dtype == "bf16" else "conv_igemm2_kernel<float>"
+    return dict(bound="mfma", kernel=kname + " fwd 3x3/s1 + BN-stat epilogue @ [B,32,32,64]x[64,3,3,64]", achieved=ach,
+                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=src,
                 launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
                 hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
 

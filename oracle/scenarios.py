@@ -431,6 +431,13 @@ def scenario_icarl(adapter, tmpdir):
         with torch.no_grad():
             p, a = m.inference(adapter.batch(tx[: 4 * c["init"]], ty[: 4 * c["init"]]))
         res["ncm_pred0"] = p.cpu().numpy()
+        # NCM decision margins of the plugin under test (best vs second-best distance, relative): lets the parity
+        # test tell a wrong decision from a near-tie that a 1e-2 change of the class means may flip
+        with torch.no_grad():
+            f = m.network.backbone(tx[: 4 * c["init"]].to(adapter.device))["features"].float().cpu().double()
+        d = torch.cdist(f, torch.as_tensor(res["class_means0"]).double()) ** 2      # un-normalised features, as in inference
+        ds_, _ = d.sort(dim=1)
+        res["ncm_margin0"] = ((ds_[:, 1] - ds_[:, 0]) / ds_[:, 1]).numpy()
         m.before_task(1, buffer, None, None)
         u_imgs, u_labs = imgs1 + list(buffer.images), labs1 + [int(v) for v in buffer.labels]
         ux, uy = load(u_imgs, u_labs)

@@ -195,7 +195,9 @@ def test_icarl_golden(golden, tmp_path):
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
     assert len(set(got["chosen0"]) & set(want["chosen0"])) >= 10     # of 24; observed 10-14 (near-tie picks)
     assert relmax(got["class_means0"], want["class_means0"]) < 2e-2
-    assert (got["ncm_pred0"] == want["ncm_pred0"]).mean() >= 0.75
+    differ = got["ncm_pred0"] != want["ncm_pred0"]                   # NCM decisions may only differ on near-ties
+    assert (got["ncm_margin0"][differ] < 0.05).all(), (got["ncm_margin0"], differ)
+    assert (~differ).mean() >= 0.5
     got = sc.scenario_icarl(adapter("bf16"), str(tmp_path / "b"))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 5e-2
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
