@@ -13,7 +13,7 @@ import types
 import numpy as np
 import torch
 
-from . import fixtures, ref_shim, scenarios
+from . import fixtures, ref_shim, scenarios, vit_scenarios
 
 
 def reference_namespace():
@@ -27,6 +27,30 @@ def reference_namespace():
     ns.LUCIR = ref_shim.load("core.model.lucir").LUCIR
     ns.Finetune = ref_shim.load("core.model.finetune").Finetune
     ns.LinearHerdingBuffer = ref_shim.load("core.model.buffer.linearherdingbuffer").LinearHerdingBuffer
+    return ns
+
+
+def reference_vit_namespace():
+    """the reference's ViT classes at the fixture configuration (ViTZoo itself hard-codes ViT-B/16, vit.py:47-51:
+    the same object graph is assembled around a small VisionTransformer)"""
+    os.environ.setdefault("PYTHONHASHSEED", "0")           # read by InfLoRA_opt.py:55,218
+    ref_shim.install_vit_standins()
+    tr = ref_shim.load("core.model.backbone.transformer")
+    vit = ref_shim.load("core.model.backbone.vit")
+    ns = types.SimpleNamespace()
+
+    def make_vit(cfg, attn_layer="MultiHeadAttention", lora_rank=0):
+        zoo = vit.ViTZoo.__new__(vit.ViTZoo)
+        torch.nn.Module.__init__(zoo)
+        kw = {"lora_rank": lora_rank} if lora_rank else {}
+        zoo.task_id, zoo.feat_dim = None, cfg["dim"]
+        zoo.feat = tr.VisionTransformer(img_size=cfg["img"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
+                                        num_heads=cfg["heads"], ckpt_layer=0, drop_path_rate=0, attn_layer=attn_layer, **kw)
+        zoo.prompt, zoo.prompt_flag = None, ""
+        return zoo
+    ns.make_vit = make_vit
+    ns.L2P = ref_shim.load("core.model.l2p").L2P
+    ns.InfLoRA_OPT = ref_shim.load("core.model.InfLoRA_opt").InfLoRA_OPT
     return ns
 
 
@@ -47,6 +71,17 @@ def main(out_dir=None):
         with tempfile.TemporaryDirectory() as d:
             return scenarios.scenario_icarl(ad, d)
     jobs["icarl"] = icarl
+    vad = [None]
+
+    def vit_job(fn):
+        def run():
+            if vad[0] is None:
+                vad[0] = vit_scenarios.VitPluginAdapter(reference_vit_namespace(), "cpu")
+            return fn(vad[0])
+        return run
+    jobs["vit_backbone"] = vit_job(vit_scenarios.scenario_vit_backbone)
+    jobs["l2p"] = vit_job(vit_scenarios.scenario_l2p)
+    jobs["inflora"] = vit_job(vit_scenarios.scenario_inflora)
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

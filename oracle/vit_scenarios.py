@@ -1,0 +1,261 @@
+"""Golden scenarios of the ViT path: backbone, L2P, InfLoRA_OPT (TEST INFRASTRUCTURE, see oracle/__init__ and
+oracle/scenarios.py for the three executors: reference -> fixtures, oracle (CPU), product (MI355X)).
+
+The reference's ViTZoo hard-codes ViT-B/16; the fixtures drive the same reference classes
+(`VisionTransformer`, `MultiHeadAttention_LoRA`, `prompt.L2P`, `L2P`, `InfLoRA_OPT`, `SiNet`) at a small
+configuration (oracle.vit.VIT_TINY) through `make_vit`, so that fp64 runs take seconds and fixtures stay small.
+"""
+import types
+
+import numpy as np
+import torch
+
+from . import detrand
+from . import fixtures as fx
+from . import vit as ov
+from .scenarios import ListLoader
+
+CFG = ov.VIT_TINY
+L2P_CFG = dict(init=3, inc=3, total=6, task_num=2, length=2, pool=6, top_k=3, coeff=1.0, bs=8, lr=0.01)
+INF_CFG = dict(init=3, inc=3, task_num=2, lame=0.9, lamb=0.6, rank=4, bs=8, lr=0.05, momentum=0.9)
+
+
+def det_images(tag, n, cfg=CFG):
+    return fx._t(detrand.uniform(tag, (n, 3, cfg["img"], cfg["img"]), -1.0, 1.0))
+
+
+def det_labels(tag, n, lo, hi):
+    return torch.from_numpy(detrand.randint(tag, (n,), lo, hi).astype(np.int64))
+
+
+def det_extra(tag, shapes, lo, hi):
+    return {k: fx._t(detrand.uniform(f"{tag}/{k}", s, lo, hi)) for k, s in shapes.items()}
+
+
+def backbone_params(tag, lora_rank=0):
+    return {k: v.to(fx._DTYPE[0]) for k, v in ov.det_params(CFG, tag, lora_rank, torch.float64).items()}
+
+
+class VitPluginAdapter:
+    """ns: namespace with `make_vit(cfg, attn_layer, lora_rank)` -> ViTZoo-like backbone, `L2P`, `InfLoRA_OPT`;
+    `optim(name, params, **kw)` -> optimizer"""
+
+    kind = "plugin"
+
+    def __init__(self, ns, device="cpu", optim=None):
+        self.ns, self.device = ns, device
+        self.optim = optim or (lambda name, params, **kw: getattr(torch.optim, name)(params, **kw))
+
+    def batch(self, x, y):
+        return {"image": x, "label": y}
+
+
+class VitOracleAdapter:
+    kind = "oracle"
+    device = "cpu"
+
+
+def _np(t):
+    return t.detach().cpu().double().numpy().copy()
+
+
+def _set_lora(bb, flag):
+    for m in bb.modules():
+        if hasattr(m, "apply_lora"):
+            m.apply_lora = flag
+
+
+# ------------------------------------------------------------------------------------------ backbone
+def scenario_vit_backbone(adapter):
+    """plain forward (cls feature) with and without an applied LoRA branch; per-block activations are not part of
+    the plugin surface, so only the features are pinned"""
+    tag = "vitbb"
+    x = det_images(tag + "/x", 5)
+    res = {}
+    for name, rank in (("plain", 0), ("lora", 4)):
+        P = backbone_params(tag, rank)
+        if rank:
+            for k in P:
+                if "lora_B" in k:
+                    P[k] = fx._t(detrand.uniform(f"{tag}/B/{k}", tuple(P[k].shape), -0.2, 0.2))
+        if adapter.kind == "oracle":
+            with torch.no_grad():
+                f = ov.cls_features(P, x, CFG, lora=bool(rank))
+        else:
+            bb = adapter.ns.make_vit(CFG, "MultiHeadAttention_LoRA" if rank else "MultiHeadAttention", rank)
+            bb.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+            bb = bb.to(adapter.device)
+            _set_lora(bb, bool(rank))
+            bb.eval()
+            with torch.no_grad():
+                f = bb(x.to(adapter.device))
+        res["feat_" + name] = _np(f)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------- L2P
+# the data tag is chosen so that no batch-majority vote has a tie at the top-k cut (its resolution is torch.topk
+# implementation-defined, prompt.py:389); scenario_l2p on the oracle asserts it
+L2P_TAG = ["l2p/v0"]
+
+
+def _l2p_state(tag):
+    c = L2P_CFG
+    D = CFG["dim"]
+    P = backbone_params(tag)
+    # keys in (0,1) like nn.init.uniform_; prompts in (0,1) as well (l2p.py:64)
+    P.update(det_extra(tag, {"prompt.prompt": (1, c["pool"], c["length"], D), "prompt.prompt_key": (c["pool"], D)}, 0.0, 1.0))
+    b = 1.0 / np.sqrt(D)
+    P.update(det_extra(tag, {"classifier.weight": (c["total"], D), "classifier.bias": (c["total"],)}, -b, b))
+    return P
+
+
+def scenario_l2p(adapter):
+    """2 tasks x 2 steps of L2P (observe does backward + clip inside; Adam outside), inference after each task"""
+    c = L2P_CFG
+    tag = L2P_TAG[0]
+    P = _l2p_state(tag)
+    ov.TIES_AT_CUT.clear()
+    xs = [det_images(f"{tag}/x{i}", c["bs"]) for i in range(4)]
+    ys = [det_labels(f"{tag}/y{i}", c["bs"], 0 if i < 2 else c["init"], c["init"] if i < 2 else c["total"]) for i in range(4)]
+    tx, ty = det_images(tag + "/tx", c["bs"]), det_labels(tag + "/ty", c["bs"], 0, c["total"])
+    res, losses, preds = {}, [], []
+    tr = ["prompt.prompt", "prompt.prompt_key", "classifier.weight", "classifier.bias"]
+    if adapter.kind == "oracle":
+        P = {k: v.clone() for k, v in P.items()}
+        m = ov.L2P(P, CFG, c["init"], c["inc"], c["total"], c["top_k"], c["coeff"])
+        opt = ov.Adam(m.parameters(), c["lr"])
+        for t in range(2):
+            m.before_task(t)
+            for i in (2 * t, 2 * t + 1):
+                pred, acc, loss, ids, norm = m.observe(xs[i], ys[i])
+                if i == 0:
+                    res["grad_prompt0"] = _np(P["prompt.prompt"].grad)
+                    res["grad_key0"] = _np(P["prompt.prompt_key"].grad)
+                    res["grad_cls_w0"] = _np(P["classifier.weight"].grad)
+                opt.step()
+                losses.append(float(loss.detach())); preds.append(pred.numpy())
+            m.after_task(t)
+            p, a = m.inference(tx, ty)
+            res[f"test_pred{t}"] = p.numpy()
+            for n in tr:
+                res[f"{n}@{t}"] = _np(P[n])
+        assert not ov.TIES_AT_CUT, f"prompt vote tie at the cut: {ov.TIES_AT_CUT}"
+    else:
+        ns = adapter.ns
+        bb = ns.make_vit(CFG, "MultiHeadAttention", 0)
+        m = ns.L2P(bb, adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"], num_class=c["total"], task_num=c["task_num"],
+                   feat_dim=CFG["dim"], prompt_length=c["length"], pool_size=c["pool"], top_k=c["top_k"], pull_constraint_coeff=c["coeff"])
+        sd = {("backbone." + k if not k.startswith("classifier") else k): v.clone() for k, v in P.items()}
+        m.network.load_state_dict(sd, strict=True)
+        m.network.to(adapter.device)
+        opt = adapter.optim("Adam", m.get_parameters({}), lr=c["lr"], betas=(0.9, 0.999), weight_decay=0)
+        named = dict(m.network.named_parameters())
+        key = lambda n: n if n.startswith("classifier") else "backbone." + n
+        for t in range(2):
+            m.before_task(t, None, None, None)
+            for i in (2 * t, 2 * t + 1):
+                m.train()
+                opt.zero_grad()
+                pred, acc, loss = m.observe(adapter.batch(xs[i], ys[i]))
+                if i == 0:
+                    res["grad_prompt0"] = _np(named[key("prompt.prompt")].grad)
+                    res["grad_key0"] = _np(named[key("prompt.prompt_key")].grad)
+                    res["grad_cls_w0"] = _np(named[key("classifier.weight")].grad)
+                opt.step()
+                losses.append(float(loss.detach())); preds.append(pred.cpu().numpy())
+            m.after_task(t, None, None, None)
+            m.eval()
+            with torch.no_grad():
+                p, a = m.inference(adapter.batch(tx, ty))
+            res[f"test_pred{t}"] = p.cpu().numpy()
+            for n in tr:
+                res[f"{n}@{t}"] = _np(named[key(n)])
+    res["losses"] = np.asarray(losses, np.float64)
+    res["preds"] = np.stack(preds)
+    return res
+
+
+# ------------------------------------------------------------------------------------------ InfLoRA
+def _inflora_state(tag):
+    c = INF_CFG
+    D = CFG["dim"]
+    P = backbone_params(tag, c["rank"])
+    b = 1.0 / np.sqrt(D)
+    for t in range(c["task_num"]):
+        n = c["init"] if t == 0 else c["inc"]
+        P.update(det_extra(tag, {f"classifier_pool.{t}.weight": (n, D), f"classifier_pool.{t}.bias": (n,)}, -b, b))
+    return P
+
+
+def scenario_inflora(adapter):
+    """2 tasks of InfLoRA_OPT: before_task (input Gram -> SVD -> lora_A), 2 SGD steps on lora_B + the task head,
+    after_task (merge into qkv, DualGPM feature update), inference.  Sign-invariant quantities only (SVD bases)."""
+    c = INF_CFG
+    tag = "inflora"
+    P = _inflora_state(tag)
+    D, depth = CFG["dim"], CFG["depth"]
+    xs = [det_images(f"{tag}/x{i}", c["bs"]) for i in range(4)]
+    ys = [det_labels(f"{tag}/y{i}", c["bs"], 0 if i < 2 else c["init"], c["init"] if i < 2 else c["init"] + c["inc"]) for i in range(4)]
+    tx, ty = det_images(tag + "/tx", c["bs"]), det_labels(tag + "/ty", c["bs"], 0, c["init"] + c["inc"])
+    res, losses, preds = {}, [], []
+    blocks = [f"feat.transformer.blocks.{i}." for i in range(depth)]
+
+    def record(t, get, feature_list, project_type):
+        for i, b in enumerate(blocks):
+            A = get(b + "attn.lora_A_k.weight")
+            res[f"AtA{i}@{t}"] = _np(A.T @ A)
+            res[f"qkv{i}@{t}"] = _np(get(b + "attn.qkv.weight"))
+            f = np.asarray(feature_list[i], np.float64)
+            res[f"proj{i}@{t}"] = f @ f.T
+            res[f"rank{i}@{t}"] = np.asarray(f.shape[1])
+        res[f"ptype@{t}"] = np.asarray([p == "retain" for p in project_type])
+
+    if adapter.kind == "oracle":
+        P = {k: v.clone() for k, v in P.items()}
+        m = ov.InfLoRA(P, CFG, c["init"], c["inc"], c["task_num"], c["lame"], c["lamb"], c["rank"])
+        from .methods import SGD
+        for t in range(2):
+            bx = [xs[2 * t], xs[2 * t + 1]]
+            m.before_task(t, bx)
+            opt = SGD(m.parameters(), c["lr"], c["momentum"], 0.0)
+            for i in (2 * t, 2 * t + 1):
+                pred, acc, loss = m.observe(xs[i], ys[i])
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.detach())); preds.append(pred.numpy())
+            m.after_task(t, bx)
+            record(t, lambda n: m.P[n], m.feature_list, m.project_type)
+            p, a = m.inference(tx, ty)
+            res[f"test_pred{t}"] = p.numpy()
+            res[f"head{t}@{t}"] = _np(m.P[f"classifier_pool.{t}.weight"])
+    else:
+        import os
+        os.environ.setdefault("PYTHONHASHSEED", "0")
+        ns = adapter.ns
+        bb = ns.make_vit(CFG, "MultiHeadAttention_LoRA", c["rank"])
+        m = ns.InfLoRA_OPT(bb, adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"], task_num=c["task_num"], lame=c["lame"],
+                           lamb=c["lamb"], dataset="cifar100", use_ca=False, embd_dim=D)
+        m._network.load_state_dict({("backbone." + k if k.startswith("feat.") else k): v.clone() for k, v in P.items()}, strict=True)
+        m._network.to(adapter.device)
+        named = lambda: dict(m._network.named_parameters())
+        test_loader = ListLoader([(tx, ty)], c["bs"], types.SimpleNamespace(trfms=None))
+        for t in range(2):
+            loader = ListLoader([(xs[2 * t], ys[2 * t]), (xs[2 * t + 1], ys[2 * t + 1])], c["bs"], types.SimpleNamespace(trfms=None))
+            m.before_task(t, None, loader, [test_loader])
+            opt = adapter.optim("SGD", m.get_parameters({}), lr=c["lr"], momentum=c["momentum"])
+            for i in (2 * t, 2 * t + 1):
+                m.train()
+                pred, acc, loss = m.observe(adapter.batch(xs[i], ys[i]))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.detach())); preds.append(pred.cpu().numpy())
+            m.after_task(t, None, loader, [test_loader])
+            nm = named()
+            record(t, lambda n: nm["backbone." + n].detach().cpu().double(), m.feature_list, m.project_type)
+            m.eval()
+            with torch.no_grad():
+                p, a = m.inference(adapter.batch(tx, ty))
+            res[f"test_pred{t}"] = p.cpu().numpy()
+            res[f"head{t}@{t}"] = _np(nm[f"classifier_pool.{t}.weight"])
+    res["losses"] = np.asarray(losses, np.float64)
+    res["preds"] = np.stack(preds)
+    return res
