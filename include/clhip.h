@@ -151,6 +151,11 @@ int clhip_linear_bwd(const float* x, const float* w, const float* dout, float* d
 int clhip_ce_slice(const float* logits, const int64_t* labels, int B, int O, int lo, int hi, int pred_hi, float weight,
                    float* loss_out, int loss_accumulate, float* dlogits /*nullable*/, int grad_accumulate,
                    int64_t* pred /*nullable*/, int32_t* correct /*nullable*/, void* stream);
+/* same with the argmax restricted to [pred_lo, pred_hi): L2P's logits masked to -inf outside the current task's classes
+ * (l2p.py:92-106) are CE over [lo,hi) and argmax over [lo,hi) */
+int clhip_ce_window(const float* logits, const int64_t* labels, int B, int O, int lo, int hi, int pred_lo, int pred_hi, float weight,
+                    float* loss_out, int loss_accumulate, float* dlogits /*nullable*/, int grad_accumulate,
+                    int64_t* pred /*nullable*/, int32_t* correct /*nullable*/, void* stream);
 /* distillation: -(softmax(soft/T) * log_softmax(pred/T)).sum()/B over the first k columns
  * (lwf.py:75-78, icarl.py:198-206); strides are the row pitches (O) of the two logit matrices.         */
 int clhip_kd_loss(const float* pred, int pred_stride, const float* soft, int soft_stride, int B, int k, float T,
@@ -209,6 +214,92 @@ int clhip_l2_normalize_rows(const float* x, float* out, int R, int D, void* stre
 int clhip_ncm_classify(const float* feats, const float* means, int B, int M, int D, int64_t* pred, void* stream);
 int clhip_herding_select(const float* feats /*[n,D], L2-normalised*/, int n, int D, int m, int32_t* chosen /*[m]*/,
                          float* ws /*[2*D + n]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ViT path: frozen ViT-B/16 backbone with L2P prompt tokens or InfLoRA's
+ * LoRA branch.  Token activations are [B*N, D] row-major in the compute dtype (batch-first: the reference's
+ * seq-first [N,B,D] layout and its two permutes per block, transformer.py:1322-1329, do not exist here).
+ *
+ * clhip_gemm_nt: C[M,N] = epi(A[M,K] . B[N,K]^T); replaces every F.linear on the path (transformer.py:172,194,
+ *   255,1267-1271) and, with the [in,out] copy of a frozen weight as B, its input gradient.  Epilogues:
+ *   0 none | 1 +bias | 2 +bias +R (residual add, :1333-1334) | 3 +bias, H <- pre-activation (nullable), GELU (:1268)
+ *   | 4 *GELU'(H) (backward of 3).  bias fp32; R, H in the compute dtype.  K % 64 == 0, N % 4 == 0.            */
+int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
+                  int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
+/* softmax(q k^T / sqrt(d)) v per (batch, head) on the packed qkv [B*N, 3D] (column = which*D + head*d + i), out [B*N, D],
+ * lse [B,H,N] (nullable in forward-only use); MultiHeadAttention.forward, transformer.py:169-197.  N <= 256, d <= 64. */
+int clhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype, void* stream);
+/* dqkv [B*N, 3D] from dout [B*N, D]; dsum_ws: [B,H,N] floats (only used by the generic fp32 path) */
+int clhip_attn_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, float* dsum_ws, int B, int N,
+                   int H, int D, int dtype, void* stream);
+/* nn.LayerNorm over the last dim (transformer.py:1331-1336): y = (x-mean)*rstd*gamma+beta; mean/rstd [M] saved when given */
+int clhip_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int D, float eps,
+                 int dtype, void* stream);
+/* g += dLN/dx^T dy  (gamma/beta are frozen on this path: input gradient only) */
+int clhip_ln_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* g, int M, int D,
+                 int dtype, void* stream);
+/* final LN (eps 1e-6) + mean over the first P tokens of each sample -> feat [B,D] fp32 (P = 1: cls token;
+ * P = top_k*length: L2P's prompt-token mean, transformer.py:2254-2261) and its backward into g [B*N, D] (rows >= P zeroed) */
+int clhip_ln_pool_fwd(const void* x, const float* gamma, const float* beta, float* feat, int B, int N, int D, int P, float eps,
+                      int dtype, void* stream);
+int clhip_ln_pool_bwd(const float* dfeat, const void* x, const float* gamma, void* g, int B, int N, int D, int P, float eps,
+                      int dtype, void* stream);
+/* images fp32 NCHW [B,3,img,img] -> patch rows [B*(img/patch)^2, 3*patch^2] (timm PatchEmbed's Conv2d as a GEMM operand) */
+int clhip_patchify(const float* images, void* patches, int B, int img, int patch, int dtype, void* stream);
+/* x [B, P+1+np, D]: prompt tokens (no pos-embed) | cls + pos[0] | patch_emb + pos[1..]   (transformer.py:2239-2243, 2010-2014) */
+int clhip_vit_assemble(const void* patch_emb, const float* cls_token, const float* pos_embed, const float* prompt_tokens, void* x,
+                       int B, int n_patches, int n_prompt, int D, int dtype, void* stream);
+/* dprompt_tokens[t] = sum_b g[b, t]  (t < n_prompt) */
+int clhip_vit_prompt_grad(const void* g, float* dprompt, int B, int N, int n_prompt, int D, int dtype, void* stream);
+/* fp32 master [rows, cols] (+ LoRA: rows [rows/3, 2rows/3) += B_k A_k, [2rows/3, rows) += B_v A_v, transformer.py:249-255)
+ * -> compute-dtype copies wt [rows, cols] and wt_t [cols, rows] (either nullable) */
+int clhip_weight_prep2(const float* w, void* wt, void* wt_t, int rows, int cols, const float* lora_a_k, const float* lora_b_k,
+                       const float* lora_a_v, const float* lora_b_v, int rank, int dtype, void* stream);
+/* merge_weight (transformer.py:228-234) on the fp32 master qkv weight [3D, D] */
+int clhip_lora_merge(float* qkv_w, const float* lora_a_k, const float* lora_b_k, const float* lora_a_v, const float* lora_b_v, int D,
+                     int rank, void* stream);
+/* d lora_B_k [D, r] += dK^T (X A_k^T), d lora_B_v likewise, dK/dV = columns [D,2D) / [2D,3D) of dqkv; x = the attention
+ * input [M, D].  ws: clhip_lora_grad_ws_bytes(M, D, rank) bytes.  Deterministic (slab partials + ordered reduce). */
+size_t clhip_lora_grad_ws_bytes(int M, int D, int rank);
+int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, const float* lora_a_v, float* d_b_k, float* d_b_v, void* ws,
+                    int M, int D, int rank, int dtype, void* stream);
+/* G [D, D] fp32 += X^T X  (MultiHeadAttention_LoRA get_input_matrix, transformer.py:241-244; the running mean is the caller's) */
+int clhip_gram_accum(const void* x, float* G, int M, int D, int dtype, void* stream);
+/* prompt.L2P.forward (prompt.py:369-406): cosine top-k per sample, batch-majority top-k ids (ties: lowest id), gathered
+ * prompt tokens [top_k*length, D], reduce_sim (scalar) and d reduce_sim / d prompt_key [pool, D].  scratch: B+pool+D floats. */
+int clhip_l2p_select(const float* cls_feat, const float* prompt_key, const float* prompt, int B, int D, int pool, int top_k, int length,
+                     int* ids, float* prompt_tokens, float* reduce_sim, float* dkey, float* scratch, void* stream);
+int clhip_l2p_scatter(const float* dtokens, const int* ids, float* dprompt_pool, int pool, int top_k, int length, int D, void* stream);
+
+/* Whole-backbone executor: one C call per forward / backward (VisionTransformer.forward, transformer.py:2222-2294, and
+ * the autograd backward of L2P.observe / the trainer's loss.backward()). */
+typedef struct clhip_vit_desc { int32_t img, patch, dim, depth, heads, mlp, lora_rank; } clhip_vit_desc;
+typedef struct clhip_vit_layer_params {
+    const float *qkv_w, *qkv_b, *proj_w, *proj_b, *ln1_w, *ln1_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln2_w, *ln2_b;
+    const float *lora_a_k, *lora_b_k, *lora_a_v, *lora_b_v;          /* NULL without LoRA */
+} clhip_vit_layer_params;
+typedef struct clhip_vit_params {
+    const float *cls_token, *pos_embed, *pe_w, *pe_b, *norm_w, *norm_b;
+    const clhip_vit_layer_params* layers;                            /* [depth] */
+} clhip_vit_params;
+typedef struct clhip_vit clhip_vit;
+clhip_vit* clhip_vit_create(const clhip_vit_desc* desc, int dtype);
+void clhip_vit_destroy(clhip_vit* v);
+size_t clhip_vit_shadow_bytes(const clhip_vit* v);
+size_t clhip_vit_workspace_bytes(const clhip_vit* v, int B, int n_prompt, int save_for_backward);
+/* fp32 masters -> compute-dtype weight copies in `shadow`; apply_lora folds B A into the k/v rows; qkv_only != 0 refreshes
+ * just the qkv copies (what changes between InfLoRA steps) */
+int clhip_vit_prep_weights(clhip_vit* v, const clhip_vit_params* P, void* shadow, int apply_lora, int qkv_only, void* stream);
+/* images fp32 [B,3,img,img]; prompt_tokens fp32 [n_prompt, D] (NULL / 0: none); feat [B, D] fp32 = final LN pooled over the
+ * prompt tokens (n_prompt > 0) or at the cls token; gram (nullable) [depth, D, D] += X^T X of every attention input */
+int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const void* shadow, void* workspace, const float* images, int B,
+                      const float* prompt_tokens, int n_prompt, int save_for_backward, float* gram, float* feat, void* stream);
+/* after a forward with save_for_backward: dprompt_tokens [n_prompt, D] (nullable); d_lora_b (nullable): [2*depth] pointers
+ * (k, v per layer) accumulated into */
+int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const void* shadow, void* workspace, const float* dfeat,
+                       float* dprompt_tokens, float* const* d_lora_b, void* stream);
+/* debug/test: copy one saved activation of layer l (0 x_in, 1 qkv, 2 attn out, 3 x_mid, 4 mlp pre-activation) to fp32 */
+int clhip_vit_read_act(clhip_vit* v, void* workspace, int layer, int which, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,19 @@ class UnitDesc(C.Structure):
                 ("rm_off", C.c_int64), ("rv_off", C.c_int64)]
 
 
+class VitDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("img", "patch", "dim", "depth", "heads", "mlp", "lora_rank")]
+
+
+class VitLayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "ln1_w", "ln1_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                          "ln2_w", "ln2_b", "lora_a_k", "lora_b_k", "lora_a_v", "lora_b_v")]
+
+
+class VitParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cls_token", "pos_embed", "pe_w", "pe_b", "norm_w", "norm_b")] + [("layers", C.POINTER(VitLayerParams))]
+
+
 def build(force=False):
     """Compile libclhip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
     script = os.path.join(_HERE, "csrc", "build.sh")
@@ -69,6 +82,7 @@ _PROTOS = {
     "clhip_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "clhip_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clhip_ce_slice": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p, _p]),
+    "clhip_ce_window": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p, _p]),
     "clhip_kd_loss": (_i, [_p, _i, _p, _i, _i, _i, _f, _f, _p, _i, _p, _i, _p]),
     "clhip_cosine_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clhip_cosine_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
@@ -88,6 +102,31 @@ _PROTOS = {
     "clhip_l2_normalize_rows": (_i, [_p, _p, _i, _i, _p]),
     "clhip_ncm_classify": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "clhip_herding_select": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
+    "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_ln_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),
+    "clhip_ln_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "clhip_ln_pool_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "clhip_ln_pool_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "clhip_patchify": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "clhip_vit_assemble": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_vit_prompt_grad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "clhip_weight_prep2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
+    "clhip_lora_merge": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "clhip_lora_grad_ws_bytes": (_sz, [_i, _i, _i]),
+    "clhip_lora_grad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "clhip_gram_accum": (_i, [_p, _p, _i, _i, _i, _p]),
+    "clhip_l2p_select": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "clhip_l2p_scatter": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "clhip_vit_create": (_p, [C.POINTER(VitDesc), _i]),
+    "clhip_vit_destroy": (None, [_p]),
+    "clhip_vit_shadow_bytes": (_sz, [_p]),
+    "clhip_vit_workspace_bytes": (_sz, [_p, _i, _i, _i]),
+    "clhip_vit_prep_weights": (_i, [_p, C.POINTER(VitParams), _p, _i, _i, _p]),
+    "clhip_vit_forward": (_i, [_p, C.POINTER(VitParams), _p, _p, _p, _i, _p, _i, _i, _p, _p, _p]),
+    "clhip_vit_backward": (_i, [_p, C.POINTER(VitParams), _p, _p, _p, _p, C.POINTER(C.c_void_p), _p]),
+    "clhip_vit_read_act": (_i, [_p, _p, _i, _i, _p, _p]),
 }
 
 _CHECKED = {}

@@ -73,16 +73,16 @@ __global__ void linear_bwd_dw_kernel(const float* __restrict__ dout, const float
 
 // ---------------------------------------------------------------------------- CE on a column slice
 __global__ __launch_bounds__(256) void ce_slice_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B,
-                                                       int O, int lo, int hi, int pred_hi, float weight, float* loss_out,
+                                                       int O, int lo, int hi, int pred_lo, int pred_hi, float weight, float* loss_out,
                                                        float* __restrict__ dlogits, int grad_acc, int64_t* pred, int32_t* correct) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const float* lr = logits + (size_t)row * O;
     const int y = (int)labels[row];
-    // argmax over [0, pred_hi): first maximal index, as torch.argmax
+    // argmax over [pred_lo, pred_hi): first maximal index, as torch.argmax
     float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int c = lane; c < pred_hi; c += 64) { float v = lr[c]; if (v > bv) { bv = v; bi = c; } }
+    for (int c = pred_lo + lane; c < pred_hi; c += 64) { float v = lr[c]; if (v > bv) { bv = v; bi = c; } }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
@@ -391,16 +391,23 @@ extern "C" int clhip_linear_bwd(const float* x, const float* w, const float* dou
     return CLHIP_OK;
 }
 
-extern "C" int clhip_ce_slice(const float* logits, const int64_t* labels, int B, int O, int lo, int hi, int pred_hi, float weight,
-                              float* loss_out, int loss_accumulate, float* dlogits, int grad_accumulate, int64_t* pred,
-                              int32_t* correct, void* stream) {
-    CLHIP_CHECK_ARG(logits && labels && loss_out && B > 0 && O > 0 && lo >= 0 && hi > lo && hi <= O && pred_hi > 0 && pred_hi <= O);
+extern "C" int clhip_ce_window(const float* logits, const int64_t* labels, int B, int O, int lo, int hi, int pred_lo, int pred_hi, float weight,
+                               float* loss_out, int loss_accumulate, float* dlogits, int grad_accumulate, int64_t* pred,
+                               int32_t* correct, void* stream) {
+    CLHIP_CHECK_ARG(logits && labels && loss_out && B > 0 && O > 0 && lo >= 0 && hi > lo && hi <= O);
+    CLHIP_CHECK_ARG(pred_lo >= 0 && pred_hi > pred_lo && pred_hi <= O);
     if (!loss_accumulate) { if (int e = zero_scalar(loss_out, 4, ST)) return e; }
     if (correct) { if (int e = zero_scalar(correct, 4, ST)) return e; }
-    hipLaunchKernelGGL(ce_slice_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, labels, B, O, lo, hi, pred_hi, weight, loss_out,
+    hipLaunchKernelGGL(ce_slice_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out,
                        dlogits, grad_accumulate, pred, correct);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
+}
+
+extern "C" int clhip_ce_slice(const float* logits, const int64_t* labels, int B, int O, int lo, int hi, int pred_hi, float weight,
+                              float* loss_out, int loss_accumulate, float* dlogits, int grad_accumulate, int64_t* pred,
+                              int32_t* correct, void* stream) {
+    return clhip_ce_window(logits, labels, B, O, lo, hi, 0, pred_hi, weight, loss_out, loss_accumulate, dlogits, grad_accumulate, pred, correct, stream);
 }
 
 extern "C" int clhip_kd_loss(const float* pred, int pred_stride, const float* soft, int soft_stride, int B, int k, float T,

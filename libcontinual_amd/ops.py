@@ -186,7 +186,7 @@ class _ClassifyLossFn(torch.autograd.Function):
     scales by the upstream gradient on device.  ewc.py:87-100, lwf.py:57-65, icarl.py:197-221."""
 
     @staticmethod
-    def forward(ctx, logits, labels, lo, hi, pred_hi, w_ce, teacher, k, T, w_kd, aux):
+    def forward(ctx, logits, labels, lo, hi, pred_hi, w_ce, teacher, k, T, w_kd, aux, pred_lo=0):
         logits = _f32c(logits)
         B, O = logits.shape
         labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
@@ -194,7 +194,7 @@ class _ClassifyLossFn(torch.autograd.Function):
         dlog = torch.empty_like(logits)
         pred = torch.empty(B, device=logits.device, dtype=torch.int64)
         correct = torch.empty(1, device=logits.device, dtype=torch.int32)
-        call("clhip_ce_slice", _ptr(logits), _ptr(labels), B, O, lo, hi, pred_hi, float(w_ce), _ptr(loss), 0, _ptr(dlog), 0,
+        call("clhip_ce_window", _ptr(logits), _ptr(labels), B, O, lo, hi, pred_lo, pred_hi, float(w_ce), _ptr(loss), 0, _ptr(dlog), 0,
              _ptr(pred), _ptr(correct), _st())
         if teacher is not None:
             teacher = _f32c(teacher)
@@ -211,14 +211,14 @@ class _ClassifyLossFn(torch.autograd.Function):
         gout = _f32c(gout.reshape(1))
         out = torch.empty_like(dlog)
         call("clhip_scale_dev", _ptr(dlog), _ptr(out), dlog.numel(), 1.0, _ptr(gout), _st())
-        return (out,) + (None,) * 10
+        return (out,) + (None,) * 11
 
 
-def classify_loss(logits, labels, lo=0, hi=None, pred_hi=None, w_ce=1.0, teacher=None, k=0, T=2.0, w_kd=0.0, aux=None):
+def classify_loss(logits, labels, lo=0, hi=None, pred_hi=None, w_ce=1.0, teacher=None, k=0, T=2.0, w_kd=0.0, aux=None, pred_lo=0):
     O = logits.shape[1]
     hi = O if hi is None else hi
     pred_hi = O if pred_hi is None else pred_hi
-    return _ClassifyLossFn.apply(logits, labels, lo, hi, pred_hi, w_ce, teacher, k, T, w_kd, aux)
+    return _ClassifyLossFn.apply(logits, labels, lo, hi, pred_hi, w_ce, teacher, k, T, w_kd, aux, pred_lo)
 
 
 def predict(logits, labels, pred_hi=None):
@@ -356,3 +356,24 @@ def herding_select(feats_normed, m):
     ws = torch.empty(2 * D + n, device=f.device, dtype=torch.float32)
     call("clhip_herding_select", _ptr(f), n, D, m, _ptr(chosen), _ptr(ws), _st())
     return chosen
+
+
+def clip_grad_norm_(params, max_norm, eps=1e-6):
+    """torch.nn.utils.clip_grad_norm_ (l2p.py:104) without a host sync: total = sqrt(sum ||g||^2) over the given
+    parameters, every gradient scaled by min(1, max_norm / (total + eps)) on the device.  Returns the norm tensor."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return None
+    _dev(*grads)
+    sq = torch.zeros(1, device=grads[0].device, dtype=torch.float32)
+    flat = []
+    for g in grads:
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            raise _lib.ClhipError("clip_grad_norm_: gradients must be contiguous fp32")
+        call("clhip_sq_norm", _ptr(g), g.numel(), _ptr(sq), 1, _st())
+        flat.append(g)
+    norm = sq.sqrt()
+    coef = (max_norm / (norm + eps)).clamp(max=1.0)
+    for g in flat:
+        call("clhip_scale_dev", _ptr(g), _ptr(g), g.numel(), 1.0, _ptr(coef), _st())
+    return norm

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import detrand
 
 VIT_B16 = dict(img=224, patch=16, dim=768, depth=12, heads=12, mlp=3072)
-VIT_TINY = dict(img=32, patch=8, dim=64, depth=2, heads=2, mlp=256)       # the fixture configuration
+VIT_TINY = dict(img=32, patch=8, dim=128, depth=2, heads=2, mlp=512)      # the fixture configuration (head dim 64)
 
 
 def n_patches(cfg):

@@ -96,7 +96,7 @@ def scenario_vit_backbone(adapter):
 # ---------------------------------------------------------------------------------------------- L2P
 # the data tag is chosen so that no batch-majority vote has a tie at the top-k cut (its resolution is torch.topk
 # implementation-defined, prompt.py:389); scenario_l2p on the oracle asserts it
-L2P_TAG = ["l2p/v0"]
+L2P_TAG = ["l2p/v1"]
 
 
 def _l2p_state(tag):
@@ -201,13 +201,16 @@ def scenario_inflora(adapter):
     res, losses, preds = {}, [], []
     blocks = [f"feat.transformer.blocks.{i}." for i in range(depth)]
 
+    # fixtures stay small: D x D quantities are stored through a fixed 6-column probe (sign-invariant products only)
+    probe = detrand.uniform(tag + "/probe", (D, 6), -1.0, 1.0)
+
     def record(t, get, feature_list, project_type):
         for i, b in enumerate(blocks):
-            A = get(b + "attn.lora_A_k.weight")
-            res[f"AtA{i}@{t}"] = _np(A.T @ A)
-            res[f"qkv{i}@{t}"] = _np(get(b + "attn.qkv.weight"))
+            A = _np(get(b + "attn.lora_A_k.weight"))
+            res[f"AtA{i}@{t}"] = A.T @ (A @ probe)
+            res[f"qkv{i}@{t}"] = _np(get(b + "attn.qkv.weight")) @ probe
             f = np.asarray(feature_list[i], np.float64)
-            res[f"proj{i}@{t}"] = f @ f.T
+            res[f"proj{i}@{t}"] = f @ (f.T @ probe)
             res[f"rank{i}@{t}"] = np.asarray(f.shape[1])
         res[f"ptype@{t}"] = np.asarray([p == "retain" for p in project_type])
 

@@ -1,0 +1,117 @@
+"""ViT path on a real MI355X: the product's ViTZoo / L2P / InfLoRA_OPT plugins driven through the SAME scenarios that
+produced tests/golden/{vit_backbone,l2p,inflora}.npz from fp64 runs of the reference's classes.
+
+f32 mode (fp32 MFMA GEMMs, generic fp32 attention) pins the wiring tightly; bf16 mode (the performance mode: bf16
+activations / weights, MFMA attention) is held to bf16-rounding tolerances on forward quantities and the first step.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import libcontinual_amd.model as M          # noqa: E402
+from libcontinual_amd import optim          # noqa: E402
+from oracle import fixtures as fx           # noqa: E402
+from oracle import vit as ov                # noqa: E402
+from oracle import vit_scenarios as vs      # noqa: E402
+
+DEV = "cuda"
+
+
+class NS:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.L2P, self.InfLoRA_OPT = M.L2P, M.InfLoRA_OPT
+
+    def make_vit(self, cfg, attn_layer="MultiHeadAttention", lora_rank=0):
+        kw = {"lora_rank": lora_rank} if lora_rank else {}
+        return M.vit_pt_imnet(pretrained=False, attn_layer=attn_layer, img_size=cfg["img"], patch_size=cfg["patch"], embed_dim=cfg["dim"],
+                              depth=cfg["depth"], num_heads=cfg["heads"], dtype=self.dtype, **kw)
+
+
+def adapter(dtype):
+    return vs.VitPluginAdapter(NS(dtype), DEV, optim=lambda name, params, **kw: getattr(optim, name)(params, **kw))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+def test_vit_backbone_golden(golden, dtype, tol):
+    want = golden("vit_backbone")
+    got = vs.scenario_vit_backbone(adapter(dtype))
+    assert rel(got["feat_plain"], want["feat_plain"]) < tol
+    assert rel(got["feat_lora"], want["feat_lora"]) < tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vit_layer_activations_vs_oracle(dtype):
+    """every saved activation of every block vs the oracle's fp64 forward on the same weights (localises a wiring error)"""
+    cfg = ov.VIT_TINY
+    with fx.use_dtype(torch.float64):
+        P = vs.backbone_params("acts", 4)
+        x = vs.det_images("acts/x", 3)
+        for k in P:
+            if "lora_B" in k:
+                P[k] = fx._t(np.asarray(ov.detrand.uniform("acts/B/" + k, tuple(P[k].shape), -0.2, 0.2)))
+        acts = []
+        with torch.no_grad():
+            ov.cls_features(P, x, cfg, lora=True, acts=acts)
+    bb = NS(dtype).make_vit(cfg, "MultiHeadAttention_LoRA", 4)
+    bb.load_state_dict({k: v.float() for k, v in P.items()}, strict=True)
+    bb = bb.to(DEV)
+    for a in bb.feat.attention_modules():
+        a.apply_lora = True
+    for p_ in bb.feat.parameters():
+        p_.requires_grad_(False)
+    for a in bb.feat.attention_modules():
+        a.lora_B_k.weight.requires_grad_(True); a.lora_B_v.weight.requires_grad_(True)
+    f = bb(x.float().to(DEV))            # grad enabled + trainable lora_B -> activations are kept
+    tol = 1e-4 if dtype == "f32" else 4e-2
+    for l in range(cfg["depth"]):
+        got = bb.feat.debug_read(l + 1, 0).double().cpu().reshape(3, -1, cfg["dim"])
+        assert rel(got, acts[l]) < tol, l
+    f.sum().backward()
+    assert all(a.lora_B_k.weight.grad is not None for a in bb.feat.attention_modules())
+
+
+def test_l2p_golden(golden):
+    want = golden("l2p")
+    got = vs.scenario_l2p(adapter("f32"))
+    assert rel(got["losses"][:1], want["losses"][:1]) < 1e-4
+    assert rel(got["losses"], want["losses"]) < 5e-3
+    np.testing.assert_array_equal(got["preds"][0], want["preds"][0])
+    for k in ("grad_prompt0", "grad_key0", "grad_cls_w0"):
+        assert rel(got[k], want[k]) < 2e-3, k                        # clipped gradients of the first step
+    touched = np.abs(got["grad_prompt0"][0]).reshape(vs.L2P_CFG["pool"], -1).max(1) > 0
+    assert (touched == (np.abs(want["grad_prompt0"][0]).reshape(vs.L2P_CFG["pool"], -1).max(1) > 0)).all()   # same voted prompts
+    for t in (0, 1):
+        assert (got[f"test_pred{t}"] == want[f"test_pred{t}"]).mean() >= 0.75
+        for n in ("prompt.prompt", "prompt.prompt_key", "classifier.weight", "classifier.bias"):
+            assert rel(got[f"{n}@{t}"], want[f"{n}@{t}"]) < 5e-2, (n, t)          # Adam: O(lr) moves on noise-level grads
+    got = vs.scenario_l2p(adapter("bf16"))
+    assert rel(got["losses"][:1], want["losses"][:1]) < 3e-2
+    assert rel(got["losses"], want["losses"]) < 0.1
+    assert rel(got["grad_cls_w0"], want["grad_cls_w0"]) < 0.1
+
+
+def test_inflora_golden(golden):
+    want = golden("inflora")
+    got = vs.scenario_inflora(adapter("f32"))
+    assert rel(got["losses"][:2], want["losses"][:2]) < 2e-4
+    assert rel(got["losses"], want["losses"]) < 5e-3
+    np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
+    for t in (0, 1):
+        np.testing.assert_array_equal(got[f"ptype@{t}"], want[f"ptype@{t}"])
+        assert rel(got[f"head{t}@{t}"], want[f"head{t}@{t}"]) < 5e-3
+        for i in range(vs.CFG["depth"]):
+            assert abs(int(got[f"rank{i}@{t}"]) - int(want[f"rank{i}@{t}"])) <= 1       # threshold on a near-flat spectrum
+            assert rel(got[f"AtA{i}@{t}"], want[f"AtA{i}@{t}"]) < 2e-2, (i, t)
+            assert rel(got[f"qkv{i}@{t}"], want[f"qkv{i}@{t}"]) < 5e-3, (i, t)
+        assert (got[f"test_pred{t}"] == want[f"test_pred{t}"]).mean() >= 0.75
+    got = vs.scenario_inflora(adapter("bf16"))
+    assert rel(got["losses"][:2], want["losses"][:2]) < 3e-2
+    assert rel(got["qkv0@0"], want["qkv0@0"]) < 3e-2
