@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_FWD_PER_IMG = {"resnet18": 1.1108e9, "cifar_resnet32": 0.13825e9}     # 2*MAC, SURVEY.md section 8(d)
+# whole-step algorithmic FLOP per image of the ViT-B/16 methods: L2P = query fwd (N=197) + prompted
+# fwd (N=222) + activation-only bwd; InfLoRA_OPT = fwd + activation bwd + rank-10 dB (the reference's dense qkv dW not counted)
+FLOP_STEP_PER_IMG = {"l2p_vitb16": 116.2e9, "inflora_vitb16": 71.5e9}
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -31,9 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 ResNet workloads, 16 L2P, 128 InfLoRA_OPT)")
     ap.add_argument("--workload", default="lwf_resnet18_b50_task0",
-                    choices=["lwf_resnet18_b50_task0", "lwf_resnet18_b50_task1", "icarl_resnet32_b50_task1", "ewc_resnet32_b50_task1"])
+                    choices=["lwf_resnet18_b50_task0", "lwf_resnet18_b50_task1", "icarl_resnet32_b50_task1", "ewc_resnet32_b50_task1",
+                             "l2p_vitb16_b10_task1", "inflora_vitb16_b20_task1"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -44,6 +48,28 @@ def build_method(workload, dtype, dev):
     """plugin + optimizer in the state of the named task (task>=1: teacher / Fisher active)"""
     import libcontinual_amd.model as M
     from libcontinual_amd import optim
+    if workload.startswith("l2p_vitb16"):
+        # config/l2p-vit-cifar100-b10-10-10.yaml: ViT-B/16, pool 10, top-5, length 5, Adam(1.875e-3), task 1 = classes 10..19
+        bb = M.vit_pt_imnet(pretrained=False, dtype=dtype)
+        m = M.L2P(bb, dev, init_cls_num=10, inc_cls_num=10, num_class=100, task_num=10, feat_dim=768, prompt_length=5, pool_size=10, top_k=5,
+                  pull_constraint_coeff=1.0)
+        m.before_task(0, None, None, None); m.after_task(0, None, None, None); m.before_task(1, None, None, None)
+        opt = optim.Adam(m.get_parameters({}), lr=0.001875, betas=(0.9, 0.999), weight_decay=0)
+        return m, opt, "l2p_vitb16", False, (10, 20)
+    if workload.startswith("inflora_vitb16"):
+        # config/InfLoRA_opt-vit-imagenetr-b20-20-10.yaml: ViT-B/16 + rank-10 LoRA on k,v; SGD(8e-3, m .9); task 1 = classes 20..39
+        os.environ.setdefault("PYTHONHASHSEED", "0")
+        bb = M.vit_pt_imnet(pretrained=False, attn_layer="MultiHeadAttention_LoRA", lora_rank=10, dtype=dtype)
+        m = M.InfLoRA_OPT(bb, dev, init_cls_num=20, inc_cls_num=20, task_num=10, lame=1.0, lamb=0.95, dataset="imagenet-r", use_ca=False, embd_dim=768)
+        m._network._cur_task_id, m._known_classes = 1, 20
+        for a in m.attention_modules:
+            a.init_param()
+            torch.nn.init.normal_(a.lora_B_k.weight, std=1e-3); torch.nn.init.normal_(a.lora_B_v.weight, std=1e-3)
+        for name, prm in m._network.named_parameters():
+            prm.requires_grad_("classifier_pool.1." in name or "lora_B" in name)
+        m._network.to(dev)
+        opt = optim.SGD(m.get_parameters({}), lr=8e-3, momentum=0.9)
+        return m, opt, "inflora_vitb16", False, (20, 40)
     if workload.startswith("lwf_resnet18"):
         bb = M.resnet18(args={"dataset": "cifar100"}, dtype=dtype)
         m = M.LWF(bb, 512, 100, device=dev, init_cls_num=50, inc_cls_num=5).to(dev)
@@ -78,9 +104,9 @@ def build_method(workload, dtype, dev):
     return m, opt, arch, teacher, (lo, hi)
 
 
-def synthetic_batch(B, lo, hi, seed, dev):
+def synthetic_batch(B, lo, hi, seed, dev, size=32):
     g = torch.Generator().manual_seed(seed)
-    x = torch.rand(B, 3, 32, 32, generator=g)
+    x = torch.rand(B, 3, size, size, generator=g)
     mean = torch.tensor([0.5071, 0.4866, 0.4409]).view(1, 3, 1, 1)
     std = torch.tensor([0.2675, 0.2565, 0.2761]).view(1, 3, 1, 1)
     x = (x - mean) / std
@@ -160,8 +186,44 @@ def dominant_kernel_roofline(dev, dtype, B):
                 hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
 
 
+def gemm_roofline(dev, dtype, M):
+    """dominant kernel of the ViT workloads: the fc1 GEMM [M,768] x [3072,768]^T with the bias+GELU epilogue, timed with HIP
+    events on the launch stream; algorithmic FLOPs = 2*M*768*3072"""
+    from libcontinual_amd import _lib
+    code = _lib.BF16 if dtype == "bf16" else _lib.F32
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    N, K = 3072, 768
+    A = torch.randn(M, K, device=dev).to(tdt)
+    W = (torch.randn(N, K, device=dev) * 0.03).to(tdt)
+    bias = torch.zeros(N, device=dev)
+    Cc = torch.empty(M, N, device=dev, dtype=tdt)
+    H = torch.empty(M, N, device=dev, dtype=tdt)
+    st = torch.cuda.current_stream().cuda_stream
+    run = lambda: _lib.call("clhip_gemm_nt", A.data_ptr(), W.data_ptr(), Cc.data_ptr(), bias.data_ptr(), None, H.data_ptr(), M, N, K, K, K, N, 0, N, 3, code, st)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * N * K
+    es = 2 if dtype == "bf16" else 4
+    alg_bytes = (M * K + N * K + 2 * M * N) * es
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel=f"gemm_nt_kernel<{dtype}, bias+GELU> fc1 @ [{M},768]x[3072,768]^T", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                frac=ach / PEAK_BF16_TFLOPS, traffic=None, launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
+                hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
+
+
 def main():
     a = parse()
+    vit = "vitb16" in a.workload
+    if a.batch is None:
+        a.batch = 16 if a.workload.startswith("l2p") else (128 if vit else 256)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -183,7 +245,7 @@ def main():
         parallel.broadcast_module_state(model)
         opt.grad_scale = 1.0 / world
     model.train()
-    batches = [synthetic_batch(a.batch, lo, hi, 100 + rank * 7 + i, dev) for i in range(4)]
+    batches = [synthetic_batch(a.batch, lo, hi, 100 + rank * 7 + i, dev, 224 if vit else 32) for i in range(4)]
     name = type(model).__name__
     meter = AverageMeter("train", ["loss", "acc1"])
 
@@ -210,20 +272,23 @@ def main():
     if rank != 0:
         return
     ips = world * a.batch * a.steps / dt
-    fwd = FLOP_FWD_PER_IMG[arch]
-    step_flops_per_img = 3 * fwd + (fwd if teacher else 0.0)
+    if vit:
+        step_flops_per_img = FLOP_STEP_PER_IMG[arch]
+    else:
+        fwd = FLOP_FWD_PER_IMG[arch]
+        step_flops_per_img = 3 * fwd + (fwd if teacher else 0.0)
     out = {
         "metric": "images/sec/node (task-0 epoch), CIFAR-100 B50-5x10" if a.workload.endswith("task0") else "images/sec/node (task>=1 step), CIFAR-100 B50-5x10",
         "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": a.workload, "method": name, "backbone": arch, "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                   "image": "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused SGD", "final_loss": loss_avg},
+        "config": {"workload": a.workload, "method": name, "backbone": "vit_base_patch16_224" if vit else arch, "per_gpu_batch": a.batch,
+                   "global_batch": a.batch * world, "image": "3x224x224" if vit else "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused SGD", "final_loss": loss_avg},
         "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }
-    out["roofline"] = dominant_kernel_roofline(dev, a.dtype, a.batch)
-    if not a.no_cpu_baseline:
+    out["roofline"] = gemm_roofline(dev, a.dtype, a.batch * (222 if a.workload.startswith("l2p") else 197)) if vit else dominant_kernel_roofline(dev, a.dtype, a.batch)
+    if not a.no_cpu_baseline and not vit:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps, 128)
     print(json.dumps(out))
 

@@ -261,8 +261,10 @@ int clhip_lora_merge(float* qkv_w, const float* lora_a_k, const float* lora_b_k,
 /* d lora_B_k [D, r] += dK^T (X A_k^T), d lora_B_v likewise, dK/dV = columns [D,2D) / [2D,3D) of dqkv; x = the attention
  * input [M, D].  ws: clhip_lora_grad_ws_bytes(M, D, rank) bytes.  Deterministic (slab partials + ordered reduce). */
 size_t clhip_lora_grad_ws_bytes(int M, int D, int rank);
-int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, const float* lora_a_v, float* d_b_k, float* d_b_v, void* ws,
-                    int M, int D, int rank, int dtype, void* stream);
+/* a_cat (nullable): [32, D] compute-dtype matrix [A_k; A_v; 0] from clhip_lora_acat -- enables the bf16 MFMA path */
+int clhip_lora_acat(const float* lora_a_k, const float* lora_a_v, void* a_cat, int D, int rank, int dtype, void* stream);
+int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, const float* lora_a_v, const void* a_cat, float* d_b_k,
+                    float* d_b_v, void* ws, int M, int D, int rank, int dtype, void* stream);
 /* G [D, D] fp32 += X^T X  (MultiHeadAttention_LoRA get_input_matrix, transformer.py:241-244; the running mean is the caller's) */
 int clhip_gram_accum(const void* x, float* G, int M, int D, int dtype, void* stream);
 /* prompt.L2P.forward (prompt.py:369-406): cosine top-k per sample, batch-majority top-k ids (ties: lowest id), gathered

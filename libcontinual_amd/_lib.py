@@ -115,7 +115,8 @@ _PROTOS = {
     "clhip_weight_prep2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
     "clhip_lora_merge": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "clhip_lora_grad_ws_bytes": (_sz, [_i, _i, _i]),
-    "clhip_lora_grad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "clhip_lora_acat": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "clhip_lora_grad": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clhip_gram_accum": (_i, [_p, _p, _i, _i, _i, _p]),
     "clhip_l2p_select": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "clhip_l2p_scatter": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

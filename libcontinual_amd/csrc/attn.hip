@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
+constexpr int BWD_WAVES = 8;      // LDS (Q, K, V, dO of one head) limits the CU to one workgroup: give it 8 waves
+
+__global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
     stage_rows(Ks, base + D, ld, N, NP2);
     stage_rows(Vs, base + 2 * D, ld, N, NP2);
     stage_rows(Gs, dob, D, N, NP2);
-    for (int q = tid; q < NP2; q += 256) {
+    for (int q = tid; q < NP2; q += 64 * BWD_WAVES) {
         float dsum = 0.f, l = INFINITY;
         if (q < N) {
             l = p.lse[((size_t)b * p.H + h) * N + q];
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
     __syncthreads();
 
     // ---- phase A: dQ.  wave <- query tile; per key-tile pair: S^T, dP^T (D layout: rows key g*4+e, col q l15)
-    for (int qt = wave; qt < nKT; qt += 4) {
+    for (int qt = wave; qt < nKT; qt += BWD_WAVES) {
         const int qrow = qt * 16 + l15;
         uint4 qf[2], gf[2];
 #pragma unroll
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
     }
 
     // ---- phase B: dK, dV.  wave <- key tile; per query-tile pair: S, dP (D layout: rows q g*4+e, col key l15)
-    for (int kt = wave; kt < nKT; kt += 4) {
+    for (int kt = wave; kt < nKT; kt += BWD_WAVES) {
         const int krow = kt * 16 + l15;
         const bool kok = krow < N;
         uint4 kf[2], vf[2];
@@ -431,7 +433,7 @@ extern "C" int clhip_attn_bwd(const void* qkv, const void* out, const float* lse
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
             done = true;
         }
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), smem, s, p);
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(64 * BWD_WAVES), smem, s, p);
     } else {
         CLHIP_CHECK_ARG(dsum_ws != nullptr);
         const int rows = B * H * N;

@@ -9,6 +9,8 @@
 //   input Gram X^T X for InfLoRA               transformer.py:241-244
 //   L2P prompt selection, pull-constraint value and key gradient                prompt.py:375-404
 // All LayerNorm / prompt parameters are frozen or tiny on this path, so the backward only produces input gradients.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -318,6 +320,88 @@ __global__ __launch_bounds__(256) void lora_db_kernel(const T* __restrict__ dqkv
     }
 }
 
+// ---- bf16 fast path.  P16 [M, 32] = X . Acat^T comes from the MFMA GEMM (Acat = [A_k; A_v; 0] as a [32, D] bf16 matrix);
+// slab[s, o, q] = sum_m dY[m, D + o] P16[m, (o >= D ? r : 0) + q] is a "TN" product: both MFMA operands are read with the
+// transposing LDS read from row-major tiles (rows = m), 32 rows per step, k-slot j of lane group g <-> row g*4 + (j&3) + 16*(j>>2)
+// on BOTH operands (the slot order of an MFMA is free), which keeps the reads bank-conflict free at these pitches.
+constexpr int YP = 160, PP = 96;      // LDS pitches (bytes) of the dY tile rows (64 bf16) and the P tile rows (32 bf16)
+
+__device__ __forceinline__ uint4 tr8v(const char* base, int addr, int second) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr + second));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+
+__global__ __launch_bounds__(256) void lora_db_mfma_kernel(const bf16_t* __restrict__ dqkv, const bf16_t* __restrict__ P16, float* __restrict__ slab,
+                                                            int M, int D, int rank, int rows_per_slab) {
+    __shared__ __attribute__((aligned(16))) char ys[2][32 * YP];
+    __shared__ __attribute__((aligned(16))) char ps[2][32 * PP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int o0 = blockIdx.x * 64;                                 // column block of [dK | dV]
+    const int m0 = blockIdx.y * rows_per_slab, m1 = min(M, m0 + rows_per_slab);
+    const int qoff = o0 >= D ? rank : 0;                            // D % 64 == 0: a block never straddles dK / dV
+    const int yr = tid >> 3, yc = tid & 7;                          // dY tile: 32 rows x 8 chunks
+    const int pr = tid >> 2, pc = tid & 3;                          // P tile: 32 rows x 4 chunks (threads < 128)
+    const bf16_t* ysrc = dqkv + (size_t)D + o0 + yc * 8;
+    uint4 ry, rp;
+    auto gload = [&](int mb) {
+        const int my = mb + yr, mp = mb + pr;
+        ry = my < m1 ? *reinterpret_cast<const uint4*>(ysrc + (size_t)my * 3 * D) : make_uint4(0, 0, 0, 0);
+        if (tid < 128) rp = mp < m1 ? *reinterpret_cast<const uint4*>(P16 + (size_t)mp * 32 + pc * 8) : make_uint4(0, 0, 0, 0);
+    };
+    auto sstore = [&](int st) {
+        *reinterpret_cast<uint4*>(ys[st] + yr * YP + yc * 16) = ry;
+        if (tid < 128) *reinterpret_cast<uint4*>(ps[st] + pr * PP + pc * 16) = rp;
+    };
+    const int ya = (g * 4 + (l15 >> 2)) * YP + (wave * 16 + (l15 & 3) * 4) * 2;
+    const int pa = (g * 4 + (l15 >> 2)) * PP + (l15 & 3) * 8;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (m0 < m1) {
+        gload(m0);
+        sstore(0);
+        __syncthreads();
+        int st = 0;
+        for (int mb = m0; mb < m1; mb += 32, st ^= 1) {
+            const bool more = mb + 32 < m1;
+            if (more) gload(mb + 32);
+            const uint4 a = tr8v(ys[st], ya, 16 * YP);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint4 b = tr8v(ps[st], pa + t * 32, 16 * PP);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[t], 0, 0, 0);
+            }
+            if (more) sstore(st ^ 1);
+            __syncthreads();
+        }
+    }
+    // D[row = o (g*4+e)][col = q (l15 + 16 t)]; keep q in [qoff, qoff + rank)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int q = l15 + 16 * t - qoff;
+        if (q >= 0 && q < rank) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = o0 + wave * 16 + g * 4 + e;
+                slab[((size_t)blockIdx.y * 2 * D + o) * rank + q] = acc[t][e];
+            }
+        }
+    }
+}
+
+// Acat [32, D] (compute dtype) = rows [A_k (rank) ; A_v (rank) ; zeros]
+template <typename T>
+__global__ __launch_bounds__(256) void lora_acat_kernel(const float* __restrict__ Ak, const float* __restrict__ Av, T* __restrict__ out, int D, int rank) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 32 * D) return;
+    const int r = idx / D, c = idx - r * D;
+    float v = 0.f;
+    if (r < rank) v = Ak[(size_t)r * D + c];
+    else if (r < 2 * rank) v = Av[(size_t)(r - rank) * D + c];
+    Elem<T>::st(out + idx, v);
+}
+
 // dBk[o, q] += sum_s slab[s, o, q];  dBv[o, q] += sum_s slab[s, D + o, q]
 __global__ __launch_bounds__(256) void lora_db_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dBk, float* __restrict__ dBv, int D, int rank,
                                                               int nslab) {
@@ -563,16 +647,38 @@ extern "C" int clhip_lora_merge(float* qkv_w, const float* lora_a_k, const float
 
 extern "C" size_t clhip_lora_grad_ws_bytes(int M, int D, int rank) {
     const int nslab = (M + 511) / 512;
-    return ((size_t)M * 2 * rank + (size_t)nslab * 2 * D * rank) * sizeof(float);
+    const size_t p = std::max((size_t)M * 2 * rank * sizeof(float), (size_t)M * 32 * 2);
+    return (p + 255) / 256 * 256 + (size_t)nslab * 2 * D * rank * sizeof(float);
 }
 
-extern "C" int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, const float* lora_a_v, float* d_b_k, float* d_b_v, void* ws, int M,
-                               int D, int rank, int dtype, void* stream) {
+extern "C" int clhip_lora_acat(const float* lora_a_k, const float* lora_a_v, void* a_cat, int D, int rank, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(lora_a_k && lora_a_v && a_cat && D > 0 && rank > 0 && rank <= 16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL(lora_acat_kernel<bf16_t>, dim3((32 * D + 255) / 256), dim3(256), 0, s, lora_a_k, lora_a_v, (bf16_t*)a_cat, D, rank),
+                hipLaunchKernelGGL(lora_acat_kernel<float>, dim3((32 * D + 255) / 256), dim3(256), 0, s, lora_a_k, lora_a_v, (float*)a_cat, D, rank));
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, const float* lora_a_v, const void* a_cat, float* d_b_k, float* d_b_v,
+                               void* ws, int M, int D, int rank, int dtype, void* stream) {
     CLHIP_CHECK_ARG(x && dqkv && lora_a_k && lora_a_v && d_b_k && d_b_v && ws && M > 0 && rank > 0 && rank <= 16);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CLHIP_BF16 && a_cat != nullptr && D % 64 == 0) {
+        // MFMA path: P16 = X . Acat^T through the GEMM kernel, then the transposing-read TN product per 1024-row slab
+        const int rows = 1024, nslab = (M + rows - 1) / rows;
+        CLHIP_CHECK_ARG(nslab <= (M + 511) / 512);
+        bf16_t* P16 = static_cast<bf16_t*>(ws);
+        float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + (std::max((size_t)M * 2 * rank * sizeof(float), (size_t)M * 32 * 2) + 255) / 256 * 256);
+        if (int rc = clhip_gemm_nt(x, a_cat, P16, nullptr, nullptr, nullptr, M, 32, D, D, D, 32, 0, 0, 0, dtype, stream)) return rc;
+        hipLaunchKernelGGL(lora_db_mfma_kernel, dim3(2 * D / 64, nslab), dim3(256), 0, s, (const bf16_t*)dqkv, P16, slab, M, D, rank, rows);
+        hipLaunchKernelGGL(lora_db_reduce_kernel, dim3((2 * D * rank + 255) / 256), dim3(256), 0, s, slab, d_b_k, d_b_v, D, rank, nslab);
+        CLHIP_LAUNCH_CHECK();
+        return CLHIP_OK;
+    }
     const int nslab = (M + 511) / 512;
     float* P = static_cast<float*>(ws);
-    float* slab = P + (size_t)M * 2 * rank;
+    float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + (std::max((size_t)M * 2 * rank * sizeof(float), (size_t)M * 32 * 2) + 255) / 256 * 256);
     dim3 g2((2 * D + 255) / 256, nslab);
     DT_DISPATCH(dtype,
                 { hipLaunchKernelGGL(lora_proj_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, lora_a_k, lora_a_v, P, M, D, rank);

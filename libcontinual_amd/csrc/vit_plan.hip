@@ -15,7 +15,7 @@ size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RES = 2, EPI_BIAS_GELU = 3, EPI_GELU_BWD = 4 };
 
-struct LayerShadow { size_t qkv_f, qkv_b, proj_f, proj_b, fc1_f, fc1_b, fc2_f, fc2_b; };
+struct LayerShadow { size_t qkv_f, qkv_b, proj_f, proj_b, fc1_f, fc1_b, fc2_f, fc2_b, acat; };
 
 struct Layout {          // byte offsets into the workspace for one (B, n_prompt, save) configuration
     int B, P, N, M, save;
@@ -109,6 +109,7 @@ extern "C" clhip_vit* clhip_vit_create(const clhip_vit_desc* desc, int dtype) {
         s.proj_f = take(D * D * e); s.proj_b = take(D * D * e);
         s.fc1_f = take(H * D * e); s.fc1_b = take(H * D * e);
         s.fc2_f = take(H * D * e); s.fc2_b = take(H * D * e);
+        s.acat = desc->lora_rank > 0 ? take(32 * D * e) : 0;
     }
     v->shadow_bytes = off;
     v->have_last = false;
@@ -134,7 +135,10 @@ extern "C" int clhip_vit_prep_weights(clhip_vit* v, const clhip_vit_params* P, v
     for (int l = 0; l < v->d.depth; ++l) {
         const clhip_vit_layer_params& p = P->layers[l];
         const LayerShadow& s = v->sh[l];
-        if (r > 0) CLHIP_CHECK_ARG(p.lora_a_k && p.lora_b_k && p.lora_a_v && p.lora_b_v);
+        if (r > 0) {
+            CLHIP_CHECK_ARG(p.lora_a_k && p.lora_b_k && p.lora_a_v && p.lora_b_v);
+            TRY(clhip_lora_acat(p.lora_a_k, p.lora_a_v, sh + s.acat, D, r, v->dtype, stream));
+        }
         TRY(clhip_weight_prep2(p.qkv_w, sh + s.qkv_f, sh + s.qkv_b, 3 * D, D, p.lora_a_k, p.lora_b_k, p.lora_a_v, p.lora_b_v, r, v->dtype, stream));
         if (qkv_only) continue;
         TRY(clhip_weight_prep2(p.proj_w, sh + s.proj_f, sh + s.proj_b, D, D, nullptr, nullptr, nullptr, nullptr, 0, v->dtype, stream));
@@ -207,8 +211,8 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
                            reinterpret_cast<float*>(ws + L.dsum), B, N, d.heads, D, dt, stream));
         if (d_lora_b) {
             CLHIP_CHECK_ARG(p.lora_a_k && p.lora_a_v && d_lora_b[2 * l] && d_lora_b[2 * l + 1]);
-            TRY(clhip_lora_grad(ws + L.h1[l], ws + L.dqkv, p.lora_a_k, p.lora_a_v, d_lora_b[2 * l], d_lora_b[2 * l + 1], ws + L.lora_ws, M, D, d.lora_rank, dt,
-                                stream));
+            TRY(clhip_lora_grad(ws + L.h1[l], ws + L.dqkv, p.lora_a_k, p.lora_a_v, sh + s.acat, d_lora_b[2 * l], d_lora_b[2 * l + 1], ws + L.lora_ws, M, D,
+                                d.lora_rank, dt, stream));
         }
         if (l == 0 && dprompt_tokens == nullptr) break;           // nothing below the first block needs a gradient
         TRY(clhip_gemm_nt(ws + L.dqkv, sh + s.qkv_b, ws + L.dtmp, nullptr, nullptr, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, 0, 0, EPI_NONE, dt, stream));
