@@ -222,10 +222,13 @@ int clhip_herding_select(const float* feats /*[n,D], L2-normalised*/, int n, int
  *
  * clhip_gemm_nt: C[M,N] = epi(A[M,K] . B[N,K]^T); replaces every F.linear on the path (transformer.py:172,194,
  *   255,1267-1271) and, with the [in,out] copy of a frozen weight as B, its input gradient.  Epilogues:
- *   0 none | 1 +bias | 2 +bias +R (residual add, :1333-1334) | 3 +bias, H <- pre-activation (nullable), GELU (:1268)
- *   | 4 *GELU'(H) (backward of 3).  bias fp32; R, H in the compute dtype.  K % 64 == 0, N % 4 == 0.            */
+ *   0 none | 1 +bias | 2 +bias +R (residual add, :1333-1334) | 3 +bias, then C <- GELU(.) (:1268) and H <- GELU'(.)
+ *   (nullable; saved for the backward) | 4 C <- (.) * H (backward of 3).  bias fp32; R, H in the compute dtype.
+ *   K % 64 == 0, N % 4 == 0.                                                                                    */
 int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                   int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
+/* tuning knob (bf16): 0 register-staged tiles, 1 LDS-DMA 128x128, 2 LDS-DMA 256x128; -1 = from $CLHIP_GEMM_IMPL (default 0) */
+void clhip_gemm_config(int impl);
 /* softmax(q k^T / sqrt(d)) v per (batch, head) on the packed qkv [B*N, 3D] (column = which*D + head*d + i), out [B*N, D],
  * lse [B,H,N] (nullable in forward-only use); MultiHeadAttention.forward, transformer.py:169-197.  N <= 256, d <= 64. */
 int clhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype, void* stream);
@@ -300,7 +303,7 @@ int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const void* shado
  * (k, v per layer) accumulated into */
 int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const void* shadow, void* workspace, const float* dfeat,
                        float* dprompt_tokens, float* const* d_lora_b, void* stream);
-/* debug/test: copy one saved activation of layer l (0 x_in, 1 qkv, 2 attn out, 3 x_mid, 4 mlp pre-activation) to fp32 */
+/* debug/test: copy one saved activation of layer l (0 x_in, 1 qkv, 2 attn out, 3 x_mid, 4 GELU derivative of the mlp) to fp32 */
 int clhip_vit_read_act(clhip_vit* v, void* workspace, int layer, int which, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -103,6 +103,7 @@ _PROTOS = {
     "clhip_ncm_classify": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "clhip_herding_select": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
+    "clhip_gemm_config": (None, [_i]),
     "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_ln_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),

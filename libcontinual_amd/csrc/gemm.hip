@@ -5,18 +5,20 @@
 // :1267-1271 fc1/fc2, timm PatchEmbed) and every activation-gradient product of its backward (dX = dY . W) is an
 // "NT" product once the frozen weight is kept in both orientations ([out,in] for the forward, [in,out] for dX),
 // so ONE kernel serves forward and backward; the epilogue carries the elementwise work the reference runs as
-// separate memory passes (bias add, residual add, exact GELU, GELU derivative).
+// separate memory passes (bias add, residual add, exact GELU and -- saved for the backward -- its derivative).
 //
-// Tiling: 128x128 output tile per 256-thread block (2x2 waves, each 64x64 = 4x4 MFMA 16x16 tiles), K step 64,
+// Tiling: (32 MT)x128 output tile per 256-thread block (2x2 waves, each (16 MT)x64 = MT x 4 MFMA 16x16 tiles; MT = 4 by default), K step 64,
 // register-staged double-buffered LDS (one barrier per K step), XOR-swizzled 128-B rows so ds_read_b128 is
 // bank-conflict free.  The MFMA "A" operand is the B (weight) tile, so a lane ends up with 4 consecutive n of
 // one output row m -> 8-byte (bf16) / 16-byte (fp32) row-contiguous stores and bias / residual loads.
 // Block ids are remapped so each XCD (own L2) walks a contiguous range of row panels over all column panels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RES = 2, EPI_BIAS_GELU = 3, EPI_GELU_BWD = 4 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RES = 2, EPI_BIAS_GELU = 3, EPI_MUL = 4 };
 
 struct GemmParams {
     const void* A; const void* B; void* C;
@@ -85,18 +87,62 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// exact GELU (nn.GELU default, transformer.py:1259): x * Phi(x), and its derivative Phi(x) + x * phi(x)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// exact (erf) GELU of nn.GELU (transformer.py:1259): gelu = x Phi(x), gelu' = Phi(x) + x phi(x).  With z = |x|/sqrt(2) the
+// Gaussian factor of Abramowitz-Stegun 7.1.26 (erf(z) = 1 - poly(t) exp(-z^2), |err| <= 1.5e-7, t = 1/(1 + p z)) is
+// exp(-x^2/2) = sqrt(2 pi) phi(x): ONE exp serves both, and the forward epilogue emits gelu AND gelu' (the backward
+// epilogue is then a plain multiply) for ~20 VALU per element instead of two libm erff/expf calls.
+__device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float e = __expf(-z * z);
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(t, pl, 1.421413741f);
+    pl = fmaf(t, pl, -0.284496736f);
+    pl = fmaf(t, pl, 0.254829592f);
+    const float erf_abs = fmaf(-pl * t, e, 1.0f);
+    const float phi = 0.5f * (1.0f + copysignf(erf_abs, x));
+    y = x * phi;
+    dy = fmaf(x * 0.3989422804014327f, e, phi);
 }
 
-constexpr int BM = 128, BN = 128, BK = 64;
-
+// epilogue of one accumulator: the lane holds C[m][n .. n+3]
 template <typename T, int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams& p, const f32x4& a, int m, int n) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if constexpr (EPI == EPI_BIAS_RES) {
+        float r[4];
+        load4<T>(static_cast<const T*>(p.R) + (size_t)m * p.ldr + n, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    if constexpr (EPI == EPI_BIAS_GELU) {
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], d[e]);
+        if (p.H) store4<T>(static_cast<T*>(p.H) + (size_t)m * p.ldh + n, d);
+    }
+    if constexpr (EPI == EPI_MUL) {
+        float h[4];
+        load4<T>(static_cast<const T*>(p.H) + (size_t)m * p.ldh + n, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= h[e];
+    }
+    store4<T>(static_cast<T*>(p.C) + (size_t)m * p.ldc + n, v);
+}
+
+constexpr int BN = 128, BK = 64;
+
+// MT = 16-row MFMA tiles per wave along M: block tile (32 MT) x 128.  MT = 4 (128 rows) is the default; MT = 5 / 2 are picked
+// when they quantise the tile count better against the 512 resident workgroups (2 per CU), see pick_mt().
+template <typename T, int EPI, int MT>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_BYTES = BM * BK * (int)sizeof(T);          // one operand tile
+    constexpr int BM = 32 * MT;
+    constexpr int A_BYTES = BM * BK * (int)sizeof(T), B_BYTES = BN * BK * (int)sizeof(T), STAGE = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -117,85 +163,174 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
 
     // global -> register staging: thread owns chunk c of rows r0 + 32 i
     const int c = tid & 7, r0 = tid >> 3;
-    const T* ag[4];
+    // rows beyond M / N are clamped to the last valid row: their products land in accumulators that are never stored
+    const T* ag[MT];
     const T* bg[4];
-    bool av[4], bv[4];
-    int st_off[4];
+    int st_off[MT > 4 ? MT : 4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = r0 + 32 * i;
-        av[i] = (m0 + row) < p.M;
-        bv[i] = (n0 + row) < p.N;
-        ag[i] = A + (size_t)(av[i] ? m0 + row : 0) * p.lda + c * 8;
-        bg[i] = B + (size_t)(bv[i] ? n0 + row : 0) * p.ldb + c * 8;
-        st_off[i] = lds_off<T>(row, c);
-    }
+    for (int i = 0; i < (MT > 4 ? MT : 4); ++i) st_off[i] = lds_off<T>(r0 + 32 * i, c);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ag[i] = A + (size_t)min(m0 + r0 + 32 * i, p.M - 1) * p.lda + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bg[i] = B + (size_t)min(n0 + r0 + 32 * i, p.N - 1) * p.ldb + c * 8;
     // per-lane fragment read offsets (row & 7 == l15 & 7 because every tile row base is a multiple of 16)
     int a_off[2], b_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        a_off[kk] = lds_off<T>(wm * 64 + l15, g + 4 * kk);
+        a_off[kk] = lds_off<T>(wm * 16 * MT + l15, g + 4 * kk);
         b_off[kk] = lds_off<T>(wn * 64 + l15, g + 4 * kk);
     }
     constexpr int ROW16 = 16 * BK * (int)sizeof(T);               // LDS bytes of 16 tile rows
 
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    Chunk<T> ra[MT], rb[4];
+    const int KT = p.K / BK;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ra[i] = cload<T>(ag[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = cload<T>(bg[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) lds_st<T>(smem, st_off[i], ra[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_st<T>(smem + A_BYTES, st_off[i], rb[i]);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* As = smem + (kt & 1) * STAGE;
+        const char* Bs = As + A_BYTES;
+        const bool more = kt + 1 < KT;
+        if (more) {
+            const int ko = (kt + 1) * BK;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ra[i] = cload<T>(ag[i] + ko);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = cload<T>(bg[i] + ko);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            Chunk<T> fa[MT], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = lds_ld<T>(Bs, b_off[kk] + j * ROW16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = lds_ld<T>(As, a_off[kk] + i * ROW16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma<T>(fb[j], fa[i], acc[i][j]);       // D[row = n][col = m]
+        }
+        if (more) {
+            char* An = smem + ((kt + 1) & 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) lds_st<T>(An, st_off[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_st<T>(An + A_BYTES, st_off[i], rb[i]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m][n .. n+3], m = m0 + wm*16*MT + i*16 + l15, n = n0 + wn*64 + j*16 + g*4
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * 16 * MT + i * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (n < p.N) epi_store<T, EPI>(p, acc[i][j], m, n);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16): the operand tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no
+// ds_write pass: in the register-staged kernel above the 16-byte LDS stores cost about as many LDS cycles as the
+// fragment reads).  The DMA writes lane-linearly (1 KB per wave-instruction = 8 rows of 128 B), so the XOR swizzle is
+// applied to the per-lane SOURCE chunk; reads use the same swizzled offsets as above.  NST-deep ring, prefetch distance
+// NST-1, counted s_waitcnt vmcnt + raw s_barrier (one per K step).  WM x WN waves, each 64x64.  Rows beyond M / N are
+// clamped to the last valid row (their results are never stored).
+template <int EPI, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    constexpr int GM = 64 * WM, GN = 64 * WN, NW = WM * WN;
+    constexpr int A_BYTES = GM * 128, B_BYTES = GN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int AI = (GM / 8) / NW, BI = (GN / 8) / NW, GRP = AI + BI;       // DMA instructions per wave per stage
+    static_assert((GM / 8) % NW == 0 && (GN / 8) % NW == 0, "row groups must divide among the waves");
+    constexpr int PD = NST - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + GN - 1) / GN;
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * GM, n0 = tn * GN;
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+    const int lr = lane >> 3, sc = ((lane & 7) ^ lr) * 8;          // row within the 8-row group, swizzled source chunk
+    const bf16_t* asrc[AI];
+    const bf16_t* bsrc[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) asrc[i] = A + (size_t)min(m0 + (wave * AI + i) * 8 + lr, p.M - 1) * p.lda + sc;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) bsrc[i] = B + (size_t)min(n0 + (wave * BI + i) * 8 + lr, p.N - 1) * p.ldb + sc;
+    auto dma = [&](int kt) {
+        char* st = smem + (kt % NST) * STAGE;
+        const int ko = kt * BK;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(asrc[i] + ko), (lvoid*)(st + (wave * AI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(bsrc[i] + ko), (lvoid*)(st + A_BYTES + (wave * BI + i) * 1024), 16, 0, 0);
+    };
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_off[kk] = lds_off<bf16_t>(wm * 64 + l15, g + 4 * kk);
+        b_off[kk] = lds_off<bf16_t>(wn * 64 + l15, g + 4 * kk);
+    }
+    constexpr int ROW16 = 16 * 128;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    Chunk<T> ra[4], rb[4];
     const int KT = p.K / BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = av[i] ? cload<T>(ag[i]) : czero<T>();
-        rb[i] = bv[i] ? cload<T>(bg[i]) : czero<T>();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lds_st<T>(smem, st_off[i], ra[i]);
-        lds_st<T>(smem + TILE_BYTES, st_off[i], rb[i]);
-    }
-    __syncthreads();
-
+    for (int s_ = 0; s_ < PD; ++s_)
+        if (s_ < KT) dma(s_);
     for (int kt = 0; kt < KT; ++kt) {
-        const char* As = smem + (kt & 1) * 2 * TILE_BYTES;
-        const char* Bs = As + TILE_BYTES;
-        const bool more = kt + 1 < KT;
-        if (more) {
-            const int ko = (kt + 1) * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = av[i] ? cload<T>(ag[i] + ko) : czero<T>();
-                rb[i] = bv[i] ? cload<T>(bg[i] + ko) : czero<T>();
-            }
-        }
+        const int rem = min(KT, kt + PD) - (kt + 1);              // DMA groups allowed to stay in flight
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GRP) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // stage kt landed for every wave; stage kt-1 is free
+        asm volatile("" ::: "memory");
+        if (kt + PD < KT) dma(kt + PD);
+        const char* As = smem + (kt % NST) * STAGE;
+        const char* Bs = As + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            Chunk<T> fa[4], fb[4];
+            Chunk<bf16_t> fa[4], fb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = lds_ld<T>(Bs, b_off[kk] + j * ROW16);
+            for (int j = 0; j < 4; ++j) fb[j] = lds_ld<bf16_t>(Bs, b_off[kk] + j * ROW16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = lds_ld<T>(As, a_off[kk] + i * ROW16);
+            for (int i = 0; i < 4; ++i) fa[i] = lds_ld<bf16_t>(As, a_off[kk] + i * ROW16);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma<T>(fb[j], fa[i], acc[i][j]);       // D[row = n][col = m]
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma<bf16_t>(fb[j], fa[i], acc[i][j]);
         }
-        if (more) {
-            char* An = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lds_st<T>(An, st_off[i], ra[i]);
-                lds_st<T>(An + TILE_BYTES, st_off[i], rb[i]);
-            }
-        }
-        __syncthreads();
     }
-
-    // epilogue: lane holds C[m][n .. n+3], m = m0 + wm*64 + i*16 + l15, n = n0 + wn*64 + j*16 + g*4
-    T* C = static_cast<T*>(p.C);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + l15;
@@ -203,60 +338,225 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + g * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if constexpr (EPI == EPI_BIAS_RES) {
-                float r[4];
-                load4<T>(static_cast<const T*>(p.R) + (size_t)m * p.ldr + n, r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r[e];
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
-                if (p.H) store4<T>(static_cast<T*>(p.H) + (size_t)m * p.ldh + n, v);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-            }
-            if constexpr (EPI == EPI_GELU_BWD) {
-                float h[4];
-                load4<T>(static_cast<const T*>(p.H) + (size_t)m * p.ldh + n, h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(h[e]);
-            }
-            store4<T>(C + (size_t)m * p.ldc + n, v);
+            if (n < p.N) epi_store<bf16_t, EPI>(p, acc[i][j], m, n);
         }
     }
 }
 
-template <typename T, int EPI> int launch(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const size_t smem = 4 * (size_t)BM * BK * sizeof(T);
+template <int EPI, int WM, int WN, int NST> int launch_glds(const GemmParams& p, hipStream_t s) {
+    constexpr int GM = 64 * WM, GN = 64 * WN;
+    const int tiles = ((p.M + GM - 1) / GM) * ((p.N + GN - 1) / GN);
+    const size_t smem = (size_t)NST * (GM + GN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<EPI, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(tiles), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<EPI, WM, WN, NST>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong variant of the LDS-DMA kernel: 256x128 tile, 8 waves (4 x 2, each 64x64), 3-stage ring.  Waves w and w+4 share
+// a SIMD; the two wave groups run the same 4-phase K step { read kk0 | mfma kk0 | read kk1 | mfma kk1 }, one workgroup
+// barrier per phase, with group 1 started one barrier late: in every interval one wave of each SIMD issues its 16 MFMAs
+// while the other fetches its next fragments from LDS, instead of both stalling on LDS at the same time.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    constexpr int WM = 4, WN = 2, NST = 3, GM = 256, GN = 128, NW = 8;
+    constexpr int A_BYTES = GM * 128, B_BYTES = GN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int AI = (GM / 8) / NW, BI = (GN / 8) / NW, GRP = AI + BI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave & 3, wn = wave >> 2;        // group (wave >> 2) = column half; waves w, w+4 share a SIMD
+    const int grp = wave >> 2;
+    const int tiles_n = (p.N + GN - 1) / GN;
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * GM, n0 = tn * GN;
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+    const int lr = lane >> 3, sc = ((lane & 7) ^ lr) * 8;
+    const bf16_t* asrc[AI];
+    const bf16_t* bsrc[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) asrc[i] = A + (size_t)min(m0 + (wave * AI + i) * 8 + lr, p.M - 1) * p.lda + sc;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) bsrc[i] = B + (size_t)min(n0 + (wave * BI + i) * 8 + lr, p.N - 1) * p.ldb + sc;
+    auto dma = [&](int kt) {
+        char* st = smem + (kt % NST) * STAGE;
+        const int ko = kt * BK;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(asrc[i] + ko), (lvoid*)(st + (wave * AI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(bsrc[i] + ko), (lvoid*)(st + A_BYTES + (wave * BI + i) * 1024), 16, 0, 0);
+    };
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_off[kk] = lds_off<bf16_t>(wm * 64 + l15, g + 4 * kk);
+        b_off[kk] = lds_off<bf16_t>(wn * 64 + l15, g + 4 * kk);
+    }
+    constexpr int ROW16 = 16 * 128;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KT = p.K / BK;
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    dma(0);
+    if (KT > 1) { dma(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();                                   // stage 0 has landed for every wave
+    if (grp == 1) PP_BARRIER();                     // stagger the second wave group by one phase
+    Chunk<bf16_t> fa[4], fb[4];
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* As = smem + (kt % NST) * STAGE;
+        const char* Bs = As + A_BYTES;
+        // phase 1: fragments of kk = 0 (+ DMA of stage kt+2 into the slot whose last readers finished two phases ago)
+        if (kt + 2 < KT) dma(kt + 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = lds_ld<bf16_t>(Bs, b_off[0] + j * ROW16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_ld<bf16_t>(As, a_off[0] + i * ROW16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // phase 2
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma<bf16_t>(fb[j], fa[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BARRIER();
+        // phase 3: fragments of kk = 1; my share of stage kt+1 must have landed before the barrier that ends this phase
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = lds_ld<bf16_t>(Bs, b_off[1] + j * ROW16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_ld<bf16_t>(As, a_off[1] + i * ROW16);
+        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // phase 4
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma<bf16_t>(fb[j], fa[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BARRIER();
+    }
+    if (grp == 0) PP_BARRIER();                     // every wave executes the same number of barriers
+#undef PP_BARRIER
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (n < p.N) epi_store<bf16_t, EPI>(p, acc[i][j], m, n);
+        }
+    }
+}
+
+template <int EPI> int launch_pp(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    const size_t smem = 3 * (size_t)(256 + 128) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(tiles), dim3(512), smem, s, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+int g_impl = -1;     // 0 register-staged (default), 1 LDS-DMA 128x128 2-stage, 2 LDS-DMA 256x128 3-stage; env CLHIP_GEMM_IMPL / clhip_gemm_config
+int gemm_impl() {
+    if (g_impl < 0) { const char* e = getenv("CLHIP_GEMM_IMPL"); g_impl = e ? atoi(e) : 0; }
+    return g_impl;
+}
+
+template <typename T, int EPI, int MT> int launch(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 32 * MT;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(T);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT>), dim3(tiles), dim3(256), smem, s, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+// rows per block tile: the candidate with the best (work / (rounds x slots)) over the 512 resident workgroups of the chip
+// (2 per CU); ties go to the larger tile.  fp32 (parity mode) always uses 128 rows.  CLHIP_GEMM_MT forces a value.
+int pick_mt(int M, int N, bool bf16) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("CLHIP_GEMM_MT"); forced = e ? atoi(e) : 0; }
+    if (!bf16) return 4;
+    if (forced == 2 || forced == 4 || forced == 5) return forced;
+    const int tn = (N + BN - 1) / BN;
+    const int cands[3] = {5, 4, 2};
+    int best = 4;
+    double best_eff = -1.0;
+    for (int mt : cands) {
+        const long tiles = (long)((M + 32 * mt - 1) / (32 * mt)) * tn;
+        const long rounds = (tiles + 511) / 512;
+        // useful rows / provisioned rows, discounted for the smaller tile's lower operand reuse
+        double eff = (double)M * tn / ((double)rounds * 512 * 32 * mt);
+        if (mt == 2) eff *= 0.8;
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = mt; }
+    }
+    return best;
+}
+
+template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        return launch<T, EPI, 4>(p, s);
+    } else {
+        const int impl = gemm_impl();
+        if (impl == 1) return launch_glds<EPI, 2, 2, 2>(p, s);
+        if (impl == 2) return launch_glds<EPI, 4, 2, 3>(p, s);
+        if (impl == 3) return launch_pp<EPI>(p, s);
+        switch (pick_mt(p.M, p.N, true)) {
+            case 5: return launch<T, EPI, 5>(p, s);
+            case 2: return launch<T, EPI, 2>(p, s);
+            default: return launch<T, EPI, 4>(p, s);
+        }
+    }
+}
+
 template <typename T> int dispatch(int epi, const GemmParams& p, hipStream_t s) {
     switch (epi) {
-        case EPI_NONE: return launch<T, EPI_NONE>(p, s);
-        case EPI_BIAS: return launch<T, EPI_BIAS>(p, s);
-        case EPI_BIAS_RES: return launch<T, EPI_BIAS_RES>(p, s);
-        case EPI_BIAS_GELU: return launch<T, EPI_BIAS_GELU>(p, s);
-        case EPI_GELU_BWD: return launch<T, EPI_GELU_BWD>(p, s);
+        case EPI_NONE: return launch_mt<T, EPI_NONE>(p, s);
+        case EPI_BIAS: return launch_mt<T, EPI_BIAS>(p, s);
+        case EPI_BIAS_RES: return launch_mt<T, EPI_BIAS_RES>(p, s);
+        case EPI_BIAS_GELU: return launch_mt<T, EPI_BIAS_GELU>(p, s);
+        case EPI_MUL: return launch_mt<T, EPI_MUL>(p, s);
     }
     clhip_set_error("clhip_gemm_nt: unknown epilogue %d", epi);
     return CLHIP_EINVAL;
 }
 
 }  // namespace
+
+extern "C" void clhip_gemm_config(int impl) { g_impl = impl; }
 
 extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                              int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream) {
@@ -266,7 +566,7 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
     if (epilogue == EPI_BIAS || epilogue == EPI_BIAS_RES || epilogue == EPI_BIAS_GELU) CLHIP_CHECK_ARG(bias != nullptr);
     if (epilogue == EPI_BIAS_RES) CLHIP_CHECK_ARG(R != nullptr && ldr % 4 == 0);
-    if (epilogue == EPI_GELU_BWD) CLHIP_CHECK_ARG(H != nullptr);
+    if (epilogue == EPI_MUL) CLHIP_CHECK_ARG(H != nullptr);
     if (H) CLHIP_CHECK_ARG(ldh % 4 == 0);
     GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh};
     hipStream_t s = static_cast<hipStream_t>(stream);

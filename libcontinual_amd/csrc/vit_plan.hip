@@ -13,7 +13,7 @@
 namespace {
 size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RES = 2, EPI_BIAS_GELU = 3, EPI_GELU_BWD = 4 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RES = 2, EPI_BIAS_GELU = 3, EPI_MUL = 4 };
 
 struct LayerShadow { size_t qkv_f, qkv_b, proj_f, proj_b, fc1_f, fc1_b, fc2_f, fc2_b, acat; };
 
@@ -202,7 +202,7 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
         const float* st1 = reinterpret_cast<const float*>(ws + L.st1[l]);
         const float* st2 = reinterpret_cast<const float*>(ws + L.st2[l]);
         // MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-        TRY(clhip_gemm_nt(g, sh + s.fc2_b, ws + L.dbig, nullptr, nullptr, ws + L.hpre[l], M, Hm, D, D, D, Hm, 0, Hm, EPI_GELU_BWD, dt, stream));
+        TRY(clhip_gemm_nt(g, sh + s.fc2_b, ws + L.dbig, nullptr, nullptr, ws + L.hpre[l], M, Hm, D, D, D, Hm, 0, Hm, EPI_MUL, dt, stream));
         TRY(clhip_gemm_nt(ws + L.dbig, sh + s.fc1_b, ws + L.dtmp, nullptr, nullptr, nullptr, M, D, Hm, Hm, Hm, D, 0, 0, EPI_NONE, dt, stream));
         TRY(clhip_ln_bwd(ws + L.dtmp, ws + L.x_mid[l], p.ln2_w, st2, st2 + M, g, M, D, dt, stream));
         // attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in))))

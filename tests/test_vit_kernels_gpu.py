@@ -38,10 +38,18 @@ def p(t):
     return t.data_ptr() if t is not None else None
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.fixture
+def gemm_impl():
+    yield lambda v: _lib.lib().clhip_gemm_config(v)
+    _lib.lib().clhip_gemm_config(-1)
+
+
+@pytest.mark.parametrize("dt,impl", [("bf16", 0), ("bf16", 1), ("bf16", 2), ("bf16", 3), ("f32", 0)])
 @pytest.mark.parametrize("M,N,K", [(197 * 2, 768, 768), (300, 192, 64), (128, 128, 128), (1000, 2304, 768), (77, 64, 3072)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
-def test_gemm_nt(dt, M, N, K, epi):
+def test_gemm_nt(dt, impl, M, N, K, epi, gemm_impl):
+    """impl: 0 register-staged tiles, 1 / 2 the LDS-DMA kernels (bf16)"""
+    gemm_impl(impl)
     td = TD[dt]
     A = rnd(M, K, seed=1).to(td)
     B = rnd(N, K, scale=1 / math.sqrt(K), seed=2).to(td)
@@ -56,11 +64,11 @@ def test_gemm_nt(dt, M, N, K, epi):
     if epi == 2:
         ref = ref + R.double()
     pre = ref.clone()
-    if epi == 3:
+    if epi == 3:        # C = gelu(pre), H = gelu'(pre)
         ref = F.gelu(ref)
-    if epi == 4:
-        h = Hin.double()
-        ref = ref * (0.5 * (1 + torch.erf(h / math.sqrt(2))) + h * torch.exp(-0.5 * h * h) / math.sqrt(2 * math.pi))
+        pre = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    if epi == 4:        # C = acc * H
+        ref = ref * Hin.double()
     Hp = Hout if epi == 3 else (Hin if epi == 4 else None)
     call("clhip_gemm_nt", p(A), p(B), p(Cc), p(bias) if epi in (1, 2, 3) else None, p(R) if epi == 2 else None, p(Hp), M, N, K, K, K, N, N, N, epi, CODE[dt], st())
     torch.cuda.synchronize()
