@@ -243,7 +243,7 @@ def main():
     model, opt, arch, teacher, (lo, hi) = build_method(a.workload, a.dtype, dev)
     if world > 1:
         parallel.broadcast_module_state(model)
-        opt.grad_scale = 1.0 / world
+    parallel.attach(model, opt, reducer)
     model.train()
     batches = [synthetic_batch(a.batch, lo, hi, 100 + rank * 7 + i, dev, 224 if vit else 32) for i in range(4)]
     name = type(model).__name__
@@ -278,12 +278,15 @@ def main():
         fwd = FLOP_FWD_PER_IMG[arch]
         step_flops_per_img = 3 * fwd + (fwd if teacher else 0.0)
     out = {
-        "metric": "images/sec/node (task-0 epoch), CIFAR-100 B50-5x10" if a.workload.endswith("task0") else "images/sec/node (task>=1 step), CIFAR-100 B50-5x10",
+        "metric": ("images/sec/node (L2P task>=1 step), ViT-B/16, CIFAR-100 B10-10x10" if a.workload.startswith("l2p") else
+                   "images/sec/node (InfLoRA_OPT task>=1 step), ViT-B/16, ImageNet-R B20-20x10" if vit else
+                   "images/sec/node (task-0 epoch), CIFAR-100 B50-5x10" if a.workload.endswith("task0") else
+                   "images/sec/node (task>=1 step), CIFAR-100 B50-5x10"),
         "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": a.workload, "method": name, "backbone": "vit_base_patch16_224" if vit else arch, "per_gpu_batch": a.batch,
-                   "global_batch": a.batch * world, "image": "3x224x224" if vit else "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused SGD", "final_loss": loss_avg},
+                   "global_batch": a.batch * world, "image": "3x224x224" if vit else "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused " + type(opt).__name__, "final_loss": loss_avg},
         "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }

@@ -73,9 +73,10 @@ def get_dataloader(config, mode, cls_map=None):
     """class order: `class_order` key if present else np.random.permutation (seeded by init_seed ->
     the seed-1993 PyCIL order), reference dataloader.py:113-122"""
     data_root = config["data_root"]
-    if "train_trfms" in config or "test_trfms" in config:
-        raise NotImplementedError("YAML-declared transforms are outside the hot-path scope")
-    trfms = T.cifar_resnet_transform(mode, config.get("image_size", 32))
+    if f"{mode}_trfms" in config:
+        trfms = T.create_transforms(config[f"{mode}_trfms"])            # YAML-declared pipeline (dataloader.py:54-55)
+    else:
+        trfms = T.cifar_resnet_transform(mode, config.get("image_size", 32))
     bs = config.get(f"{mode}_batch_size", config["batch_size"])
     if config["dataset"] == "synthetic":
         return synthetic_datasets(config, mode, trfms, bs)

@@ -26,6 +26,9 @@ class Model(nn.Module):
 
 
 class L2P(nn.Module):
+    reduces_own_gradients = True      # data parallel: the gradient is all-reduced INSIDE observe, before the norm clip
+    grad_reducer = None
+
     def __init__(self, backbone, device, **kwargs):
         super().__init__()
         self.device = device
@@ -68,6 +71,8 @@ class L2P(nn.Module):
         ce = ops.classify_loss(logits, y, lo=lo, hi=hi, pred_hi=hi, aux=aux, pred_lo=lo)
         loss = ce - self.pull_constraint_coeff * reduce_sim
         loss.backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer.reduce_mean(self.network)
         ops.clip_grad_norm_(self.unfrezeed_params, 1.0)
         self._last_aux = aux
         return aux.pred, aux.acc(), loss.detach()

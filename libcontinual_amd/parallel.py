@@ -61,6 +61,21 @@ class GradientReducer:
         for w in works:
             w.wait()
 
+    def reduce_mean(self, module):
+        """all-reduce AND divide by the world size in place: for plugins that post-process the averaged gradient inside
+        `observe` (L2P clips its norm there, l2p.py:103-104 -- the clip must see the reduced gradient)"""
+        if self.world == 1:
+            return
+        self.reduce(module)
+        s = 1.0 / self.world
+        for p in module.parameters():
+            if p.requires_grad and p.grad is not None:
+                if p.grad.is_cuda:
+                    from . import ops
+                    ops.scale_(p.grad, s)
+                else:
+                    p.grad.mul_(s)
+
     def mean_scalar(self, value, device):
         """average a python float over ranks (epoch loss/acc, core/trainer.py:347-354)"""
         if self.world == 1:
@@ -68,6 +83,19 @@ class GradientReducer:
         t = torch.tensor([value], device=device, dtype=torch.float64)
         dist.all_reduce(t, group=self.group)
         return float(t.item()) / self.world
+
+
+def attach(model, optimizer, reducer):
+    """Wire data parallelism into a (plugin, optimizer) pair.  Plugins that run backward inside `observe` and then touch the
+    gradient (class attribute `reduces_own_gradients`) get the reducer and average the gradient themselves; for all others
+    the trainer reduces after backward and the 1/world factor is folded into the fused optimizer step.  Returns True when
+    the plugin owns the reduction."""
+    own = reducer is not None and bool(getattr(model, "reduces_own_gradients", False))
+    if hasattr(model, "grad_reducer") or own:
+        model.grad_reducer = reducer if own else None
+    if hasattr(optimizer, "grad_scale"):
+        optimizer.grad_scale = 1.0 if (own or reducer is None) else 1.0 / reducer.world
+    return own
 
 
 def broadcast_module_state(module, src=0, group=None):

@@ -44,7 +44,7 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
                 output, acc, loss = model.observe(batch)
                 optimizer.zero_grad()
                 loss.backward()
-            if reducer is not None:
+            if reducer is not None and getattr(model, "grad_reducer", None) is None:
                 reducer.reduce(model)
             optimizer.step()
             if meter is not None:
@@ -132,8 +132,7 @@ class Trainer:
         key = "init_optimizer" if (self.task_idx == 0 and "init_optimizer" in config) else "optimizer"
         ns = self.optim_ns if hasattr(self.optim_ns, config[key]["name"]) else torch.optim
         optimizer = get_instance(ns, key, config, params=self.model.get_parameters(config))
-        if self.distribute and hasattr(optimizer, "grad_scale"):
-            optimizer.grad_scale = 1.0 / self.world
+        parallel.attach(self.model, optimizer, self.reducer)
         name = config["lr_scheduler"]["name"]
         kw = config["lr_scheduler"].get("kwargs") or {}
         if name == "CosineSchedule":

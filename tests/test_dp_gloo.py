@@ -46,6 +46,27 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(ref) for _ in range(world)]
     dist.all_gather(gathered, ref)
     ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)          # broadcast made the ranks identical
+    # plugins that clip inside observe (L2P) own the reduction: mean gradient first, then the clip, optimizer unscaled
+    class SelfReducing(torch.nn.Module):
+        reduces_own_gradients = True
+        grad_reducer = None
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(4))
+
+    class Opt:
+        grad_scale = 7.0
+
+    sr, opt2 = SelfReducing(), Opt()
+    ok = ok and parallel.attach(sr, opt2, red) and sr.grad_reducer is red and opt2.grad_scale == 1.0
+    sr.w.grad = torch.full((4,), 3.0 * (rank + 1))
+    sr.grad_reducer.reduce_mean(sr)
+    ok = ok and torch.allclose(sr.w.grad, torch.full((4,), 4.5))                 # mean of 3 and 6
+    norm = torch.nn.utils.clip_grad_norm_([sr.w], 1.0)
+    ok = ok and abs(float(norm) - 9.0) < 1e-5 and abs(float(sr.w.grad.norm()) - 1.0) < 1e-4
+    plain, opt3 = torch.nn.Linear(2, 2), Opt()
+    ok = ok and (not parallel.attach(plain, opt3, red)) and opt3.grad_scale == 0.5
     m = red.mean_scalar(float(rank), "cpu")
     ok = ok and abs(m - 0.5) < 1e-12
     q.put((rank, bool(ok)))

@@ -50,3 +50,38 @@ def test_methods_train_end_to_end(method, backbone, extra):
             assert len(tr.buffer.labels) > 0
             assert out["batch_last_acc"] > 20.0, (method, dtype, acc)   # 10 classes at the end: chance = 10 %
         torch.cuda.synchronize()
+
+
+def vit_cfg(method, dtype):
+    cfg = Config().get_config_dict()
+    bb_kw = {"pretrained": False, "img_size": 32, "patch_size": 8, "embed_dim": 128, "depth": 2, "num_heads": 2, "dtype": dtype}
+    if method == "L2P":
+        kw = {"init_cls_num": 4, "inc_cls_num": 3, "num_class": 10, "task_num": 3, "feat_dim": 128, "prompt_length": 2, "pool_size": 6, "top_k": 3,
+              "pull_constraint_coeff": 1.0}
+        opt = {"name": "Adam", "kwargs": {"lr": 0.01, "betas": [0.9, 0.999], "weight_decay": 0}}
+    else:
+        bb_kw.update(attn_layer="MultiHeadAttention_LoRA", lora_rank=4)
+        kw = {"use_ca": False, "dataset": "synthetic", "init_cls_num": 4, "inc_cls_num": 3, "task_num": 3, "lame": 0.9, "lamb": 0.6, "embd_dim": 128}
+        opt = {"name": "SGD", "kwargs": {"lr": 0.05, "momentum": 0.9}}
+    cfg.update(dict(dataset="synthetic", image_size=32, init_cls_num=4, inc_cls_num=3, task_num=3, epoch=4, init_epoch=6, batch_size=32,
+                    val_per_epoch=10, testing_times=1, num_workers=0, save_path="", synthetic_per_class=96, synthetic_test_per_class=16, seed=5,
+                    backbone={"name": "vit_pt_imnet", "kwargs": bb_kw}, classifier={"name": method, "kwargs": kw}, optimizer=opt,
+                    lr_scheduler={"name": "Constant"}))
+    return cfg
+
+
+@pytest.mark.parametrize("method", ["L2P", "InfLoRA_OPT"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_vit_methods_train_end_to_end(method, dtype):
+    """the ViT plugins through the product Trainer (L2P does backward + clip inside observe; InfLoRA_OPT runs its Gram / SVD /
+    DualGPM hooks around every task) on a small random-init ViT: finite, task 0 learned above chance"""
+    import os
+    os.environ.setdefault("PYTHONHASHSEED", "0")
+    tr = Trainer(0, vit_cfg(method, dtype), log=lambda *a, **k: None)
+    out = tr.train_loop()
+    acc = out["acc_table"]
+    assert np.isfinite(acc).all()
+    assert acc[0, 0] > 40.0, (method, dtype, acc)                 # 4 classes: chance = 25 %
+    if method == "InfLoRA_OPT":
+        assert len(tr.model.feature_list) == 2 and all(a.apply_lora is False for a in tr.model.attention_modules)
+    torch.cuda.synchronize()

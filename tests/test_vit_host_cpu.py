@@ -1,0 +1,67 @@
+"""Host-side pieces of the ViT path that need no GPU: the shipped L2P / InfLoRA_OPT YAMLs load through Config and resolve
+to registered plugin / backbone names; YAML-declared transforms build and produce the declared shapes; the ViT module
+mirrors the reference's parameter names; compute entry points refuse to run without a HIP device."""
+import numpy as np
+import pytest
+import torch
+
+import libcontinual_amd.model as M
+from libcontinual_amd import _lib
+from libcontinual_amd.config import Config
+from libcontinual_amd.data import transforms as T
+from oracle import vit as ov
+
+
+@pytest.mark.parametrize("yaml,cls,bb", [("config/l2p-vit-cifar100-b10-10-10.yaml", "L2P", "vit_pt_imnet"),
+                                          ("config/InfLoRA_opt-vit-imagenetr-b20-20-10.yaml", "InfLoRA_OPT", "vit_pt_imnet")])
+def test_vit_yaml_configs_resolve(yaml, cls, bb):
+    cfg = Config(yaml).get_config_dict()
+    assert cfg["classifier"]["name"] == cls and hasattr(M, cls)
+    assert cfg["backbone"]["name"] == bb and hasattr(M, bb)
+    assert cfg["image_size"] == 224 and "train_trfms" in cfg and "test_trfms" in cfg
+    T.create_transforms(cfg["train_trfms"]); T.create_transforms(cfg["test_trfms"])
+
+
+def test_yaml_transforms_shapes_and_determinism():
+    img = (np.random.RandomState(0).rand(40, 56, 3) * 255).astype(np.uint8)
+    train = T.create_transforms([{"RandomResizedCrop": {"size": 32, "scale": [0.05, 1.0], "ratio": [0.75, 1.3333], "interpolation": "BILINEAR"}},
+                                 {"RandomHorizontalFlip": {"p": 0.5}}, {"ToTensor": {}}])
+    test = T.create_transforms([{"Resize": {"size": 36, "interpolation": "BICUBIC"}}, {"CenterCrop": {"size": 32}}, {"ToTensor": {}},
+                                {"Normalize": {"mean": [0.0, 0.0, 0.0], "std": [1.0, 1.0, 1.0]}}])
+    torch.manual_seed(3)
+    a = train(img)
+    torch.manual_seed(3)
+    b = train(img)
+    assert a.shape == (3, 32, 32) and a.dtype == torch.float32 and torch.equal(a, b) and 0 <= float(a.min()) and float(a.max()) <= 1
+    t = test(img)
+    assert t.shape == (3, 32, 32)
+    assert T.Resize(36)(img).shape[:2] == (36, 50)            # shorter side -> 36, aspect kept
+    with pytest.raises(NotImplementedError):
+        T.create_transforms([{"AutoAugment": {}}])
+
+
+def test_vit_parameter_names_match_reference_layout():
+    cfg = ov.VIT_TINY
+    bb = M.vit_pt_imnet(pretrained=False, attn_layer="MultiHeadAttention_LoRA", lora_rank=4, img_size=cfg["img"], patch_size=cfg["patch"],
+                        embed_dim=cfg["dim"], depth=cfg["depth"], num_heads=cfg["heads"])
+    got = {k: tuple(v.shape) for k, v in bb.state_dict().items()}
+    want = dict(ov.param_shapes(cfg, 4))
+    assert got == {k: tuple(v) for k, v in want.items()}
+    m = M.L2P(M.vit_pt_imnet(pretrained=False, img_size=32, patch_size=8, embed_dim=128, depth=1, num_heads=2), "cpu", init_cls_num=3, inc_cls_num=3,
+              num_class=6, task_num=2, feat_dim=128, prompt_length=2, pool_size=6, top_k=3, pull_constraint_coeff=1.0)
+    names = [n for n, p_ in m.network.named_parameters() if p_.requires_grad]
+    assert names == ["backbone.prompt.prompt", "backbone.prompt.prompt_key", "classifier.weight", "classifier.bias"]
+    assert len(m.get_parameters({})) == 4
+
+
+def test_vit_refuses_cpu():
+    bb = M.vit_pt_imnet(pretrained=False, img_size=32, patch_size=8, embed_dim=128, depth=1, num_heads=2)
+    with pytest.raises(_lib.ClhipError):
+        bb(torch.zeros(2, 3, 32, 32))
+
+
+def test_pretrained_without_checkpoint_is_a_clear_error(tmp_path, monkeypatch):
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("CLHIP_VIT_CHECKPOINT", raising=False)
+    with pytest.raises(FileNotFoundError):
+        M.vit_pt_imnet(pretrained=True, model_name="vit_base_patch16_224", img_size=32, patch_size=8, embed_dim=128, depth=1, num_heads=2)
