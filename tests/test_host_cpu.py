@@ -127,7 +127,7 @@ def test_config_loader_semantics(tmp_path, monkeypatch):
             monkeypatch.chdir(ROOT)
             cc = Config(os.path.join(ROOT, "config", f)).get_config_dict()
             assert hasattr(M, cc["backbone"]["name"]) and hasattr(M, cc["classifier"]["name"]) and hasattr(M, cc["buffer"]["name"])
-            assert cc["init_cls_num"] + (cc["task_num"] - 1) * cc["inc_cls_num"] == 100
+            assert cc["init_cls_num"] + (cc["task_num"] - 1) * cc["inc_cls_num"] == cc.get("total_cls_num", 100)
 
 
 def test_metrics_and_meter():
