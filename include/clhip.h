@@ -271,7 +271,7 @@ int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, cons
 /* G [D, D] fp32 += X^T X  (MultiHeadAttention_LoRA get_input_matrix, transformer.py:241-244; the running mean is the caller's) */
 int clhip_gram_accum(const void* x, float* G, int M, int D, int dtype, void* stream);
 /* prompt.L2P.forward (prompt.py:369-406): cosine top-k per sample, batch-majority top-k ids (ties: lowest id), gathered
- * prompt tokens [top_k*length, D], reduce_sim (scalar) and d reduce_sim / d prompt_key [pool, D].  scratch: B+pool+D floats. */
+ * prompt tokens [top_k*length, D], reduce_sim (scalar) and d reduce_sim / d prompt_key [pool, D].  scratch: B+pool+D+B*pool floats. */
 int clhip_l2p_select(const float* cls_feat, const float* prompt_key, const float* prompt, int B, int D, int pool, int top_k, int length,
                      int* ids, float* prompt_tokens, float* reduce_sim, float* dkey, float* scratch, void* stream);
 int clhip_l2p_scatter(const float* dtokens, const int* ids, float* dprompt_pool, int pool, int top_k, int length, int D, void* stream);

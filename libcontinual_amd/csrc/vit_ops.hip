@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const T* __restrict__ x, floa
 __global__ __launch_bounds__(256) void l2p_select_kernel(const float* __restrict__ q, const float* __restrict__ key, const float* __restrict__ prompt,
                                                           int B, int D, int pool, int top_k, int length, int* __restrict__ ids,
                                                           float* __restrict__ prompt_tokens, float* __restrict__ reduce_sim, float* __restrict__ dkey,
-                                                          float* __restrict__ scratch /* [B + pool + D] */) {
+                                                          float* __restrict__ scratch /* [B + pool + D + B*pool] */) {
     __shared__ int counts[64];
     __shared__ int sel[64];
     __shared__ float red[4];
@@ -478,19 +478,24 @@ __global__ __launch_bounds__(256) void l2p_select_kernel(const float* __restrict
     }
     if (tid < 64) counts[tid] = 0;
     __syncthreads();
-    // per-sample top-k over pool (pool <= 64): one wave per sample, lane = prompt id
+    // cosine similarities sim[b][j] (one wave per pair, lanes over D: coalesced), then per-sample top-k: one wave per sample,
+    // lane = prompt id (pool <= 64)
+    float* sim = scratch + B + pool + D;   // [B * pool]
+    for (int pr = wave; pr < B * pool; pr += 4) {
+        const int b = pr / pool, j = pr - b * pool;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += q[(size_t)b * D + c] * key[(size_t)j * D + c];
+        s = wave_sum(s);
+        if (lane == 0) sim[pr] = s * qinv[b] * kinv[j];
+    }
+    __syncthreads();
     for (int b = wave; b < B; b += 4) {
-        float sim = -INFINITY;
-        if (lane < pool) {
-            float s = 0.f;
-            for (int c = 0; c < D; ++c) s += q[(size_t)b * D + c] * key[(size_t)lane * D + c];
-            sim = s * qinv[b] * kinv[lane];
-        }
+        float sv = lane < pool ? sim[b * pool + lane] : -INFINITY;
         for (int k = 0; k < top_k; ++k) {
-            float best = wave_max(sim);
-            unsigned long long m = __ballot(sim == best && lane < pool);
+            float best = wave_max(sv);
+            unsigned long long m = __ballot(sv == best && lane < pool);
             const int win = __ffsll((long long)m) - 1;
-            if (lane == win) { atomicAdd(&counts[lane], 1); sim = -INFINITY; }
+            if (lane == win) { atomicAdd(&counts[lane], 1); sv = -INFINITY; }
         }
     }
     __syncthreads();

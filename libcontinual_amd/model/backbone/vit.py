@@ -370,7 +370,7 @@ class _L2PSelectFn(torch.autograd.Function):
         tokens = torch.empty(top_k * length, D, device=dev)
         rs = torch.empty(1, device=dev)
         dkey = torch.empty(pool, D, device=dev)
-        scratch = torch.empty(B + pool + D, device=dev)
+        scratch = torch.empty(B + pool + D + B * pool, device=dev)
         call("clhip_l2p_select", q.data_ptr(), key.detach().contiguous().data_ptr(), prompt.detach().contiguous().data_ptr(), B, D, pool, top_k, length,
              ids.data_ptr(), tokens.data_ptr(), rs.data_ptr(), dkey.data_ptr(), scratch.data_ptr(), _st())
         ctx.save_for_backward(ids, dkey)

@@ -235,7 +235,7 @@ def test_l2p_select():
     tokens = torch.empty(top_k * length, D, device=DEV)
     rs = torch.empty(1, device=DEV)
     dkey = torch.empty(pool, D, device=DEV)
-    scratch = torch.empty(B + pool + D, device=DEV)
+    scratch = torch.empty(B + pool + D + B * pool, device=DEV)
     call("clhip_l2p_select", p(q), p(key), p(prompt), B, D, pool, top_k, length, p(ids), p(tokens), p(rs), p(dkey), p(scratch), st())
     torch.cuda.synchronize()
     kd = key.double().requires_grad_(True)
