@@ -551,7 +551,7 @@ int launch_wgrad_cfg(WgradParams2& p, hipStream_t st) {
     int gx = (p.J + BJ - 1) / BJ, gy = (p.K + BO - 1) / BO;
     int tiles = gx * gy;
     int max_splits = (p.M + 255) / 256;            // >= 4 K-steps per workgroup
-    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 1536;
+    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 256;     // measured: 256 beats 128 / 512 / 1536 on every stride-2 / 1x1 / stem shape (atomic contention vs parallelism)
     static const int dbg = getenv("CLHIP_WGRAD_DEBUG") ? atoi(getenv("CLHIP_WGRAD_DEBUG")) : 0;
     p.debug = dbg;
     int splits = (target + tiles - 1) / tiles;
