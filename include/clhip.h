@@ -135,6 +135,12 @@ int clhip_plan_forward(clhip_plan*, const float* x, const float* params, float* 
 /* dfeat: fp32 [N, feat_dim]; grads: flat fp32 buffer laid out like params, accumulated into (+=).      */
 int clhip_plan_backward(clhip_plan*, const float* dfeat, const float* params, const void* shadow, void* workspace,
                         float* grads, void* stream);
+/* the same backward in pieces: units [unit_lo, unit_hi) in reverse order (unit_hi == number of units starts from dfeat).  Lets
+ * the data-parallel host start the all-reduce of the deepest layers' gradients (the tail of the flat gradient buffer: the
+ * parameters are laid out in unit order) while the backward of the shallower layers is still running. */
+int clhip_plan_num_units(const clhip_plan* p);
+int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, const float* params, const void* shadow, void* workspace,
+                              float* grads, int unit_hi, int unit_lo, void* stream);
 /* debugging / tests: copy activation `idx` (0=input) as fp32 NCHW; which: 0 = y, 1 = pre-BN z (idx>=1), 2 = dy */
 int clhip_plan_read_act(clhip_plan*, const void* workspace, int idx, int which, float* out_nchw, void* stream);
 

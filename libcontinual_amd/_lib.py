@@ -78,6 +78,8 @@ _PROTOS = {
     "clhip_plan_prep_weights": (_i, [_p, _p, _p, _p]),
     "clhip_plan_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "clhip_plan_backward": (_i, [_p, _p, _p, _p, _p, _p, _p]),
+    "clhip_plan_num_units": (_i, [_p]),
+    "clhip_plan_backward_range": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "clhip_plan_read_act": (_i, [_p, _p, _i, _i, _p, _p]),
     "clhip_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "clhip_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

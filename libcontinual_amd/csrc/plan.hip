@@ -218,15 +218,26 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
     return CLHIP_OK;
 }
 
+extern "C" int clhip_plan_num_units(const clhip_plan* p) { return p ? (int)p->units.size() : 0; }
+
 extern "C" int clhip_plan_backward(clhip_plan* p, const float* dfeat, const float* params, const void* shadow, void* workspace,
                                    float* grads, void* stream) {
+    CLHIP_CHECK_ARG(p);
+    return clhip_plan_backward_range(p, dfeat, params, shadow, workspace, grads, (int)p->units.size(), 0, stream);
+}
+
+extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, const float* params, const void* shadow, void* workspace,
+                                         float* grads, int unit_hi, int unit_lo, void* stream) {
     CLHIP_CHECK_ARG(p && dfeat && params && shadow && workspace && grads);
+    CLHIP_CHECK_ARG(0 <= unit_lo && unit_lo < unit_hi && unit_hi <= (int)p->units.size());
     char* ws = static_cast<char*>(workspace);
     const char* sh = static_cast<const char*>(shadow);
     float* fr = reinterpret_cast<float*>(ws + p->f_base);
-    const Act& last = p->acts.back();
-    TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
-    for (int i = (int)p->units.size() - 1; i >= 0; --i) {
+    if (unit_hi == (int)p->units.size()) {
+        const Act& last = p->acts.back();
+        TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
+    }
+    for (int i = unit_hi - 1; i >= unit_lo; --i) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];

@@ -218,6 +218,8 @@ class HipResNet(nn.Module):
         self._generation = 0
         self._grads_live = False
         self._last_state = None
+        self._grad_segment_hook = None      # set by parallel.GradientReducer while a DP training loop runs
+        self._grad_segment_cuts = []
 
     # ------------------------------------------------------------------ parameter plumbing
     def _tag_params(self):
@@ -383,9 +385,30 @@ class HipResNet(nn.Module):
             raise _lib.ClhipError("backward through an eval-mode (running-stat BatchNorm) forward is not supported")
         dfeat = dfeat.contiguous().float()
         _, g = self.flat_parameters()
-        call("clhip_plan_backward", state["plan"], dfeat.data_ptr(), self._flat.data_ptr(), self._shadow.data_ptr(),
-             state["ws"].data_ptr(), g.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        st = torch.cuda.current_stream().cuda_stream
+        hook = self._grad_segment_hook
+        if hook is None:
+            call("clhip_plan_backward", state["plan"], dfeat.data_ptr(), self._flat.data_ptr(), self._shadow.data_ptr(),
+                 state["ws"].data_ptr(), g.data_ptr(), st)
+        else:
+            # data parallel: run the backward in pieces and announce each finished range of the flat gradient buffer
+            # (deepest layers first = the tail of the buffer), so its all-reduce overlaps the rest of the backward
+            hi = len(self._units)
+            for lo in self._grad_segment_cuts + [0]:
+                call("clhip_plan_backward_range", state["plan"], dfeat.data_ptr(), self._flat.data_ptr(), self._shadow.data_ptr(),
+                     state["ws"].data_ptr(), g.data_ptr(), hi, lo, st)
+                end = self._nflat if hi == len(self._units) else self._layout[3 * hi][2]
+                hook(self, self._layout[3 * lo][2], end)
+                hi = lo
         self.attach_grads()
+
+    def grad_cut_for_fraction(self, frac=0.5):
+        """unit index k such that the parameters of units >= k (the tail of the flat buffer, whose gradients the backward
+        produces first) hold at least `frac` of all parameter elements, k as large as possible"""
+        for k in range(len(self._units) - 1, 0, -1):
+            if self._nflat - self._layout[3 * k][2] >= frac * self._nflat:
+                return k
+        return 0
 
     def forward(self, x):
         require_gpu(x)

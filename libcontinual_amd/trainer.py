@@ -34,7 +34,9 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
     -> step -> meters.  Shared by Trainer._train and bench.py so that the benchmark times exactly what
     training runs.  Loss / accuracy stay on the device (ops.Deferred): no host sync inside the loop."""
     on_gpu = device is not None and torch.device(device).type == "cuda"
-    with ops.deferred_metrics(on_gpu):
+    import contextlib
+    overlap = reducer.overlap(model) if (reducer is not None and hasattr(reducer, "overlap")) else contextlib.nullcontext()
+    with ops.deferred_metrics(on_gpu), overlap:
         for b, batch in enumerate(batches):
             batch["batch_id"] = b
             if method_name in _OBSERVE_DOES_BACKWARD:

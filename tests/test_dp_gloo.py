@@ -46,6 +46,18 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(ref) for _ in range(world)]
     dist.all_gather(gathered, ref)
     ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)          # broadcast made the ranks identical
+    # overlapped exchange: the tail of the flat buffer is handed over early (as the segmented backward does), reduce() finishes
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    head.weight.grad = torch.full_like(head.weight, float(rank + 1))
+    with red.overlap(net, fraction=0.5):
+        k = bb.grad_cut_for_fraction(0.5)
+        cut = bb._layout[3 * k][2]
+        ok = ok and k > 0 and bb._grad_segment_hook is not None and bb._nflat - cut >= 0.5 * bb._nflat
+        bb._grad_segment_hook(bb, cut, bb._nflat)          # "units >= k are done"
+        bb._grad_segment_hook(bb, 0, cut)                  # the head of the buffer is left to reduce()
+        red.reduce(net)
+    ok = ok and bb._grad_segment_hook is None and not red._early
+    ok = ok and torch.allclose(gflat * scale, want) and torch.allclose(head.weight.grad * scale, torch.full_like(head.weight, 1.5))
     # plugins that clip inside observe (L2P) own the reduction: mean gradient first, then the clip, optimizer unscaled
     class SelfReducing(torch.nn.Module):
         reduces_own_gradients = True

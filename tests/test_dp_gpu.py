@@ -1,0 +1,91 @@
+"""Data-parallel plumbing on ONE MI355X: the segmented backward (clhip_plan_backward_range) with the overlapped all-reduce of
+the finished tail of the flat gradient buffer, over a real RCCL process group of world size 1 (the reducer is told the
+world is 2 so that every code path runs; a 1-rank all-reduce returns its input, so the result must equal the plain
+single-call backward).  The multi-rank arithmetic is covered on CPU by tests/test_dp_gloo.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+import libcontinual_amd.model as M                     # noqa: E402
+from libcontinual_amd import ops, optim, parallel      # noqa: E402
+from libcontinual_amd.trainer import train_steps       # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def rccl_group():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+def _make(seed):
+    torch.manual_seed(seed)
+    bb = M.resnet18(args={"dataset": "cifar100"}, dtype="bf16")
+    m = M.LWF(bb, 512, 100, device="cuda", init_cls_num=50, inc_cls_num=5).to("cuda")
+    m.before_task(0, None, None, None)
+    return m
+
+
+def _batch(seed, B=32):
+    g = torch.Generator().manual_seed(seed)
+    return {"image": torch.randn(B, 3, 32, 32, generator=g).cuda(), "label": torch.randint(0, 50, (B,), generator=g).cuda()}
+
+
+def test_segmented_backward_matches_single_call():
+    m1, m2 = _make(3), _make(3)
+    b = _batch(1)
+    for m in (m1, m2):
+        m.train()
+    bb2 = m2.backbone
+    seen = []
+    bb2._grad_segment_cuts = [bb2.grad_cut_for_fraction(0.5), 5]
+    bb2._grad_segment_hook = lambda bb, lo, hi: seen.append((lo, hi))
+    for m in (m1, m2):
+        _, _, loss = m.observe(b)
+        loss.backward()
+    torch.cuda.synchronize()
+    g1, g2 = m1.backbone.flat_parameters()[1], bb2.flat_parameters()[1]
+    # same kernels in the same order; the stride-2 / 1x1 weight gradients use fp32 atomics, so equality is up to their
+    # summation order
+    assert float((g1 - g2).abs().max()) <= 2e-3 * float(g1.abs().max())
+    assert seen[0][1] == bb2._nflat and seen[-1][0] == 0 and all(seen[i][0] == seen[i + 1][1] for i in range(len(seen) - 1))
+    assert bb2._nflat - seen[0][0] >= 0.5 * bb2._nflat            # ResNet-18: layer4 holds > 50 % of the parameters
+
+
+def test_overlapped_reduce_on_rccl(rccl_group):
+    m1, m2 = _make(4), _make(4)
+    batches = [_batch(10)]
+    o1 = optim.SGD(m1.get_parameters({}), lr=0.05, momentum=0.9)
+    o2 = optim.SGD(m2.get_parameters({}), lr=0.05, momentum=0.9)
+    for m in (m1, m2):
+        m.train()
+    train_steps(m1, o1, batches, None, "LWF", None, "cuda")
+    red = parallel.GradientReducer()
+    red.world = 2                                                 # exercise every DP code path on a 1-rank RCCL group
+    parallel.attach(m2, o2, red)
+    assert o2.grad_scale == 0.5
+    o2.grad_scale = 1.0                                           # ... whose "sum over ranks" is the local gradient
+    calls = []
+    orig = red._on_segment
+    red._on_segment = lambda bb, lo, hi: (calls.append((lo, hi)), orig(bb, lo, hi))[1]
+    train_steps(m2, o2, batches, red, "LWF", None, "cuda")
+    torch.cuda.synchronize()
+    assert len(calls) == 2 * len(batches) and m2.backbone._grad_segment_hook is None     # hooks removed after the loop
+    f1, f2 = m1.backbone.flat_parameters()[0], m2.backbone.flat_parameters()[0]
+    assert float((f1 - f2).abs().max()) <= 2e-3 * float(f1.abs().max())        # one step; fp32-atomic summation order only
+    assert float((m1.classifier.weight - m2.classifier.weight).detach().abs().max()) <= 1e-4
