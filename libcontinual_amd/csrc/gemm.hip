@@ -134,14 +134,15 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, const f32x4& a, i
     store4<T>(static_cast<T*>(p.C) + (size_t)m * p.ldc + n, v);
 }
 
-constexpr int BN = 128, BK = 64;
+constexpr int BK = 64;
 
-// MT = 16-row MFMA tiles per wave along M: block tile (32 MT) x 128.  MT = 4 (128 rows) is the default; MT = 5 / 2 are picked
-// when they quantise the tile count better against the 512 resident workgroups (2 per CU), see pick_mt().
-template <typename T, int EPI, int MT>
+// MT / NT = 16-row / 16-column MFMA tiles per wave: block tile (32 MT) x (32 NT).  4 x 4 (128 x 128) is the default; MT = 5 is
+// picked when it quantises the tile count better against the 512 resident workgroups (2 per CU), 2 x 2 (64 x 64 tiles) when
+// the problem is too small to fill the chip with 128-wide tiles (L2P: 16 images x 222 tokens), see pick_tile().
+template <typename T, int EPI, int MT, int NT>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 32 * MT;
+    constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int A_BYTES = BM * BK * (int)sizeof(T), B_BYTES = BN * BK * (int)sizeof(T), STAGE = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -165,39 +166,40 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
     const int c = tid & 7, r0 = tid >> 3;
     // rows beyond M / N are clamped to the last valid row: their products land in accumulators that are never stored
     const T* ag[MT];
-    const T* bg[4];
-    int st_off[MT > 4 ? MT : 4];
+    const T* bg[NT];
+    constexpr int RMAX = MT > NT ? MT : NT;
+    int st_off[RMAX];
 #pragma unroll
-    for (int i = 0; i < (MT > 4 ? MT : 4); ++i) st_off[i] = lds_off<T>(r0 + 32 * i, c);
+    for (int i = 0; i < RMAX; ++i) st_off[i] = lds_off<T>(r0 + 32 * i, c);
 #pragma unroll
     for (int i = 0; i < MT; ++i) ag[i] = A + (size_t)min(m0 + r0 + 32 * i, p.M - 1) * p.lda + c * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bg[i] = B + (size_t)min(n0 + r0 + 32 * i, p.N - 1) * p.ldb + c * 8;
+    for (int i = 0; i < NT; ++i) bg[i] = B + (size_t)min(n0 + r0 + 32 * i, p.N - 1) * p.ldb + c * 8;
     // per-lane fragment read offsets (row & 7 == l15 & 7 because every tile row base is a multiple of 16)
     int a_off[2], b_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         a_off[kk] = lds_off<T>(wm * 16 * MT + l15, g + 4 * kk);
-        b_off[kk] = lds_off<T>(wn * 64 + l15, g + 4 * kk);
+        b_off[kk] = lds_off<T>(wn * 16 * NT + l15, g + 4 * kk);
     }
     constexpr int ROW16 = 16 * BK * (int)sizeof(T);               // LDS bytes of 16 tile rows
 
-    f32x4 acc[MT][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    Chunk<T> ra[MT], rb[4];
+    Chunk<T> ra[MT], rb[NT];
     const int KT = p.K / BK;
 #pragma unroll
     for (int i = 0; i < MT; ++i) ra[i] = cload<T>(ag[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = cload<T>(bg[i]);
+    for (int i = 0; i < NT; ++i) rb[i] = cload<T>(bg[i]);
 #pragma unroll
     for (int i = 0; i < MT; ++i) lds_st<T>(smem, st_off[i], ra[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lds_st<T>(smem + A_BYTES, st_off[i], rb[i]);
+    for (int i = 0; i < NT; ++i) lds_st<T>(smem + A_BYTES, st_off[i], rb[i]);
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -209,38 +211,38 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
 #pragma unroll
             for (int i = 0; i < MT; ++i) ra[i] = cload<T>(ag[i] + ko);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[i] = cload<T>(bg[i] + ko);
+            for (int i = 0; i < NT; ++i) rb[i] = cload<T>(bg[i] + ko);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            Chunk<T> fa[MT], fb[4];
+            Chunk<T> fa[MT], fb[NT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = lds_ld<T>(Bs, b_off[kk] + j * ROW16);
+            for (int j = 0; j < NT; ++j) fb[j] = lds_ld<T>(Bs, b_off[kk] + j * ROW16);
 #pragma unroll
             for (int i = 0; i < MT; ++i) fa[i] = lds_ld<T>(As, a_off[kk] + i * ROW16);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma<T>(fb[j], fa[i], acc[i][j]);       // D[row = n][col = m]
+                for (int j = 0; j < NT; ++j) acc[i][j] = mma<T>(fb[j], fa[i], acc[i][j]);       // D[row = n][col = m]
         }
         if (more) {
             char* An = smem + ((kt + 1) & 1) * STAGE;
 #pragma unroll
             for (int i = 0; i < MT; ++i) lds_st<T>(An, st_off[i], ra[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_st<T>(An + A_BYTES, st_off[i], rb[i]);
+            for (int i = 0; i < NT; ++i) lds_st<T>(An + A_BYTES, st_off[i], rb[i]);
         }
         __syncthreads();
     }
 
-    // epilogue: lane holds C[m][n .. n+3], m = m0 + wm*16*MT + i*16 + l15, n = n0 + wn*64 + j*16 + g*4
+    // epilogue: lane holds C[m][n .. n+3], m = m0 + wm*16*MT + i*16 + l15, n = n0 + wn*16*NT + j*16 + g*4
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * 16 * MT + i * 16 + l15;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + g * 4;
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * 16 * NT + j * 16 + g * 4;
             if (n < p.N) epi_store<T, EPI>(p, acc[i][j], m, n);
         }
     }
@@ -490,37 +492,35 @@ int gemm_impl() {
     return g_impl;
 }
 
-template <typename T, int EPI, int MT> int launch(const GemmParams& p, hipStream_t s) {
-    constexpr int BM = 32 * MT;
+template <typename T, int EPI, int MT, int NT> int launch(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(T);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT>), dim3(tiles), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT, NT>), dim3(tiles), dim3(256), smem, s, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
 
-// rows per block tile: the candidate with the best (work / (rounds x slots)) over the 512 resident workgroups of the chip
-// (2 per CU); ties go to the larger tile.  fp32 (parity mode) always uses 128 rows.  CLHIP_GEMM_MT forces a value.
-int pick_mt(int M, int N, bool bf16) {
+// block tile: 64 x 64 when 128-wide tiles cannot fill half of the 512 resident workgroups (2 per CU); otherwise 128 columns and
+// the row count (160 / 128) with the better work / (rounds x slots) quantisation.  fp32 (parity mode): 128 x 128.
+// CLHIP_GEMM_MT forces 2 (64 x 64), 4 or 5.
+int pick_tile(int M, int N) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("CLHIP_GEMM_MT"); forced = e ? atoi(e) : 0; }
-    if (!bf16) return 4;
     if (forced == 2 || forced == 4 || forced == 5) return forced;
-    const int tn = (N + BN - 1) / BN;
-    const int cands[3] = {5, 4, 2};
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 < 256) return 2;
     int best = 4;
     double best_eff = -1.0;
-    for (int mt : cands) {
-        const long tiles = (long)((M + 32 * mt - 1) / (32 * mt)) * tn;
+    for (int mt : {5, 4}) {
+        const long tiles = (long)((M + 32 * mt - 1) / (32 * mt)) * ((N + 127) / 128);
         const long rounds = (tiles + 511) / 512;
-        // useful rows / provisioned rows, discounted for the smaller tile's lower operand reuse
-        double eff = (double)M * tn / ((double)rounds * 512 * 32 * mt);
-        if (mt == 2) eff *= 0.8;
+        const double eff = (double)M * ((N + 127) / 128) / ((double)rounds * 512 * 32 * mt);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = mt; }
     }
     return best;
@@ -528,16 +528,16 @@ int pick_mt(int M, int N, bool bf16) {
 
 template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
-        return launch<T, EPI, 4>(p, s);
+        return launch<T, EPI, 4, 4>(p, s);
     } else {
         const int impl = gemm_impl();
         if (impl == 1) return launch_glds<EPI, 2, 2, 2>(p, s);
         if (impl == 2) return launch_glds<EPI, 4, 2, 3>(p, s);
         if (impl == 3) return launch_pp<EPI>(p, s);
-        switch (pick_mt(p.M, p.N, true)) {
-            case 5: return launch<T, EPI, 5>(p, s);
-            case 2: return launch<T, EPI, 2>(p, s);
-            default: return launch<T, EPI, 4>(p, s);
+        switch (pick_tile(p.M, p.N)) {
+            case 5: return launch<T, EPI, 5, 4>(p, s);
+            case 2: return launch<T, EPI, 2, 2>(p, s);
+            default: return launch<T, EPI, 4, 4>(p, s);
         }
     }
 }
