@@ -70,6 +70,10 @@ int clhip_conv_weight_prep(const float* w, void* w_fwd, void* w_dg, int K, int t
 int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize, int stride, int pad);
 int clhip_conv_fwd(const void* x, const void* w_fwd, void* z, float* stat_partials, int N, int H, int W, int C, int K,
                    int ksize, int stride, int pad, int dtype, void* stream);
+/* same forward, but the per-channel sums of z and z^2 are ADDED into stat_acc[2][K] (fp64, hardware atomics; zeroed by the
+ * caller) instead of written as per-tile partial rows: the consumer (clhip_bn_apply_train) then needs no finalize launch */
+int clhip_conv_fwd_acc(const void* x, const void* w_fwd, void* z, double* stat_acc, int N, int H, int W, int C, int K, int ksize,
+                       int stride, int pad, int dtype, void* stream);
 int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C, int K,
                      int ksize, int stride, int pad, int dtype, void* stream);
 size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
@@ -94,6 +98,19 @@ int clhip_bn_eval_affine(const float* gamma, const float* beta, const float* run
                          float eps, int C, float* scale, float* shift, void* stream);
 int clhip_bn_apply(const void* z, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C,
                    int relu, int dtype, void* stream);
+/* training-mode BatchNorm straight from the fp64 sums of clhip_conv_fwd_acc: y = relu?(bn(z) + res?), batch mean / invstd saved
+ * for the backward, running statistics updated (momentum, unbiased variance) -- bn_stats_finalize + bn_apply in ONE launch.
+ * C must be a power of two. */
+int clhip_bn_apply_train(const void* z, const double* stat_acc, int64_t M, int C, const float* gamma, const float* beta, float* rm,
+                         float* rv, float momentum, float eps, float* mean, float* invstd, const void* res /*nullable*/, void* y,
+                         int relu, int dtype, void* stream);
+/* clhip_bn_bwd with the two per-channel sums accumulated into acc[2][C] (fp64 atomics, zeroed by the caller) and consumed
+ * directly by the apply pass: no partial buffer, no finalize launch */
+int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
+                     float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu, double* acc,
+                     int dtype, void* stream);
+/* number of reduction workgroups clhip_bn_bwd / clhip_bn_bwd_acc launch (= producers adding into the accumulator) */
+int clhip_bn_bwd_blocks(int64_t M, int C);
 size_t clhip_bn_bwd_ws_floats(int64_t M, int C);
 int clhip_bn_bwd(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
                  float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu,

@@ -60,12 +60,16 @@ _PROTOS = {
     "clhip_conv_weight_prep": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_conv_fwd_tiles": (_i, [_i] * 8),
     "clhip_conv_fwd": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p]),
+    "clhip_conv_fwd_acc": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p]),
+    "clhip_bn_apply_train": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _i, _p]),
+    "clhip_bn_bwd_acc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "clhip_conv_dgrad": (_i, [_p, _p, _p, _i] + [_i] * 9 + [_p]),
     "clhip_conv_wgrad_ws_bytes": (_sz, [_i] * 10),
     "clhip_conv_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_bn_stats_finalize": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "clhip_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "clhip_bn_apply": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),
+    "clhip_bn_bwd_blocks": (_i, [_l, _i]),
     "clhip_bn_bwd_ws_floats": (_sz, [_l, _i]),
     "clhip_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "clhip_avgpool_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -85,7 +85,7 @@ template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                             const T* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            int64_t M, int C) {
+                                                            double* __restrict__ acc, int64_t M, int C) {
     extern __shared__ __attribute__((aligned(16))) float red[];     // [256][16]
     const int cpr = C >> 3;
     const int rpi = 256 / cpr;
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         int col = c >> 3, e = c & 7;
         float s = 0.f;
         for (int q = 0; q < rpi; ++q) s += red[(q * cpr + col) * 16 + which * 8 + e];
-        part[((size_t)blockIdx.x * 2 + which) * C + c] = s;
+        if (acc != nullptr) atomicAdd(acc + (size_t)which * C + c, (double)s);
+        else part[((size_t)blockIdx.x * 2 + which) * C + c] = s;
     }
 }
 
@@ -168,6 +169,104 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const float is = invstd[c];
             const float xh = (zz[e] - mean[c]) * is;
             o[e] = gamma[c] * is * (gg - coef[c] - xh * coef[C + c]);
+            g[e] = gg;
+            if (DRES == 2) rr[e] += gg;
+        }
+        store8<T>(dz + i * 8, o);
+        if (DRES == 1) store8<T>(dres + i * 8, g);
+        if (DRES == 2) store8<T>(dres + i * 8, rr);
+    }
+}
+
+// ---------------------------------------------------------------------------- accumulator ("acc") variants
+// The per-layer finalize launches (bn_finalize, bn_bwd_finalize: 40 x ~6 us of a 3.3 ms ResNet-18 step) disappear when the
+// producer adds its per-channel sums into a [2][C] fp64 accumulator with hardware fp64 atomics (order-independent to ~1e-16)
+// and the consumer derives scale / shift (forward) or the two mean terms (backward) itself: a handful of flops per thread,
+// hoisted out of the grid-stride loop because a thread's 8 channels are fixed when the grid stride is a multiple of C/8.
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict__ z, const double* __restrict__ acc, double invM, double unbias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* rm, float* rv,
+                                                             float momentum, float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                             const T* __restrict__ res, T* __restrict__ y, int64_t nchunks, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)((i0 * 8) % C);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double mean = acc[c0 + e] * invM;
+        double var = acc[C + c0 + e] * invM - mean * mean;      // the cancellation happens in fp64 ...
+        if (var < 0.0) var = 0.0;
+        // ... the well-conditioned rest in fp32 in the bf16 mode (no fp64 sqrt / divide per thread); the fp32 parity mode keeps
+        // the finalize kernel's exact fp64 expression
+        float istd;
+        if constexpr (sizeof(T) == 4) istd = (float)(1.0 / sqrt(var + (double)eps));
+        else istd = rsqrtf((float)var + eps);
+        sc[e] = gamma[c0 + e] * istd;
+        sh[e] = beta[c0 + e] - (float)mean * sc[e];
+    }
+    if (blockIdx.x == 0) {                 // saved statistics for the backward + running-stat update, once
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const double mean = acc[c] * invM;
+            double var = acc[C + c] * invM - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mean_o[c] = (float)mean;
+            if constexpr (sizeof(T) == 4) invstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
+            else invstd_o[c] = rsqrtf((float)var + eps);
+            if (rm != nullptr) {
+                rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+                rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * unbias);
+            }
+        }
+    }
+    for (int64_t i = i0; i < nchunks; i += stride) {
+        float v[8], r[8];
+        load8<T>(z + i * 8, v);
+        if (RES) load8<T>(res + i * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = fmaf(v[e], sc[e], sh[e]);
+            if (RES) o += r[e];
+            if (RELU) o = fmaxf(o, 0.f);
+            v[e] = o;
+        }
+        store8<T>(y + i * 8, v);
+    }
+}
+
+template <typename T, bool RELU, int DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ z,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const double* __restrict__ acc, double invM,
+                                                               float* dgamma, float* dbeta, T* __restrict__ dz, T* __restrict__ dres,
+                                                               int64_t nchunks, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)((i0 * 8) % C);
+    float k0[8], k1[8], gi[8], mu[8], is[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        k0[e] = (float)(acc[c0 + e] * invM);
+        k1[e] = (float)(acc[C + c0 + e] * invM);
+        mu[e] = mean[c0 + e];
+        is[e] = invstd[c0 + e];
+        gi[e] = gamma[c0 + e] * is[e];
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] += (float)acc[c]; dgamma[c] += (float)acc[C + c]; }
+    }
+    for (int64_t i = i0; i < nchunks; i += stride) {
+        float g[8], yy[8], zz[8], o[8], rr[8];
+        load8<T>(dy + i * 8, g);
+        load8<T>(z + i * 8, zz);
+        if (RELU) load8<T>(y + i * 8, yy);
+        if (DRES == 2) load8<T>(dres + i * 8, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gg = g[e];
+            if (RELU) gg = yy[e] > 0.f ? gg : 0.f;
+            const float xh = (zz[e] - mu[e]) * is[e];
+            o[e] = gi[e] * (gg - k0[e] - xh * k1[e]);
             g[e] = gg;
             if (DRES == 2) rr[e] += gg;
         }
@@ -310,6 +409,8 @@ extern "C" int clhip_bn_apply(const void* z, const float* scale, const float* sh
     return CLHIP_EINVAL;
 }
 
+extern "C" int clhip_bn_bwd_blocks(int64_t M, int C) { return bn_bwd_blocks(M, C); }
+
 extern "C" size_t clhip_bn_bwd_ws_floats(int64_t M, int C) { return (size_t)bn_bwd_blocks(M, C) * 2 * C + 2 * (size_t)C; }
 
 template <typename T>
@@ -321,8 +422,8 @@ static int bn_bwd_t(const void* dy, const void* y, const void* z, const float* m
     float* coef = ws + (size_t)G * 2 * C;
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = 256 * 16 * sizeof(float);
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, M, C);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, M, C);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, M, C);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, M, C);
     CLHIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, G, 1.0 / (double)M, C, dgamma, dbeta, coef);
     CLHIP_LAUNCH_CHECK();
@@ -348,6 +449,71 @@ extern "C" int clhip_bn_bwd(const void* dy, const void* y, const void* z, const 
         return bn_bwd_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, ws, (hipStream_t)stream);
     if (dtype == CLHIP_F32)
         return bn_bwd_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, ws, (hipStream_t)stream);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+static bool acc_ok(int C) { return C >= 8 && C <= 2048 && (C & (C - 1)) == 0; }
+
+template <typename T>
+static int bn_apply_train_t(const void* z, const double* acc, int64_t M, const float* gamma, const float* beta, float* rm, float* rv, float momentum,
+                            float eps, float* mean, float* invstd, const void* res, void* y, int C, int relu, hipStream_t st) {
+    const int64_t nch = M * C / 8;
+    dim3 g(ew_blocks(nch)), b(256);
+    const double invM = 1.0 / (double)M, unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
+    const T* zz = (const T*)z; const T* rr = (const T*)res; T* yy = (T*)y;
+#define APPLY_TRAIN(R, L) hipLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, 0, st, zz, acc, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C)
+    if (res && relu) APPLY_TRAIN(true, true);
+    else if (res) APPLY_TRAIN(true, false);
+    else if (relu) APPLY_TRAIN(false, true);
+    else APPLY_TRAIN(false, false);
+#undef APPLY_TRAIN
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int64_t M, int C, const float* gamma, const float* beta, float* rm, float* rv,
+                                    float momentum, float eps, float* mean, float* invstd, const void* res, void* y, int relu, int dtype,
+                                    void* stream) {
+    CLHIP_CHECK_ARG(z && stat_acc && gamma && beta && mean && invstd && y && M > 0 && acc_ok(C));
+    CLHIP_CHECK_ARG((rm == nullptr) == (rv == nullptr));
+    if (dtype == CLHIP_BF16) return bn_apply_train_t<bf16_t>(z, stat_acc, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, relu, (hipStream_t)stream);
+    if (dtype == CLHIP_F32) return bn_apply_train_t<float>(z, stat_acc, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, relu, (hipStream_t)stream);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+template <typename T>
+static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                        float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, hipStream_t st) {
+    const int G = bn_bwd_blocks(M, C);
+    const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
+    size_t lds = 256 * 16 * sizeof(float);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, M, C);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, M, C);
+    CLHIP_LAUNCH_CHECK();
+    const int64_t nch = M * C / 8;
+    dim3 g(ew_blocks(nch)), b(256);
+    T* dzz = (T*)dz; T* dr = (T*)dres;
+    const double invM = 1.0 / (double)M;
+    int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
+#define BWD_ACC(R, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, 0, st, dyy, yy, zz, mean, invstd, gamma, acc, invM, dgamma, dbeta, dzz, dr, nch, C)
+    if (relu) { if (mode == 0) BWD_ACC(true, 0); else if (mode == 1) BWD_ACC(true, 1); else BWD_ACC(true, 2); }
+    else { if (mode == 0) BWD_ACC(false, 0); else if (mode == 1) BWD_ACC(false, 1); else BWD_ACC(false, 2); }
+#undef BWD_ACC
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu,
+                                double* acc, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dy && z && mean && invstd && gamma && dgamma && dbeta && dz && acc && M > 0 && acc_ok(C));
+    CLHIP_CHECK_ARG(!relu || y);
+    if (dtype == CLHIP_BF16)
+        return bn_bwd_acc_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, (hipStream_t)stream);
+    if (dtype == CLHIP_F32)
+        return bn_bwd_acc_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, (hipStream_t)stream);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }

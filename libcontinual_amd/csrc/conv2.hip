@@ -25,6 +25,7 @@ struct ConvParams2 {
     const void* wt;
     void* dst;
     float* stats;
+    double* stat_acc;   // alternative to `stats`: per-channel [2][Cd] fp64 sums, accumulated with atomics
     int N, Hs, Ws, Cs, log2Cs, Hd, Wd, Cd, ksize, stride, pad, accumulate;
     int M, K;
     int cls_tiles;      // > 0: stride-2 dgrad parity decomposition, tiles per (h&1, w&1) class
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
         }
     }
 
-    if (p.stats != nullptr) {
+    if (p.stats != nullptr || p.stat_acc != nullptr) {
         float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN]; all LDS reads of the K loop are behind the last barrier
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -293,7 +294,10 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
-            if (n0 + c < p.Cd) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + c] = t;
+            if (n0 + c < p.Cd) {
+                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + (size_t)which * p.Cd + n0 + c, (double)t);
+                else p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + c] = t;
+            }
         }
     }
 }
@@ -364,10 +368,10 @@ int launch2(const ConvParams2& p, hipStream_t st) {
 // entry points used by conv.hip's C ABI functions
 int clhip_conv2_tiles_m(int M, int Cd) { return (M + pick_tile(M, Cd).bm - 1) / pick_tile(M, Cd).bm; }
 
-int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
                        int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st) {
     ConvParams2 p;
-    p.src = src; p.wt = wt; p.dst = dst; p.stats = stats;
+    p.src = src; p.wt = wt; p.dst = dst; p.stats = stats; p.stat_acc = stat_acc;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.log2Cs = ilog2_exact(Cs); p.Hd = Hd; p.Wd = Wd; p.Cd = Cd;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.M = N * Hd * Wd; p.K = ksize * ksize * Cs;

@@ -4,6 +4,7 @@
 // here allocates or synchronises).  Replaces CifarResNet.forward / ResNet._forward_impl /
 // modified_ResNet.forward (core/model/backbone/resnet.py:381-395, 215-223, 549-560) and the autograd
 // backward the reference trainer triggers with loss.backward() (core/trainer.py:604).
+#include <stdlib.h>
 #include <vector>
 #include <new>
 
@@ -31,6 +32,8 @@ struct Unit {
     size_t z_off;
     size_t sh_fwd, sh_dg;          // byte offsets in the shadow buffer
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
+    size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([2][cout] each)
+    bool acc_fwd, acc_bwd;                       // statistics through fp64 atomics (few producers) or partial rows + finalize (many)
     int dx_acc, dres_acc;
 };
 }  // namespace
@@ -44,6 +47,8 @@ struct clhip_plan {
     size_t f_base;           // byte offset of the fp32 region
     size_t f_part, f_bnws;   // float offsets: conv stat partials, bn backward scratch
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
+    size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
+    bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
     int feat_dim;
 };
 
@@ -61,7 +66,13 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     Act a0{H, W, p->Cin_pad, 0, 0, (size_t)N * H * W * p->Cin_pad * p->esize};
     a0.y_off = off; off = align_up(off + a0.bytes);
     p->acts.push_back(a0);
-    size_t max_z = 0, max_part = 0, max_bnws = 0, nfloat = 0, max_wg = 0;
+    size_t max_z = 0, max_part = 0, max_bnws = 0, nfloat = 0, max_wg = 0, ndouble = 0;
+    // BN statistics: with FEW producer workgroups per layer, fp64 atomics into one [2][C] accumulator (consumer finalises on the
+    // fly, no finalize launch: -2 launches per layer, +15 % img/s on the launch-bound batch-32 step); with MANY producers the
+    // same-address atomic traffic costs more than the ~6 us launch it saves (measured: +5..9 us per kernel at 1024 tiles), so
+    // those layers keep the per-tile partial rows + finalize.  Threshold: CLHIP_BN_ACC_TILES (default 128, 0 disables).
+    const int acc_tiles = getenv("CLHIP_BN_ACC_TILES") ? atoi(getenv("CLHIP_BN_ACC_TILES")) : 128;
+    p->use_acc = false;
     for (int i = 0; i < n_units; ++i) {
         Unit u{};
         u.d = units[i];
@@ -100,6 +111,12 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
         u.sh_dg = sh; sh = align_up(sh + wbytes);
         u.f_mean = nfloat; u.f_invstd = nfloat + u.d.cout; u.f_scale = nfloat + 2 * (size_t)u.d.cout; u.f_shift = nfloat + 3 * (size_t)u.d.cout;
         nfloat += 4 * (size_t)u.d.cout;
+        u.a_fwd = ndouble; u.a_bwd = ndouble + 2 * (size_t)u.d.cout;
+        ndouble += 4 * (size_t)u.d.cout;
+        const bool pow2 = (u.d.cout & (u.d.cout - 1)) == 0;
+        u.acc_fwd = pow2 && u.tiles <= acc_tiles;
+        u.acc_bwd = pow2 && clhip_bn_bwd_blocks(u.M, u.d.cout) <= acc_tiles;
+        if (u.acc_fwd || u.acc_bwd) p->use_acc = true;
         if (bytes > max_z) max_z = bytes;
         size_t part = (size_t)u.tiles * 2 * u.d.cout;
         if (part > max_part) max_part = part;
@@ -117,6 +134,8 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     p->f_part = nfloat; nfloat += (max_part + 63) / 64 * 64;
     p->f_bnws = nfloat; nfloat += (max_bnws + 63) / 64 * 64;
     off = align_up(off + nfloat * sizeof(float));
+    p->acc_off = off; p->acc_bytes = ndouble * sizeof(double);
+    off = align_up(off + p->acc_bytes);
     p->ws_bytes = off;
     p->shadow_bytes = sh;
     p->feat_dim = p->units.back().d.cout;
@@ -195,10 +214,26 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
     const char* sh = static_cast<const char*>(shadow);
     float* fr = reinterpret_cast<float*>(ws + p->f_base);
     TRY(clhip_nchw_to_nhwc(x, ws + p->acts[0].y_off, p->N, p->Cin, p->H, p->W, p->Cin_pad, p->dtype, stream));
+    double* acc = reinterpret_cast<double*>(ws + p->acc_off);
+    const bool use_acc = training && p->use_acc;
+    if (use_acc && hipMemsetAsync(acc, 0, p->acc_bytes, (hipStream_t)stream) != hipSuccess) {
+        clhip_set_error("clhip_plan_forward: hipMemsetAsync failed");
+        return CLHIP_EHIP;
+    }
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
+        if (use_acc && u.acc_fwd) {
+            // conv epilogue adds the per-channel sums into the fp64 accumulator; BN-apply derives scale / shift on the fly
+            TRY(clhip_conv_fwd_acc(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
+                                   u.d.stride, u.d.pad, p->dtype, stream));
+            const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
+            TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
+                                     bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
+                                     ws + dst.y_off, u.d.relu, p->dtype, stream));
+            continue;
+        }
         float* part = training ? fr + p->f_part : nullptr;
         TRY(clhip_conv_fwd(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, part, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
                            u.d.stride, u.d.pad, p->dtype, stream));
@@ -242,9 +277,15 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
         void* dres = u.d.res >= 0 ? ws + p->acts[u.d.res].dy_off : nullptr;
-        TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                         grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
-                         fr + p->f_bnws, p->dtype, stream));
+        if (u.acc_bwd) {
+            TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
+                                 grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                                 reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, p->dtype, stream));
+        } else {
+            TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
+                             grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                             fr + p->f_bnws, p->dtype, stream));
+        }
         TRY(clhip_conv_wgrad(ws + src.y_off, ws + p->dz_off, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         if (u.d.src != 0) {

@@ -253,6 +253,28 @@ def test_batchnorm_fwd_bwd(shape, mode, relu, res):
         call("clhip_bn_bwd", dyd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(),
              dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), dres.data_ptr(), 1, M, C, relu, ws.data_ptr(), code, st())
         assert (from_nhwc(dres).double() - 2 * rr.grad).abs().max() <= tol(mode, rr.grad) * 3
+    # accumulator variants (what the plan runs): fp64 sums instead of per-tile partial rows, no finalize launches;
+    # must reproduce the partial-buffer path on the same inputs
+    acc = torch.stack([z2.sum(0), (z2 * z2).sum(0)]).to(DEV)                       # [2, C] fp64, as the conv epilogue accumulates it
+    rm2, rv2 = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    mean2, invstd2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    y2 = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+    call("clhip_bn_apply_train", zd.data_ptr(), acc.data_ptr(), M, C, gd.data_ptr(), bd.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), 0.1, 1e-5,
+         mean2.data_ptr(), invstd2.data_ptr(), rd.data_ptr() if res else None, y2.data_ptr(), relu, code, st())
+    assert torch.allclose(mean2, mean, rtol=1e-5, atol=1e-6) and torch.allclose(invstd2, invstd, rtol=1e-5)
+    assert torch.allclose(rm2.cpu().double(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(rv2.cpu().double(), rv, rtol=1e-4, atol=1e-6)
+    assert (from_nhwc(y2).double() - yref).abs().max() <= tol(mode, yref)
+    bacc = torch.zeros(2, C, dtype=torch.float64, device=DEV)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz2 = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+    dres2 = torch.empty(N, H, W, C, dtype=tdt, device=DEV) if res else None
+    call("clhip_bn_bwd_acc", dyd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), dg2.data_ptr(),
+         db2.data_ptr(), dz2.data_ptr(), dres2.data_ptr() if res else None, 0, M, C, relu, bacc.data_ptr(), code, st())
+    assert (from_nhwc(dz2).double() - gz).abs().max() <= tol(mode, gz) * 2
+    assert (dg2.cpu().double() - g64.grad).abs().max() <= 2e-3 * (g64.grad.abs().max() + 1e-9) + 1e-4
+    assert (db2.cpu().double() - b64.grad).abs().max() <= 2e-3 * (b64.grad.abs().max() + 1e-9) + 1e-4
+    if res:
+        assert (from_nhwc(dres2).double() - rr.grad).abs().max() <= tol(mode, rr.grad)
     # eval-mode affine
     call("clhip_bn_eval_affine", gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, C, scale.data_ptr(),
          shift.data_ptr(), st())
@@ -400,3 +422,27 @@ def test_ncm_and_herding_match_reference_math():
     means = rnd((7, 64), 91)
     pred = ops.ncm_classify(feats.to(DEV), means.to(DEV)).cpu()
     assert torch.equal(pred, om.ncm_distance(feats, means).argmin(1))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64, 3, 1), (4, 16, 16, 64, 128, 3, 2), (4, 8, 8, 32, 64, 1, 2), (16, 32, 32, 8, 16, 3, 1)])
+def test_conv_fwd_stat_accumulator(mode, shape):
+    """clhip_conv_fwd_acc: same z as clhip_conv_fwd, per-channel sums of z and z^2 added into a zeroed fp64 [2][K] buffer
+    (= the column sums of the partial rows of the partial-buffer entry point)"""
+    N, H, W, C, K, ks, stride = shape
+    code, tdt = DT[mode]
+    pad = 1 if ks == 3 else 0
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    x = (torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(5)) * 0.5).to(tdt).to(DEV)
+    w = (torch.randn(K, ks * ks, C, generator=torch.Generator().manual_seed(6)) * 0.1).to(tdt).to(DEV)
+    tiles = _lib.lib().clhip_conv_fwd_tiles(N, H, W, C, K, ks, stride, pad)
+    part = torch.empty(tiles, 2, K, device=DEV)
+    z1 = torch.empty(N, Ho, Wo, K, dtype=tdt, device=DEV)
+    z2 = torch.empty_like(z1)
+    acc = torch.zeros(2, K, dtype=torch.float64, device=DEV)
+    call("clhip_conv_fwd", x.data_ptr(), w.data_ptr(), z1.data_ptr(), part.data_ptr(), N, H, W, C, K, ks, stride, pad, code, st())
+    call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z2.data_ptr(), acc.data_ptr(), N, H, W, C, K, ks, stride, pad, code, st())
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2)
+    ref = part.double().sum(0)
+    assert float((acc - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
