@@ -136,17 +136,25 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, const f32x4& a, i
 
 constexpr int BK = 64;
 
-// MT / NT = 16-row / 16-column MFMA tiles per wave: block tile (32 MT) x (32 NT).  4 x 4 (128 x 128) is the default; MT = 5 is
-// picked when it quantises the tile count better against the 512 resident workgroups (2 per CU), 2 x 2 (64 x 64 tiles) when
-// the problem is too small to fill the chip with 128-wide tiles (L2P: 16 images x 222 tokens), see pick_tile().
-template <typename T, int EPI, int MT, int NT>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(GemmParams p) {
+// WM x WN waves per workgroup, each wave MT x NT MFMA tiles of 16 x 16: block tile (16 MT WM) x (16 NT WN).
+//   2x2 waves, 4x4 tiles  = 128 x 128, two workgroups per CU: the default
+//   2x2 waves, 5x4 / 2x2  = 160 x 128 / 64 x 64: better tile-count quantisation / problems too small to fill the chip
+//   2x4 waves, 8x4 tiles  = 256 x 256, one 8-wave workgroup per CU: half the global->LDS and LDS->register traffic per MFMA of the
+//                           128 x 128 tile.  Ablation of the 128 x 128 kernel (profiles/r01_gemm_ablation.txt): removing the MFMAs
+//                           does not shorten it, removing the global loads / LDS stores / fragment reads does -- the operand
+//                           delivery path, not the matrix cores, bounds the loop -- so the tile must grow where the shape allows
+//                           (N >= 2304: enough tiles to keep 256 CUs busy).
+template <typename T, int EPI, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int NTH = 64 * WM * WN, RPP = NTH / 8;                 // threads, tile rows covered per staging pass
+    constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+    constexpr int AL = BM / RPP, BL = BN / RPP;                       // staging chunks per thread
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must divide among the staging passes");
     constexpr int A_BYTES = BM * BK * (int)sizeof(T), B_BYTES = BN * BK * (int)sizeof(T), STAGE = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware bijective remap of the block id (8 XCDs, round-robin dispatch): XCD x gets a contiguous range
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -162,19 +170,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
     const T* A = static_cast<const T*>(p.A);
     const T* B = static_cast<const T*>(p.B);
 
-    // global -> register staging: thread owns chunk c of rows r0 + 32 i
+    // global -> register staging: thread owns chunk c of rows r0 + RPP i.  Rows beyond M / N are clamped to the last valid row:
+    // their products land in accumulators that are never stored
     const int c = tid & 7, r0 = tid >> 3;
-    // rows beyond M / N are clamped to the last valid row: their products land in accumulators that are never stored
-    const T* ag[MT];
-    const T* bg[NT];
-    constexpr int RMAX = MT > NT ? MT : NT;
+    const T* ag[AL];
+    const T* bg[BL];
+    constexpr int RMAX = AL > BL ? AL : BL;
     int st_off[RMAX];
 #pragma unroll
-    for (int i = 0; i < RMAX; ++i) st_off[i] = lds_off<T>(r0 + 32 * i, c);
+    for (int i = 0; i < RMAX; ++i) st_off[i] = lds_off<T>(r0 + RPP * i, c);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) ag[i] = A + (size_t)min(m0 + r0 + 32 * i, p.M - 1) * p.lda + c * 8;
+    for (int i = 0; i < AL; ++i) ag[i] = A + (size_t)min(m0 + r0 + RPP * i, p.M - 1) * p.lda + c * 8;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) bg[i] = B + (size_t)min(n0 + r0 + 32 * i, p.N - 1) * p.ldb + c * 8;
+    for (int i = 0; i < BL; ++i) bg[i] = B + (size_t)min(n0 + r0 + RPP * i, p.N - 1) * p.ldb + c * 8;
     // per-lane fragment read offsets (row & 7 == l15 & 7 because every tile row base is a multiple of 16)
     int a_off[2], b_off[2];
 #pragma unroll
@@ -190,16 +198,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    Chunk<T> ra[MT], rb[NT];
+    Chunk<T> ra[AL], rb[BL];
     const int KT = p.K / BK;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) ra[i] = cload<T>(ag[i]);
+    for (int i = 0; i < AL; ++i) ra[i] = cload<T>(ag[i]);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) rb[i] = cload<T>(bg[i]);
+    for (int i = 0; i < BL; ++i) rb[i] = cload<T>(bg[i]);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) lds_st<T>(smem, st_off[i], ra[i]);
+    for (int i = 0; i < AL; ++i) lds_st<T>(smem, st_off[i], ra[i]);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) lds_st<T>(smem + A_BYTES, st_off[i], rb[i]);
+    for (int i = 0; i < BL; ++i) lds_st<T>(smem + A_BYTES, st_off[i], rb[i]);
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -209,9 +217,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
         if (more) {
             const int ko = (kt + 1) * BK;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) ra[i] = cload<T>(ag[i] + ko);
+            for (int i = 0; i < AL; ++i) ra[i] = cload<T>(ag[i] + ko);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) rb[i] = cload<T>(bg[i] + ko);
+            for (int i = 0; i < BL; ++i) rb[i] = cload<T>(bg[i] + ko);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -228,9 +236,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void gemm_nt_kernel(Ge
         if (more) {
             char* An = smem + ((kt + 1) & 1) * STAGE;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) lds_st<T>(An, st_off[i], ra[i]);
+            for (int i = 0; i < AL; ++i) lds_st<T>(An, st_off[i], ra[i]);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) lds_st<T>(An + A_BYTES, st_off[i], rb[i]);
+            for (int i = 0; i < BL; ++i) lds_st<T>(An + A_BYTES, st_off[i], rb[i]);
         }
         __syncthreads();
     }
@@ -492,29 +500,34 @@ int gemm_impl() {
     return g_impl;
 }
 
-template <typename T, int EPI, int MT, int NT> int launch(const GemmParams& p, hipStream_t s) {
-    constexpr int BM = 32 * MT, BN = 32 * NT;
+template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launch(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(T);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT, NT>), dim3(tiles), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), dim3(tiles), dim3(64 * WM * WN), smem, s, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
 
 // block tile: 64 x 64 when 128-wide tiles cannot fill half of the 512 resident workgroups (2 per CU); otherwise 128 columns and
 // the row count (160 / 128) with the better work / (rounds x slots) quantisation.  fp32 (parity mode): 128 x 128.
-// CLHIP_GEMM_MT forces 2 (64 x 64), 4 or 5.
+// CLHIP_GEMM_MT forces 2 (64 x 64), 4, 5 or 8 (256 x 256, 8 waves).
 int pick_tile(int M, int N) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("CLHIP_GEMM_MT"); forced = e ? atoi(e) : 0; }
-    if (forced == 2 || forced == 4 || forced == 5) return forced;
+    if (forced == 2 || forced == 4 || forced == 5 || forced == 8) return forced;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 < 256) return 2;
+    {   // 256 x 256 tiles (one 8-wave workgroup per CU) when they still fill the chip for >= 3.4 rounds at >= 85 % quantisation
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        const long rounds = (t256 + 255) / 256;
+        if (N % 256 == 0 && t256 >= 768 && (double)t256 / (double)(rounds * 256) >= 0.85) return 8;
+    }
     int best = 4;
     double best_eff = -1.0;
     for (int mt : {5, 4}) {
@@ -535,6 +548,7 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s)
         if (impl == 2) return launch_glds<EPI, 4, 2, 3>(p, s);
         if (impl == 3) return launch_pp<EPI>(p, s);
         switch (pick_tile(p.M, p.N)) {
+            case 8: return launch<T, EPI, 8, 4, 2, 4>(p, s);
             case 5: return launch<T, EPI, 5, 4>(p, s);
             case 2: return launch<T, EPI, 2, 2>(p, s);
             default: return launch<T, EPI, 4, 4>(p, s);
