@@ -54,11 +54,19 @@ __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, size_t 
     }
 }
 
+// NKT = number of 16-key tiles (compile time: 13 / 14 for N = 197 / 222; 0 = run-time count, up to 16).  Instruction diet
+// (PMC of the first version: 18 VALU per MFMA, the kernel was issue-bound): the softmax scale is folded into the exponent
+// (one v_fma + one v_exp per score, exp2 domain), only the last key tile is masked, P stays unnormalised in bf16 and 1/sum
+// is applied to the 16 output accumulators instead of the 52 probabilities.
+template <int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const int N = p.N, D = p.D, nKT = (N + 15) >> 4, NP2 = ((nKT + 1) & ~1) * 16;
+    const int N = p.N, D = p.D;
+    const int nKT = NKT > 0 ? NKT : (N + 15) >> 4;
+    constexpr int KTMAX = NKT > 0 ? NKT : 16;
+    const int NP2 = ((nKT + 1) & ~1) * 16;
     const size_t ld = 3 * (size_t)D;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (size_t)b * N * ld + h * 64;
     char* Ks = smem;
@@ -66,6 +74,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     stage_rows(Ks, base + D, ld, N, NP2);
     stage_rows(Vs, base + 2 * D, ld, N, NP2);
     __syncthreads();
+    const float c = p.scale * 1.4426950408889634f;          // scores -> exp2 domain
+    const int last0 = (nKT - 1) * 16 + g * 4;               // first key this lane holds in the last tile
 
     for (int qt = wave; qt < nKT; qt += 4) {
         const int qrow = qt * 16 + l15;
@@ -74,44 +84,44 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
             qf[kk] = qok ? *reinterpret_cast<const uint4*>(base + (size_t)qrow * ld + (g + 4 * kk) * 8) : make_uint4(0, 0, 0, 0);
-        f32x4 s[16];
+        f32x4 s[KTMAX + 1];
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt) {
+        for (int kt = 0; kt < KTMAX; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kt < nKT) {
+            if (NKT > 0 || kt < nKT) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) s[kt] = mfma_bf16(ldsq(Ks, (kt * 16 + l15) * KP + (g + 4 * kk) * 16), qf[kk], s[kt]);
+                if (kt == nKT - 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = (kt * 16 + g * 4 + e) < N ? s[kt][e] * p.scale : -INFINITY;
-                    s[kt][e] = v;
-                    mx = fmaxf(mx, v);
+                    for (int e = 0; e < 4; ++e) if (last0 + e >= N) s[kt][e] = -INFINITY;
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[kt][e]);
             }
         }
+        s[KTMAX] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * c;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt) {
-            if (kt < nKT) {
+        for (int kt = 0; kt < KTMAX; ++kt) {
+            if (NKT > 0 || kt < nKT) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float e_ = __expf(s[kt][e] - mx); s[kt][e] = e_; sum += e_; }
+                for (int e = 0; e < 4; ++e) { const float e_ = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, -mc)); s[kt][e] = e_; sum += e_; }
             }
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        if (g == 0 && qok && p.lse) p.lse[((size_t)b * p.H + h) * N + qrow] = mx + __logf(sum);
+        if (g == 0 && qok && p.lse) p.lse[((size_t)b * p.H + h) * N + qrow] = mx * p.scale + __logf(sum);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (2 * ks < nKT) {
-                f32x4 p0 = s[2 * ks] * inv, p1 = s[2 * ks + 1] * inv;      // tiles >= nKT are zero
-                const uint4 pb = pack8(p0, p1);
+        for (int ks = 0; ks < (KTMAX + 1) / 2; ++ks) {
+            if (NKT > 0 || 2 * ks < nKT) {
+                const uint4 pb = pack8(s[2 * ks], s[2 * ks + 1]);           // tiles >= nKT are zero
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const uint4 vt = tr8(Vs, (2 * ks * 16 + g * 4 + (l15 >> 2)) * KP + (dt * 16 + (l15 & 3) * 4) * 2, 16 * KP);
@@ -120,10 +130,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
             }
         }
         if (qok) {
+            const float inv = 1.0f / sum;
             bf16_t* orow = static_cast<bf16_t*>(p.out) + ((size_t)b * N + qrow) * D + h * 64 + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(orow + dt * 16) = make_uint2(pack_bf16x2(o[dt][0], o[dt][1]), pack_bf16x2(o[dt][2], o[dt][3]));
+                *reinterpret_cast<uint2*>(orow + dt * 16) = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
         }
     }
 }
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParam
     char* Ks = Qs + NP2 * KP;
     char* Vs = Ks + NP2 * KP;
     char* Gs = Vs + NP2 * KP;                                  // dO
-    float* lse_s = reinterpret_cast<float*>(Gs + NP2 * KP);    // [NP2]  (+inf beyond N -> P = 0)
+    float* lse_s = reinterpret_cast<float*>(Gs + NP2 * KP);    // [NP2]  lse * log2(e)  (+inf beyond N -> P = 0)
     float* dq_s = lse_s + NP2;                                 // [NP2]  rowsum(dO * O)
     stage_rows(Qs, base, ld, N, NP2);
     stage_rows(Ks, base + D, ld, N, NP2);
@@ -163,10 +174,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParam
                 for (int j = 0; j < 8; ++j) dsum += x[j] * y[j];
             }
         }
-        lse_s[q] = l;
+        lse_s[q] = l * 1.4426950408889634f;
         dq_s[q] = dsum;
     }
     __syncthreads();
+    const float c = p.scale * 1.4426950408889634f;          // scores -> exp2 domain
 
     // ---- phase A: dQ.  wave <- query tile; per key-tile pair: S^T, dP^T (D layout: rows key g*4+e, col q l15)
     for (int qt = wave; qt < nKT; qt += BWD_WAVES) {
@@ -192,10 +204,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParam
                     s = mfma_bf16(ldsq(Ks, krow * KP + (g + 4 * kk) * 16), qf[kk], s);
                     dp = mfma_bf16(ldsq(Vs, krow * KP + (g + 4 * kk) * 16), gf[kk], dp);
                 }
+                const bool tail = (2 * ks + t) >= nKT - 1;               // only the last key tile holds keys >= N
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = (2 * ks + t) * 16 + g * 4 + e;
-                    const float pr = key < N ? __expf(s[e] * p.scale - lq) : 0.f;
+                    float pr = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lq));
+                    if (tail && (2 * ks + t) * 16 + g * 4 + e >= N) pr = 0.f;
                     ds[t][e] = pr * (dp[e] - dq);
                 }
             }
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParam
                 const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = kok ? __expf(s[e] * p.scale - le[e]) : 0.f;      // lse = +inf beyond N -> 0
+                    const float pe = kok ? __builtin_amdgcn_exp2f(fmaf(s[e], c, -le[e])) : 0.f;      // lse = +inf beyond N -> 0
                     pr[t][e] = pe;
                     ds[t][e] = pe * (dp[e] - de[e]);
                 }
@@ -406,8 +419,16 @@ extern "C" int clhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int
         const int NP2 = ((((N + 15) >> 4) + 1) & ~1) * 16;
         const size_t smem = 2 * (size_t)NP2 * KP;
         static bool done = false;
-        if (!done) { hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * KP); done = true; }
-        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), smem, s, p);
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * KP);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * KP);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * KP);
+            done = true;
+        }
+        const int nkt = (N + 15) >> 4;
+        if (nkt == 13) hipLaunchKernelGGL(attn_fwd_mfma_kernel<13>, dim3(B * H), dim3(256), smem, s, p);
+        else if (nkt == 14) hipLaunchKernelGGL(attn_fwd_mfma_kernel<14>, dim3(B * H), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL(attn_fwd_mfma_kernel<0>, dim3(B * H), dim3(256), smem, s, p);
     } else {
         const int rows = B * H * N;
         if (dtype == CLHIP_BF16) hipLaunchKernelGGL(attn_fwd_generic_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, p, hd);
