@@ -105,6 +105,27 @@ __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
     dy = fmaf(x * 0.3989422804014327f, e, phi);
 }
 
+// two elements at a time on <2 x float>: the FMA-type operations become v_pk_fma_f32 / v_pk_mul_f32 (half the issue slots);
+// the two transcendental ops per element (v_rcp_f32, v_exp_f32) stay scalar
+typedef __attribute__((ext_vector_type(2))) float f2;
+__device__ __forceinline__ void gelu_both2(f2 x, f2& y, f2& dy) {
+    const f2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f2 z = ax * 0.70710678118654752f;
+    const f2 den = z * 0.3275911f + 1.0f;
+    const f2 t = {__frcp_rn(den.x), __frcp_rn(den.y)};
+    const f2 nz2 = -(z * z);
+    const f2 e = {__expf(nz2.x), __expf(nz2.y)};
+    f2 pl = t * 1.061405429f + (-1.453152027f);
+    pl = t * pl + 1.421413741f;
+    pl = t * pl + (-0.284496736f);
+    pl = t * pl + 0.254829592f;
+    const f2 erf_abs = 1.0f - pl * t * e;
+    const f2 se = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+    const f2 phi = se * 0.5f + 0.5f;
+    y = x * phi;
+    dy = x * 0.3989422804014327f * e + phi;
+}
+
 // epilogue of one accumulator: the lane holds C[m][n .. n+3]
 template <typename T, int EPI>
 __device__ __forceinline__ void epi_store(const GemmParams& p, const f32x4& a, int m, int n) {
@@ -121,8 +142,11 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, const f32x4& a, i
     }
     if constexpr (EPI == EPI_BIAS_GELU) {
         float d[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], d[e]);
+        f2 y0, d0, y1, d1;
+        gelu_both2((f2){v[0], v[1]}, y0, d0);
+        gelu_both2((f2){v[2], v[3]}, y1, d1);
+        v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
+        d[0] = d0.x; d[1] = d0.y; d[2] = d1.x; d[3] = d1.y;
         if (p.H) store4<T>(static_cast<T*>(p.H) + (size_t)m * p.ldh + n, d);
     }
     if constexpr (EPI == EPI_MUL) {
