@@ -297,7 +297,7 @@ class VisionTransformer(nn.Module):
         dprompt = torch.empty(n_prompt, self.embed_dim, device=dev) if want_prompt else None
         dl, arr = None, None
         if want_lora:
-            dl = [torch.zeros(self.embed_dim, self.lora_rank, device=dev) for _ in range(2 * self.depth)]
+            dl = list(torch.zeros(2 * self.depth, self.embed_dim, self.lora_rank, device=dev).unbind(0))     # one fill, 2*depth views
             arr = (C.c_void_p * (2 * self.depth))(*[t.data_ptr() for t in dl])
         call("clhip_vit_backward", s.handle, C.byref(s.cparams), s.shadow.data_ptr(), s.ws.data_ptr(), dfeat.data_ptr(),
              dprompt.data_ptr() if want_prompt else None, arr, _st())
