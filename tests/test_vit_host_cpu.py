@@ -65,3 +65,19 @@ def test_pretrained_without_checkpoint_is_a_clear_error(tmp_path, monkeypatch):
     monkeypatch.delenv("CLHIP_VIT_CHECKPOINT", raising=False)
     with pytest.raises(FileNotFoundError):
         M.vit_pt_imnet(pretrained=True, model_name="vit_base_patch16_224", img_size=32, patch_size=8, embed_dim=128, depth=1, num_heads=2)
+
+
+def test_pretrained_checkpoint_key_mapping(tmp_path):
+    """a timm-named state dict (blocks.N.norm1 / norm2, head.*) loads through the reference's key mapping (vit.py:69-84)"""
+    kw = dict(img_size=32, patch_size=8, embed_dim=128, depth=2, num_heads=2)
+    src = M.vit_pt_imnet(pretrained=False, **kw)
+    timm_sd = {}
+    for k, v in src.feat.state_dict().items():
+        k = k.replace("transformer.blocks.", "blocks.").replace(".ln_1.", ".norm1.").replace(".ln_2.", ".norm2.")
+        timm_sd[k] = v.clone() + 0.5
+    timm_sd["head.weight"], timm_sd["head.bias"] = torch.zeros(10, 128), torch.zeros(10)       # silently dropped, as in the reference
+    path = tmp_path / "vit_tiny.pt"
+    torch.save(timm_sd, path)
+    dst = M.vit_pt_imnet(pretrained=True, model_name="vit_tiny", checkpoint=str(path), **kw)
+    for (k, a), (_, b) in zip(src.feat.state_dict().items(), dst.feat.state_dict().items()):
+        assert torch.equal(a + 0.5, b), k
