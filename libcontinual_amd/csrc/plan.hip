@@ -168,19 +168,38 @@ constexpr int kPrepMax = 48;
 struct PrepEntry { int64_t w_off; int64_t wf_off, wd_off; int K, taps, Creal, Cpad; unsigned first_block; };
 struct PrepTable { int n; PrepEntry e[kPrepMax]; };
 
+// block = one (tap, 32 out-channels x 32 in-channels) tile: coalesced fp32 reads along C, coalesced writes of the forward copy
+// along C and -- through a 32 x 33 LDS transpose -- of the dgrad copy along K (the first version wrote the dgrad copy with a
+// K*taps element stride per lane: 88 us for ResNet-18's 11.2 M weights, ~1 TB/s)
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* __restrict__ params, char* __restrict__ shadow, PrepTable t) {
+    __shared__ float tile[32][33];
     int u = 0;
     while (u + 1 < t.n && blockIdx.x >= t.e[u + 1].first_block) ++u;
     const PrepEntry& d = t.e[u];
-    const int64_t idx = (int64_t)(blockIdx.x - d.first_block) * 256 + threadIdx.x;
-    if (idx >= (int64_t)d.K * d.taps * d.Cpad) return;
-    const int c = (int)(idx % d.Cpad);
-    const int64_t r = idx / d.Cpad;
-    const int tap = (int)(r % d.taps), k = (int)(r / d.taps);
-    const float v = c < d.Creal ? params[d.w_off + ((size_t)k * d.taps + tap) * d.Creal + c] : 0.f;
-    Elem<T>::st(reinterpret_cast<T*>(shadow + d.wf_off) + idx, v);
-    if (d.wd_off >= 0) Elem<T>::st(reinterpret_cast<T*>(shadow + d.wd_off) + ((size_t)c * d.taps + tap) * d.K + k, v);
+    const int kb = (d.K + 31) / 32, cb = (d.Cpad + 31) / 32;
+    int r = blockIdx.x - d.first_block;
+    const int c0 = (r % cb) * 32; r /= cb;
+    const int k0 = (r % kb) * 32;
+    const int tap = r / kb;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* wf = reinterpret_cast<T*>(shadow + d.wf_off);
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (k < d.K && c < d.Cpad) {
+            if (c < d.Creal) v = params[d.w_off + ((size_t)k * d.taps + tap) * d.Creal + c];
+            Elem<T>::st(wf + ((size_t)k * d.taps + tap) * d.Cpad + c, v);
+        }
+        tile[i][tx] = v;
+    }
+    if (d.wd_off < 0) return;
+    __syncthreads();
+    T* wd = reinterpret_cast<T*>(shadow + d.wd_off);
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        if (c < d.Cpad && k < d.K) Elem<T>::st(wd + ((size_t)c * d.taps + tap) * d.K + k, tile[tx][i]);
+    }
 }
 }  // namespace
 
@@ -198,7 +217,7 @@ extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void*
             e.w_off = u.d.w_off; e.wf_off = (int64_t)u.sh_fwd; e.wd_off = u.d.src != 0 ? (int64_t)u.sh_dg : -1;
             e.K = u.d.cout; e.taps = u.d.ksize * u.d.ksize; e.Creal = u.d.cin; e.Cpad = u.cin_pad;
             e.first_block = blocks;
-            blocks += (unsigned)(((int64_t)e.K * e.taps * e.Cpad + 255) / 256);
+            blocks += (unsigned)(e.taps * ((e.K + 31) / 32) * ((e.Cpad + 31) / 32));
         }
         if (p->dtype == CLHIP_BF16) hipLaunchKernelGGL(weight_prep_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);
         else hipLaunchKernelGGL(weight_prep_multi_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);
