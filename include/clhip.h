@@ -70,10 +70,11 @@ int clhip_conv_weight_prep(const float* w, void* w_fwd, void* w_dg, int K, int t
 int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize, int stride, int pad);
 int clhip_conv_fwd(const void* x, const void* w_fwd, void* z, float* stat_partials, int N, int H, int W, int C, int K,
                    int ksize, int stride, int pad, int dtype, void* stream);
-/* same forward, but the per-channel sums of z and z^2 are ADDED into stat_acc[2][K] (fp64, hardware atomics; zeroed by the
- * caller) instead of written as per-tile partial rows: the consumer (clhip_bn_apply_train) then needs no finalize launch */
-int clhip_conv_fwd_acc(const void* x, const void* w_fwd, void* z, double* stat_acc, int N, int H, int W, int C, int K, int ksize,
-                       int stride, int pad, int dtype, void* stream);
+/* same forward, but the per-channel sums of z and z^2 are ADDED into stat_acc[replicas][2][K] (fp64, hardware atomics; zeroed
+ * by the caller; a workgroup uses replica blockIdx & (replicas-1), replicas = power of two <= 64) instead of written as per-tile
+ * partial rows: the consumer (clhip_bn_apply_train) sums the replicas itself and needs no finalize launch */
+int clhip_conv_fwd_acc(const void* x, const void* w_fwd, void* z, double* stat_acc, int replicas, int N, int H, int W, int C, int K,
+                       int ksize, int stride, int pad, int dtype, void* stream);
 int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C, int K,
                      int ksize, int stride, int pad, int dtype, void* stream);
 size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
@@ -101,14 +102,14 @@ int clhip_bn_apply(const void* z, const float* scale, const float* shift, const 
 /* training-mode BatchNorm straight from the fp64 sums of clhip_conv_fwd_acc: y = relu?(bn(z) + res?), batch mean / invstd saved
  * for the backward, running statistics updated (momentum, unbiased variance) -- bn_stats_finalize + bn_apply in ONE launch.
  * C must be a power of two. */
-int clhip_bn_apply_train(const void* z, const double* stat_acc, int64_t M, int C, const float* gamma, const float* beta, float* rm,
+int clhip_bn_apply_train(const void* z, const double* stat_acc, int replicas, int64_t M, int C, const float* gamma, const float* beta, float* rm,
                          float* rv, float momentum, float eps, float* mean, float* invstd, const void* res /*nullable*/, void* y,
                          int relu, int dtype, void* stream);
-/* clhip_bn_bwd with the two per-channel sums accumulated into acc[2][C] (fp64 atomics, zeroed by the caller) and consumed
- * directly by the apply pass: no partial buffer, no finalize launch */
+/* clhip_bn_bwd with the two per-channel sums accumulated into acc[replicas][2][C] (fp64 atomics, zeroed by the caller) and
+ * consumed directly by the apply pass: no partial buffer, no finalize launch */
 int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
                      float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu, double* acc,
-                     int dtype, void* stream);
+                     int replicas, int dtype, void* stream);
 /* number of reduction workgroups clhip_bn_bwd / clhip_bn_bwd_acc launch (= producers adding into the accumulator) */
 int clhip_bn_bwd_blocks(int64_t M, int C);
 size_t clhip_bn_bwd_ws_floats(int64_t M, int C);

@@ -85,7 +85,7 @@ template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                             const T* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            double* __restrict__ acc, int64_t M, int C) {
+                                                            double* __restrict__ acc, int rep, int64_t M, int C) {
     extern __shared__ __attribute__((aligned(16))) float red[];     // [256][16]
     const int cpr = C >> 3;
     const int rpi = 256 / cpr;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         int col = c >> 3, e = c & 7;
         float s = 0.f;
         for (int q = 0; q < rpi; ++q) s += red[(q * cpr + col) * 16 + which * 8 + e];
-        if (acc != nullptr) atomicAdd(acc + (size_t)which * C + c, (double)s);
+        if (acc != nullptr) atomicAdd(acc + ((size_t)(blockIdx.x & (rep - 1)) * 2 + which) * C + c, (double)s);
         else part[((size_t)blockIdx.x * 2 + which) * C + c] = s;
     }
 }
@@ -184,41 +184,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // and the consumer derives scale / shift (forward) or the two mean terms (backward) itself: a handful of flops per thread,
 // hoisted out of the grid-stride loop because a thread's 8 channels are fixed when the grid stride is a multiple of C/8.
 template <typename T, bool RES, bool RELU>
-__global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict__ z, const double* __restrict__ acc, double invM, double unbias,
+__global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict__ z, const double* __restrict__ acc, int rep, double invM, double unbias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* rm, float* rv,
                                                              float momentum, float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                              const T* __restrict__ res, T* __restrict__ y, int64_t nchunks, int C) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c0 = (int)((i0 * 8) % C);
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const double mean = acc[c0 + e] * invM;
-        double var = acc[C + c0 + e] * invM - mean * mean;      // the cancellation happens in fp64 ...
+    extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: scale, shift
+    // block-cooperative finalize: sum the accumulator replicas, derive scale / shift once per workgroup
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < rep; ++r) { s1 += acc[((size_t)r * 2 + 0) * C + c]; s2 += acc[((size_t)r * 2 + 1) * C + c]; }
+        const double mean = s1 * invM;
+        double var = s2 * invM - mean * mean;       // the cancellation happens in fp64 ...
         if (var < 0.0) var = 0.0;
-        // ... the well-conditioned rest in fp32 in the bf16 mode (no fp64 sqrt / divide per thread); the fp32 parity mode keeps
-        // the finalize kernel's exact fp64 expression
+        // ... the well-conditioned rest in fp32 in the bf16 mode; the fp32 parity mode keeps the finalize kernel's fp64 expression
         float istd;
         if constexpr (sizeof(T) == 4) istd = (float)(1.0 / sqrt(var + (double)eps));
         else istd = rsqrtf((float)var + eps);
-        sc[e] = gamma[c0 + e] * istd;
-        sh[e] = beta[c0 + e] - (float)mean * sc[e];
-    }
-    if (blockIdx.x == 0) {                 // saved statistics for the backward + running-stat update, once
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const double mean = acc[c] * invM;
-            double var = acc[C + c] * invM - mean * mean;
-            if (var < 0.0) var = 0.0;
+        const float sc = gamma[c] * istd;
+        coefs[c] = sc;
+        coefs[C + c] = beta[c] - (float)mean * sc;
+        if (blockIdx.x == 0) {                 // saved statistics for the backward + running-stat update, once
             mean_o[c] = (float)mean;
-            if constexpr (sizeof(T) == 4) invstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
-            else invstd_o[c] = rsqrtf((float)var + eps);
+            invstd_o[c] = istd;
             if (rm != nullptr) {
                 rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
                 rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * unbias);
             }
         }
     }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)((i0 * 8) % C);                                // fixed per thread: the grid stride is a multiple of C/8
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = coefs[c0 + e]; sh[e] = coefs[C + c0 + e]; }
     for (int64_t i = i0; i < nchunks; i += stride) {
         float v[8], r[8];
         load8<T>(z + i * 8, v);
@@ -237,23 +237,29 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
 template <typename T, bool RELU, int DRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ z,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                               const float* __restrict__ gamma, const double* __restrict__ acc, double invM,
+                                                               const float* __restrict__ gamma, const double* __restrict__ acc, int rep, double invM,
                                                                float* dgamma, float* dbeta, T* __restrict__ dz, T* __restrict__ dres,
                                                                int64_t nchunks, int C) {
+    extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: mean(g), mean(g * xhat)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < rep; ++r) { s1 += acc[((size_t)r * 2 + 0) * C + c]; s2 += acc[((size_t)r * 2 + 1) * C + c]; }
+        coefs[c] = (float)(s1 * invM);
+        coefs[C + c] = (float)(s2 * invM);
+        if (blockIdx.x == 0) { dbeta[c] += (float)s1; dgamma[c] += (float)s2; }
+    }
+    __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c0 = (int)((i0 * 8) % C);
     float k0[8], k1[8], gi[8], mu[8], is[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        k0[e] = (float)(acc[c0 + e] * invM);
-        k1[e] = (float)(acc[C + c0 + e] * invM);
+        k0[e] = coefs[c0 + e];
+        k1[e] = coefs[C + c0 + e];
         mu[e] = mean[c0 + e];
         is[e] = invstd[c0 + e];
         gi[e] = gamma[c0 + e] * is[e];
-    }
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] += (float)acc[c]; dgamma[c] += (float)acc[C + c]; }
     }
     for (int64_t i = i0; i < nchunks; i += stride) {
         float g[8], yy[8], zz[8], o[8], rr[8];
@@ -422,8 +428,8 @@ static int bn_bwd_t(const void* dy, const void* y, const void* z, const float* m
     float* coef = ws + (size_t)G * 2 * C;
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = 256 * 16 * sizeof(float);
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, M, C);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, M, C);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C);
     CLHIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, G, 1.0 / (double)M, C, dgamma, dbeta, coef);
     CLHIP_LAUNCH_CHECK();
@@ -454,15 +460,24 @@ extern "C" int clhip_bn_bwd(const void* dy, const void* y, const void* z, const 
 }
 
 static bool acc_ok(int C) { return C >= 8 && C <= 2048 && (C & (C - 1)) == 0; }
+// fewer, longer workgroups than the plain elementwise kernels: every workgroup pays the cooperative finalize prologue
+static int acc_blocks(int64_t nchunks) {
+    int64_t b = (nchunks + 256 * 4 - 1) / (256 * 4);
+    if (b < 512) { b = (nchunks + 255) / 256; if (b > 512) b = 512; }      // small layers: fill the chip first
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
 
 template <typename T>
-static int bn_apply_train_t(const void* z, const double* acc, int64_t M, const float* gamma, const float* beta, float* rm, float* rv, float momentum,
+static int bn_apply_train_t(const void* z, const double* acc, int rep, int64_t M, const float* gamma, const float* beta, float* rm, float* rv, float momentum,
                             float eps, float* mean, float* invstd, const void* res, void* y, int C, int relu, hipStream_t st) {
     const int64_t nch = M * C / 8;
-    dim3 g(ew_blocks(nch)), b(256);
+    dim3 g(acc_blocks(nch)), b(256);
+    const size_t lds = 2 * (size_t)C * sizeof(float);
     const double invM = 1.0 / (double)M, unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
     const T* zz = (const T*)z; const T* rr = (const T*)res; T* yy = (T*)y;
-#define APPLY_TRAIN(R, L) hipLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, 0, st, zz, acc, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C)
+#define APPLY_TRAIN(R, L) hipLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, lds, st, zz, acc, rep, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C)
     if (res && relu) APPLY_TRAIN(true, true);
     else if (res) APPLY_TRAIN(true, false);
     else if (relu) APPLY_TRAIN(false, true);
@@ -472,32 +487,33 @@ static int bn_apply_train_t(const void* z, const double* acc, int64_t M, const f
     return CLHIP_OK;
 }
 
-extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int64_t M, int C, const float* gamma, const float* beta, float* rm, float* rv,
+extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int replicas, int64_t M, int C, const float* gamma, const float* beta, float* rm, float* rv,
                                     float momentum, float eps, float* mean, float* invstd, const void* res, void* y, int relu, int dtype,
                                     void* stream) {
     CLHIP_CHECK_ARG(z && stat_acc && gamma && beta && mean && invstd && y && M > 0 && acc_ok(C));
-    CLHIP_CHECK_ARG((rm == nullptr) == (rv == nullptr));
-    if (dtype == CLHIP_BF16) return bn_apply_train_t<bf16_t>(z, stat_acc, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, relu, (hipStream_t)stream);
-    if (dtype == CLHIP_F32) return bn_apply_train_t<float>(z, stat_acc, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, relu, (hipStream_t)stream);
+    CLHIP_CHECK_ARG((rm == nullptr) == (rv == nullptr) && replicas >= 1 && replicas <= 64);
+    if (dtype == CLHIP_BF16) return bn_apply_train_t<bf16_t>(z, stat_acc, replicas, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, relu, (hipStream_t)stream);
+    if (dtype == CLHIP_F32) return bn_apply_train_t<float>(z, stat_acc, replicas, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, relu, (hipStream_t)stream);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }
 
 template <typename T>
 static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                        float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, hipStream_t st) {
+                        float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, int rep, hipStream_t st) {
     const int G = bn_bwd_blocks(M, C);
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = 256 * 16 * sizeof(float);
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, M, C);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, M, C);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C);
     CLHIP_LAUNCH_CHECK();
     const int64_t nch = M * C / 8;
-    dim3 g(ew_blocks(nch)), b(256);
+    dim3 g(acc_blocks(nch)), b(256);
+    const size_t lds2 = 2 * (size_t)C * sizeof(float);
     T* dzz = (T*)dz; T* dr = (T*)dres;
     const double invM = 1.0 / (double)M;
     int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
-#define BWD_ACC(R, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, 0, st, dyy, yy, zz, mean, invstd, gamma, acc, invM, dgamma, dbeta, dzz, dr, nch, C)
+#define BWD_ACC(R, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, lds2, st, dyy, yy, zz, mean, invstd, gamma, acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C)
     if (relu) { if (mode == 0) BWD_ACC(true, 0); else if (mode == 1) BWD_ACC(true, 1); else BWD_ACC(true, 2); }
     else { if (mode == 0) BWD_ACC(false, 0); else if (mode == 1) BWD_ACC(false, 1); else BWD_ACC(false, 2); }
 #undef BWD_ACC
@@ -507,13 +523,14 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
 
 extern "C" int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
                                 float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu,
-                                double* acc, int dtype, void* stream) {
+                                double* acc, int replicas, int dtype, void* stream) {
     CLHIP_CHECK_ARG(dy && z && mean && invstd && gamma && dgamma && dbeta && dz && acc && M > 0 && acc_ok(C));
+    CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
     CLHIP_CHECK_ARG(!relu || y);
     if (dtype == CLHIP_BF16)
-        return bn_bwd_acc_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, (hipStream_t)stream);
+        return bn_bwd_acc_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, replicas, (hipStream_t)stream);
     if (dtype == CLHIP_F32)
-        return bn_bwd_acc_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, (hipStream_t)stream);
+        return bn_bwd_acc_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, replicas, (hipStream_t)stream);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }

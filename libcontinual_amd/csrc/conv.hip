@@ -435,13 +435,13 @@ int check_conv(int N, int H, int W, int C, int K, int ksize, int stride, int pad
 
 // conv2.hip
 int clhip_conv2_tiles_m(int M, int Cd);
-int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
                        int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st);
 int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
                         int pad, int dtype, hipStream_t st);
 bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
 int clhip_conv3_tiles_m(int M, int Cd);
-int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int N, int H, int W, int Cs, int Cd, int accumulate,
+int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, int accumulate,
                        int mode, hipStream_t st);
 bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st);
@@ -471,21 +471,21 @@ extern "C" int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize
     return (M + bm - 1) / bm;
 }
 
-static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_partials, double* stat_acc, int N, int H, int W, int C,
+static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_partials, double* stat_acc, int stat_rep, int N, int H, int W, int C,
                          int K, int ksize, int stride, int pad, int dtype, void* stream);
 
 extern "C" int clhip_conv_fwd(const void* x, const void* w_fwd, void* z, float* stat_partials, int N, int H, int W, int C,
                               int K, int ksize, int stride, int pad, int dtype, void* stream) {
-    return conv_fwd_impl(x, w_fwd, z, stat_partials, nullptr, N, H, W, C, K, ksize, stride, pad, dtype, stream);
+    return conv_fwd_impl(x, w_fwd, z, stat_partials, nullptr, 1, N, H, W, C, K, ksize, stride, pad, dtype, stream);
 }
 
-extern "C" int clhip_conv_fwd_acc(const void* x, const void* w_fwd, void* z, double* stat_acc, int N, int H, int W, int C,
+extern "C" int clhip_conv_fwd_acc(const void* x, const void* w_fwd, void* z, double* stat_acc, int replicas, int N, int H, int W, int C,
                                   int K, int ksize, int stride, int pad, int dtype, void* stream) {
-    CLHIP_CHECK_ARG(stat_acc != nullptr);
-    return conv_fwd_impl(x, w_fwd, z, nullptr, stat_acc, N, H, W, C, K, ksize, stride, pad, dtype, stream);
+    CLHIP_CHECK_ARG(stat_acc != nullptr && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    return conv_fwd_impl(x, w_fwd, z, nullptr, stat_acc, replicas, N, H, W, C, K, ksize, stride, pad, dtype, stream);
 }
 
-static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_partials, double* stat_acc, int N, int H, int W, int C,
+static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_partials, double* stat_acc, int stat_rep, int N, int H, int W, int C,
                          int K, int ksize, int stride, int pad, int dtype, void* stream) {
     if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
     CLHIP_CHECK_ARG(x && w_fwd && z);
@@ -504,14 +504,14 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
         int tiles_used = clhip_conv3_tiles_m(p.M, K);
         if (stat_partials && tiles_alloc > tiles_used)
             hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
-        return clhip_conv3_launch(x, w_fwd, z, stat_partials, stat_acc, N, H, W, C, K, 0, 0, st);
+        return clhip_conv3_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, K, 0, 0, st);
     }
     if (!use_v1()) {
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
         int tiles_used = clhip_conv2_tiles_m(p.M, K);
         if (stat_partials && tiles_alloc > tiles_used)
             hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
-        return clhip_conv2_launch(x, w_fwd, z, stat_partials, stat_acc, N, H, W, C, p.Hd, p.Wd, K, ksize, stride, pad, 0, 0, dtype, st);
+        return clhip_conv2_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, p.Hd, p.Wd, K, ksize, stride, pad, 0, 0, dtype, st);
     }
     if (dtype == CLHIP_BF16) return launch_igemm<bf16_t, 0>(p, st);
     if (dtype == CLHIP_F32) return launch_igemm<float, 0>(p, st);
@@ -535,8 +535,8 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, K, C, ksize, stride, pad, dtype))
-        return clhip_conv3_launch(dz, w_dg, dx, nullptr, nullptr, N, H, W, K, C, accumulate, 1, st);
-    if (!use_v1()) return clhip_conv2_launch(dz, w_dg, dx, nullptr, nullptr, N, p.Hs, p.Ws, K, H, W, C, ksize, stride, pad, accumulate, 1, dtype, st);
+        return clhip_conv3_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, st);
+    if (!use_v1()) return clhip_conv2_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, p.Hs, p.Ws, K, H, W, C, ksize, stride, pad, accumulate, 1, dtype, st);
     if (dtype == CLHIP_BF16) return launch_igemm<bf16_t, 1>(p, st);
     if (dtype == CLHIP_F32) return launch_igemm<float, 1>(p, st);
     CLHIP_CHECK_ARG(!"dtype");

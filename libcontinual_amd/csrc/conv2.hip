@@ -25,7 +25,8 @@ struct ConvParams2 {
     const void* wt;
     void* dst;
     float* stats;
-    double* stat_acc;   // alternative to `stats`: per-channel [2][Cd] fp64 sums, accumulated with atomics
+    double* stat_acc;   // alternative to `stats`: per-channel [stat_rep][2][Cd] fp64 sums, accumulated with atomics
+    int stat_rep;       // number of accumulator replicas (power of two); a workgroup adds into replica blockIdx.x & (stat_rep - 1)
     int N, Hs, Ws, Cs, log2Cs, Hd, Wd, Cd, ksize, stride, pad, accumulate;
     int M, K;
     int cls_tiles;      // > 0: stride-2 dgrad parity decomposition, tiles per (h&1, w&1) class
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
             if (n0 + c < p.Cd) {
-                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + (size_t)which * p.Cd + n0 + c, (double)t);
+                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * p.Cd + n0 + c, (double)t);
                 else p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + c] = t;
             }
         }
@@ -368,10 +369,10 @@ int launch2(const ConvParams2& p, hipStream_t st) {
 // entry points used by conv.hip's C ABI functions
 int clhip_conv2_tiles_m(int M, int Cd) { return (M + pick_tile(M, Cd).bm - 1) / pick_tile(M, Cd).bm; }
 
-int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
                        int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st) {
     ConvParams2 p;
-    p.src = src; p.wt = wt; p.dst = dst; p.stats = stats; p.stat_acc = stat_acc;
+    p.src = src; p.wt = wt; p.dst = dst; p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.log2Cs = ilog2_exact(Cs); p.Hd = Hd; p.Wd = Wd; p.Cd = Cd;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.M = N * Hd * Wd; p.K = ksize * ksize * Cs;

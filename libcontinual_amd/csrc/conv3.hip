@@ -22,7 +22,8 @@ struct Conv3Params {
     const bf16_t* wt;    // [Cd][9][Cs]
     bf16_t* dst;         // [N,H,W,Cd]
     float* stats;
-    double* stat_acc;   // alternative to `stats`: per-channel [2][Cd] fp64 sums, accumulated with atomics
+    double* stat_acc;   // alternative to `stats`: per-channel [stat_rep][2][Cd] fp64 sums, accumulated with atomics
+    int stat_rep;       // number of accumulator replicas (power of two); a workgroup adds into replica blockIdx.x & (stat_rep - 1)
     int N, H, W, Cs, Cd, accumulate;
     int M;               // N*H*W
     int np;              // patch pixels = BM + 2W + 2
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
 #pragma unroll
             for (int w2 = 0; w2 < WM; ++w2) t += red[(w2 * 2 + which) * BN + cc];
             if (n0 + cc < p.Cd) {
-                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + (size_t)which * p.Cd + n0 + cc, (double)t);
+                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * p.Cd + n0 + cc, (double)t);
                 else p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + cc] = t;
             }
         }
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
 #pragma unroll
             for (int w2 = 0; w2 < WM; ++w2) t += red[(w2 * 2 + which) * BN + cc];
             if (n0 + cc < p.Cd) {
-                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + (size_t)which * p.Cd + n0 + cc, (double)t);
+                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * p.Cd + n0 + cc, (double)t);
                 else p.stats[((size_t)blockIdx.x * 2 + which) * p.Cd + n0 + cc] = t;
             }
         }
@@ -523,11 +524,11 @@ bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, 
 
 int clhip_conv3_tiles_m(int M, int Cd) { return (M + pick3(M, Cd).wm * 64 - 1) / (pick3(M, Cd).wm * 64); }
 
-int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int N, int H, int W, int Cs, int Cd, int accumulate,
+int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, int accumulate,
                        int mode, hipStream_t st) {
     Conv3Params p;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
-    p.stats = stats; p.stat_acc = stat_acc; p.N = N; p.H = H; p.W = W; p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;
+    p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1; p.N = N; p.H = H; p.W = W; p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;
     static const int dbg = getenv("CLHIP_CONV3_DEBUG") ? atoi(getenv("CLHIP_CONV3_DEBUG")) : 0;
     p.debug = dbg;
     Cfg3 c = pick3(p.M, Cd);

@@ -32,8 +32,8 @@ struct Unit {
     size_t z_off;
     size_t sh_fwd, sh_dg;          // byte offsets in the shadow buffer
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
-    size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([2][cout] each)
-    bool acc_fwd, acc_bwd;                       // statistics through fp64 atomics (few producers) or partial rows + finalize (many)
+    size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([rep][2][cout] each)
+    int rep_fwd, rep_bwd;                        // accumulator replicas (power of two): ~64 producer workgroups per replica
     int dx_acc, dres_acc;
 };
 }  // namespace
@@ -67,11 +67,13 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     a0.y_off = off; off = align_up(off + a0.bytes);
     p->acts.push_back(a0);
     size_t max_z = 0, max_part = 0, max_bnws = 0, nfloat = 0, max_wg = 0, ndouble = 0;
-    // BN statistics: with FEW producer workgroups per layer, fp64 atomics into one [2][C] accumulator (consumer finalises on the
-    // fly, no finalize launch: -2 launches per layer, +15 % img/s on the launch-bound batch-32 step); with MANY producers the
-    // same-address atomic traffic costs more than the ~6 us launch it saves (measured: +5..9 us per kernel at 1024 tiles), so
-    // those layers keep the per-tile partial rows + finalize.  Threshold: CLHIP_BN_ACC_TILES (default 128, 0 disables).
-    const int acc_tiles = getenv("CLHIP_BN_ACC_TILES") ? atoi(getenv("CLHIP_BN_ACC_TILES")) : 128;
+    // BN statistics go through fp64 atomic accumulators (conv epilogue / backward-reduce workgroups ADD their per-channel sums,
+    // the apply kernels finalise on the fly): no finalize launches, no per-tile partial rows.  Same-address atomic traffic is
+    // what it costs (measured: +5..9 us per kernel with 1024 producers on ONE accumulator), so a layer gets one replica per
+    // ~64 producer workgroups (blockIdx & (rep-1)); the consumers sum the replicas in a block-cooperative prologue.
+    // CLHIP_BN_PARTIALS=1 restores the partial-row + finalize path.
+    const bool want_acc = getenv("CLHIP_BN_PARTIALS") == nullptr;
+    auto replicas = [](int producers) { int r = 1; while (r < 32 && producers > 64 * r) r <<= 1; return r; };
     p->use_acc = false;
     for (int i = 0; i < n_units; ++i) {
         Unit u{};
@@ -111,12 +113,12 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
         u.sh_dg = sh; sh = align_up(sh + wbytes);
         u.f_mean = nfloat; u.f_invstd = nfloat + u.d.cout; u.f_scale = nfloat + 2 * (size_t)u.d.cout; u.f_shift = nfloat + 3 * (size_t)u.d.cout;
         nfloat += 4 * (size_t)u.d.cout;
-        u.a_fwd = ndouble; u.a_bwd = ndouble + 2 * (size_t)u.d.cout;
-        ndouble += 4 * (size_t)u.d.cout;
         const bool pow2 = (u.d.cout & (u.d.cout - 1)) == 0;
-        u.acc_fwd = pow2 && u.tiles <= acc_tiles;
-        u.acc_bwd = pow2 && clhip_bn_bwd_blocks(u.M, u.d.cout) <= acc_tiles;
-        if (u.acc_fwd || u.acc_bwd) p->use_acc = true;
+        u.rep_fwd = (want_acc && pow2) ? replicas(u.tiles) : 0;
+        u.rep_bwd = (want_acc && pow2) ? replicas(clhip_bn_bwd_blocks(u.M, u.d.cout)) : 0;
+        u.a_fwd = ndouble; ndouble += 2 * (size_t)u.d.cout * (u.rep_fwd > 0 ? u.rep_fwd : 1);
+        u.a_bwd = ndouble; ndouble += 2 * (size_t)u.d.cout * (u.rep_bwd > 0 ? u.rep_bwd : 1);
+        if (u.rep_fwd || u.rep_bwd) p->use_acc = true;
         if (bytes > max_z) max_z = bytes;
         size_t part = (size_t)u.tiles * 2 * u.d.cout;
         if (part > max_part) max_part = part;
@@ -243,12 +245,12 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
-        if (use_acc && u.acc_fwd) {
+        if (use_acc && u.rep_fwd > 0) {
             // conv epilogue adds the per-channel sums into the fp64 accumulator; BN-apply derives scale / shift on the fly
-            TRY(clhip_conv_fwd_acc(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
+            TRY(clhip_conv_fwd_acc(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
                                    u.d.stride, u.d.pad, p->dtype, stream));
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
-            TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
+            TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
                                      bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
                                      ws + dst.y_off, u.d.relu, p->dtype, stream));
             continue;
@@ -296,10 +298,10 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
         void* dres = u.d.res >= 0 ? ws + p->acts[u.d.res].dy_off : nullptr;
-        if (u.acc_bwd) {
+        if (u.rep_bwd > 0) {
             TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
                                  grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
-                                 reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, p->dtype, stream));
+                                 reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else {
             TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
                              grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,

@@ -255,21 +255,23 @@ def test_batchnorm_fwd_bwd(shape, mode, relu, res):
         assert (from_nhwc(dres).double() - 2 * rr.grad).abs().max() <= tol(mode, rr.grad) * 3
     # accumulator variants (what the plan runs): fp64 sums instead of per-tile partial rows, no finalize launches;
     # must reproduce the partial-buffer path on the same inputs
-    acc = torch.stack([z2.sum(0), (z2 * z2).sum(0)]).to(DEV)                       # [2, C] fp64, as the conv epilogue accumulates it
+    REP = 4                                                                        # accumulator replicas: the sums split over 4 copies
+    full = torch.stack([z2.sum(0), (z2 * z2).sum(0)])                              # [2, C] fp64, as the conv epilogue accumulates it
+    acc = torch.stack([full * f for f in (0.4, 0.3, 0.2, 0.1)]).to(DEV)            # [REP, 2, C]
     rm2, rv2 = rm0.clone().to(DEV), rv0.clone().to(DEV)
     mean2, invstd2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     y2 = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
-    call("clhip_bn_apply_train", zd.data_ptr(), acc.data_ptr(), M, C, gd.data_ptr(), bd.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), 0.1, 1e-5,
+    call("clhip_bn_apply_train", zd.data_ptr(), acc.data_ptr(), REP, M, C, gd.data_ptr(), bd.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), 0.1, 1e-5,
          mean2.data_ptr(), invstd2.data_ptr(), rd.data_ptr() if res else None, y2.data_ptr(), relu, code, st())
     assert torch.allclose(mean2, mean, rtol=1e-5, atol=1e-6) and torch.allclose(invstd2, invstd, rtol=1e-5)
     assert torch.allclose(rm2.cpu().double(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(rv2.cpu().double(), rv, rtol=1e-4, atol=1e-6)
     assert (from_nhwc(y2).double() - yref).abs().max() <= tol(mode, yref)
-    bacc = torch.zeros(2, C, dtype=torch.float64, device=DEV)
+    bacc = torch.zeros(REP, 2, C, dtype=torch.float64, device=DEV)
     dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dz2 = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
     dres2 = torch.empty(N, H, W, C, dtype=tdt, device=DEV) if res else None
     call("clhip_bn_bwd_acc", dyd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), dg2.data_ptr(),
-         db2.data_ptr(), dz2.data_ptr(), dres2.data_ptr() if res else None, 0, M, C, relu, bacc.data_ptr(), code, st())
+         db2.data_ptr(), dz2.data_ptr(), dres2.data_ptr() if res else None, 0, M, C, relu, bacc.data_ptr(), REP, code, st())
     assert (from_nhwc(dz2).double() - gz).abs().max() <= tol(mode, gz) * 2
     assert (dg2.cpu().double() - g64.grad).abs().max() <= 2e-3 * (g64.grad.abs().max() + 1e-9) + 1e-4
     assert (db2.cpu().double() - b64.grad).abs().max() <= 2e-3 * (b64.grad.abs().max() + 1e-9) + 1e-4
@@ -439,10 +441,13 @@ def test_conv_fwd_stat_accumulator(mode, shape):
     part = torch.empty(tiles, 2, K, device=DEV)
     z1 = torch.empty(N, Ho, Wo, K, dtype=tdt, device=DEV)
     z2 = torch.empty_like(z1)
-    acc = torch.zeros(2, K, dtype=torch.float64, device=DEV)
     call("clhip_conv_fwd", x.data_ptr(), w.data_ptr(), z1.data_ptr(), part.data_ptr(), N, H, W, C, K, ks, stride, pad, code, st())
-    call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z2.data_ptr(), acc.data_ptr(), N, H, W, C, K, ks, stride, pad, code, st())
-    torch.cuda.synchronize()
-    assert torch.equal(z1, z2)
     ref = part.double().sum(0)
-    assert float((acc - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    for rep in (1, 4):
+        acc = torch.zeros(rep, 2, K, dtype=torch.float64, device=DEV)
+        call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z2.data_ptr(), acc.data_ptr(), rep, N, H, W, C, K, ks, stride, pad, code, st())
+        torch.cuda.synchronize()
+        assert torch.equal(z1, z2)
+        assert float((acc.sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        if rep > 1 and tiles >= rep:
+            assert (acc.abs().amax(dim=(1, 2)) > 0).all()          # every replica received some workgroups
