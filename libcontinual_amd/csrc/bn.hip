@@ -5,6 +5,8 @@
 //
 // Reference semantics: nn.BatchNorm2d(momentum=0.1, eps=1e-5) + F.relu + residual add,
 // core/model/backbone/resnet.py:296-316; nn.AvgPool2d(8) / AdaptiveAvgPool2d(1), :160, :344.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -462,9 +464,10 @@ extern "C" int clhip_bn_bwd(const void* dy, const void* y, const void* z, const 
 static bool acc_ok(int C) { return C >= 8 && C <= 2048 && (C & (C - 1)) == 0; }
 // fewer, longer workgroups than the plain elementwise kernels: every workgroup pays the cooperative finalize prologue
 static int acc_blocks(int64_t nchunks) {
-    int64_t b = (nchunks + 256 * 4 - 1) / (256 * 4);
+    static const int cpt = getenv("CLHIP_BN_ACC_CPT") ? atoi(getenv("CLHIP_BN_ACC_CPT")) : 8;      // chunks per thread (swept 1..32: 8)
+    int64_t b = (nchunks + 256 * cpt - 1) / (256 * cpt);
     if (b < 512) { b = (nchunks + 255) / 256; if (b > 512) b = 512; }      // small layers: fill the chip first
-    if (b > 2048) b = 2048;
+    if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     return (int)b;
 }
