@@ -282,6 +282,11 @@ int clhip_vit_prompt_grad(const void* g, float* dprompt, int B, int N, int n_pro
  * -> compute-dtype copies wt [rows, cols] and wt_t [cols, rows] (either nullable) */
 int clhip_weight_prep2(const float* w, void* wt, void* wt_t, int rows, int cols, const float* lora_a_k, const float* lora_b_k,
                        const float* lora_a_v, const float* lora_b_v, int rank, int dtype, void* stream);
+/* per-step refresh of the k / v rows of the effective qkv copies (W + B A) of `layers` layers in ONE launch: arrays of `layers`
+ * device pointers (fp32 masters and LoRA factors; wt [3D, D] and wt_t [D, 3D] in the compute dtype); q rows are left untouched */
+int clhip_lora_qkv_refresh(int layers, const float* const* qkv_w, const float* const* lora_a_k, const float* const* lora_b_k,
+                           const float* const* lora_a_v, const float* const* lora_b_v, void* const* wt, void* const* wt_t, int D, int rank,
+                           int dtype, void* stream);
 /* merge_weight (transformer.py:228-234) on the fp32 master qkv weight [3D, D] */
 int clhip_lora_merge(float* qkv_w, const float* lora_a_k, const float* lora_b_k, const float* lora_a_v, const float* lora_b_v, int D,
                      int rank, void* stream);

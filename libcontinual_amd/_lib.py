@@ -120,6 +120,7 @@ _PROTOS = {
     "clhip_vit_assemble": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_vit_prompt_grad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_weight_prep2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
+    "clhip_lora_qkv_refresh": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clhip_lora_merge": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "clhip_lora_grad_ws_bytes": (_sz, [_i, _i, _i]),
     "clhip_lora_acat": (_i, [_p, _p, _p, _i, _i, _i, _p]),

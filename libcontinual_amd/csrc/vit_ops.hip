@@ -246,6 +246,42 @@ __global__ __launch_bounds__(256) void weight_prep2_kernel(const float* __restri
     }
 }
 
+// per-step refresh of the k / v rows of EVERY layer's effective qkv copies in one launch (lora_B moves every optimizer step;
+// the q rows and lora_A do not): blockIdx.z = layer, descriptors by value
+constexpr int kQkvMax = 32;
+struct QkvEntry { const float *w, *Ak, *Bk, *Av, *Bv; void *wt, *wtT; };
+struct QkvTable { QkvEntry e[kQkvMax]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void lora_qkv_refresh_kernel(QkvTable t, int D, int rank) {
+    __shared__ float tile[32][33];
+    const QkvEntry& d = t.e[blockIdx.z];
+    const int R = 3 * D, C = D;
+    const int c0 = blockIdx.x * 32, r0 = D + blockIdx.y * 32;        // rows [D, 3D): k then v
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* wt = static_cast<T*>(d.wt);
+    T* wtT = static_cast<T*>(d.wtT);
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            const bool isk = r < 2 * D;
+            const float* Bm = (isk ? d.Bk : d.Bv) + (size_t)(r - (isk ? D : 2 * D)) * rank;
+            const float* Am = isk ? d.Ak : d.Av;
+            float a = 0.f;
+            for (int q = 0; q < rank; ++q) a += Bm[q] * Am[(size_t)q * C + c];
+            v = d.w[(size_t)r * C + c] + a;
+            Elem<T>::st(wt + (size_t)r * C + c, v);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) Elem<T>::st(wtT + (size_t)c * R + r, tile[tx][i]);
+    }
+}
+
 // merged fp32 master: qkv_w[k rows] += B_k A_k, qkv_w[v rows] += B_v A_v   (merge_weight, transformer.py:228-234)
 __global__ __launch_bounds__(256) void lora_merge_master_kernel(float* __restrict__ w, const float* __restrict__ Ak, const float* __restrict__ Bk,
                                                                  const float* __restrict__ Av, const float* __restrict__ Bv, int D, int rank) {
@@ -638,6 +674,26 @@ extern "C" int clhip_weight_prep2(const float* w, void* wt, void* wt_t, int rows
                 hipLaunchKernelGGL(weight_prep2_kernel<bf16_t>, grid, dim3(256), 0, s, w, (bf16_t*)wt, (bf16_t*)wt_t, rows, cols, lora_a_k, lora_b_k, lora_a_v, lora_b_v, rank, rows / 3),
                 hipLaunchKernelGGL(weight_prep2_kernel<float>, grid, dim3(256), 0, s, w, (float*)wt, (float*)wt_t, rows, cols, lora_a_k, lora_b_k, lora_a_v, lora_b_v, rank, rows / 3));
     CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_lora_qkv_refresh(int layers, const float* const* qkv_w, const float* const* lora_a_k, const float* const* lora_b_k,
+                                      const float* const* lora_a_v, const float* const* lora_b_v, void* const* wt, void* const* wt_t, int D, int rank,
+                                      int dtype, void* stream) {
+    CLHIP_CHECK_ARG(layers > 0 && qkv_w && lora_a_k && lora_b_k && lora_a_v && lora_b_v && wt && wt_t && D > 0 && D % 32 == 0 && rank > 0 && rank <= 16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int l0 = 0; l0 < layers; l0 += kQkvMax) {
+        const int n = layers - l0 < kQkvMax ? layers - l0 : kQkvMax;
+        QkvTable t;
+        for (int i = 0; i < n; ++i) {
+            CLHIP_CHECK_ARG(qkv_w[l0 + i] && lora_a_k[l0 + i] && lora_b_k[l0 + i] && lora_a_v[l0 + i] && lora_b_v[l0 + i] && wt[l0 + i] && wt_t[l0 + i]);
+            t.e[i] = QkvEntry{qkv_w[l0 + i], lora_a_k[l0 + i], lora_b_k[l0 + i], lora_a_v[l0 + i], lora_b_v[l0 + i], wt[l0 + i], wt_t[l0 + i]};
+        }
+        dim3 grid(D / 32, 2 * D / 32, n);
+        DT_DISPATCH(dtype, hipLaunchKernelGGL(lora_qkv_refresh_kernel<bf16_t>, grid, dim3(256), 0, s, t, D, rank),
+                    hipLaunchKernelGGL(lora_qkv_refresh_kernel<float>, grid, dim3(256), 0, s, t, D, rank));
+        CLHIP_LAUNCH_CHECK();
+    }
     return CLHIP_OK;
 }
 

@@ -131,6 +131,18 @@ extern "C" int clhip_vit_prep_weights(clhip_vit* v, const clhip_vit_params* P, v
     CLHIP_CHECK_ARG(v && P && P->layers && shadow);
     char* sh = static_cast<char*>(shadow);
     const int D = v->d.dim, H = v->d.mlp, r = apply_lora ? v->d.lora_rank : 0;
+    if (qkv_only && r > 0) {
+        // between optimizer steps only lora_B moves: refresh the k / v rows of all layers' qkv copies in one launch
+        const int n = v->d.depth;
+        std::vector<const float*> w(n), ak(n), bk(n), av(n), bv(n);
+        std::vector<void*> wt(n), wtt(n);
+        for (int l = 0; l < n; ++l) {
+            const clhip_vit_layer_params& p = P->layers[l];
+            w[l] = p.qkv_w; ak[l] = p.lora_a_k; bk[l] = p.lora_b_k; av[l] = p.lora_a_v; bv[l] = p.lora_b_v;
+            wt[l] = sh + v->sh[l].qkv_f; wtt[l] = sh + v->sh[l].qkv_b;
+        }
+        return clhip_lora_qkv_refresh(n, w.data(), ak.data(), bk.data(), av.data(), bv.data(), wt.data(), wtt.data(), D, r, v->dtype, stream);
+    }
     if (!qkv_only) TRY(clhip_weight_prep2(P->pe_w, sh + v->pe_f, nullptr, D, v->Kp, nullptr, nullptr, nullptr, nullptr, 0, v->dtype, stream));
     for (int l = 0; l < v->d.depth; ++l) {
         const clhip_vit_layer_params& p = P->layers[l];

@@ -248,7 +248,11 @@ class VisionTransformer(nn.Module):
         lora_on = bool(self.lora_rank) and any(a.apply_lora for a in self.attention_modules())
         if lora_on and not all(a.apply_lora for a in self.attention_modules()):
             raise _lib.ClhipError("apply_lora must be set on all attention layers or none")
-        sig = (tuple((t.data_ptr(), t._version) for t in self._frozen_tensors()), lora_on)
+        frozen = self._frozen_tensors()
+        if self.lora_rank:            # lora_A is fixed within a task: a change (init_param / SVD in before_task) forces the full preparation
+            for a in self.attention_modules():
+                frozen = frozen + [a.lora_A_k.weight, a.lora_A_v.weight]
+        sig = (tuple((t.data_ptr(), t._version) for t in frozen), lora_on)
         if s.sig != sig:
             call("clhip_vit_prep_weights", s.handle, C.byref(s.cparams), s.shadow.data_ptr(), int(lora_on), 0, _st())
             s.sig = sig

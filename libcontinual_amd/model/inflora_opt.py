@@ -112,8 +112,8 @@ class InfLoRA_OPT(nn.Module):
                 cur_matrix = cur_matrix - feature_mat @ cur_matrix if self.project_type[i] == "remove" else feature_mat @ cur_matrix
             U, _, _ = torch.linalg.svd(cur_matrix, full_matrices=False)
             A = (U[:, : module.lora_rank].T / math.sqrt(3)).to(module.lora_A_k.weight)
-            module.lora_A_k.weight.data.copy_(A)
-            module.lora_A_v.weight.data.copy_(A)
+            module.lora_A_k.weight.copy_(A)          # in-place on the Parameter (not .data): bumps its version, which the
+            module.lora_A_v.weight.copy_(A)          # executor watches to refresh its [A_k; A_v] copy
             module.reset_input_matrix()
 
     def after_task(self, task_idx, buffer, train_loader, test_loaders):
