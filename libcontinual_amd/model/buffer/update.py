@@ -1,57 +1,64 @@
-"""Trainer-side buffer updates (reference core/model/buffer/update.py:7-80)."""
+"""Trainer-side buffer updates (reference core/model/buffer/update.py:7-80): `random_update` and the per-class greedy
+`herding_update` the trainer calls after every task (core/trainer.py:410-418)."""
 import copy
-from collections import Counter
 
 import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from ... import ops
+__all__ = ["random_update", "herding_update", "construct_examplar"]
+
+
+def _pool(datasets, buffer):
+    """candidates = the task's samples followed by what the buffer already holds"""
+    return np.asarray(list(datasets.images) + list(buffer.images)), np.asarray(list(datasets.labels) + list(buffer.labels))
 
 
 def random_update(datasets, buffer):
-    images = np.array(list(datasets.images) + list(buffer.images))
-    labels = np.array(list(datasets.labels) + list(buffer.labels))
-    perm = np.random.permutation(len(labels))
-    buffer.images = images[perm[: buffer.buffer_size]].tolist()
-    buffer.labels = labels[perm[: buffer.buffer_size]].tolist()
+    """keep a uniformly random subset of the pool (global numpy RNG, like the reference: update.py:7-16)"""
+    images, labels = _pool(datasets, buffer)
+    keep = np.random.permutation(labels.shape[0])[: buffer.buffer_size]
+    buffer.images, buffer.labels = images[keep].tolist(), labels[keep].tolist()
 
 
 def herding_update(datasets, buffer, feature_extractor, device):
-    """per class, pick buffer_size // total_classes exemplars (update.py:18-45)"""
-    per_classes = buffer.buffer_size // buffer.total_classes
-    sel_images, sel_labels = [], []
-    images = np.array(list(datasets.images) + list(buffer.images))
-    labels = np.array(list(datasets.labels) + list(buffer.labels))
+    """buffer_size // total_classes exemplars per seen class, chosen by `construct_examplar` (update.py:18-45)"""
+    quota = buffer.buffer_size // buffer.total_classes
+    images, labels = _pool(datasets, buffer)
+    kept_images, kept_labels = [], []
     for cls in range(buffer.total_classes):
-        idx = np.where(labels == cls)
-        ci, cl = construct_examplar(copy.copy(datasets), images[idx], labels[idx], feature_extractor, per_classes, device)
-        sel_images.extend(ci)
-        sel_labels.extend(cl)
-    buffer.images, buffer.labels = list(sel_images), list(sel_labels)
+        mine = np.where(labels == cls)
+        ci, cl = construct_examplar(copy.copy(datasets), images[mine], labels[mine], feature_extractor, quota, device)
+        kept_images += list(ci)
+        kept_labels += list(cl)
+    buffer.images, buffer.labels = kept_images, kept_labels
+
+
+def _features_of(datasets, images, labels, feature_extractor, device):
+    datasets.images, datasets.labels = list(images), list(labels)
+    out = []
+    with torch.no_grad():
+        for batch in DataLoader(datasets, shuffle=False, batch_size=256, drop_last=False):
+            out.append(feature_extractor(batch["image"].to(device))["features"].float().cpu())
+    return torch.cat(out).numpy().astype(np.float64)
 
 
 def construct_examplar(datasets, images, labels, feature_extractor, per_classes, device):
-    """update.py:47-80: greedy choice where S is the MEAN of the already selected features (sic) and the
-    chosen row is deleted from the candidate set."""
+    """Greedy herding with the reference's two quirks (update.py:47-80): the running term S is the MEAN of the features picked
+    so far (not their sum), and a picked row leaves the candidate set.  Candidates are masked instead of deleted; the argmin
+    over the survivors in their original order is the same row `np.delete` + `argmin` would pick."""
     if len(images) <= per_classes:
         return list(images), list(labels)
-    datasets.images, datasets.labels = list(images), list(labels)
-    loader = DataLoader(datasets, shuffle=False, batch_size=256, drop_last=False)
-    feats = []
-    with torch.no_grad():
-        for data in loader:
-            feats.append(feature_extractor(data["image"].to(device))["features"].float().cpu())
-    features = torch.cat(feats).numpy().astype(np.float64)
-    images, labels = np.array(images), np.array(labels)
-    class_mean = np.mean(features, axis=0)
-    sel_images, sel_labels, sel_feats = [], [], []
+    feats = _features_of(datasets, images, labels, feature_extractor, device)
+    target = feats.mean(axis=0)
+    alive = np.ones(feats.shape[0], dtype=bool)
+    picked = []
     for k in range(1, per_classes + 1):
-        S = np.zeros_like(features[0]) if not sel_feats else np.mean(np.array(sel_feats), axis=0)
-        mu_p = (S + features) / k
-        i = int(np.argmin(np.sqrt(np.sum((class_mean - mu_p) ** 2, axis=1))))
-        sel_images.append(images[i]); sel_labels.append(labels[i]); sel_feats.append(features[i])
-        features = np.delete(features, i, axis=0)
-        images = np.delete(images, i)
-        labels = np.delete(labels, i)
-    return sel_images, sel_labels
+        S = feats[picked].mean(axis=0) if picked else np.zeros_like(target)
+        dist = np.sqrt((((S + feats) / k - target) ** 2).sum(axis=1))
+        dist[~alive] = np.inf
+        j = int(np.argmin(dist))
+        alive[j] = False
+        picked.append(j)
+    images, labels = np.asarray(images), np.asarray(labels)
+    return [images[j] for j in picked], [labels[j] for j in picked]

@@ -1,4 +1,6 @@
-"""Finetune: the base plugin (reference core/model/finetune.py:4-51) on the HIP hot path."""
+"""Finetune: the base plugin (reference core/model/finetune.py:4-51) on the HIP hot path -- backbone + one linear head,
+plain cross entropy, no continual-learning mechanism.  The other ResNet methods derive from it for `device`, `_xy` and the
+default hooks."""
 import torch
 from torch import nn
 
@@ -9,39 +11,42 @@ from .heads import HipLinear
 class Finetune(nn.Module):
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__()
-        self.backbone = backbone
-        self.feat_dim = feat_dim
-        self.num_class = num_class
-        self.classifier = HipLinear(feat_dim, num_class)
-        self.loss_fn = nn.CrossEntropyLoss(reduction="mean")   # kept for attribute compatibility; the fused kernel computes it
-        self.device = kwargs["device"]
         self.kwargs = kwargs
+        self.device = kwargs["device"]
+        self.backbone, self.feat_dim, self.num_class = backbone, feat_dim, num_class
+        self.classifier = HipLinear(feat_dim, num_class)
+        # attribute kept because reference plugins / user code read it; the fused kernel computes the same mean CE
+        self.loss_fn = nn.CrossEntropyLoss(reduction="mean")
 
+    # ---- helpers shared with the subclasses
     def _xy(self, data):
+        """batch dict -> (images, labels) on the plugin's device"""
         return data["image"].to(self.device), data["label"].to(self.device)
 
+    def _logits(self, x):
+        return self.classifier(self.backbone(x)["features"])
+
+    def forward(self, x):
+        return self._logits(x)
+
+    # ---- plugin surface
     def observe(self, data):
         x, y = self._xy(data)
-        logit = self.classifier(self.backbone(x)["features"])
         aux = ops.LossAux()
-        loss = ops.classify_loss(logit, y, aux=aux)
+        loss = ops.classify_loss(self._logits(x), y, aux=aux)      # loss, dlogits, argmax and the correct count in one launch
         self._last_aux = aux
         return aux.pred, aux.acc(), loss
 
     def inference(self, data):
         x, y = self._xy(data)
-        logit = self.classifier(self.backbone(x)["features"])
-        pred, correct = ops.predict(logit, y)
+        pred, correct = ops.predict(self._logits(x), y)
         return pred, correct.item() / x.size(0)
 
-    def forward(self, x):
-        return self.classifier(self.backbone(x)["features"])
-
     def before_task(self, task_idx, buffer, train_loader, test_loaders):
-        pass
+        """nothing to prepare"""
 
     def after_task(self, task_idx, buffer, train_loader, test_loaders):
-        pass
+        """nothing to consolidate"""
 
     def get_parameters(self, config):
         return [{"params": self.backbone.parameters()}, {"params": self.classifier.parameters()}]

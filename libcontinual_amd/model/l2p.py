@@ -13,8 +13,13 @@ import torch.nn as nn
 from .. import ops
 from .heads import HipLinear
 
+_TRAINABLE_TAGS = ("prompt", "classifier")       # l2p.py:72-77: everything else of the network is frozen
+_CLIP_NORM = 1.0                                 # l2p.py:104
+
 
 class Model(nn.Module):
+    """prompted backbone + one head over ALL classes (l2p.py:36-44)"""
+
     def __init__(self, backbone, embed_dim, total_cls_num):
         super().__init__()
         self.backbone = backbone
@@ -32,48 +37,48 @@ class L2P(nn.Module):
     def __init__(self, backbone, device, **kwargs):
         super().__init__()
         self.device = device
-        self.init_cls_num = kwargs["init_cls_num"]
-        self.inc_cls_num = kwargs["inc_cls_num"]
-        self.total_cls_num = kwargs["num_class"]
-        self.task_num = kwargs["task_num"]
-        self.embed_dim = kwargs["feat_dim"]
-        self.pull_constraint_coeff = kwargs["pull_constraint_coeff"]
-        self.cur_task_id = 0
-        self._known_classes = 0
+        for attr, key in (("init_cls_num", "init_cls_num"), ("inc_cls_num", "inc_cls_num"), ("total_cls_num", "num_class"),
+                          ("task_num", "task_num"), ("embed_dim", "feat_dim"), ("pull_constraint_coeff", "pull_constraint_coeff")):
+            setattr(self, attr, kwargs[key])
+        self.cur_task_id, self._known_classes = 0, 0
         self.network = Model(backbone, self.embed_dim, self.total_cls_num)
-        self.network.backbone.create_prompt(prompt_flag="l2p", length=kwargs["prompt_length"], prompt_init=nn.init.uniform_,
-                                            pool_size=kwargs["pool_size"], top_k=kwargs["top_k"], num_layers=1, embed_dim=self.embed_dim)
-        self.network.to(self.device)
-        self.unfrezeed_params = []
-        for name, param in self.network.named_parameters():
-            param.requires_grad_(False)
-            if "prompt" in name or "classifier" in name:
-                param.requires_grad_(True)
-                self.unfrezeed_params.append(param)
+        backbone.create_prompt(prompt_flag="l2p", length=kwargs["prompt_length"], prompt_init=nn.init.uniform_, pool_size=kwargs["pool_size"],
+                               top_k=kwargs["top_k"], num_layers=1, embed_dim=self.embed_dim)
+        self.network.to(device)
+        self.unfrezeed_params = self._freeze_all_but(_TRAINABLE_TAGS)
 
+    def _freeze_all_but(self, tags):
+        kept = []
+        for name, prm in self.network.named_parameters():
+            on = any(t in name for t in tags)
+            prm.requires_grad_(on)
+            if on:
+                kept.append(prm)
+        return kept
+
+    # ------------------------------------------------------------------------------------------ hooks
     def before_task(self, task_idx, buffer, train_loader, test_loaders):
         self.cur_task_id = task_idx
 
     def after_task(self, task_idx, buffer, train_loader, test_loaders):
-        self._known_classes += self.init_cls_num if task_idx == 0 else self.inc_cls_num
+        self._known_classes += self.inc_cls_num if task_idx else self.init_cls_num
 
     def _window(self):
+        """[lo, hi): the classes of the current task -- the only logits left finite by the reference's -inf mask"""
         if self.cur_task_id == 0:
             return 0, self.init_cls_num
         return self._known_classes, self._known_classes + self.inc_cls_num
 
     def observe(self, data):
         x, y = data["image"].to(self.device), data["label"].to(self.device)
-        logits, reduce_sim = self.network(x, train=True)
         lo, hi = self._window()
+        logits, reduce_sim = self.network(x, train=True)
         aux = ops.LossAux()
-        # CE over logits masked to -inf outside [lo, hi) (l2p.py:92-101); argmax over the same window
-        ce = ops.classify_loss(logits, y, lo=lo, hi=hi, pred_hi=hi, aux=aux, pred_lo=lo)
-        loss = ce - self.pull_constraint_coeff * reduce_sim
+        loss = ops.classify_loss(logits, y, lo=lo, hi=hi, pred_lo=lo, pred_hi=hi, aux=aux) - self.pull_constraint_coeff * reduce_sim
         loss.backward()
         if self.grad_reducer is not None:
             self.grad_reducer.reduce_mean(self.network)
-        ops.clip_grad_norm_(self.unfrezeed_params, 1.0)
+        ops.clip_grad_norm_(self.unfrezeed_params, _CLIP_NORM)
         self._last_aux = aux
         return aux.pred, aux.acc(), loss.detach()
 

@@ -6,66 +6,56 @@ the YAML `lamda` is ignored); because the teacher is an nn.Module attribute, `mo
 BatchNorm back in train mode -- reproduced simply by being an nn.Module too.
 CE on the new-class slice and the KD term are fused into one loss node (ce_slice + kd kernels).
 """
-import copy
-
 import torch
 import torch.nn as nn
 
 from .. import ops
 from .finetune import Finetune
-from .heads import HipLinear
+from .heads import HipLinear, teacher_of, widened
+
+_KD_WEIGHT, _KD_TEMPERATURE = 3.0, 2.0          # lwf.py:62-64 (not configurable there either)
 
 
 class LWF(Finetune):
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__(backbone, feat_dim, num_class, **kwargs)
-        self.kwargs = kwargs
-        self.feat_dim = feat_dim
-        self.classifier = HipLinear(self.feat_dim, kwargs["init_cls_num"])
-        self.old_fc = None
-        self.init_cls_num = kwargs["init_cls_num"]
-        self.inc_cls_num = kwargs["inc_cls_num"]
-        self.known_cls_num = 0
-        self.total_cls_num = 0
-        self.old_backbone = None
+        self.kwargs, self.feat_dim = kwargs, feat_dim
+        self.init_cls_num, self.inc_cls_num = kwargs["init_cls_num"], kwargs["inc_cls_num"]
+        self.known_cls_num = self.total_cls_num = 0
+        self.classifier = HipLinear(feat_dim, self.init_cls_num)
+        self.old_fc = self.old_backbone = None          # the teacher: previous head / previous backbone
 
+    # kept for API compatibility (lwf.py:22-26)
     def freeze(self, module):
-        for p in module.parameters():
-            p.requires_grad = False
-        module.eval()
-        return module
+        for q in module.parameters():
+            q.requires_grad = False
+        return module.eval()
 
     def update_fc(self):
-        fc = HipLinear(self.feat_dim, self.total_cls_num).to(self.device)
-        if self.classifier is not None:
-            self.old_fc = self.freeze(copy.deepcopy(self.classifier))
-            old_out = self.classifier.out_features
-            with torch.no_grad():
-                fc.weight.data[:old_out] = self.classifier.weight.data
-                fc.bias.data[:old_out] = self.classifier.bias.data
-        self.classifier = fc
+        """snapshot the current head as the teacher head, then widen it to `total_cls_num` outputs (lwf.py:28-40)"""
+        self.old_fc = teacher_of(self.classifier)
+        self.classifier = widened(self.classifier, self.total_cls_num, self.device)
 
     def before_task(self, task_idx, buffer, train_loader, test_loaders):
         self.task_idx = task_idx
-        self.known_cls_num = self.total_cls_num
-        self.total_cls_num = self.init_cls_num + self.task_idx * self.inc_cls_num
+        self.known_cls_num, self.total_cls_num = self.total_cls_num, self.init_cls_num + task_idx * self.inc_cls_num
         self.update_fc()
         self.loss_fn = nn.CrossEntropyLoss()
-        if task_idx != 0:
-            self.old_backbone = self.freeze(copy.deepcopy(self.backbone)).to(self.device)
+        if task_idx > 0:
+            self.old_backbone = teacher_of(self.backbone, self.device)
 
     def observe(self, data):
         x, y = self._xy(data)
         logit = self.classifier(self.backbone(x)["features"])
         aux = ops.LossAux()
+        old = self.known_cls_num
         if self.task_idx == 0:
             loss = ops.classify_loss(logit, y, aux=aux)
         else:
-            k = self.known_cls_num
             with torch.no_grad():
                 soft = self.old_fc(self.old_backbone(x)["features"])
-            # loss = 3 * KD(logit[:, :k], soft, T=2) + CE(logit[:, k:], y - k)     (lwf.py:61-65)
-            loss = ops.classify_loss(logit, y, lo=k, hi=logit.shape[1], w_ce=1.0, teacher=soft, k=k, T=2.0, w_kd=3.0, aux=aux)
+            # 3 * KD(logit[:, :old], soft, T=2) + CE(logit[:, old:], y - old) in one fused node
+            loss = ops.classify_loss(logit, y, lo=old, hi=logit.shape[1], w_ce=1.0, teacher=soft, k=old, T=_KD_TEMPERATURE, w_kd=_KD_WEIGHT, aux=aux)
         self._last_aux = aux
         return aux.pred, aux.acc(), loss
 

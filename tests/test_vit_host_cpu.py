@@ -12,8 +12,8 @@ from libcontinual_amd.data import transforms as T
 from oracle import vit as ov
 
 
-@pytest.mark.parametrize("yaml,cls,bb", [("config/l2p-vit-cifar100-b10-10-10.yaml", "L2P", "vit_pt_imnet"),
-                                          ("config/InfLoRA_opt-vit-imagenetr-b20-20-10.yaml", "InfLoRA_OPT", "vit_pt_imnet")])
+@pytest.mark.parametrize("yaml,cls,bb", [("config/l2p-vitb16-cifar100-b10x10.yaml", "L2P", "vit_pt_imnet"),
+                                          ("config/inflora_opt-vitb16-imagenetr-b20x10.yaml", "InfLoRA_OPT", "vit_pt_imnet")])
 def test_vit_yaml_configs_resolve(yaml, cls, bb):
     cfg = Config(yaml).get_config_dict()
     assert cfg["classifier"]["name"] == cls and hasattr(M, cls)
