@@ -48,74 +48,66 @@ class LUCIR(Finetune):
         self.ref_model = None
         self.task_idx = 0
 
+    # ------------------------------------------------------------------------------------------ head growth
+    def _split_head(self, n_new):
+        """new SplitCosineLinear whose fc1 holds every embedding learned so far (one block at task 1, fc1 ++ fc2 later) and
+        whose fc2 has `n_new` fresh rows; sigma is carried over (lucir.py:84-108).  Returns (head, number of old classes)."""
+        old = self.network.classifier
+        parts = [old.weight] if isinstance(old, CosineLinear) else [old.fc1.weight, old.fc2.weight]
+        carried = torch.cat([w.data for w in parts], dim=0)
+        head = SplitCosineLinear(old.in_features, carried.shape[0], n_new).to(carried.device)
+        head.fc1.weight.data = carried
+        head.sigma.data = old.sigma.data
+        return head, carried.shape[0]
+
     def before_task(self, task_idx, buffer, train_loader, test_loaders):
         self.task_idx = task_idx
-        net = self.network
-        inc = self.kwargs["inc_cls_num"]
-        if task_idx == 1:
-            self.ref_model = copy.deepcopy(net)
-            old = net.classifier
-            new_fc = SplitCosineLinear(old.in_features, old.out_features, inc).to(old.weight.device)
-            new_fc.fc1.weight.data = old.weight.data
-            new_fc.sigma.data = old.sigma.data
-            net.classifier = new_fc
-            lamda_mult = old.out_features * 1.0 / inc
-        elif task_idx > 1:
-            self.ref_model = copy.deepcopy(net)
-            old = net.classifier
-            o1, o2 = old.fc1.out_features, old.fc2.out_features
-            new_fc = SplitCosineLinear(old.in_features, o1 + o2, inc).to(self.device)
-            new_fc.fc1.weight.data[:o1] = old.fc1.weight.data
-            new_fc.fc1.weight.data[o1:] = old.fc2.weight.data
-            new_fc.sigma.data = old.sigma.data
-            net.classifier = new_fc
-            lamda_mult = (o1 + o2) * 1.0 / inc
+        self.cur_lamda = self.kwargs["lamda"]
         if task_idx > 0:
-            self.cur_lamda = self.kwargs["lamda"] * math.sqrt(lamda_mult)     # lucir.py:110
-        else:
-            self.cur_lamda = self.kwargs["lamda"]
-        self._init_new_fc(task_idx, buffer, train_loader)
-        if task_idx > 0:
+            inc = self.kwargs["inc_cls_num"]
+            self.ref_model = copy.deepcopy(self.network)                     # frozen previous model (features + scores)
+            self.network.classifier, n_old = self._split_head(inc)
+            self.cur_lamda = self.kwargs["lamda"] * math.sqrt(n_old / inc)      # adaptive less-forget weight, lucir.py:110
+            self._init_new_fc(task_idx, buffer, train_loader)
             self.ref_model.eval()
             self.num_old_classes = self.ref_model.classifier.out_features
-        self.network = self.network.to(self.device)
-        if self.ref_model is not None:
             self.ref_model = self.ref_model.to(self.device)
+        self.network = self.network.to(self.device)
+
+    def _class_features(self, dataset, indices):
+        """eval-mode backbone features [len(indices), feat_dim] (fp64 numpy) of the given samples, in order"""
+        sub = copy.deepcopy(dataset)
+        sub.images = np.array([dataset.images[i] for i in indices])
+        sub.labels = np.array([dataset.labels[i] for i in indices])
+        return self._compute_feature(self.network.backbone, DataLoader(sub, batch_size=128, shuffle=False, num_workers=0), len(indices),
+                                     self.network.classifier.in_features)
 
     def _init_new_fc(self, task_idx, buffer, train_loader):
-        """imprint fc2 from normalised class-mean features times the mean old-embedding norm (lucir.py:134-159)"""
+        """imprint fc2: row c = normalised mean of the L2-normalised features of class c, scaled to the mean norm of the old
+        embeddings (lucir.py:134-159); classes are visited in label order like the reference (same RNG consumption)"""
         if task_idx == 0:
             return
-        cls = self.network.classifier
-        old_norm = cls.fc1.weight.data.norm(dim=1, keepdim=True)
-        avg_old = torch.mean(old_norm, dim=0).to("cpu").type(torch.DoubleTensor)
-        nfeat = cls.in_features
-        novel = torch.zeros((self.kwargs["inc_cls_num"], nfeat))
-        tmp = copy.deepcopy(train_loader.dataset)
-        data, target = train_loader.dataset.images, train_loader.dataset.labels
-        for cls_idx in range(cls.fc1.out_features, cls.fc1.out_features + cls.fc2.out_features):
-            ind = np.where(np.array(target) == cls_idx)[0]
-            tmp.images = np.array([data[i] for i in ind])
-            tmp.labels = np.array([target[i] for i in ind])
-            loader = DataLoader(tmp, batch_size=128, shuffle=False, num_workers=0)
-            feats = self._compute_feature(self.network.backbone, loader, len(ind), nfeat)
-            nf = torch.nn.functional.normalize(torch.from_numpy(feats), p=2, dim=1)
-            emb = torch.mean(nf, dim=0)
-            novel[cls_idx - cls.fc1.out_features] = torch.nn.functional.normalize(emb, p=2, dim=0) * avg_old
+        head = self.network.classifier
+        first, count = head.fc1.out_features, head.fc2.out_features
+        scale = head.fc1.weight.data.norm(dim=1, keepdim=True).mean(dim=0).cpu().double()
+        labels = np.asarray(train_loader.dataset.labels)
+        rows = []
+        for c in range(first, first + count):
+            f = torch.from_numpy(self._class_features(train_loader.dataset, np.flatnonzero(labels == c)))
+            proto = torch.nn.functional.normalize(f, p=2, dim=1).mean(dim=0)
+            rows.append(torch.nn.functional.normalize(proto, p=2, dim=0) * scale)
         self.network.to(self.device)
-        cls.fc2.weight.data = novel.to(self.device)
+        head.fc2.weight.data = torch.stack(rows).float().to(self.device)
 
     def _compute_feature(self, feature_model, loader, num_samples, num_features):
         feature_model.eval()
-        feats = np.zeros([num_samples, num_features])
-        s = 0
+        chunks = []
         with torch.no_grad():
             for batch in loader:
-                x = batch["image"].to(self.device)
-                feats[s:s + x.shape[0], :] = feature_model.feature(x).cpu().numpy()
-                s += x.shape[0]
-        assert s == num_samples
-        return feats
+                chunks.append(feature_model.feature(batch["image"].to(self.device)).cpu().double())
+        out = torch.cat(chunks).numpy() if chunks else np.zeros([0, num_features])
+        assert out.shape == (num_samples, num_features)
+        return out
 
     def observe(self, data):
         x, y = self._xy(data)
@@ -143,9 +135,11 @@ class LUCIR(Finetune):
         return pred, correct.item() / x.size(0)
 
     def get_parameters(self, config):
-        if self.task_idx > 0:
-            ignored = list(map(id, self.network.classifier.fc1.parameters()))
-            base = filter(lambda p: id(p) not in ignored, self.network.parameters())
-            return [{"params": base, "lr": 0.1, "weight_decay": 5e-4},
-                    {"params": self.network.classifier.fc1.parameters(), "lr": 0, "weight_decay": 0}]
-        return self.network.parameters()
+        """task 0: everything at the YAML's settings; later the old-class embeddings fc1 sit in an lr = 0 group and the rest is
+        hard-wired to lr 0.1 / wd 5e-4, overriding the YAML (lucir.py:229-236)"""
+        if self.task_idx == 0:
+            return self.network.parameters()
+        frozen = list(self.network.classifier.fc1.parameters())
+        held = {id(q) for q in frozen}
+        return [{"params": [q for q in self.network.parameters() if id(q) not in held], "lr": 0.1, "weight_decay": 5e-4},
+                {"params": frozen, "lr": 0, "weight_decay": 0}]
