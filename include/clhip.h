@@ -335,6 +335,19 @@ int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const void* shad
 /* debug/test: copy one saved activation of layer l (0 x_in, 1 qkv, 2 attn out, 3 x_mid, 4 GELU derivative of the mlp) to fp32 */
 int clhip_vit_read_act(clhip_vit* v, void* workspace, int layer, int which, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input pipeline on the GPU.  store: uint8 [Nimg, H, W, 3] resident in HBM; index [B]: rows
+ * of the store that form the batch; out: fp32 NCHW [B, 3, S, S].  mean3 / std3 are HOST pointers (3 floats each).
+ * crop_flip = RandomCrop(S, padding=pad) + RandomHorizontalFlip + ColorJitter(brightness) + ToTensor + Normalize of the
+ *   reference's CIFAR ResNet pipeline (core/data/data.py:4-19); params [B,3] = (dy, dx in [0, H+2pad-S], flip 0/1) drawn by the
+ *   caller; brightness [B] factors or NULL.  (dy = dx = pad, flip = 0, brightness NULL = the test transform.)
+ * rrc_flip  = RandomResizedCrop(S) (bilinear) + RandomHorizontalFlip + ToTensor [+ Normalize] of the ViT configs
+ *   (config/l2p-...yaml train_trfms); params [B,5] = (y0, x0, h, w, flip): the crop box in source pixels. */
+int clhip_augment_crop_flip(const uint8_t* store, const int64_t* index, const int32_t* params, const float* brightness /*nullable*/,
+                            float* out, int B, int H, int W, int S, int pad, const float* mean3, const float* std3, void* stream);
+int clhip_augment_rrc_flip(const uint8_t* store, const int64_t* index, const int32_t* params, float* out, int B, int H, int W, int S,
+                           const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

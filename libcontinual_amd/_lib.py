@@ -108,6 +108,8 @@ _PROTOS = {
     "clhip_l2_normalize_rows": (_i, [_p, _p, _i, _i, _p]),
     "clhip_ncm_classify": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "clhip_herding_select": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "clhip_augment_crop_flip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
+    "clhip_augment_rrc_flip": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_gemm_config": (None, [_i]),
     "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -1,0 +1,99 @@
+// augment.hip -- the input pipeline on the GPU: the whole uint8 image store of a dataset stays
+// resident in HBM (CIFAR-100: 150 MB of 288 GB) and a batch is produced by ONE gather + augment + normalise kernel, instead of
+// the reference's PIL-per-sample transforms in DataLoader workers (core/data/dataset.py:248-266, core/data/data.py:4-67), which
+// cap a real epoch far below the GPU step rate.
+//   crop_flip : RandomCrop(S, padding) + RandomHorizontalFlip + ColorJitter(brightness) + ToTensor + Normalize   (CIFAR ResNets)
+//   rrc_flip  : RandomResizedCrop(S, box) with bilinear interpolation + RandomHorizontalFlip + ToTensor [+ Normalize]  (ViT)
+// The random parameters (offsets, flips, brightness factors, crop boxes) are drawn on the host side of the boundary with the
+// seeded torch generator and passed in; the kernels are pure functions of (store, index, params).
+#include "common.h"
+
+namespace {
+
+// out[b, c, y, x] (fp32 NCHW) = normalise(clip(trunc(src * f))) where src is the zero-padded, shifted, optionally mirrored source
+__global__ __launch_bounds__(256) void crop_flip_kernel(const uint8_t* __restrict__ store, const int64_t* __restrict__ index,
+                                                        const int32_t* __restrict__ params /* [B,3]: dy, dx, flip */,
+                                                        const float* __restrict__ bright /* [B] or null */, float* __restrict__ out, int B, int H,
+                                                        int W, int S, int pad, float m0, float m1, float m2, float i0, float i1, float i2) {
+    const int64_t total = (int64_t)B * S * S;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % S), y = (int)((t / S) % S), b = (int)(t / ((int64_t)S * S));
+        const int dy = params[b * 3 + 0], dx = params[b * 3 + 1], flip = params[b * 3 + 2];
+        const int xs = flip ? S - 1 - x : x;                  // flip acts on the cropped image
+        const int sy = y + dy - pad, sx = xs + dx - pad;      // position in the unpadded source
+        float r = 0.f, g = 0.f, bl = 0.f;
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+            const uint8_t* p = store + (((size_t)index[b] * H + sy) * W + sx) * 3;
+            r = p[0]; g = p[1]; bl = p[2];
+        }
+        if (bright != nullptr) {
+            const float f = bright[b];
+            r = fminf(floorf(r * f), 255.f); g = fminf(floorf(g * f), 255.f); bl = fminf(floorf(bl * f), 255.f);
+        }
+        const size_t plane = (size_t)S * S;
+        float* o = out + (size_t)b * 3 * plane + (size_t)y * S + x;
+        o[0] = (r * (1.f / 255.f) - m0) * i0;
+        o[plane] = (g * (1.f / 255.f) - m1) * i1;
+        o[2 * plane] = (bl * (1.f / 255.f) - m2) * i2;
+    }
+}
+
+// bilinear resize of the box (x0, y0, w, h) of a source image to S x S (half-pixel centres, edge clamp; the 32 -> 224 upscaling
+// of the L2P / CIFAR pipeline never needs an anti-aliasing filter), then flip / scale to [0,1] / normalise
+__global__ __launch_bounds__(256) void rrc_flip_kernel(const uint8_t* __restrict__ store, const int64_t* __restrict__ index,
+                                                       const int32_t* __restrict__ params /* [B,5]: y0, x0, h, w, flip */, float* __restrict__ out,
+                                                       int B, int H, int W, int S, float m0, float m1, float m2, float i0, float i1, float i2) {
+    const int64_t total = (int64_t)B * S * S;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % S), y = (int)((t / S) % S), b = (int)(t / ((int64_t)S * S));
+        const int32_t* q = params + b * 5;
+        const int y0 = q[0], x0 = q[1], bh = q[2], bw = q[3], flip = q[4];
+        const int xs = flip ? S - 1 - x : x;
+        const float fy = ((float)y + 0.5f) * ((float)bh / (float)S) - 0.5f;
+        const float fx = ((float)xs + 0.5f) * ((float)bw / (float)S) - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        const float wy = fy - (float)iy, wx = fx - (float)ix;
+        const int ya = y0 + min(max(iy, 0), bh - 1), yb = y0 + min(max(iy + 1, 0), bh - 1);
+        const int xa = x0 + min(max(ix, 0), bw - 1), xb = x0 + min(max(ix + 1, 0), bw - 1);
+        const uint8_t* img = store + (size_t)index[b] * H * W * 3;
+        const uint8_t* p00 = img + ((size_t)ya * W + xa) * 3;
+        const uint8_t* p01 = img + ((size_t)ya * W + xb) * 3;
+        const uint8_t* p10 = img + ((size_t)yb * W + xa) * 3;
+        const uint8_t* p11 = img + ((size_t)yb * W + xb) * 3;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = (float)p00[c] + wx * ((float)p01[c] - (float)p00[c]);
+            const float bot = (float)p10[c] + wx * ((float)p11[c] - (float)p10[c]);
+            v[c] = floorf(top + wy * (bot - top) + 0.5f);          // back to the uint8 grid like PIL, then ToTensor
+        }
+        const size_t plane = (size_t)S * S;
+        float* o = out + (size_t)b * 3 * plane + (size_t)y * S + x;
+        o[0] = (v[0] * (1.f / 255.f) - m0) * i0;
+        o[plane] = (v[1] * (1.f / 255.f) - m1) * i1;
+        o[2 * plane] = (v[2] * (1.f / 255.f) - m2) * i2;
+    }
+}
+
+inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 65536 ? b : 65536); }
+
+}  // namespace
+
+extern "C" int clhip_augment_crop_flip(const uint8_t* store, const int64_t* index, const int32_t* params, const float* brightness, float* out, int B,
+                                       int H, int W, int S, int pad, const float* mean3, const float* std3, void* stream) {
+    CLHIP_CHECK_ARG(store && index && params && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && S > 0 && pad >= 0);
+    CLHIP_CHECK_ARG(S <= H + 2 * pad && S <= W + 2 * pad);
+    hipLaunchKernelGGL(crop_flip_kernel, dim3(blocks_for((int64_t)B * S * S)), dim3(256), 0, static_cast<hipStream_t>(stream), store, index, params,
+                       brightness, out, B, H, W, S, pad, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_augment_rrc_flip(const uint8_t* store, const int64_t* index, const int32_t* params, float* out, int B, int H, int W, int S,
+                                      const float* mean3, const float* std3, void* stream) {
+    CLHIP_CHECK_ARG(store && index && params && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && S > 0);
+    hipLaunchKernelGGL(rrc_flip_kernel, dim3(blocks_for((int64_t)B * S * S)), dim3(256), 0, static_cast<hipStream_t>(stream), store, index, params, out,
+                       B, H, W, S, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}

@@ -8,7 +8,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value"
 mkdir -p obj
 pids=()
-for f in api conv conv2 conv3 bn elementwise head plan gemm attn vit_ops vit_plan; do
+for f in api conv conv2 conv3 bn elementwise head plan gemm attn vit_ops vit_plan augment; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ ../../include/clhip.h -nt obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)

@@ -1,1 +1,1 @@
-from .dataset import get_dataloader, ContinualDatasets, SingleDataset, ArrayDataset  # noqa: F401
+from .dataset import get_dataloader, make_loader, ContinualDatasets, SingleDataset, ArrayDataset  # noqa: F401

@@ -38,11 +38,24 @@ class SingleDataset(Dataset):
 
 
 class ArrayDataset(Dataset):
-    """`store` is a uint8 array [N,H,W,3]; `images` holds indices into it."""
+    """`store` is a uint8 array [N,H,W,3]; `images` holds indices into it.  The store object is shared by every per-task view
+    (and by copies of a view); `device_store()` uploads it once and keeps it resident for the GPU input pipeline."""
 
-    def __init__(self, store, images, labels, trfms, mode="train"):
+    def __init__(self, store, images, labels, trfms, mode="train", resident=None):
         self.store, self.trfms, self.mode, self.data_root = store, trfms, mode, None
         self.images, self.labels = list(images), list(labels)
+        self._resident = resident if resident is not None else {}       # device -> uint8 tensor, shared between views
+
+    def __deepcopy__(self, memo):
+        """views are copied (the trainer and the plugins edit `images` / `labels` of copies), the image store and its device
+        copy are shared"""
+        return ArrayDataset(self.store, list(self.images), list(self.labels), self.trfms, self.mode, self._resident)
+
+    def device_store(self, device):
+        key = str(device)
+        if key not in self._resident:
+            self._resident[key] = torch.as_tensor(np.ascontiguousarray(self.store)).to(device)
+        return self._resident[key]
 
     def __len__(self):
         return len(self.labels)
@@ -55,21 +68,31 @@ class ContinualDatasets:
     """task t covers labels [start_t, end_t): 0..init for t=0, then inc per task (dataset.py:81-92).
     train: get_loader(t) -> the task's loader; test: the list of loaders of tasks 0..t (dataset.py:94-99)."""
 
-    def __init__(self, mode, task_num, init_cls_num, inc_cls_num, make_dataset, batch_size, num_workers=0, cls_map=None):
+    def __init__(self, mode, task_num, init_cls_num, inc_cls_num, make_dataset, batch_size, num_workers=0, cls_map=None, device=None):
         self.mode, self.task_num, self.cls_map = mode, task_num, cls_map
         self.dataloaders = []
         for i in range(task_num):
             s = 0 if i == 0 else init_cls_num + (i - 1) * inc_cls_num
             e = s + (init_cls_num if i == 0 else inc_cls_num)
-            self.dataloaders.append(DataLoader(make_dataset(s, e), shuffle=True, batch_size=batch_size, drop_last=False,
-                                               num_workers=num_workers, pin_memory=False))
+            self.dataloaders.append(make_loader(make_dataset(s, e), batch_size, True, num_workers, device))
 
     def get_loader(self, task_idx):
         assert 0 <= task_idx < self.task_num
         return self.dataloaders[task_idx] if self.mode == "train" else self.dataloaders[: task_idx + 1]
 
 
-def get_dataloader(config, mode, cls_map=None):
+def make_loader(dataset, batch_size, shuffle, num_workers=0, device=None):
+    """the loader of a (per-task or merged) dataset: batches produced on the GPU when the dataset has a resident store, a
+    transform pipeline the augment kernels implement and `device` is a HIP device; otherwise torch's DataLoader"""
+    if device is not None and torch.device(device).type == "cuda" and hasattr(dataset, "device_store"):
+        from .gpu_loader import GpuBatchLoader, gpu_plan
+        plan = gpu_plan(dataset.trfms)
+        if plan is not None:
+            return GpuBatchLoader(dataset, batch_size, shuffle, device, plan)
+    return DataLoader(dataset, shuffle=shuffle, batch_size=batch_size, drop_last=False, num_workers=num_workers, pin_memory=False)
+
+
+def get_dataloader(config, mode, cls_map=None, device=None):
     """class order: `class_order` key if present else np.random.permutation (seeded by init_seed ->
     the seed-1993 PyCIL order), reference dataloader.py:113-122"""
     data_root = config["data_root"]
@@ -78,8 +101,12 @@ def get_dataloader(config, mode, cls_map=None):
     else:
         trfms = T.cifar_resnet_transform(mode, config.get("image_size", 32))
     bs = config.get(f"{mode}_batch_size", config["batch_size"])
+    if not config.get("gpu_input_pipeline", True):
+        device = None
     if config["dataset"] == "synthetic":
-        return synthetic_datasets(config, mode, trfms, bs)
+        return synthetic_datasets(config, mode, trfms, bs, device)
+    if config.get("preload", False):
+        return preloaded_datasets(config, mode, trfms, bs, cls_map, device)
     if cls_map is None:
         cls_list = sorted(os.listdir(os.path.join(data_root, mode)))
         perm = config["class_order"] if "class_order" in config else np.random.permutation(len(cls_list))
@@ -87,6 +114,33 @@ def get_dataloader(config, mode, cls_map=None):
     mk = lambda s, e: SingleDataset(data_root, mode, cls_map, trfms, s, e)
     return ContinualDatasets(mode, config["task_num"], config["init_cls_num"], config["inc_cls_num"], mk, bs,
                              config["num_workers"], cls_map)
+
+
+def preloaded_datasets(config, mode, trfms, bs, cls_map, device):
+    """`preload: true`: decode the whole class-folder tree ONCE into a uint8 store (all images must share one size, e.g. the
+    CIFAR-100 PNG export: 50 000 x 32 x 32 x 3 = 150 MB) so that the per-task datasets are index views and the GPU input pipeline
+    can serve every batch from HBM.  Same class order / task split as the on-disk path."""
+    from PIL import Image
+    data_root = config["data_root"]
+    if cls_map is None:
+        cls_list = sorted(os.listdir(os.path.join(data_root, mode)))
+        perm = config["class_order"] if "class_order" in config else np.random.permutation(len(cls_list))
+        cls_map = {label: cls_list[ori] for label, ori in enumerate(perm)}
+    n_cls = config["init_cls_num"] + (config["task_num"] - 1) * config["inc_cls_num"]
+    frames, labels = [], []
+    for label in range(n_cls):
+        d = os.path.join(data_root, mode, cls_map[label])
+        for f in sorted(os.listdir(d)):
+            frames.append(np.asarray(Image.open(os.path.join(d, f)).convert("RGB")))
+            labels.append(label)
+    store = np.stack(frames)
+    labels = np.asarray(labels)
+    shared = {}
+
+    def mk(s, e):
+        idx = np.flatnonzero((labels >= s) & (labels < e))
+        return ArrayDataset(store, idx.tolist(), labels[idx].tolist(), trfms, mode, shared)
+    return ContinualDatasets(mode, config["task_num"], config["init_cls_num"], config["inc_cls_num"], mk, bs, config["num_workers"], cls_map, device)
 
 
 def synthetic_store(n_classes, per_class, size, seed, split=0):
@@ -109,12 +163,14 @@ def synthetic_store(n_classes, per_class, size, seed, split=0):
     return imgs, labels
 
 
-def synthetic_datasets(config, mode, trfms, bs):
+def synthetic_datasets(config, mode, trfms, bs, device=None):
     n_cls = config["init_cls_num"] + (config["task_num"] - 1) * config["inc_cls_num"]
     per = config.get("synthetic_per_class", 20) if mode == "train" else config.get("synthetic_test_per_class", 5)
     store, labels = synthetic_store(n_cls, per, config["image_size"], config["seed"], 0 if mode == "train" else 1)
 
+    shared = {}
+
     def mk(s, e):
         idx = [i for i in range(len(labels)) if s <= labels[i] < e]
-        return ArrayDataset(store, idx, [int(labels[i]) for i in idx], trfms, mode)
-    return ContinualDatasets(mode, config["task_num"], config["init_cls_num"], config["inc_cls_num"], mk, bs, 0, None)
+        return ArrayDataset(store, idx, [int(labels[i]) for i in idx], trfms, mode, shared)
+    return ContinualDatasets(mode, config["task_num"], config["init_cls_num"], config["inc_cls_num"], mk, bs, 0, None, device)

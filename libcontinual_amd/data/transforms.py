@@ -161,7 +161,9 @@ class RandomResizedCrop:
                 cw, ch = w, h
             i, j = (h - ch) // 2, (w - cw) // 2
             box = (j, i, j + cw, i + ch)
-        return np.asarray(im.resize((self.size[1], self.size[0]), self.interp, box=box))
+        # crop THEN resize (torchvision's F.resized_crop): the interpolation clamps at the crop border instead of reading the
+        # source pixels around the box, which `resize(box=...)` would do
+        return np.asarray(im.crop(box).resize((self.size[1], self.size[0]), self.interp))
 
 
 _BY_NAME = {}

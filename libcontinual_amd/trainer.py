@@ -117,14 +117,16 @@ class Trainer:
 
     def _init_dataloader(self, config):
         from .data import get_dataloader
-        train = get_dataloader(config, "train")
-        test = get_dataloader(config, "test", cls_map=train.cls_map)
+        train = get_dataloader(config, "train", device=self.device)
+        test = get_dataloader(config, "test", cls_map=train.cls_map, device=self.device)
         return train, test
 
     def _shard_loader(self, loader):
         """per-rank loader: DistributedSampler(shuffle) + batch_size // n_gpu (core/trainer.py:229-241)"""
         if not self.distribute:
             return loader
+        if hasattr(loader, "shard"):                                  # GPU input pipeline: rank slice of every permutation
+            return loader.shard(self.rank, self.world)
         sampler = torch.utils.data.distributed.DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.rank, shuffle=True)
         return DataLoader(loader.dataset, sampler=sampler, batch_size=max(1, loader.batch_size // self.world),
                           num_workers=loader.num_workers, drop_last=loader.drop_last)
@@ -181,8 +183,9 @@ class Trainer:
                     ds.labels = np.concatenate((ds.labels, self.buffer.labels), axis=0)
                 else:
                     assert 0
-                dataloader = DataLoader(ds, shuffle=True, batch_size=self.config["batch_size"], drop_last=False,
-                                        num_workers=self.config["num_workers"])
+                from .data import make_loader
+                dataloader = make_loader(ds, self.config["batch_size"], True, self.config["num_workers"],
+                                         self.device if self.config.get("gpu_input_pipeline", True) else None)
             dataloader = self._shard_loader(dataloader)
             self.log(f"================Task {task_idx} Training!================")
             self.log(f"The training samples number : {len(dataloader.dataset)}")
@@ -305,8 +308,9 @@ class Trainer:
                 merged = copy.deepcopy(datasets[0])
                 merged.images = np.concatenate([ds.images for ds in datasets], axis=0)
                 merged.labels = np.concatenate([ds.labels for ds in datasets], axis=0)
-                loader = DataLoader(merged, shuffle=True, batch_size=self.config["batch_size"], drop_last=False,
-                                    num_workers=self.config["num_workers"])
+                from .data import make_loader
+                loader = make_loader(merged, self.config["batch_size"], True, self.config["num_workers"],
+                                     self.device if self.config.get("gpu_input_pipeline", True) else None)
                 bounds, s = [], 0
                 for t in range(task_idx + 1):
                     n = self.init_cls_num if t == 0 else self.inc_cls_num

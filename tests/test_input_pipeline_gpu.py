@@ -1,0 +1,124 @@
+"""GPU input pipeline (csrc/augment.hip + data/gpu_loader.py): the augment kernels vs the CPU transforms on the same images
+with the SAME random parameters (exact for crop / flip / brightness / normalise; bilinear RandomResizedCrop vs PIL within one
+uint8 step), and the loader contract (coverage of an epoch, sharding, drop-in batch dicts)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from libcontinual_amd._lib import call                         # noqa: E402
+from libcontinual_amd.data import ArrayDataset, make_loader    # noqa: E402
+from libcontinual_amd.data import transforms as T              # noqa: E402
+from libcontinual_amd.data.gpu_loader import GpuBatchLoader, gpu_plan   # noqa: E402
+
+DEV = "cuda"
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def store_of(n, size=32, seed=0):
+    return (np.random.RandomState(seed).rand(n, size, size, 3) * 255).astype(np.uint8)
+
+
+def test_crop_flip_kernel_matches_cpu_transforms():
+    store = store_of(20)
+    B, S, pad = 12, 32, 4
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 20, (B,), generator=g)
+    params = torch.stack([torch.randint(0, 2 * pad + 1, (B,), generator=g), torch.randint(0, 2 * pad + 1, (B,), generator=g),
+                          torch.randint(0, 2, (B,), generator=g)], 1).int()
+    bright = torch.empty(B).uniform_(0.75, 1.25, generator=g)
+    out = torch.empty(B, 3, S, S, device=DEV)
+    mean, std = (C.c_float * 3)(*T.CIFAR_MEAN), (C.c_float * 3)(*T.CIFAR_STD)
+    sd, idx_d, par_d, bri_d = torch.as_tensor(store).to(DEV), idx.to(DEV), params.to(DEV), bright.to(DEV)     # keep the device copies alive
+    call("clhip_augment_crop_flip", sd.data_ptr(), idx_d.data_ptr(), par_d.data_ptr(), bri_d.data_ptr(), out.data_ptr(),
+         B, 32, 32, S, pad, mean, std, st())
+    torch.cuda.synchronize()
+    norm = T.Normalize(T.CIFAR_MEAN, T.CIFAR_STD)
+    for b in range(B):
+        a = np.pad(store[int(idx[b])], ((pad, pad), (pad, pad), (0, 0)))
+        dy, dx, flip = (int(v) for v in params[b])
+        a = a[dy:dy + S, dx:dx + S]
+        if flip:
+            a = a[:, ::-1]
+        a = np.clip(a.astype(np.float32) * float(bright[b]), 0, 255).astype(np.uint8)
+        want = norm(T.ToTensor()(a))
+        assert torch.allclose(out[b].cpu(), want, atol=1e-6), b
+    # test-time transform: no crop shift, no flip, no jitter
+    p0 = torch.tensor([[0, 0, 0]] * B, dtype=torch.int32).to(DEV)
+    call("clhip_augment_crop_flip", sd.data_ptr(), idx_d.data_ptr(), p0.data_ptr(), None, out.data_ptr(), B, 32, 32, S, 0, mean, std, st())
+    torch.cuda.synchronize()
+    for b in range(B):
+        assert torch.allclose(out[b].cpu(), norm(T.ToTensor()(store[int(idx[b])])), atol=1e-6)
+
+
+def test_rrc_kernel_close_to_pil_bilinear():
+    from PIL import Image
+    store = store_of(6, 32, seed=3)
+    B, S = 6, 64
+    params = torch.tensor([[0, 0, 32, 32, 0], [3, 5, 20, 17, 1], [10, 2, 9, 28, 0], [0, 7, 32, 11, 1], [16, 16, 16, 16, 0], [1, 1, 30, 30, 1]], dtype=torch.int32)
+    idx = torch.arange(B)
+    out = torch.empty(B, 3, S, S, device=DEV)
+    mean, std = (C.c_float * 3)(0.0, 0.0, 0.0), (C.c_float * 3)(1.0, 1.0, 1.0)
+    sd, idx_d, par_d = torch.as_tensor(store).to(DEV), idx.to(DEV), params.to(DEV)
+    call("clhip_augment_rrc_flip", sd.data_ptr(), idx_d.data_ptr(), par_d.data_ptr(), out.data_ptr(), B, 32, 32, S, mean, std, st())
+    torch.cuda.synchronize()
+    for b in range(B):
+        y0, x0, h, w, flip = (int(v) for v in params[b])
+        im = Image.fromarray(store[b]).crop((x0, y0, x0 + w, y0 + h)).resize((S, S), Image.BILINEAR)      # crop, then resize
+        a = np.asarray(im)
+        if flip:
+            a = a[:, ::-1]
+        want = T.ToTensor()(a)
+        diff = (out[b].cpu() - want).abs() * 255
+        assert float(diff.max()) <= 1.01 and float(diff.mean()) < 0.35, (b, float(diff.max()), float(diff.mean()))   # PIL: two fixed-point passes with an intermediate uint8 rounding
+
+
+def test_loader_contract_and_sharding():
+    store = store_of(50)
+    labels = list(np.arange(50) % 5)
+    ds = ArrayDataset(store, list(range(50)), labels, T.cifar_resnet_transform("train", 32), "train")
+    assert gpu_plan(ds.trfms)["kind"] == "crop_flip" and gpu_plan(ds.trfms)["brightness"] > 0
+    assert gpu_plan(T.create_transforms([{"Resize": {"size": 36}}, {"ToTensor": {}}])) is None        # no GPU plan -> CPU DataLoader
+    loader = make_loader(ds, 16, True, 0, DEV)
+    assert isinstance(loader, GpuBatchLoader) and len(loader) == 4 and loader.batch_size == 16 and loader.dataset is ds
+    torch.manual_seed(0)
+    seen = []
+    for batch in loader:
+        assert batch["image"].is_cuda and batch["image"].dtype == torch.float32 and batch["image"].shape[1:] == (3, 32, 32)
+        assert batch["label"].is_cuda and batch["label"].dtype == torch.int64 and torch.isfinite(batch["image"]).all()
+        seen += batch["label"].tolist()
+    assert sorted(seen) == sorted(labels)                                  # one epoch = every sample once
+    parts = [loader.shard(r, 2) for r in range(2)]
+    torch.manual_seed(5)
+    a = [l for b in parts[0] for l in b["label"].tolist()]
+    torch.manual_seed(5)
+    b = [l for bt in parts[1] for l in bt["label"].tolist()]
+    assert len(a) + len(b) == 50 and parts[0].batch_size == 8
+    # test-mode views and copies share the resident store
+    import copy
+    ds2 = copy.deepcopy(ds)
+    ds2.images = ds2.images[:10]; ds2.labels = ds2.labels[:10]
+    assert ds2.device_store(DEV) is ds.device_store(DEV) and len(ds.images) == 50
+    ev = make_loader(ArrayDataset(store, list(range(50)), labels, T.cifar_resnet_transform("test", 32), "test"), 25, False, 0, DEV)
+    first = next(iter(ev))
+    want = T.cifar_resnet_transform("test", 32)(store[0])
+    assert torch.allclose(first["image"][0].cpu(), want, atol=1e-6) and first["label"].tolist() == labels[:25]
+
+
+def test_rrc_loader_for_vit_pipeline():
+    store = store_of(24)
+    ds = ArrayDataset(store, list(range(24)), [0] * 24,
+                      T.create_transforms([{"RandomResizedCrop": {"size": 64, "scale": [0.05, 1.0], "ratio": [0.75, 1.3333], "interpolation": "BILINEAR"}},
+                                           {"RandomHorizontalFlip": {"p": 0.5}}, {"ToTensor": {}}]), "train")
+    loader = make_loader(ds, 8, True, 0, DEV)
+    assert isinstance(loader, GpuBatchLoader) and loader.plan["kind"] == "rrc_flip"
+    torch.manual_seed(1)
+    for batch in loader:
+        x = batch["image"]
+        assert x.shape == (8, 3, 64, 64) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
