@@ -5,7 +5,8 @@ PIL-per-sample transforms in DataLoader workers (core/data/dataset.py:248-266). 
 {"image", "label"} dicts) -- the tensors it yields already live on the device.
 
 Random parameters are drawn on the host with torch's global generator (seeded per epoch by the trainer, core/trainer.py:584):
-one permutation per epoch, then per batch the crop offsets / flips / brightness factors (or RandomResizedCrop boxes).  The draw
+one permutation per epoch and, in the same breath, the crop offsets / flips / brightness factors (or RandomResizedCrop boxes)
+of the whole epoch -- a single upload; per batch only pointer offsets change.  The draw
 ORDER differs from the per-sample CPU pipeline, so the augmentations of a given seed differ; their distribution is the same.
 """
 import ctypes as C
@@ -116,27 +117,29 @@ class GpuBatchLoader:
         S = plan["size"] or H
         mean, std = (C.c_float * 3)(*plan["mean"]), (C.c_float * 3)(*plan["std"])
         st = torch.cuda.current_stream(dev).cuda_stream
-        stop = (order.numel() // self.batch_size) * self.batch_size if self.drop_last else order.numel()
+        total = order.numel()
+        stop = (total // self.batch_size) * self.batch_size if self.drop_last else total
+        # the whole epoch's random parameters in one draw and ONE upload (per batch only pointer offsets change)
+        flip = (torch.rand(total) < plan["flip"]).int() if plan["flip"] > 0 else torch.zeros(total, dtype=torch.int32)
+        bright = None
+        if plan["kind"] == "crop_flip":
+            span_y, span_x = H + 2 * plan["pad"] - S + 1, W + 2 * plan["pad"] - S + 1
+            dy = torch.randint(0, span_y, (total,), dtype=torch.int32) if span_y > 1 else torch.zeros(total, dtype=torch.int32)
+            dx = torch.randint(0, span_x, (total,), dtype=torch.int32) if span_x > 1 else torch.zeros(total, dtype=torch.int32)
+            params = torch.stack([dy, dx, flip], 1).contiguous().to(dev)
+            if plan["brightness"] > 0:
+                b = plan["brightness"]
+                bright = torch.empty(total).uniform_(max(0.0, 1 - b), 1 + b).to(dev)
+        else:
+            params = torch.cat([_rrc_boxes(total, H, W, plan["scale"], plan["ratio"]), flip[:, None]], 1).contiguous().to(dev)
         for s in range(0, stop, self.batch_size):
             idx = rows[s:s + self.batch_size]
             B = idx.numel()
             out = torch.empty(B, 3, S, S, device=dev, dtype=torch.float32)
-            flip = (torch.rand(B) < plan["flip"]).int() if plan["flip"] > 0 else torch.zeros(B, dtype=torch.int32)
+            par = params[s:s + B]
             if plan["kind"] == "crop_flip":
-                span_y, span_x = H + 2 * plan["pad"] - S + 1, W + 2 * plan["pad"] - S + 1
-                if plan["pad"] > 0 or span_y > 1 or span_x > 1:
-                    dy, dx = torch.randint(0, span_y, (B,), dtype=torch.int32), torch.randint(0, span_x, (B,), dtype=torch.int32)
-                else:
-                    dy = dx = torch.zeros(B, dtype=torch.int32)
-                params = torch.stack([dy, dx, flip], 1).contiguous().to(dev)
-                bright = None
-                if plan["brightness"] > 0:
-                    b = plan["brightness"]
-                    bright = torch.empty(B).uniform_(max(0.0, 1 - b), 1 + b).to(dev)
-                call("clhip_augment_crop_flip", store.data_ptr(), idx.data_ptr(), params.data_ptr(), bright.data_ptr() if bright is not None else None,
+                call("clhip_augment_crop_flip", store.data_ptr(), idx.data_ptr(), par.data_ptr(), bright[s:s + B].data_ptr() if bright is not None else None,
                      out.data_ptr(), B, H, W, S, plan["pad"], mean, std, st)
             else:
-                boxes = _rrc_boxes(B, H, W, plan["scale"], plan["ratio"])
-                params = torch.cat([boxes, flip[:, None]], 1).contiguous().to(dev)
-                call("clhip_augment_rrc_flip", store.data_ptr(), idx.data_ptr(), params.data_ptr(), out.data_ptr(), B, H, W, S, mean, std, st)
+                call("clhip_augment_rrc_flip", store.data_ptr(), idx.data_ptr(), par.data_ptr(), out.data_ptr(), B, H, W, S, mean, std, st)
             yield {"image": out, "label": labels[s:s + self.batch_size]}
