@@ -7,6 +7,8 @@ from .ewc import EWC  # noqa: F401
 from .lwf import LWF  # noqa: F401
 from .icarl import ICarl  # noqa: F401
 from .lucir import LUCIR  # noqa: F401
+from .wa import WA  # noqa: F401
+from .der import DER  # noqa: F401
 from .l2p import L2P  # noqa: F401
 from .inflora_opt import InfLoRA_OPT  # noqa: F401
 from .heads import HipLinear  # noqa: F401

@@ -26,6 +26,15 @@ def reference_namespace():
     ns.ICarl = ref_shim.load("core.model.icarl").ICarl
     ns.LUCIR = ref_shim.load("core.model.lucir").LUCIR
     ns.Finetune = ref_shim.load("core.model.finetune").Finetune
+    ns.WA = ref_shim.load("core.model.wa").WA
+    # der.py:26-27 imports its extractor factories from the backbone PACKAGE and `get_instance` (unused) from core.utils;
+    # the shim's packages are empty, so hand it the reference's own objects
+    for n in ("resnet18", "resnet34", "resnet50"):
+        setattr(sys.modules["core.model.backbone"], n, getattr(resnet, n))
+    utils = types.ModuleType("core.utils")
+    utils.get_instance = None
+    sys.modules.setdefault("core.utils", utils)
+    ns.DER = ref_shim.load("core.model.der").DER
     ns.LinearHerdingBuffer = ref_shim.load("core.model.buffer.linearherdingbuffer").LinearHerdingBuffer
     return ns
 
@@ -66,6 +75,8 @@ def main(out_dir=None):
     jobs["lwf_resnet18"] = lambda: scenarios.scenario_lwf(ad)
     jobs["lwf_cifar_resnet32"] = lambda: scenarios.scenario_lwf(ad, dict(arch="cifar_resnet32", feat_dim=64, bs=8))
     jobs["lucir"] = lambda: scenarios.scenario_lucir(ad)
+    jobs["wa"] = lambda: scenarios.scenario_wa(ad)
+    jobs["der"] = lambda: scenarios.scenario_der(ad)
 
     def icarl():
         with tempfile.TemporaryDirectory() as d:

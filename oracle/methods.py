@@ -185,6 +185,113 @@ class LWF:
         return _acc(self.network.logits(x, False), y)
 
 
+# ---------------------------------------------------------------------------------------------- WA
+def align_new_rows(w, n_new):
+    """wa.py:96-109 / der.py:182-190: scale the last `n_new` rows by mean|old rows| / mean|new rows|; returns (w, gamma)."""
+    norms = torch.norm(w, p=2, dim=1)
+    gamma = norms[:-n_new].mean() / norms[-n_new:].mean()
+    w = w.clone()
+    w[-n_new:] *= gamma
+    return w, gamma
+
+
+class WA:
+    """reference core/model/wa.py:141-243.  `total` grows by init_cls_num per task (wa.py:222); the logits head is not among
+    the optimised parameters (Finetune.get_parameters, finetune.py:46-50, lists Finetune's own unused classifier instead) --
+    `trainable()` returns what the reference optimizer really steps."""
+
+    def __init__(self, net, init_cls_num):
+        self.network = net                        # net.head_* plays network.classifier
+        self.init_cls_num = init_cls_num
+        self.known, self.total, self.task_idx = 0, 0, 0
+        self.old = None
+
+    def trainable(self):
+        return list(self.network.P.values())
+
+    def before_task(self, new_rows):
+        self.total += self.init_cls_num
+        net = self.network
+        w, b = new_rows[0].detach().clone(), new_rows[1].detach().clone()
+        if self.task_idx > 0:
+            n_old = net.head_w.shape[0]
+            w[:n_old] = net.head_w.detach(); b[:n_old] = net.head_b.detach()          # wa.py:84-91
+        net.head_w, net.head_b = w.requires_grad_(True), b.requires_grad_(True)
+
+    def observe(self, x, y, train=True):
+        logits = self.network.logits(x, train)
+        loss = F.cross_entropy(logits, y)
+        if self.task_idx > 0:
+            lam = self.known / self.total
+            with torch.no_grad():
+                soft = self.old.logits(x, train)                                      # teacher follows model.train()
+            loss = (1 - lam) * loss + lam * kd_loss(logits[:, : self.known], soft, 2.0)   # wa.py:172-178
+        pred, acc = _acc(logits, y)
+        return pred, acc, loss
+
+    def after_task(self):
+        gamma = None
+        if self.task_idx > 0:
+            w, gamma = align_new_rows(self.network.head_w.detach(), self.total - self.known)
+            self.network.head_w = w.requires_grad_(True)
+        self.old = self.network.clone(grad=False)
+        self.known = self.total
+        self.task_idx += 1
+        return gamma
+
+    def inference(self, x, y):
+        return _acc(self.network.logits(x, False), y)
+
+
+# --------------------------------------------------------------------------------------------- DER
+class DER:
+    """reference core/model/der.py:66-226: one feature extractor per task (copied from the previous one, earlier ones frozen),
+    `fc` over the concatenated features, `aux_fc` over the newest extractor's features."""
+
+    def __init__(self, arch, init_cls_num, inc_cls_num):
+        self.arch, self.init_cls_num, self.inc_cls_num = arch, init_cls_num, inc_cls_num
+        self.P, self.Bf = [], []                  # per extractor
+        self.fc_w = self.fc_b = self.aux_w = self.aux_b = None
+        self.known = self.total = 0
+        self.task_idx = 0
+
+    def before_task(self, task_idx, fc_rows, aux_rows, first=None):
+        """`fc_rows` / `aux_rows` = (w, b) supplying the fresh entries; `first` = (P, Bf) of extractor 0"""
+        self.task_idx, self.known, self.total = task_idx, self.total, self.init_cls_num + task_idx * self.inc_cls_num
+        self.P = [{k: v.detach() for k, v in P.items()} for P in self.P]              # freeze_convnets (der.py:176-179)
+        if first is not None:
+            P, Bf = first
+        else:
+            P, Bf = self.P[-1], self.Bf[-1]                                           # load_state_dict of the previous one
+        self.P.append(_clone_dict(P, grad=True)); self.Bf.append(_clone_dict(Bf))
+        w, b = fc_rows[0].detach().clone(), fc_rows[1].detach().clone()
+        if self.fc_w is not None:
+            r, c = self.fc_w.shape
+            w[:r, :c] = self.fc_w.detach(); b[:r] = self.fc_b.detach()                # der.py:160-165
+        self.fc_w, self.fc_b = w.requires_grad_(True), b.requires_grad_(True)
+        self.aux_w, self.aux_b = aux_rows[0].detach().clone().requires_grad_(True), aux_rows[1].detach().clone().requires_grad_(True)
+
+    def trainable(self):
+        return list(self.P[-1].values()) + [self.fc_w, self.fc_b, self.aux_w, self.aux_b]
+
+    def features(self, x, train):
+        return torch.cat([nets.forward(self.arch, P, Bf, x, train) for P, Bf in zip(self.P, self.Bf)], 1)
+
+    def observe(self, x, y, train=True):
+        f = self.features(x, train)                # every extractor follows model.train(), frozen ones included
+        logit = F.linear(f, self.fc_w, self.fc_b)
+        loss = F.cross_entropy(logit, y)
+        if self.task_idx > 0:
+            aux_y = torch.clamp(y - self.known + 1, min=0)                            # der.py:117-123
+            d = f.shape[1] // len(self.P)
+            loss = F.cross_entropy(F.linear(f[:, -d:], self.aux_w, self.aux_b), aux_y) + loss
+        pred, acc = _acc(logit, y)
+        return pred, acc, loss
+
+    def inference(self, x, y):
+        return _acc(F.linear(self.features(x, False), self.fc_w, self.fc_b), y)
+
+
 # ------------------------------------------------------------------------------------------- iCaRL
 class ICarl:
     """reference core/model/icarl.py:42-287."""

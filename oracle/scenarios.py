@@ -462,6 +462,194 @@ def scenario_icarl(adapter, tmpdir):
     return res
 
 
+# ------------------------------------------------------------------------------------ scenario: WA
+WA_CFG = dict(arch="cifar_resnet32", feat_dim=64, init=3, bs=8, lr=0.02, momentum=0.9, wd=2e-4)
+
+
+class RecordingBuffer:
+    """stands in for the herding buffer (covered by the iCaRL scenario): records what the plugin asks of it"""
+
+    def __init__(self):
+        self.calls = []
+
+    def reduce_old_data(self, task_idx, total):
+        self.calls.append(("reduce", int(task_idx), int(total)))
+
+    def update(self, network, train_loader, trfms, task_idx, total, cur_classes, device):
+        self.calls.append(("update", int(task_idx), int(total), [int(v) for v in cur_classes]))
+
+
+class _Trfms:
+    trfms = None
+
+
+def scenario_wa(adapter):
+    """task 0: 2 steps of CE; after_task (teacher snapshot, no alignment); task 1 (classes grow by init_cls_num): 2 steps of
+    (1-l) CE + l KD(T=2) with the teacher in train mode; after_task aligns the new head rows.  The optimizer is built from
+    `get_parameters`, which (reference quirk) leaves the logits head out."""
+    c = WA_CFG
+    tag = "wa"
+    n0, n1 = c["init"], 2 * c["init"]
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    w0, b0 = fx.det_linear(tag + "/head0", n0, c["feat_dim"])
+    w1, b1 = fx.det_linear(tag + "/head1", n1, c["feat_dim"])
+    w1 = w1 * 1.7                                   # new rows deliberately off-scale so that the alignment matters
+    t0 = [fx.det_batch(f"{tag}/t0/{i}", c["bs"], 0, n0) for i in range(2)]
+    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], 0, n1) for i in range(2)]
+    ex, ey = fx.det_batch(f"{tag}/eval", c["bs"], 0, n1)
+    losses, preds = [], []
+    if adapter.kind == "oracle":
+        net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()},
+                     {k: v.clone() for k, v in Bf.items()}, None, None)
+        m = om.WA(net, c["init"])
+
+        def run(batches):
+            opt = om.SGD(m.trainable(), c["lr"], c["momentum"], c["wd"])
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item()); preds.append(pred.numpy())
+        m.before_task((w0, b0)); run(t0); m.after_task()
+        m.before_task((w1, b1)); run(t1)
+        head_before = net.head_w.detach().clone()
+        gamma = m.after_task()
+        head_after = net.head_w.detach()
+        epred, _ = m.inference(ex, ey)
+        logits = net.logits(ex, False).detach()
+        teacher_rm = m.old.Bf[_last_bn(c["arch"]) + ".running_mean"]
+        params = {"backbone." + k: v for k, v in net.P.items()}
+        calls = [("reduce", 0, n0), ("update", 0, n0, list(range(0, n0))), ("reduce", 1, n1), ("update", 1, n1, list(range(n0, n1)))]
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.WA(bb, c["feat_dim"], 100, device=adapter.device, init_cls_num=c["init"], inc_cls_num=c["init"]).to(adapter.device)
+        buffer = RecordingBuffer()
+        tl = [ListLoader([], c["bs"], _Trfms())]
+
+        def set_head(w, b, old):
+            m.network.to(adapter.device)
+            with torch.no_grad():
+                m.network.classifier.weight.data[old:] = adapter.to_dev(w[old:])
+                m.network.classifier.bias.data[old:] = adapter.to_dev(b[old:])
+
+        def run(batches):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], momentum=c["momentum"], weight_decay=c["wd"])
+            m.train()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
+        m.before_task(0, buffer, None, tl); set_head(w0, b0, 0); run(t0); m.after_task(0, buffer, None, tl)
+        m.before_task(1, buffer, None, tl); set_head(w1, b1, n0); run(t1)
+        head_before = m.network.classifier.weight.detach().cpu().clone()
+        m.after_task(1, buffer, None, tl)
+        head_after = m.network.classifier.weight.detach().cpu()
+        gamma = (head_after[-1].norm() / head_before[-1].norm())
+        m.eval()
+        with torch.no_grad():
+            epred, _ = m.inference(adapter.batch(ex, ey))
+            logits = m.network(adapter.to_dev(ex)).cpu()
+        teacher_rm = dict(m.old_network.backbone.named_buffers())[_last_bn(c["arch"]) + ".running_mean"].cpu()
+        params = {("backbone." + k): v.detach().cpu() for k, v in m.backbone.named_parameters()}
+        calls = buffer.calls
+    out = dict(losses=np.asarray(losses, np.float64), preds=np.stack(preds), logits_eval=logits.numpy(), eval_pred=np.asarray(epred.cpu()),
+               head_before=head_before.numpy(), head_after=head_after.numpy(), gamma=np.float64(float(gamma)),
+               teacher_rm=teacher_rm.numpy(), buffer_calls=np.asarray(repr(calls)))
+    names, rows = fx.summarize(params)
+    out["param_names"], out["param_rows"] = np.asarray(names), rows
+    return out
+
+
+# ----------------------------------------------------------------------------------- scenario: DER
+DER_CFG = dict(arch="resnet18", feat_dim=512, init=4, inc=2, bs=4, lr=0.02, momentum=0.9, wd=2e-4)
+
+
+def scenario_der(adapter):
+    """task 0: 1 step (one extractor, CE); task 1: a second extractor copied from the first, `fc` widened over 1024 features,
+    fresh aux head; 2 steps of CE + aux CE.  The frozen first extractor keeps running in train mode (its BN running stats
+    move), its parameters do not."""
+    c = DER_CFG
+    tag = "der"
+    D, n0, n1 = c["feat_dim"], c["init"], c["init"] + c["inc"]
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    fc0 = fx.det_linear(tag + "/fc0", n0, D)
+    aux0 = fx.det_linear(tag + "/aux0", n0 + 1, D)
+    fc1 = fx.det_linear(tag + "/fc1", n1, 2 * D)
+    aux1 = fx.det_linear(tag + "/aux1", c["inc"] + 1, D)
+    t0 = [fx.det_batch(f"{tag}/t0/{i}", c["bs"], 0, n0) for i in range(1)]
+    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], 0, n1) for i in range(2)]       # rehearsal-style: old and new labels
+    ex, ey = fx.det_batch(f"{tag}/eval", c["bs"], 0, n1)
+    losses, preds = [], []
+    last_rm = _last_bn(c["arch"]) + ".running_mean"
+    if adapter.kind == "oracle":
+        m = om.DER(c["arch"], c["init"], c["inc"])
+
+        def run(batches):
+            opt = om.SGD(m.trainable(), c["lr"], c["momentum"], c["wd"])
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item()); preds.append(pred.numpy())
+        m.before_task(0, fc0, aux0, first=(P, Bf)); run(t0)
+        first_after_t0 = {k: v.detach().clone() for k, v in m.P[0].items()}
+        m.before_task(1, fc1, aux1); run(t1)
+        epred, _ = m.inference(ex, ey)
+        logits = F_linear(m.features(ex, False), m.fc_w, m.fc_b).detach()
+        frozen_same = all(torch.equal(first_after_t0[k], m.P[0][k]) for k in first_after_t0)
+        rm0, rm1 = m.Bf[0][last_rm], m.Bf[1][last_rm]
+        params = {"convnets.1." + k: v for k, v in m.P[1].items() if not k.startswith("fc.")}
+        params.update({"fc.weight": m.fc_w, "fc.bias": m.fc_b, "aux_fc.weight": m.aux_w, "aux_fc.bias": m.aux_b})
+    else:
+        ns = adapter.ns
+        m = ns.DER(None, D, 100, device=adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"]).to(adapter.device)
+
+        def fill(lin, w, b, keep_rows=0, keep_cols=0):
+            with torch.no_grad():
+                w, b = adapter.to_dev(w.clone()), adapter.to_dev(b.clone())
+                if keep_rows:
+                    w[:keep_rows, :keep_cols] = lin.weight.data[:keep_rows, :keep_cols]
+                    b[:keep_rows] = lin.bias.data[:keep_rows]
+                lin.weight.data.copy_(w); lin.bias.data.copy_(b)
+
+        def run(batches):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], momentum=c["momentum"], weight_decay=c["wd"])
+            m.train()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
+        m.before_task(0, None, None, None)
+        sd = {k: v.clone() for k, v in P.items()}
+        sd.update({k: v.clone() for k, v in Bf.items()})
+        m.convnets[0].load_state_dict(sd)
+        m.convnets.to(adapter.device)
+        fill(m.fc, *fc0); fill(m.aux_fc, *aux0)
+        run(t0)
+        first_after_t0 = {k: v.detach().cpu().clone() for k, v in m.convnets[0].named_parameters()}
+        m.before_task(1, None, None, None)
+        fill(m.fc, *fc1, keep_rows=n0, keep_cols=D); fill(m.aux_fc, *aux1)
+        run(t1)
+        m.eval()
+        with torch.no_grad():
+            epred, _ = m.inference(adapter.batch(ex, ey))
+            logits = m(adapter.to_dev(ex))["logits"].cpu()
+        frozen_same = all(torch.equal(first_after_t0[k], v.detach().cpu()) for k, v in m.convnets[0].named_parameters())
+        rm0 = dict(m.convnets[0].named_buffers())[last_rm].cpu()
+        rm1 = dict(m.convnets[1].named_buffers())[last_rm].cpu()
+        params = {"convnets.1." + k: v.detach().cpu() for k, v in m.convnets[1].named_parameters() if not k.startswith("fc.")}
+        params.update({"fc.weight": m.fc.weight.detach().cpu(), "fc.bias": m.fc.bias.detach().cpu(),
+                       "aux_fc.weight": m.aux_fc.weight.detach().cpu(), "aux_fc.bias": m.aux_fc.bias.detach().cpu()})
+    out = dict(losses=np.asarray(losses, np.float64), preds=np.stack(preds), logits_eval=logits.numpy(), eval_pred=np.asarray(epred.cpu()),
+               frozen_same=np.asarray(bool(frozen_same)), rm_frozen=rm0.numpy(), rm_new=rm1.numpy())
+    names, rows = fx.summarize(params)
+    out["param_names"], out["param_rows"] = np.asarray(names), rows
+    return out
+
+
+def F_linear(x, w, b):
+    return torch.nn.functional.linear(x, w, b)
+
+
 # --------------------------------------------------------------------------------- scenario: LUCIR
 LUCIR_CFG = dict(arch="resnet32_V2", feat_dim=64, init=6, inc=2, bs=8, lr=0.02, momentum=0.9, wd=5e-4,
                  lamda=5.0, K=2, lw_mr=1.0, dist=0.5, per_class=10)

@@ -21,12 +21,16 @@ def cfg_for(method, backbone, dtype, **over):
         kw["task_num"] = 3
     if method == "LUCIR":
         kw.update(lamda=5, K=2, lw_mr=1, dist=0.5)
+    if method == "WA":                                # wa.py:222 grows the head by init_cls_num per task: only equal splits make sense
+        kw.update(init_cls_num=3)
     cfg.update(dict(dataset="synthetic", image_size=32, init_cls_num=4, inc_cls_num=3, task_num=3, epoch=5, init_epoch=8, batch_size=64,
                     val_per_epoch=10, testing_times=1, num_workers=0, save_path="", synthetic_per_class=200, synthetic_test_per_class=20,
                     seed=7, backbone={"name": backbone, "kwargs": {"num_classes": 10, "dtype": dtype, "args": {"dataset": "cifar100"}}},
                     classifier={"name": method, "kwargs": kw},
                     optimizer={"name": "SGD", "kwargs": {"lr": 0.02, "momentum": 0.9, "weight_decay": 5e-4}},
                     lr_scheduler={"name": "MultiStepLR", "kwargs": {"milestones": [3, 6], "gamma": 0.2}}))
+    if method == "WA":
+        cfg.update(init_cls_num=3)
     cfg.update(over)
     return cfg
 
@@ -36,20 +40,28 @@ def cfg_for(method, backbone, dtype, **over):
     ("LWF", "resnet18", {}),
     ("ICarl", "cifar_resnet32", {"buffer": {"name": "LinearHerdingBuffer", "kwargs": {"buffer_size": 60, "batch_size": 32}}}),
     ("LUCIR", "resnet32_V2", {"buffer": {"name": "LinearBuffer", "kwargs": {"buffer_size": 60, "batch_size": 32, "strategy": "herding"}}}),
+    ("WA", "cifar_resnet32", {"buffer": {"name": "LinearHerdingBuffer", "kwargs": {"buffer_size": 60, "batch_size": 32}}}),
+    ("DER", "resnet18", {"buffer": {"name": "LinearBuffer", "kwargs": {"buffer_size": 60, "batch_size": 32, "strategy": "random"}}}),
 ])
-def test_methods_train_end_to_end(method, backbone, extra):
+def test_methods_train_end_to_end(method, backbone, extra, monkeypatch):
     res = {}
     for dtype in ("bf16", "f32"):
+        monkeypatch.setenv("CLHIP_DTYPE", dtype)                 # DER builds its extractors itself: their dtype comes from the env
         tr = Trainer(0, cfg_for(method, backbone, dtype, **extra), log=lambda *a, **k: None)
         out = tr.train_loop()
         res[dtype] = out
         acc = out["acc_table"]
         assert np.isfinite(acc).all()
         assert acc[0, 0] > 40.0, (method, dtype, acc)            # 4 classes: chance = 25 % (short run: eval-mode BN lags the batch statistics)
-        if method in ("ICarl", "LUCIR"):                          # rehearsal methods fill their buffer
+        if method in ("ICarl", "LUCIR", "WA", "DER"):             # rehearsal methods fill their buffer
             assert len(tr.buffer.labels) > 0
         if method == "ICarl":                                     # NCM over the herded exemplars keeps the old classes alive
             assert out["batch_last_acc"] > 14.0, (method, dtype, acc)   # 10 classes at the end: chance = 10 % (short noisy run)
+        if method == "DER":                                       # one extractor per task, all but the last frozen
+            assert len(tr.model.convnets) == 3 and tr.model.fc.in_features == 3 * 512
+            assert not any(q.requires_grad for q in tr.model.convnets[0].parameters())
+        if method == "WA":
+            assert tr.model.network.classifier.out_features == 9 and tr.model.old_network is not None
         torch.cuda.synchronize()
 
 
