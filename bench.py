@@ -226,7 +226,7 @@ def main():
         a.batch = 16 if a.workload.startswith("l2p") else (128 if vit else 256)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("CLHIP_SHARED_GPU") else int(os.environ.get("LOCAL_RANK", "0"))     # test hook: ranks share cuda:0
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")

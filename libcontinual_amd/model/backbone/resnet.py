@@ -216,7 +216,6 @@ class HipResNet(nn.Module):
         self._shadow = None
         self._shadow_version = None
         self._generation = 0
-        self._grads_live = False
         self._last_state = None
         self._grad_segment_hook = None      # set by parallel.GradientReducer while a DP training loop runs
         self._grad_segment_cuts = []
@@ -298,7 +297,6 @@ class HipResNet(nn.Module):
             self._flat, self._stats, self._nbt = flat, stats, nbt
             self._gflat = None
             self._shadow_version = None
-            self._grads_live = False
         return True
 
     def flat_parameters(self):
@@ -307,7 +305,6 @@ class HipResNet(nn.Module):
         self._ensure_flat(dev)
         if self._gflat is None or self._gflat.device != dev:
             self._gflat = torch.zeros(self._nflat, device=dev, dtype=torch.float32)
-            self._grads_live = False
         return self._flat, self._gflat
 
     def _grad_view(self, i):
@@ -323,15 +320,17 @@ class HipResNet(nn.Module):
                     g.copy_(p.grad)
                 p.grad = g
 
-    def _begin_grad_step(self):
-        """Called by a training forward.  If no parameter holds a gradient (the state after
-        optimizer.zero_grad(set_to_none=True)) the flat gradient buffer is zeroed, so that everything
-        written during the following backward -- by this plan, by the EWC term, in any order -- is a pure
-        accumulation."""
+    def begin_grad_write(self):
+        """Every writer of the flat gradient buffer (this plan's backward, the fused EWC term) calls this first.  torch
+        semantics on a flat buffer: a parameter whose `.grad` is None receives a fresh gradient, one that holds a gradient
+        accumulates.  So if NO parameter holds a gradient -- the state `optimizer.zero_grad()` leaves, whether it ran before
+        the forward or, as in the reference trainer (core/trainer.py:602-604), between forward and backward -- the buffer is
+        zeroed and everything written during this backward, by any writer in any order, is a pure accumulation (the first
+        writer attaches the views, so the later ones see live gradients and add).  Returns the gradient buffer."""
         _, g = self.flat_parameters()
         if all(p.grad is None for p in self._params):
             g.zero_()
-        self._grads_live = True
+        return g
 
     # ------------------------------------------------------------------------------ execution
     def _plan_for(self, x):
@@ -384,7 +383,7 @@ class HipResNet(nn.Module):
         if not state["training"]:
             raise _lib.ClhipError("backward through an eval-mode (running-stat BatchNorm) forward is not supported")
         dfeat = dfeat.contiguous().float()
-        _, g = self.flat_parameters()
+        g = self.begin_grad_write()
         st = torch.cuda.current_stream().cuda_stream
         hook = self._grad_segment_hook
         if hook is None:
@@ -428,7 +427,7 @@ class HipResNet(nn.Module):
         if self.training:
             self._nbt.add_(1)
         if need_grad:
-            self._begin_grad_step()
+            self.flat_parameters()
             feats = _BackboneFn.apply(x, self._params[0], self, state)
         else:
             feats = self._forward_impl(x, state)
@@ -482,7 +481,6 @@ class HipResNet(nn.Module):
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         new._shadow_version = None
-        new._grads_live = False
         # re-point the parameter list at the copied Parameter objects
         named = dict(new.named_parameters())
         new._params = [named[nm] for nm, *_ in new._layout]

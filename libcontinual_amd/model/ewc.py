@@ -73,7 +73,8 @@ class _EwcLossFn(torch.autograd.Function):
         dl = torch.empty_like(dlog)
         call("clhip_scale_dev", dlog.data_ptr(), dl.data_ptr(), dlog.numel(), 1.0, gout.data_ptr(), st)
         bb = owner.network.backbone
-        flat, gflat = bb.flat_parameters()
+        gflat = bb.begin_grad_write()              # zeroes the buffer if this is the first write after zero_grad()
+        flat, _ = bb.flat_parameters()
         lam = float(owner.lamda)
         ops.ewc_grad(flat, owner._ref_flat, owner._fisher_flat, gflat, lam, gout)
         bb.attach_grads()

@@ -1,0 +1,86 @@
+"""The real N>1 code path on a 1-GPU box: two processes share cuda:0 and exchange through gloo (RCCL refuses two ranks on
+one device; the env hooks CLHIP_DIST_BACKEND / CLHIP_SHARED_GPU exist for exactly this).  Everything except the transport is
+what an 8-GPU run executes: rank-0 broadcast, per-rank batches, segmented backward with the overlapped all-reduce of the flat
+gradient tail, the small bucket for the head, 1/world folded into the fused optimizer step, bench.py's barrier / max-over-ranks
+timing contract."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(script_args, timeout=600):
+    env = dict(os.environ, CLHIP_DIST_BACKEND="gloo", CLHIP_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_ranks_train_in_lockstep_and_match_the_emulation(tmp_path):
+    steps = 3
+    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path), str(steps)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # ranks end with the same parameters: bit-identical (same reduced gradient, same fused step)
+    np.testing.assert_array_equal(a["flat"], b["flat"])
+    np.testing.assert_array_equal(a["head"], b["head"])
+    assert np.abs(a["rm"] - b["rm"]).max() > 0          # ... but per-rank BatchNorm statistics (DDP-faithful)
+
+    # single-process emulation: two replicas, each on its rank's batches, gradients averaged by hand, same optimizer
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker as W
+    from libcontinual_amd import optim
+    reps = [W.make(100), W.make(100)]
+    opts = [optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9, weight_decay=5e-4) for m in reps]
+    for m in reps:
+        m.train()
+    for i in range(steps):
+        for rank, (m, o) in enumerate(zip(reps, opts)):
+            _, _, loss = m.observe(W.batch(1000 * rank + i))
+            o.zero_grad()
+            loss.backward()
+        gs = [m.backbone.flat_parameters()[1] for m in reps]
+        mean = (gs[0] + gs[1]) / 2
+        hw = (reps[0].classifier.weight.grad + reps[1].classifier.weight.grad) / 2
+        hb = (reps[0].classifier.bias.grad + reps[1].classifier.bias.grad) / 2
+        for m, o in zip(reps, opts):
+            m.backbone.flat_parameters()[1].copy_(mean)
+            m.classifier.weight.grad.copy_(hw)
+            m.classifier.bias.grad.copy_(hb)
+            o.step()
+    torch.cuda.synchronize()
+    flat = reps[0].backbone.flat_parameters()[0].cpu().numpy()
+    # equal up to the summation order of the fp32-atomic weight gradients (and sum-then-scale vs scale-in-step rounding)
+    assert np.abs(flat - a["flat"]).max() <= 2e-3 * np.abs(flat).max()
+    assert np.abs(reps[0].classifier.weight.detach().cpu().numpy() - a["head"]).max() <= 1e-4
+    np.testing.assert_allclose(reps[0].backbone._stats.cpu().numpy(), a["rm"], rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("workload", ["lwf_resnet18_b50_task0", "icarl_resnet32_b50_task1"])
+def test_bench_contract_at_two_ranks(workload):
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--batch", "64",
+                 "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE json line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
+    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]

@@ -255,6 +255,39 @@ def test_der_golden(golden, monkeypatch):
     assert relmax(got["rm_frozen"], want["rm_frozen"]) < 3e-2
 
 
+@pytest.mark.parametrize("order", ["zero_forward_backward", "forward_zero_backward"])
+def test_gradient_buffer_restarts_after_zero_grad(order):
+    """the flat gradient buffer holds THIS step's gradient whichever side of the forward `optimizer.zero_grad()` runs on
+    (the reference trainer calls it between observe and backward, core/trainer.py:602-604), and accumulates when nobody
+    zeroes (torch semantics)"""
+    torch.manual_seed(0)
+    bb = M.cifar_resnet32(dtype="f32").to(DEV)
+    bb.train()
+    opt = optim.SGD(bb.parameters(), lr=0.0)
+    xs = [torch.randn(8, 3, 32, 32, device=DEV) for _ in range(3)]
+    cw = torch.randn(8, 64, device=DEV)
+    single = []
+    for x in xs:                                   # each gradient on its own, from a clean buffer
+        for p in bb.parameters():
+            p.grad = None
+        (bb(x)["features"] * cw).sum().backward()
+        single.append(bb._gflat.clone())
+    for p in bb.parameters():
+        p.grad = None
+    for x, want in zip(xs, single):
+        if order == "zero_forward_backward":
+            opt.zero_grad()
+            f = bb(x)["features"]
+        else:
+            f = bb(x)["features"]
+            opt.zero_grad()
+        (f * cw).sum().backward()
+        opt.step()
+        assert relnorm(bb._gflat.cpu(), want.cpu()) < 1e-3      # fp32-atomic summation order only
+    (bb(xs[0])["features"] * cw).sum().backward()               # no zero_grad: accumulates onto the last gradient
+    assert relnorm(bb._gflat.cpu(), (single[2] + single[0]).cpu()) < 1e-3
+
+
 def test_full_size_properties_bf16():
     """BASELINE size (ResNet-18, batch 256, bf16): size-independent properties instead of a CPU oracle run.
     (1) backward is linear in dfeat; (2) train-mode BN output statistics: the normalised stem pre-activation
