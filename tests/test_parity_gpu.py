@@ -5,13 +5,11 @@
   - bf16 mode: the performance mode                        -> tolerance stated per quantity
 * the golden scenarios (tests/golden/*.npz = fp64 runs of the REFERENCE) driven through the product's
   plugin classes with the same adapter that drove the reference.
-Tolerances.  Forward quantities and the FIRST optimisation step are held tight (f32 mode: 2e-4).  Later steps
-cannot be: these scenarios use batch 4-8, where a single ReLU whose pre-activation sits within fp32 rounding
-of zero flips its mask between two fp32 evaluations and alone moves a gradient by ~5e-3 (1/sqrt(#activations);
-measured with tools/diag_backbone.py), and the next forward amplifies that (tests/test_oracle_golden.py::*_fp32
-shows the CPU fp32 oracle drifting from the fp64 reference the same way).  So step >= 3 losses, Fisher entries
-and final parameters carry chaos-level bounds; the arithmetic itself is pinned kernel by kernel in
-test_kernels_gpu.py.
+Tolerances.  Forward quantities and the FIRST optimisation step are held tight (f32 mode: 2e-4).  Later steps drift the
+way any fp32 evaluation of these batch-4..8 scenarios drifts from the fp64 reference (tests/test_oracle_golden.py::*_fp32
+shows the CPU fp32 oracle 3e-3 .. 5e-3 off at the fourth step of the EWC / WA scenarios): observed on the MI355X in f32
+mode -- losses 2e-4 (LwF, DER, LUCIR), 1e-3 (iCaRL), 7e-3 .. 9e-3 (EWC, WA at step 4); final parameters <= 8e-3 of their
+abs-sum; bounds below are ~3x the observed values.  The arithmetic itself is pinned kernel by kernel in test_kernels_gpu.py.
 """
 import numpy as np
 import pytest
@@ -156,11 +154,11 @@ def test_ewc_golden(golden):
     want = golden("ewc")
     got = sc.scenario_ewc(adapter("f32"))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 2e-4
-    assert relmax(got["losses"], want["losses"]) < 0.1
+    assert relmax(got["losses"], want["losses"]) < 2.5e-2           # 7e-3 observed at the 4th step (CPU fp32 oracle: 5e-3)
     np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
-    assert relnorm(got["fisher_head_w"], want["fisher_head_w"]) < 0.15
-    assert _param_rel(got, want) < 0.1
-    assert relmax(got["rm_last"], want["rm_last"]) < 3e-2
+    assert relnorm(got["fisher_head_w"], want["fisher_head_w"]) < 0.05
+    assert _param_rel(got, want) < 2e-2
+    assert relmax(got["rm_last"], want["rm_last"]) < 1e-2
     got = sc.scenario_ewc(adapter("bf16"))
     assert relmax(got["losses"][:3], want["losses"][:3]) < 5e-2
     assert relnorm(got["fisher_head_w"], want["fisher_head_w"]) < 0.2
@@ -172,9 +170,11 @@ def test_lwf_golden(golden, name, cfg):
     want = golden(name)
     got = sc.scenario_lwf(adapter("f32"), cfg)
     assert relmax(got["losses"][:2], want["losses"][:2]) < 2e-4     # task-0 step, then first task-1 step (teacher + KD)
-    assert relmax(got["losses"], want["losses"]) < 3e-2
-    np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
+    assert relmax(got["losses"], want["losses"]) < 1e-3             # 2e-4 observed
+    np.testing.assert_array_equal(got["preds"], want["preds"])
     assert relmax(got["teacher_rm"], want["teacher_rm"]) < 1e-3      # teacher BN drifts in train mode (quirk a10)
+    assert relmax(got["logits_eval"], want["logits_eval"]) < 3e-2    # eval-mode logits after the three updates (9e-3 observed)
+    assert _param_rel(got, want) < 5e-3
     got = sc.scenario_lwf(adapter("bf16"), cfg)
     assert relmax(got["losses"], want["losses"]) < 5e-2
     assert relmax(got["teacher_rm"], want["teacher_rm"]) < 3e-2
@@ -184,8 +184,9 @@ def test_icarl_golden(golden, tmp_path):
     want = golden("icarl")
     got = sc.scenario_icarl(adapter("f32"), str(tmp_path))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 5e-4
-    assert relmax(got["losses"], want["losses"]) < 5e-2
+    assert relmax(got["losses"], want["losses"]) < 5e-3             # 1e-3 observed
     np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
+    assert _param_rel(got, want) < 2e-2
     # the greedy herding picks after the first one are near-ties on this synthetic data (class = fixed pattern +
     # noise): the selection KERNEL is checked for exact equality with the reference's loop on given features in
     # test_kernels_gpu.py::test_ncm_and_herding_match_reference_math; here (features recomputed after two SGD steps
@@ -208,9 +209,10 @@ def test_lucir_golden(golden):
     got = sc.scenario_lucir(adapter("f32"))
     assert relmax(got["fc2_imprint_norm"], want["fc2_imprint_norm"]) < 1e-9
     assert relmax(got["losses"][:2], want["losses"][:2]) < 2e-4     # CE on the cosine head; first step with all 3 LUCIR terms
-    assert relmax(got["losses"], want["losses"]) < 2e-2
-    np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
-    assert relmax(got["fc2_w"], want["fc2_w"]) < 2e-2
+    assert relmax(got["losses"], want["losses"]) < 5e-4             # 3e-5 observed
+    np.testing.assert_array_equal(got["preds"], want["preds"])
+    assert relmax(got["fc2_w"], want["fc2_w"]) < 2e-3
+    assert _param_rel(got, want) < 2e-2
     got = sc.scenario_lucir(adapter("bf16"))
     assert relmax(got["losses"], want["losses"]) < 5e-2
 
@@ -219,18 +221,18 @@ def test_wa_golden(golden):
     want = golden("wa")
     got = sc.scenario_wa(adapter("f32"))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 2e-4     # the two CE steps of task 0
-    assert relmax(got["losses"], want["losses"]) < 3e-2             # (1-l) CE + l KD steps come after two updates: chaos bound
+    assert relmax(got["losses"], want["losses"]) < 3e-2             # 9e-3 observed at the 4th step (CPU fp32 oracle: 4e-3)
     np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
     # the logits head is outside the optimizer (reference quirk) and only the alignment rescales its new rows: exact
     np.testing.assert_allclose(got["head_before"], want["head_before"], rtol=1e-6)
     np.testing.assert_allclose(got["head_after"], want["head_after"], rtol=1e-5)
     assert abs(float(got["gamma"]) - float(want["gamma"])) < 1e-5
     assert str(got["buffer_calls"]) == str(want["buffer_calls"])
-    assert relmax(got["teacher_rm"], want["teacher_rm"]) < 2e-2      # second teacher = snapshot after all four updates (5e-3 observed)
-    # eval-mode logits of this 4-update net are not compared: with running statistics from four batch-8 steps the eval forward
-    # amplifies the 1e-2 drift of the stage-1 BN biases to 30 % (the CPU fp32 oracle is already 4 % off the fp64 reference);
-    # the eval forward itself matches the oracle at EQUAL parameters to 4e-7 (test_backbone_vs_oracle_random_init)
-    assert _param_rel(got, want) < 0.1
+    assert relmax(got["teacher_rm"], want["teacher_rm"]) < 1e-2      # second teacher = snapshot after all four updates (3e-3 observed)
+    # eval-mode logits of this 4-update net: running statistics from four batch-8 steps make the eval forward amplify the
+    # parameter drift (the CPU fp32 oracle is 4.4 % off the fp64 reference here; 4.6 % observed on the GPU)
+    assert relmax(got["logits_eval"], want["logits_eval"]) < 0.15
+    assert _param_rel(got, want) < 2.5e-2
     got = sc.scenario_wa(adapter("bf16"))
     assert relmax(got["losses"], want["losses"]) < 5e-2
     assert relmax(got["teacher_rm"], want["teacher_rm"]) < 3e-2
@@ -241,13 +243,13 @@ def test_der_golden(golden, monkeypatch):
     monkeypatch.setenv("CLHIP_DTYPE", "f32")          # DER builds its own extractors (der.py:31-41): dtype comes from the env
     got = sc.scenario_der(adapter("f32"))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 2e-4     # task-0 step, then the first two-extractor CE + aux CE step
-    assert relmax(got["losses"], want["losses"]) < 3e-2
-    np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
+    assert relmax(got["losses"], want["losses"]) < 2e-4             # 7e-6 observed
+    np.testing.assert_array_equal(got["preds"], want["preds"])
     assert bool(got["frozen_same"])                                  # frozen extractor: parameters bit-identical ...
     assert relmax(got["rm_frozen"], want["rm_frozen"]) < 1e-3        # ... but its BN running stats move (train mode quirk)
     assert relmax(got["rm_new"], want["rm_new"]) < 1e-3
-    assert relmax(got["logits_eval"], want["logits_eval"]) < 0.15     # eval-mode logits after 3 batch-4 updates (7e-2 observed)
-    assert _param_rel(got, want) < 0.1
+    assert relmax(got["logits_eval"], want["logits_eval"]) < 5e-3     # eval-mode logits after the three updates (9e-4 observed)
+    assert _param_rel(got, want) < 2e-3
     monkeypatch.setenv("CLHIP_DTYPE", "bf16")
     got = sc.scenario_der(adapter("bf16"))
     assert relmax(got["losses"], want["losses"]) < 5e-2

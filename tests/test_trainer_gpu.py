@@ -52,15 +52,17 @@ def test_methods_train_end_to_end(method, backbone, extra, monkeypatch):
         res[dtype] = out
         acc = out["acc_table"]
         assert np.isfinite(acc).all()
-        assert acc[0, 0] > 40.0, (method, dtype, acc)            # 4 classes: chance = 25 % (short run: eval-mode BN lags the batch statistics)
+        assert acc[0, 0] > 90.0, (method, dtype, acc)            # first task learned (96-100 % observed; chance 25-33 %)
         if method in ("ICarl", "LUCIR", "WA", "DER"):             # rehearsal methods fill their buffer
             assert len(tr.buffer.labels) > 0
         if method == "ICarl":                                     # NCM over the herded exemplars keeps the old classes alive
-            assert out["batch_last_acc"] > 14.0, (method, dtype, acc)   # 10 classes at the end: chance = 10 % (short noisy run)
+            assert out["batch_last_acc"] > 80.0, (method, dtype, acc)   # 10 classes at the end (92-100 % observed; chance 10 %)
         if method == "DER":                                       # one extractor per task, all but the last frozen
+            assert out["batch_last_acc"] > 60.0, (method, dtype, acc)   # frozen extractors keep the old tasks (71-80 % observed)
             assert len(tr.model.convnets) == 3 and tr.model.fc.in_features == 3 * 512
             assert not any(q.requires_grad for q in tr.model.convnets[0].parameters())
         if method == "WA":
+            assert out["batch_last_acc"] > 45.0, (method, dtype, acc)   # 9 classes (55-57 % observed: the untrained-head quirk caps it)
             assert tr.model.network.classifier.out_features == 9 and tr.model.old_network is not None
         torch.cuda.synchronize()
 
