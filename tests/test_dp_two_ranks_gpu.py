@@ -70,17 +70,20 @@ def test_two_ranks_train_in_lockstep_and_match_the_emulation(tmp_path):
     # equal up to the summation order of the fp32-atomic weight gradients (and sum-then-scale vs scale-in-step rounding)
     assert np.abs(flat - a["flat"]).max() <= 2e-3 * np.abs(flat).max()
     assert np.abs(reps[0].classifier.weight.detach().cpu().numpy() - a["head"]).max() <= 1e-4
-    np.testing.assert_allclose(reps[0].backbone._stats.cpu().numpy(), a["rm"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(reps[0].backbone._stats.cpu().numpy(), a["rm"], rtol=2e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("workload", ["lwf_resnet18_b50_task0", "icarl_resnet32_b50_task1"])
-def test_bench_contract_at_two_ranks(workload):
-    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--batch", "64",
+@pytest.mark.parametrize("workload,batch", [("lwf_resnet18_b50_task0", 64), ("icarl_resnet32_b50_task1", 64), ("ewc_resnet32_b50_task1", 64),
+                                            ("l2p_vitb16_b10_task1", 8), ("inflora_vitb16_b20_task1", 8)])
+def test_bench_contract_at_two_ranks(workload, batch):
+    """every bench workload through the N=2 path: the trainer-side reduce (ResNet methods, InfLoRA_OPT's lora_B bucket) and
+    the plugin-side reduce-then-clip of L2P"""
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--batch", str(batch),
                  "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                      # rank 0 prints ONE json line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * batch and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
-    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert abs(out["value"] - 2 * batch * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
