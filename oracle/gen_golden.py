@@ -74,6 +74,7 @@ def main(out_dir=None):
     jobs["ewc"] = lambda: scenarios.scenario_ewc(ad)
     jobs["lwf_resnet18"] = lambda: scenarios.scenario_lwf(ad)
     jobs["lwf_cifar_resnet32"] = lambda: scenarios.scenario_lwf(ad, dict(arch="cifar_resnet32", feat_dim=64, bs=8))
+    jobs["lwf_long"] = lambda: scenarios.scenario_lwf(ad, scenarios.LWF_LONG_CFG)
     jobs["lucir"] = lambda: scenarios.scenario_lucir(ad)
     jobs["wa"] = lambda: scenarios.scenario_wa(ad)
     jobs["der"] = lambda: scenarios.scenario_der(ad)

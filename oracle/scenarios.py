@@ -240,27 +240,35 @@ def scenario_ewc(adapter):
 
 # ----------------------------------------------------------------------------------- scenario: LwF
 LWF_CFG = dict(arch="resnet18", feat_dim=512, init=6, inc=2, bs=4, lr=0.02)
+# a longer trajectory through the same plugin: 6 + 6 steps with momentum, weight decay and a learning-rate drop inside each
+# task (fresh optimizer per task, trainer.py:294) -- pins the optimizer / scheduler / gradient-buffer handling over many steps
+LWF_LONG_CFG = dict(arch="cifar_resnet32", feat_dim=64, bs=32, lr=0.01, momentum=0.9, wd=5e-4, n0=6, n1=6, decay_at=4, tag="lwf_long")
 
 
 def scenario_lwf(adapter, cfg=None):
     """task 0: 1 step (CE); task 1: 2 steps with CE(new) + 3*KD(T=2) against the frozen copy whose BN is
     (quirk a10) in train mode.  SGD lr .1 without momentum (config/lwf.yaml:14-17)."""
     c = dict(LWF_CFG, **(cfg or {}))
-    tag = "lwf/" + c["arch"]
+    tag = c.get("tag", "lwf") + "/" + c["arch"]
     P, Bf = fx.det_backbone_state(c["arch"], tag)
     w0, b0 = fx.det_linear(tag + "/head0", c["init"], c["feat_dim"])
     w1, b1 = fx.det_linear(tag + "/head1", c["init"] + c["inc"], c["feat_dim"])
-    t0 = [fx.det_batch(f"{tag}/t0/{i}", c["bs"], 0, c["init"]) for i in range(1)]
-    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], c["init"], c["init"] + c["inc"]) for i in range(2)]
+    t0 = [fx.det_batch(f"{tag}/t0/{i}", c["bs"], 0, c["init"]) for i in range(c.get("n0", 1))]
+    t1 = [fx.det_batch(f"{tag}/t1/{i}", c["bs"], c["init"], c["init"] + c["inc"]) for i in range(c.get("n1", 2))]
     losses, preds = [], []
+    mom, wd, decay_at = c.get("momentum", 0.0), c.get("wd", 0.0), c.get("decay_at")      # decay_at: lr *= 0.1 from that step on
+
+    def lr_of(step):
+        return c["lr"] * (0.1 if decay_at is not None and step >= decay_at else 1.0)
     if adapter.kind == "oracle":
         net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()},
                      {k: v.clone() for k, v in Bf.items()}, w0.clone().requires_grad_(True), b0.clone().requires_grad_(True))
         m = om.LWF(net, c["init"], c["inc"])
 
         def run(batches):
-            opt = om.SGD(net.parameters(), c["lr"])
-            for x, y in batches:
+            opt = om.SGD(net.parameters(), c["lr"], mom, wd)
+            for i, (x, y) in enumerate(batches):
+                opt.lr = lr_of(i)
                 pred, acc, loss = m.observe(x, y, True)
                 opt.zero_grad(); loss.backward(); opt.step()
                 losses.append(loss.item()); preds.append(pred.numpy())
@@ -280,11 +288,13 @@ def scenario_lwf(adapter, cfg=None):
                 m.classifier.bias.data[old:] = adapter.to_dev(b[old:])
 
         def run(batches):
-            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"])
+            kw = dict(momentum=mom, weight_decay=wd) if (mom or wd) else {}
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], **kw)
+            sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: lr_of(e) / c["lr"])     # stepped per batch here
             m.train()
             for x, y in batches:
                 pred, acc, loss = m.observe(adapter.batch(x, y))
-                opt.zero_grad(); loss.backward(); opt.step()
+                opt.zero_grad(); loss.backward(); opt.step(); sched.step()
                 losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
         m.before_task(0, None, None, None); set_head(w0, b0, 0); run(t0)
         m.before_task(1, None, None, None); set_head(w1, b1, c["init"]); run(t1)
