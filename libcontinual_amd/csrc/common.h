@@ -112,3 +112,14 @@ static inline int ilog2_exact(int v) {   // -1 if not a power of two
     return l;
 }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: four v_add_f32 with a DPP source
+// modifier (quad_perm xor 1, xor 2, then row_half_mirror, row_mirror) -- no LDS crossbar traffic, no address arithmetic
+// (the __shfl_xor form compiles to ds_bpermute_b32 + address VALU + s_waitcnt per step)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
                 if (fr == 0) {
                     int c = (wn * NT + j) * 16 + fg * 4 + e;
                     red[(wm * 2 + 0) * BN + c] = s1;

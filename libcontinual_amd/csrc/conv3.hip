@@ -25,12 +25,31 @@ struct Conv3Params {
     double* stat_acc;   // alternative to `stats`: per-channel [stat_rep][2][Cd] fp64 sums, accumulated with atomics
     int stat_rep;       // number of accumulator replicas (power of two); a workgroup adds into replica blockIdx.x & (stat_rep - 1)
     int N, H, W, Cs, Cd, accumulate;
+    int wshift, hshift;  // log2(W), log2(H) when they are powers of two, else -1
     int M;               // N*H*W
     int np;              // patch pixels = BM + 2W + 2
     int patch_bytes;     // np*128 rounded up to 256
     int nbuf;            // patch buffers (2 when Cs > 64)
     int debug;           // perf experiments only (CLHIP_CONV3_DEBUG): 1 = skip weight streaming, 2 = skip MFMA
 };
+
+// 9-bit mask of the taps whose source pixel lies inside the image, for output pixel g (tap t = 3 r + s reads the pixel at
+// (h + dh, w + dw), dh = r - 1 / dw = s - 1 forward, mirrored for dgrad): border rows / columns knock out three taps each.
+// Image sides that are powers of two (every CIFAR-style layer) avoid the integer divisions.
+template <int MODE>
+__device__ __forceinline__ unsigned tap_mask(int g, const Conv3Params& p) {
+    int w, h;
+    if (p.wshift >= 0 && p.hshift >= 0) { w = g & (p.W - 1); h = (g >> p.wshift) & (p.H - 1); }
+    else { w = g % p.W; h = (g / p.W) % p.H; }
+    constexpr unsigned UP = MODE == 0 ? 0x007u : 0x1c0u, DOWN = MODE == 0 ? 0x1c0u : 0x007u;      // taps with dh = -1 / dh = +1
+    constexpr unsigned LEFT = MODE == 0 ? 0x049u : 0x124u, RIGHT = MODE == 0 ? 0x124u : 0x049u;  // taps with dw = -1 / dw = +1
+    unsigned m = 0x1ffu;
+    if (h == 0) m &= ~UP;
+    if (h == p.H - 1) m &= ~DOWN;
+    if (w == 0) m &= ~LEFT;
+    if (w == p.W - 1) m &= ~RIGHT;
+    return m;
+}
 
 __device__ __forceinline__ uint4 ldsq(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
@@ -67,17 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
     for (int i = 0; i < 4; ++i) {
         const int pl = wm * 64 + i * 16 + fr;               // tile-relative output pixel
         const int g = m0 + pl;
-        unsigned m = 0;
-        if (g < p.M) {
-            const int w = g % W, h = (g / W) % H;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t - 3 * r;
-                const int dh = MODE == 0 ? r - 1 : 1 - r, dw = MODE == 0 ? s - 1 : 1 - s;
-                if ((unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) m |= 1u << t;
-            }
-        }
-        tmask[i] = m;
+        tmask[i] = g < p.M ? tap_mask<MODE>(g, p) : 0u;
         xaddr[i] = (pl + halo) * PITCH + fg * 16;
     }
     int waddr[4];
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
             for (int j = 0; j < 4; ++j) {
                 const int cl = wn * 64 + j * 16 + fg * 4;
                 float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-                if (p.accumulate) {                          // dx += result: add in fp32, round once
+                if (MODE == 1 && p.accumulate) {                          // dx += result: add in fp32, round once
                     const int pix = m0 + pl, o = n0 + cl;
                     if (pix < p.M && o < p.Cd) {
                         const uint2 old = *reinterpret_cast<const uint2*>(p.dst + (size_t)pix * p.Cd + o);
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
         }
         __syncthreads();
     }
-    if (p.stats != nullptr || p.stat_acc != nullptr) {
+    if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float* red = reinterpret_cast<float*>(smem);        // [WM][2][BN]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -225,8 +234,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
                 if (fr == 0) {
                     const int cc = wn * 64 + j * 16 + fg * 4 + e;
                     red[(wm * 2 + 0) * BN + cc] = s1;
@@ -282,17 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
     for (int i = 0; i < 4; ++i) {
         const int pl = wm * 64 + i * 16 + fr;
         const int g = m0 + pl;
-        unsigned m = 0;
-        if (g < p.M) {
-            const int w = g % W, h = (g / W) % H;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t - 3 * r;
-                const int dh = MODE == 0 ? r - 1 : 1 - r, dw = MODE == 0 ? s - 1 : 1 - s;
-                if ((unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) m |= 1u << t;
-            }
-        }
-        tmask[i] = m;
+        tmask[i] = g < p.M ? tap_mask<MODE>(g, p) : 0u;
         xaddr[i] = (pl + halo) * PITCH + fg * 16;
     }
     int waddr[4][2];
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
             for (int j = 0; j < 4; ++j) {
                 const int cl = wn * 64 + j * 16 + fg * 4;
                 float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-                if (p.accumulate) {
+                if (MODE == 1 && p.accumulate) {
                     const int pix = m0 + pl, o = n0 + cl;
                     if (pix < p.M && o < p.Cd) {
                         const uint2 old = *reinterpret_cast<const uint2*>(p.dst + (size_t)pix * p.Cd + o);
@@ -440,7 +439,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
         }
         __syncthreads();
     }
-    if (p.stats != nullptr || p.stat_acc != nullptr) {
+    if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -449,8 +448,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
                 if (fr == 0) {
                     const int cc = wn * 64 + j * 16 + fg * 4 + e;
                     red[(wm * 2 + 0) * BN + cc] = s1;
@@ -528,7 +527,7 @@ int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats,
                        int mode, hipStream_t st) {
     Conv3Params p;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
-    p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1; p.N = N; p.H = H; p.W = W; p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;
+    p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1; p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;
     static const int dbg = getenv("CLHIP_CONV3_DEBUG") ? atoi(getenv("CLHIP_CONV3_DEBUG")) : 0;
     p.debug = dbg;
     Cfg3 c = pick3(p.M, Cd);
