@@ -123,3 +123,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
     return v;
 }
+
+// N independent 16-lane sums, step-major: between two dependent DPP adds of one value sit the N - 1 others, so the
+// VALU-write -> DPP-read hazard needs no s_nop padding
+template <int N>
+__device__ __forceinline__ void row16_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[q]), 0xB1, 0xF, 0xF, true));
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[q]), 0x4E, 0xF, 0xF, true));
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[q]), 0x141, 0xF, 0xF, true));
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[q]), 0x140, 0xF, 0xF, true));
+}

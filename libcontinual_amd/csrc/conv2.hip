@@ -273,20 +273,24 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
 
     if (p.stats != nullptr || p.stat_acc != nullptr) {
         float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN]; all LDS reads of the K loop are behind the last barrier
+        float sv[8 * NT];                                 // [j][e] sums, then [j][e] sums of squares
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
-                s1 = row16_sum(s1);
-                s2 = row16_sum(s2);
-                if (fr == 0) {
-                    int c = (wn * NT + j) * 16 + fg * 4 + e;
-                    red[(wm * 2 + 0) * BN + c] = s1;
-                    red[(wm * 2 + 1) * BN + c] = s2;
-                }
+                for (int i = 0; i < MT; ++i) { const float v = acc[i][j][e]; s1 += v; s2 = fmaf(v, v, s2); }
+                sv[j * 4 + e] = s1;
+                sv[4 * NT + j * 4 + e] = s2;
+            }
+        row16_sum_n(sv);
+        if (fr == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {                  // channels fg*4 .. fg*4+3 of tile j are contiguous: 16-byte stores
+                const int c = (wn * NT + j) * 16 + fg * 4;
+                *reinterpret_cast<float4*>(red + (wm * 2 + 0) * BN + c) = make_float4(sv[j * 4], sv[j * 4 + 1], sv[j * 4 + 2], sv[j * 4 + 3]);
+                *reinterpret_cast<float4*>(red + (wm * 2 + 1) * BN + c) = make_float4(sv[4 * NT + j * 4], sv[4 * NT + j * 4 + 1], sv[4 * NT + j * 4 + 2], sv[4 * NT + j * 4 + 3]);
             }
         }
         __syncthreads();

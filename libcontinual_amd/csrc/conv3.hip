@@ -227,20 +227,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
     }
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float* red = reinterpret_cast<float*>(smem);        // [WM][2][BN]
+        float sv[32];                                     // [j][e] sums, then [j][e] sums of squares
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { float v = acc[i][j][e]; s1 += v; s2 += v * v; }
-                s1 = row16_sum(s1);
-                s2 = row16_sum(s2);
-                if (fr == 0) {
-                    const int cc = wn * 64 + j * 16 + fg * 4 + e;
-                    red[(wm * 2 + 0) * BN + cc] = s1;
-                    red[(wm * 2 + 1) * BN + cc] = s2;
-                }
+                for (int i = 0; i < 4; ++i) { const float v = acc[i][j][e]; s1 += v; s2 = fmaf(v, v, s2); }
+                sv[j * 4 + e] = s1;
+                sv[16 + j * 4 + e] = s2;
+            }
+        row16_sum_n(sv);
+        if (fr == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                   // channels fg*4 .. fg*4+3 of tile j are contiguous: 16-byte stores
+                const int cc = wn * 64 + j * 16 + fg * 4;
+                *reinterpret_cast<float4*>(red + (wm * 2 + 0) * BN + cc) = make_float4(sv[j * 4], sv[j * 4 + 1], sv[j * 4 + 2], sv[j * 4 + 3]);
+                *reinterpret_cast<float4*>(red + (wm * 2 + 1) * BN + cc) = make_float4(sv[16 + j * 4], sv[17 + j * 4], sv[18 + j * 4], sv[19 + j * 4]);
             }
         }
         __syncthreads();
