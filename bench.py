@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (must be set before the HIP runtime starts)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -20,6 +20,8 @@ def init_distributed(device_is_cuda=True):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # this pool's host driver only supports dmabuf IPC: without it RCCL's peer setup fails with hipIpcGetMemHandle errors
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # CLHIP_DIST_BACKEND=gloo: test hook -- several ranks sharing ONE GPU (RCCL refuses duplicate devices; gloo stages
