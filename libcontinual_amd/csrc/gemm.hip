@@ -24,6 +24,7 @@ struct GemmParams {
     const void* A; const void* B; void* C;
     const float* bias; const void* R; void* H;
     int M, N, K, lda, ldb, ldc, ldr, ldh;
+    int group_m;      // row panels per rasterisation group (gemm_nt_kernel), 1 = plain row-major
 };
 
 template <typename T> struct Chunk;
@@ -188,7 +189,18 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    // within an XCD's range the tiles are walked in groups of GM row panels, column-major inside a group: the ~32 workgroups an
+    // XCD runs at a time then cover a GM x (32 / GM) block of tiles and share GM + 32 / GM operand panels in its L2 instead of
+    // 1 + 32 (row-major order on 8192^3: L2 hit rate 50 %, 4.6 GB of misses per launch -- profiles/r01_gemm_ablation.txt)
+    int tm, tn;
+    {
+        const int GM = p.group_m;
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int per = GM * tiles_n, grp = wg / per, in = wg - grp * per;
+        const int first = grp * GM, gsz = min(tiles_m - first, GM);
+        tn = in / gsz;
+        tm = first + (in - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const T* A = static_cast<const T*>(p.A);
@@ -627,7 +639,8 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
     if (epilogue == EPI_BIAS_RES) CLHIP_CHECK_ARG(R != nullptr && ldr % 4 == 0);
     if (epilogue == EPI_MUL) CLHIP_CHECK_ARG(H != nullptr);
     if (H) CLHIP_CHECK_ARG(ldh % 4 == 0);
-    GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh};
+    static const int gm_env = getenv("CLHIP_GEMM_GROUP_M") ? atoi(getenv("CLHIP_GEMM_GROUP_M")) : 0;
+    GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, gm_env > 0 ? gm_env : (N >= 4096 ? 4 : 1)};     // wide outputs: 8192^3 991 -> 1046 TFLOP/s; the ViT shapes (N <= 3072) are indifferent
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == CLHIP_BF16 ? dispatch<bf16_t>(epilogue, p, s) : dispatch<float>(epilogue, p, s);
 }
