@@ -254,6 +254,8 @@ def main():
     def run(n):
         train_steps(model, opt, (batches[i % len(batches)] for i in range(n)), reducer, name, meter, dev)
 
+    from libcontinual_amd.utils import quiesce_gc
+    quiesce_gc()          # what Trainer.train_loop does after building a task's optimizer (no 80 ms generation-2 GC stalls mid-epoch)
     run(a.warmup)
     torch.cuda.synchronize()
     if world > 1:

@@ -24,7 +24,7 @@ from torch.utils.data import DataLoader
 
 from . import ops, parallel
 from . import scheduler as sched
-from .utils import AverageMeter, compute_bwt, compute_frgt, count_all_parameters, count_parameters, get_instance, init_seed
+from .utils import AverageMeter, compute_bwt, compute_frgt, count_all_parameters, count_parameters, get_instance, init_seed, quiesce_gc
 
 _OBSERVE_DOES_BACKWARD = ("L2P",)      # core/trainer.py:593-596 (subset on the hot path)
 
@@ -171,6 +171,7 @@ class Trainer:
                 model.before_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))
             self.log(f"Trainable Parameters for Task {task_idx} : {count_parameters(model)} / {count_all_parameters(model)}")
             _, _, self.optimizer, self.scheduler = self._init_optim(self.config)
+            quiesce_gc()                                  # model, optimizer and loaders of this task are built: keep them out of later GC passes
             dataloader = self.train_loader.get_loader(task_idx)
             from .model.buffer import LinearBuffer, LinearHerdingBuffer
             if isinstance(self.buffer, (LinearBuffer, LinearHerdingBuffer)) and self.buffer.buffer_size > 0 and task_idx > 0:

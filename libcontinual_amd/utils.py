@@ -60,6 +60,16 @@ class AverageMeter:
         return self._total[key]
 
 
+def quiesce_gc():
+    """Collect once, then move every surviving object to the permanent generation (`gc.freeze`).  A training process holds
+    ~10^6 long-lived Python objects (torch, numpy, the model); every generation-2 collection walks all of them -- measured
+    80-90 ms of host stall in the middle of a 30-step bench run, during which the launch queue drains and the GPU idles.
+    After the freeze a full collection only visits what was allocated since, i.e. the per-step garbage."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def init_seed(seed=0, deterministic=False):
     os.environ["PYTHONHASHSEED"] = str(seed)
     random.seed(seed)
