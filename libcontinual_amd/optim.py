@@ -37,8 +37,8 @@ class _FusedBase(torch.optim.Optimizer):
         owners = _tag_backbones(params)
         whole, covered = [], set()
         for oid, (o, ps) in owners.items():
-            if len(ps) == len(o._params) and all(p.grad is not None for p in o._params) and o._gflat is not None:
-                ok = all(p.grad.data_ptr() == o._gflat.data_ptr() + 4 * o._layout[i][2] for i, p in enumerate(o._params))
+            if len(ps) == len(o._params) and o._gflat is not None and all(p.grad is not None for p in o._params):
+                ok = o.grads_attached() or all(p.grad.data_ptr() == o._gflat.data_ptr() + 4 * o._layout[i][2] for i, p in enumerate(o._params))
                 if ok:
                     whole.append(o)
                     covered.update(id(p) for p in ps)
