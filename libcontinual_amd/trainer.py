@@ -225,6 +225,11 @@ class Trainer:
                         break
                 else:
                     self.scheduler.step()
+            if self.distribute:
+                # parameters are identical on every rank (same reduced gradients); BatchNorm running statistics are not (per-rank
+                # batches).  Before anything is DERIVED from the model -- herding picks, class means, Fisher, evaluation -- every
+                # rank takes rank 0's buffers (what DDP's broadcast_buffers does on every forward), so the replicas stay one model
+                parallel.broadcast_module_state(model)
             if hasattr(model, "after_task"):
                 self.hook_trace.append(("after_task", task_idx, -1))
                 model.after_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))

@@ -39,8 +39,10 @@ def main(out_dir, steps):
     train_steps(m, opt, [batch(1000 * rank + i) for i in range(steps)], red, "LWF", None, "cuda")
     torch.cuda.synchronize()
     flat = m.backbone.flat_parameters()[0]
+    rm = m.backbone._stats.cpu().numpy()
+    parallel.broadcast_module_state(m)                 # what the Trainer does before after_task: rank 0's running statistics everywhere
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=flat.cpu().numpy(), head=m.classifier.weight.detach().cpu().numpy(),
-             rm=m.backbone._stats.cpu().numpy())
+             rm=rm, rm_synced=m.backbone._stats.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
