@@ -307,7 +307,11 @@ int clhip_l2p_scatter(const float* dtokens, const int* ids, float* dprompt_pool,
 
 /* Whole-backbone executor: one C call per forward / backward (VisionTransformer.forward, transformer.py:2222-2294, and
  * the autograd backward of L2P.observe / the trainer's loss.backward()). */
-typedef struct clhip_vit_desc { int32_t img, patch, dim, depth, heads, mlp, lora_rank; } clhip_vit_desc;
+typedef struct clhip_vit_desc {
+    int32_t img, patch, dim, depth, heads, mlp, lora_rank;
+    float block_ln_eps;   /* eps of the per-block LayerNorms: 0 -> 1e-5 (transformer.py nn.LayerNorm default); timm-style trees
+                           * (vit_inflora.py:375) use 1e-6 everywhere.  The final norm is 1e-6 in both. */
+} clhip_vit_desc;
 typedef struct clhip_vit_layer_params {
     const float *qkv_w, *qkv_b, *proj_w, *proj_b, *ln1_w, *ln1_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln2_w, *ln2_b;
     const float *lora_a_k, *lora_b_k, *lora_a_v, *lora_b_v;          /* NULL without LoRA */

@@ -27,7 +27,7 @@ class UnitDesc(C.Structure):
 
 
 class VitDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("img", "patch", "dim", "depth", "heads", "mlp", "lora_rank")]
+    _fields_ = [(n, C.c_int32) for n in ("img", "patch", "dim", "depth", "heads", "mlp", "lora_rank")] + [("block_ln_eps", C.c_float)]
 
 
 class VitLayerParams(C.Structure):

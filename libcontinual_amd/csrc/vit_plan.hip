@@ -172,6 +172,7 @@ extern "C" int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const 
     char* ws = static_cast<char*>(workspace);
     const char* sh = static_cast<const char*>(shadow);
     const int D = d.dim, Hm = d.mlp, M = L.M, N = L.N, dt = v->dtype;
+    const float beps = d.block_ln_eps > 0.f ? d.block_ln_eps : 1e-5f;
     // patch embedding (timm PatchEmbed = Conv2d(3, D, p, stride p)) as patchify + GEMM, then token assembly
     TRY(clhip_patchify(images, ws + L.patches, B, d.img, d.patch, dt, stream));
     TRY(clhip_gemm_nt(ws + L.patches, sh + v->pe_f, ws + L.pe_out, P->pe_b, nullptr, nullptr, B * v->np, D, v->Kp, v->Kp, v->Kp, D, 0, 0, EPI_BIAS, dt, stream));
@@ -182,12 +183,12 @@ extern "C" int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const 
         float* st1 = reinterpret_cast<float*>(ws + L.st1[l]);
         float* st2 = reinterpret_cast<float*>(ws + L.st2[l]);
         char* h1 = ws + L.h1[l];
-        TRY(clhip_ln_fwd(ws + L.x_in[l], p.ln1_w, p.ln1_b, h1, st1, st1 + M, M, D, 1e-5f, dt, stream));
+        TRY(clhip_ln_fwd(ws + L.x_in[l], p.ln1_w, p.ln1_b, h1, st1, st1 + M, M, D, beps, dt, stream));
         if (gram) TRY(clhip_gram_accum(h1, gram + (size_t)l * D * D, M, D, dt, stream));
         TRY(clhip_gemm_nt(h1, sh + s.qkv_f, ws + L.qkv[l], p.qkv_b, nullptr, nullptr, M, 3 * D, D, D, D, 3 * D, 0, 0, EPI_BIAS, dt, stream));
         TRY(clhip_attn_fwd(ws + L.qkv[l], ws + L.attn_o[l], reinterpret_cast<float*>(ws + L.lse[l]), B, N, d.heads, D, dt, stream));
         TRY(clhip_gemm_nt(ws + L.attn_o[l], sh + s.proj_f, ws + L.x_mid[l], p.proj_b, ws + L.x_in[l], nullptr, M, D, D, D, D, D, D, 0, EPI_BIAS_RES, dt, stream));
-        TRY(clhip_ln_fwd(ws + L.x_mid[l], p.ln2_w, p.ln2_b, ws + L.ln_out, st2, st2 + M, M, D, 1e-5f, dt, stream));
+        TRY(clhip_ln_fwd(ws + L.x_mid[l], p.ln2_w, p.ln2_b, ws + L.ln_out, st2, st2 + M, M, D, beps, dt, stream));
         TRY(clhip_gemm_nt(ws + L.ln_out, sh + s.fc1_f, ws + L.act, p.fc1_b, nullptr, save ? ws + L.hpre[l] : nullptr, M, Hm, D, D, D, Hm, 0, Hm, EPI_BIAS_GELU, dt,
                           stream));
         TRY(clhip_gemm_nt(ws + L.act, sh + s.fc2_f, ws + L.x_in[l + 1], p.fc2_b, ws + L.x_mid[l], nullptr, M, D, Hm, Hm, Hm, D, D, 0, EPI_BIAS_RES, dt, stream));

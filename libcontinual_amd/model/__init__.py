@@ -11,4 +11,5 @@ from .wa import WA  # noqa: F401
 from .der import DER  # noqa: F401
 from .l2p import L2P  # noqa: F401
 from .inflora_opt import InfLoRA_OPT  # noqa: F401
+from .inflora import InfLoRA  # noqa: F401
 from .heads import HipLinear  # noqa: F401

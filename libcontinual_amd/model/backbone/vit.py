@@ -214,7 +214,8 @@ class VisionTransformer(nn.Module):
     def _ensure(self, dev):
         s = self._s
         if s.handle is None:
-            desc = _lib.VitDesc(self.img_size, self.patch_size, self.embed_dim, self.depth, self.num_heads, self.mlp_dim, self.lora_rank)
+            desc = _lib.VitDesc(self.img_size, self.patch_size, self.embed_dim, self.depth, self.num_heads, self.mlp_dim, self.lora_rank,
+                                float(getattr(self, "block_ln_eps", 0.0)))
             h = _lib.lib().clhip_vit_create(C.byref(desc), _DT[self.compute_dtype][0])
             if not h:
                 raise _lib.ClhipError(_lib.lib().clhip_last_error().decode())

@@ -58,6 +58,37 @@ def reference_vit_namespace():
         zoo.prompt, zoo.prompt_flag = None, ""
         return zoo
     ns.make_vit = make_vit
+
+    def make_sinet(cfg, total_sessions, rank, init_cls):
+        """SiNet_vit.__init__ downloads vit_base_patch16_224_in21k (SiNet.py:72-73): the same object graph around a small
+        ViT_lora_co"""
+        sn = ref_shim.load("core.model.backbone.SiNet")
+        net = sn.SiNet_vit.__new__(sn.SiNet_vit)
+        torch.nn.Module.__init__(net)
+        net.image_encoder = sn.ViT_lora_co(img_size=cfg["img"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
+                                           num_heads=cfg["heads"], n_tasks=total_sessions, rank=rank)
+        net.class_num = init_cls
+        net.classifier_pool = torch.nn.ModuleList([torch.nn.Linear(cfg["dim"], init_cls, bias=True) for _ in range(total_sessions)])
+        net.classifier_pool_backup = torch.nn.ModuleList([torch.nn.Linear(cfg["dim"], init_cls, bias=True) for _ in range(total_sessions)])
+        net.numtask = 0
+        return net
+    ns.make_sinet = make_sinet
+    inflora_mod = ref_shim.load("core.model.InfLoRA")
+    # InfLoRA.py hands torch tensors to np.linalg.svd.  Under the numpy 1.x it was written for, linalg results come back as
+    # ndarrays (`_makearray` looks for `__array_prepare__`); numpy 2.x looks for `__array_wrap__`, which torch defines, returns
+    # Tensors and the method's next line (`feature_list[p].transpose()`, InfLoRA.py:207) raises.  Give the module numpy-1.x
+    # behaviour: a `np` whose linalg.svd sees ndarrays.
+    real_np = inflora_mod.np
+    proxy_linalg = types.SimpleNamespace(**{k: getattr(real_np.linalg, k) for k in dir(real_np.linalg) if not k.startswith("_")})
+    proxy_linalg.svd = lambda a, *args, **kw: real_np.linalg.svd(real_np.asarray(a), *args, **kw)
+
+    class _Np1:
+        linalg = proxy_linalg
+
+        def __getattr__(self, k):
+            return getattr(real_np, k)
+    inflora_mod.np = _Np1()
+    ns.InfLoRA = inflora_mod.InfLoRA
     ns.L2P = ref_shim.load("core.model.l2p").L2P
     ns.InfLoRA_OPT = ref_shim.load("core.model.InfLoRA_opt").InfLoRA_OPT
     return ns
@@ -94,6 +125,7 @@ def main(out_dir=None):
     jobs["vit_backbone"] = vit_job(vit_scenarios.scenario_vit_backbone)
     jobs["l2p"] = vit_job(vit_scenarios.scenario_l2p)
     jobs["inflora"] = vit_job(vit_scenarios.scenario_inflora)
+    jobs["inflora_orig"] = vit_job(vit_scenarios.scenario_inflora_orig)
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

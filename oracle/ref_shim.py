@@ -79,13 +79,42 @@ def install_vit_standins():
         def forward(self, x):
             return x
 
+    class Mlp(nn.Module):
+        """timm.models.layers.Mlp: fc1 -> act -> drop -> fc2 -> drop"""
+
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            assert drop == 0.0
+            self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    def named_apply(fn, module, name="", depth_first=True, include_root=False):
+        """timm.models.helpers.named_apply"""
+        if not depth_first and include_root:
+            fn(module=module, name=name)
+        for cn, cm in module.named_children():
+            named_apply(fn, cm, ".".join((name, cn)) if name else cn, depth_first, True)
+        if depth_first and include_root:
+            fn(module=module, name=name)
+        return module
+
+    def lecun_normal_(t):
+        fan_in = t.shape[1] if t.dim() > 1 else t.shape[0]
+        return torch.nn.init.trunc_normal_(t, std=(1.0 / fan_in) ** 0.5 / .87962566103423978)
+
     ident = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
     mod("timm", create_model=None)
     mod("timm.models")
     mod("timm.models.vision_transformer", PatchEmbed=PatchEmbed, _cfg=lambda **k: dict(k))
-    mod("timm.models.layers", trunc_normal_=torch.nn.init.trunc_normal_, DropPath=DropPath)
+    mod("timm.models.layers", trunc_normal_=torch.nn.init.trunc_normal_, DropPath=DropPath, PatchEmbed=PatchEmbed, Mlp=Mlp, lecun_normal_=lecun_normal_)
     mod("timm.models.registry", register_model=ident)
-    mod("timm.models.helpers", named_apply=None, adapt_input_conv=None)
+    mod("timm.models.helpers", named_apply=named_apply, adapt_input_conv=None, build_model_with_cfg=None, resolve_pretrained_cfg=None, checkpoint_seq=None)
+    mod("timm.data", IMAGENET_DEFAULT_MEAN=(0.485, 0.456, 0.406), IMAGENET_DEFAULT_STD=(0.229, 0.224, 0.225),
+        IMAGENET_INCEPTION_MEAN=(0.5, 0.5, 0.5), IMAGENET_INCEPTION_STD=(0.5, 0.5, 0.5))
     mod("torchvision")
     mod("torchvision.models")
     mod("ftfy", fix_text=lambda t: t)

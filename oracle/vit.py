@@ -106,17 +106,17 @@ def attention(P, b, x, heads, lora=False):
     return F.linear(o, P[b + "attn.proj.weight"], P[b + "attn.proj.bias"])
 
 
-def block(P, i, x, heads, lora=False, gram=None):
+def block(P, i, x, heads, lora=False, gram=None, eps=1e-5):
     """pre-LN residual block (transformer.py:1331-1336); `gram` collects the attention input's X^T X and token
     count (transformer.py:241-244)"""
     b = f"feat.transformer.blocks.{i}."
     D = x.shape[-1]
-    h = F.layer_norm(x, (D,), P[b + "ln_1.weight"], P[b + "ln_1.bias"], 1e-5)
+    h = F.layer_norm(x, (D,), P[b + "ln_1.weight"], P[b + "ln_1.bias"], eps)
     if gram is not None:
         hd = h.detach()
         gram.append((torch.einsum("bni,bnj->ij", hd, hd), hd.shape[0] * hd.shape[1]))
     x = x + attention(P, b, h, heads, lora)
-    h = F.layer_norm(x, (D,), P[b + "ln_2.weight"], P[b + "ln_2.bias"], 1e-5)
+    h = F.layer_norm(x, (D,), P[b + "ln_2.weight"], P[b + "ln_2.bias"], eps)
     h = F.linear(F.gelu(F.linear(h, P[b + "mlp.fc1.weight"], P[b + "mlp.fc1.bias"])), P[b + "mlp.fc2.weight"], P[b + "mlp.fc2.bias"])
     return x + h
 
@@ -130,7 +130,7 @@ def tokens(P, img, cfg):
 
 def encode(P, x, cfg, lora=False, gram=None, acts=None):
     for i in range(cfg["depth"]):
-        x = block(P, i, x, cfg["heads"], lora, gram)
+        x = block(P, i, x, cfg["heads"], lora, gram, cfg.get("block_eps", 1e-5))
         if acts is not None:
             acts.append(x)
     D = x.shape[-1]
@@ -375,3 +375,134 @@ class Adam:
                 mh = m / (1 - self.b1 ** self.t)
                 vh = v / (1 - self.b2 ** self.t)
                 p.sub_(self.lr * mh / (vh.sqrt() + self.eps))
+
+
+# --------------------------------------------------------------------------------- InfLoRA (original, multi-branch)
+class InfLoRAOrig:
+    """InfLoRA.py:36-308 over SiNet.py:62-156 / vit_inflora.py:176-263 (timm tree: every LayerNorm has eps 1e-6 ->
+    cfg['block_eps']).  P: backbone under the oracle's names, `...attn.lora_{A,B}_{k,v}.{t}.weight` per task and
+    `classifier_pool.{t}.*`; the forward applies the pairs of ALL tasks up to the running one."""
+
+    def __init__(self, P, cfg, inc_cls, total_sessions, lame, lamb, rank):
+        self.P, self.cfg, self.rank = P, dict(cfg, block_eps=1e-6), rank
+        self.inc_cls, self.total_sessions, self.lame, self.lamb = inc_cls, total_sessions, lame, lamb
+        self.known = self.total = 0
+        self.cur_task = -1
+        self.feature_list, self.project_type, self.feature_mat = [], [], []
+        self.trainable = []
+
+    def _blocks(self):
+        return [f"feat.transformer.blocks.{i}." for i in range(self.cfg["depth"])]
+
+    def _view(self):
+        """parameter dict of a single-pair LoRA ViT equivalent to the multi-branch forward of task `cur_task`:
+        finished pairs folded (without gradient) into qkv.weight, the running task's pair as the LoRA branch"""
+        t, D = self.cur_task, self.cfg["dim"]
+        V = dict(self.P)
+        for b in self._blocks():
+            W = self.P[b + "attn.qkv.weight"].detach().clone()
+            for s_ in range(t):
+                W[D:2 * D] += (self.P[f"{b}attn.lora_B_k.{s_}.weight"] @ self.P[f"{b}attn.lora_A_k.{s_}.weight"]).detach()
+                W[2 * D:] += (self.P[f"{b}attn.lora_B_v.{s_}.weight"] @ self.P[f"{b}attn.lora_A_v.{s_}.weight"]).detach()
+            V[b + "attn.qkv.weight"] = W
+            for n in ("lora_A_k", "lora_B_k", "lora_A_v", "lora_B_v"):
+                V[f"{b}attn.{n}.weight"] = self.P[f"{b}attn.{n}.{max(t, 0)}.weight"]
+        return V
+
+    def features(self, x, gram=None):
+        return cls_features(self._view(), x, self.cfg, self.cur_task >= 0, gram)
+
+    def _head(self, f, t):
+        return F.linear(f, self.P[f"classifier_pool.{t}.weight"], self.P[f"classifier_pool.{t}.bias"])
+
+    def observe(self, x, y):
+        y = y - self.known
+        logits = self._head(self.features(x), self.cur_task)
+        loss = F.cross_entropy(logits, y)
+        pred = logits.argmax(1)
+        return pred, (pred == y).sum().item() / y.shape[0], loss
+
+    def inference(self, x, y):
+        with torch.no_grad():
+            f = self.features(x)
+            logits = torch.cat([self._head(f, t) for t in range(self.cur_task + 1)], 1)
+        pred = logits.argmax(1)
+        return pred, (pred == y).sum().item() / y.shape[0]
+
+    def parameters(self):
+        return [self.P[n] for n in self.trainable]
+
+    def _gram(self, batches):
+        cur = [torch.zeros(self.cfg["dim"], self.cfg["dim"], dtype=next(iter(self.P.values())).dtype) for _ in self._blocks()]
+        n = [0] * len(cur)
+        with torch.no_grad():
+            for x in batches:
+                g = []
+                self.features(x, g)
+                for i, (m, cnt) in enumerate(g):
+                    cur[i] = (cur[i] * n[i] + m) / (n[i] + cnt)
+                    n[i] += cnt
+        return cur
+
+    def before_task(self, batches):
+        """InfLoRA.py:108-183"""
+        self.known = self.total
+        self.cur_task += 1
+        self.total = self.known + self.inc_cls
+        t = self.cur_task
+        self.trainable = [n for n in self.P if n.startswith(f"classifier_pool.{t}.") or f"lora_B_k.{t}." in n or f"lora_B_v.{t}." in n]
+        for n, p in self.P.items():
+            p.requires_grad_(n in self.trainable)
+        cur = self._gram(batches)                       # B_t = 0: the running pair does not change this pass
+        for i, b in enumerate(self._blocks()):
+            m = cur[i]
+            if t > 0:
+                fm = self.feature_mat[i].to(m.dtype)
+                m = m - fm @ m if self.project_type[i] == "remove" else fm @ m
+            U = torch.linalg.svd(m, full_matrices=False)[0]
+            A = (U[:, : self.rank].T / math.sqrt(3)).clone()
+            self.P[f"{b}attn.lora_A_k.{t}.weight"] = A.clone()
+            self.P[f"{b}attn.lora_A_v.{t}.weight"] = A.clone()
+
+    def after_task(self, batches):
+        """InfLoRA.py:185-308"""
+        cur = self._gram(batches)
+        thr = (self.lame - self.lamb) * self.cur_task / self.total_sessions + self.lamb
+        first = len(self.feature_list) == 0
+        for i in range(len(cur)):
+            act = cur[i].numpy()
+            if first:
+                U, S, _ = np.linalg.svd(act, full_matrices=False)
+                r = int(np.sum(np.cumsum(S ** 2 / (S ** 2).sum()) < thr))
+                self.feature_list.append(U[:, : max(r, 1)])
+                self.project_type.append("remove" if r < act.shape[0] / 2 else "retain")
+                continue
+            total = (np.linalg.svd(act, compute_uv=False) ** 2).sum()
+            f = self.feature_list[i]
+            if self.project_type[i] == "remove":
+                U, S, _ = np.linalg.svd(act - f @ f.T @ act, full_matrices=False)
+                ratio, acc, r = S ** 2 / total, (total - (S ** 2).sum()) / total, 0
+                for v in ratio:
+                    if acc < thr:
+                        acc += v; r += 1
+                    else:
+                        break
+                if r:
+                    Ui = np.hstack((f, U[:, :r]))
+                    self.feature_list[i] = Ui[:, : Ui.shape[0]] if Ui.shape[1] > Ui.shape[0] else Ui
+            else:
+                U, S, _ = np.linalg.svd(f @ f.T @ act, full_matrices=False)
+                ratio, acc, r = S ** 2 / total, (S ** 2).sum() / total, 0
+                for v in ratio:
+                    if acc >= 1 - thr:
+                        acc -= v; r += 1
+                    else:
+                        break
+                if r:
+                    rest = f - U[:, :r] @ U[:, :r].T @ f
+                    self.feature_list[i] = np.linalg.svd(rest)[0][:, : f.shape[1] - r]
+        for i, f in enumerate(self.feature_list):
+            if self.project_type[i] == "remove" and f.shape[1] > f.shape[0] / 2:
+                self.feature_list[i] = np.linalg.svd(f)[0][:, f.shape[1]:]
+                self.project_type[i] = "retain"
+        self.feature_mat = [torch.as_tensor(f @ f.T) for f in self.feature_list]

@@ -262,3 +262,108 @@ def scenario_inflora(adapter):
     res["losses"] = np.asarray(losses, np.float64)
     res["preds"] = np.stack(preds)
     return res
+
+
+# ------------------------------------------------------------------------------- InfLoRA (original, multi-branch)
+# the reference resizes the inputs of its Gram passes to 224 (InfLoRA.py:147, 194) whatever the model: the fixture model
+# therefore takes 224 x 224 images (4 x 4 patches of 56 pixels), everything else as small as the other ViT fixtures
+ORIG_VIT = dict(img=224, patch=56, dim=128, depth=2, heads=2, mlp=512)
+ORIG_CFG = dict(inc=3, total_sessions=3, lame=0.9, lamb=0.6, rank=4, bs=4, lr=0.05, momentum=0.9)
+
+
+def _timm_name(k):
+    """oracle / transformer.py parameter name -> timm tree of SiNet_vit.image_encoder"""
+    k = k.replace("feat.transformer.blocks.", "blocks.").replace("feat.", "").replace(".ln_1.", ".norm1.").replace(".ln_2.", ".norm2.")
+    return "image_encoder." + k
+
+
+def _orig_state(tag):
+    c, D = ORIG_CFG, ORIG_VIT["dim"]
+    P = {k: v.to(fx._DTYPE[0]) for k, v in ov.det_params(ORIG_VIT, tag, 0, torch.float64).items()}
+    b = 1.0 / np.sqrt(D)
+    for i in range(ORIG_VIT["depth"]):
+        blk = f"feat.transformer.blocks.{i}.attn."
+        for t in range(c["total_sessions"]):
+            P.update(det_extra(tag, {f"{blk}lora_A_k.{t}.weight": (c["rank"], D), f"{blk}lora_A_v.{t}.weight": (c["rank"], D)}, -b, b))
+            P[f"{blk}lora_B_k.{t}.weight"] = torch.zeros(D, c["rank"], dtype=fx._DTYPE[0])
+            P[f"{blk}lora_B_v.{t}.weight"] = torch.zeros(D, c["rank"], dtype=fx._DTYPE[0])
+    for t in range(c["total_sessions"]):
+        P.update(det_extra(tag, {f"classifier_pool.{t}.weight": (c["inc"], D), f"classifier_pool.{t}.bias": (c["inc"],)}, -b, b))
+    return P
+
+
+def scenario_inflora_orig(adapter):
+    """2 of 3 tasks of the original InfLoRA: before_task (Gram -> [projection] -> SVD -> this task's lora_A), 2 SGD steps on this
+    task's lora_B pair + head, after_task (DualGPM), inference over all heads with all pairs applied."""
+    c, V = ORIG_CFG, ORIG_VIT
+    tag = "inflora_orig"
+    P = _orig_state(tag)
+    D, depth = V["dim"], V["depth"]
+    xs = [det_images(f"{tag}/x{i}", c["bs"], V) for i in range(4)]
+    ys = [det_labels(f"{tag}/y{i}", c["bs"], 0 if i < 2 else c["inc"], c["inc"] if i < 2 else 2 * c["inc"]) for i in range(4)]
+    tx, ty = det_images(tag + "/tx", c["bs"], V), det_labels(tag + "/ty", c["bs"], 0, 2 * c["inc"])
+    res, losses, preds = {}, [], []
+    blocks = [f"feat.transformer.blocks.{i}." for i in range(depth)]
+    probe = detrand.uniform(tag + "/probe", (D, 6), -1.0, 1.0)
+
+    def record(t, get, feature_list, project_type):
+        for i, b in enumerate(blocks):
+            A = _np(get(f"{b}attn.lora_A_k.{t}.weight"))
+            res[f"AtA{i}@{t}"] = A.T @ (A @ probe)
+            Bk, Bv = _np(get(f"{b}attn.lora_B_k.{t}.weight")), _np(get(f"{b}attn.lora_B_v.{t}.weight"))
+            res[f"BAk{i}@{t}"] = Bk @ (A @ probe)                       # sign-invariant: B_t A_t applied to the probe
+            res[f"BAv{i}@{t}"] = Bv @ (_np(get(f"{b}attn.lora_A_v.{t}.weight")) @ probe)
+            f = np.asarray(feature_list[i], np.float64)
+            res[f"proj{i}@{t}"] = f @ (f.T @ probe)
+            res[f"rank{i}@{t}"] = np.asarray(f.shape[1])
+        res[f"ptype@{t}"] = np.asarray([p == "retain" for p in project_type])
+
+    if adapter.kind == "oracle":
+        P = {k: v.clone() for k, v in P.items()}
+        m = ov.InfLoRAOrig(P, V, c["inc"], c["total_sessions"], c["lame"], c["lamb"], c["rank"])
+        from .methods import SGD
+        for t in range(2):
+            bx = [xs[2 * t], xs[2 * t + 1]]
+            m.before_task(bx)
+            opt = SGD(m.parameters(), c["lr"], c["momentum"], 0.0)
+            for i in (2 * t, 2 * t + 1):
+                pred, acc, loss = m.observe(xs[i], ys[i])
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.detach())); preds.append(pred.numpy())
+            m.after_task(bx)
+            record(t, lambda n: m.P[n], m.feature_list, m.project_type)
+            p, a = m.inference(tx, ty)
+            res[f"test_pred{t}"] = p.numpy()
+            res[f"head{t}@{t}"] = _np(m.P[f"classifier_pool.{t}.weight"])
+    else:
+        ns = adapter.ns
+        net = ns.make_sinet(V, c["total_sessions"], c["rank"], c["inc"])
+        m = ns.InfLoRA(net, 64, 2 * c["inc"], device=adapter.device, inc_cls_num=c["inc"], lame=c["lame"], lamb=c["lamb"],
+                       total_sessions=c["total_sessions"])
+        own = net.state_dict()
+        sd = {(k if k.startswith("classifier_pool.") else _timm_name(k)): v.clone() for k, v in P.items()}
+        assert all(k in own for k in sd), [k for k in sd if k not in own][:5]
+        net.load_state_dict(sd, strict=False)
+        net.to(adapter.device)
+        named = lambda: dict(net.named_parameters())
+        test_loader = ListLoader([(tx, ty)], c["bs"], types.SimpleNamespace(trfms=None))
+        for t in range(2):
+            loader = ListLoader([(xs[2 * t], ys[2 * t]), (xs[2 * t + 1], ys[2 * t + 1])], c["bs"], types.SimpleNamespace(trfms=None))
+            m.before_task(t, None, loader, [test_loader])
+            opt = adapter.optim("SGD", m.get_parameters({}), lr=c["lr"], momentum=c["momentum"])
+            for i in (2 * t, 2 * t + 1):
+                m.train()
+                pred, acc, loss = m.observe(adapter.batch(xs[i], ys[i]))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.detach())); preds.append(pred.cpu().numpy())
+            m.after_task(t, None, loader, [test_loader])
+            nm = named()
+            record(t, lambda n: nm[_timm_name(n)].detach().cpu().double(), m.feature_list, m.project_type)
+            m.eval()
+            with torch.no_grad():
+                p, a = m.inference(adapter.batch(tx, ty))
+            res[f"test_pred{t}"] = p.cpu().numpy()
+            res[f"head{t}@{t}"] = _np(nm[f"classifier_pool.{t}.weight"])
+    res["losses"] = np.asarray(losses, np.float64)
+    res["preds"] = np.stack(preds)
+    return res

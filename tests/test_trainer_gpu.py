@@ -85,6 +85,33 @@ def vit_cfg(method, dtype):
     return cfg
 
 
+def inflora_orig_cfg(dtype):
+    cfg = vit_cfg("InfLoRA_OPT", dtype)
+    cfg.update(init_cls_num=3, inc_cls_num=3, task_num=3,
+               backbone={"name": "SiNet_vit", "kwargs": {"total_sessions": 3, "rank": 4, "init_cls": 3, "embd_dim": 128, "img_size": 32, "patch_size": 8,
+                                                         "depth": 2, "num_heads": 2, "dtype": dtype}},
+               classifier={"name": "InfLoRA", "kwargs": {"feat_dim": 64, "num_class": 9, "inc_cls_num": 3, "lame": 0.9, "lamb": 0.6, "total_sessions": 3,
+                                                         "gram_size": 32}})
+    return cfg
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_inflora_original_trains_end_to_end(dtype):
+    """the multi-branch InfLoRA through the product Trainer: three tasks, one LoRA pair and one head per task"""
+    tr = Trainer(0, inflora_orig_cfg(dtype), log=lambda *a, **k: None)
+    out = tr.train_loop()
+    acc = out["acc_table"]
+    assert np.isfinite(acc).all()
+    assert acc[0, 0] > 50.0, (dtype, acc)                         # 3 classes: chance = 33 %
+    net = tr.model._network
+    assert net.numtask == 3 and len(tr.model.feature_list) == 2
+    a0 = net.image_encoder.blocks[0].attn
+    assert all(float(a0.lora_B_k[t].weight.detach().abs().max()) > 0 for t in range(3))          # every task trained ITS pair
+    trainable = [n for n, q in net.named_parameters() if q.requires_grad]
+    assert trainable and all(".2." in n for n in trainable)       # ... and only the last task's pair + head is still trainable
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("method", ["L2P", "InfLoRA_OPT"])
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_vit_methods_train_end_to_end(method, dtype):

@@ -22,7 +22,11 @@ DEV = "cuda"
 class NS:
     def __init__(self, dtype):
         self.dtype = dtype
-        self.L2P, self.InfLoRA_OPT = M.L2P, M.InfLoRA_OPT
+        self.L2P, self.InfLoRA_OPT, self.InfLoRA = M.L2P, M.InfLoRA_OPT, M.InfLoRA
+
+    def make_sinet(self, cfg, total_sessions, rank, init_cls):
+        return M.SiNet_vit(total_sessions=total_sessions, rank=rank, init_cls=init_cls, embd_dim=cfg["dim"], img_size=cfg["img"],
+                           patch_size=cfg["patch"], depth=cfg["depth"], num_heads=cfg["heads"], dtype=self.dtype)
 
     def make_vit(self, cfg, attn_layer="MultiHeadAttention", lora_rank=0):
         kw = {"lora_rank": lora_rank} if lora_rank else {}
@@ -115,3 +119,24 @@ def test_inflora_golden(golden):
     got = vs.scenario_inflora(adapter("bf16"))
     assert rel(got["losses"][:2], want["losses"][:2]) < 3e-2
     assert rel(got["qkv0@0"], want["qkv0@0"]) < 3e-2
+
+
+def test_inflora_original_golden(golden):
+    """the multi-branch InfLoRA on SiNet_vit (timm-named tree, LayerNorm eps 1e-6, finished tasks folded into the executor's base
+    qkv weights) against the fp64 run of the reference's own classes.  Observed: f32 losses 1e-6, every basis / pair quantity
+    <= 1e-5; bf16 losses 2e-3, pair products <= 2.2e-2."""
+    want = golden("inflora_orig")
+    for dtype, ltol, qtol in (("f32", 2e-5, 2e-4), ("bf16", 2e-2, 8e-2)):
+        got = vs.scenario_inflora_orig(adapter(dtype))
+        assert rel(got["losses"], want["losses"]) < ltol, dtype
+        np.testing.assert_array_equal(got["preds"], want["preds"])
+        for t in (0, 1):
+            np.testing.assert_array_equal(got[f"ptype@{t}"], want[f"ptype@{t}"])
+            np.testing.assert_array_equal(got[f"test_pred{t}"], want[f"test_pred{t}"])
+            assert rel(got[f"head{t}@{t}"], want[f"head{t}@{t}"]) < qtol
+            for i in range(vs.ORIG_VIT["depth"]):
+                assert abs(int(got[f"rank{i}@{t}"]) - int(want[f"rank{i}@{t}"])) <= (0 if dtype == "f32" else 1)
+                for k in ("AtA", "BAk", "BAv"):
+                    assert rel(got[f"{k}{i}@{t}"], want[f"{k}{i}@{t}"]) < qtol, (dtype, k, i, t)
+                if int(got[f"rank{i}@{t}"]) == int(want[f"rank{i}@{t}"]):
+                    assert rel(got[f"proj{i}@{t}"], want[f"proj{i}@{t}"]) < qtol, (dtype, i, t)
