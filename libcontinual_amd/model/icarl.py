@@ -56,12 +56,12 @@ class ICarl(nn.Module):
 
     def observe(self, data):
         x, y = self._xy(data)
+        teacher = ops.TeacherPass(x, lambda: self.old_network(x)) if self.cur_task_id > 0 else None
         logits = self.network(x)
         aux = ops.LossAux()
         n = self.accu_cls_num
         if self.cur_task_id > 0:
-            with torch.no_grad():
-                old_logits = self.old_network(x)
+            old_logits = teacher.result()
             # CE(logits[:, :n], y) + KD(logits[:, :prev], old[:, :prev], T=2)      (icarl.py:208-219)
             loss = ops.classify_loss(logits, y, lo=0, hi=n, pred_hi=n, w_ce=1.0, teacher=old_logits, k=self.prev_cls_num,
                                      T=2.0, w_kd=1.0, aux=aux)

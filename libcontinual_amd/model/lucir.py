@@ -111,13 +111,16 @@ class LUCIR(Finetune):
 
     def observe(self, data):
         x, y = self._xy(data)
+
+        def ref_pass():
+            self.ref_model(x)
+            return self.ref_model.last_features
+        teacher = ops.TeacherPass(x, ref_pass) if self.task_idx > 0 else None
         logit = self.network(x)
         aux = ops.LossAux()
         loss = ops.classify_loss(logit, y, aux=aux)                                   # CE over all seen classes
         if self.task_idx > 0:
-            with torch.no_grad():
-                self.ref_model(x)
-                ref_features = self.ref_model.last_features
+            ref_features = teacher.result()
             cur_features = self.network.last_features
             loss = loss + ops.cos_embed_loss(cur_features, ref_features, self.cur_lamda)          # lucir.py:182-183
             scores = self.network.classifier.last_scores                                          # pre-sigma, all classes

@@ -46,14 +46,14 @@ class LWF(Finetune):
 
     def observe(self, data):
         x, y = self._xy(data)
+        teacher = ops.TeacherPass(x, lambda: self.old_fc(self.old_backbone(x)["features"])) if self.task_idx > 0 else None
         logit = self.classifier(self.backbone(x)["features"])
         aux = ops.LossAux()
         old = self.known_cls_num
         if self.task_idx == 0:
             loss = ops.classify_loss(logit, y, aux=aux)
         else:
-            with torch.no_grad():
-                soft = self.old_fc(self.old_backbone(x)["features"])
+            soft = teacher.result()
             # 3 * KD(logit[:, :old], soft, T=2) + CE(logit[:, old:], y - old) in one fused node
             loss = ops.classify_loss(logit, y, lo=old, hi=logit.shape[1], w_ce=1.0, teacher=soft, k=old, T=_KD_TEMPERATURE, w_kd=_KD_WEIGHT, aux=aux)
         self._last_aux = aux

@@ -72,12 +72,12 @@ class WA(Finetune):
 
     def observe(self, data):
         x, y = self._xy(data)
+        teacher = ops.TeacherPass(x, lambda: self.old_network(x)) if self.task_idx > 0 else None
         logits = self.network(x)
         aux = ops.LossAux()
         if self.task_idx > 0:
             lam = self.known_classes / self.total_classes
-            with torch.no_grad():
-                soft = self.old_network(x)
+            soft = teacher.result()
             loss = ops.classify_loss(logits, y, w_ce=1.0 - lam, teacher=soft, k=self.known_classes, T=2.0, w_kd=lam, aux=aux)
         else:
             loss = ops.classify_loss(logits, y, aux=aux)

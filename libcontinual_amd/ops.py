@@ -377,3 +377,45 @@ def clip_grad_norm_(params, max_norm, eps=1e-6):
     for g in flat:
         call("clhip_scale_dev", _ptr(g), _ptr(g), g.numel(), 1.0, _ptr(coef), _st())
     return norm
+
+
+# ------------------------------------------------------------------------------ frozen teacher on a second stream
+_SIDE_STREAMS = {}
+
+
+class TeacherPass:
+    """Runs a frozen teacher's forward on a second HIP stream, concurrently with the student's forward, and joins before the
+    loss.  The two forwards are independent until then, and same-shape conv layers spend their time in alternating
+    load / compute / store phases that add up instead of overlapping (profiles/r01_conv3_ablation_and_pmc.txt): kernels of the
+    other stream fill those gaps -- LwF ResNet-18 task >= 1 step 4.11 -> 3.55 ms.  `CLHIP_TEACHER_STREAM=0` runs it inline.
+
+        tp = ops.TeacherPass(x, lambda: teacher(x))      # before the student's forward
+        ... student forward ...
+        soft = tp.result()                                # main stream now waits for the side stream
+    """
+
+    enabled = __import__("os").environ.get("CLHIP_TEACHER_STREAM", "1") != "0"
+
+    def __init__(self, x, fn):
+        self._fn, self._out, self._side = fn, None, None
+        if self.enabled and x.is_cuda:
+            key = x.device.index or 0
+            side = _SIDE_STREAMS.get(key)
+            if side is None:
+                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))        # x (and the teacher's weights) are ready
+            with torch.cuda.stream(side), torch.no_grad():
+                self._out = fn()
+            self._side = side
+
+    def result(self):
+        if self._side is None:
+            with torch.no_grad():
+                return self._fn()
+        main = torch.cuda.current_stream()
+        main.wait_stream(self._side)
+        outs = self._out if isinstance(self._out, (tuple, list)) else (self._out,)
+        for t in outs:
+            if torch.is_tensor(t):
+                t.record_stream(main)                                     # allocated on the side stream, consumed on this one
+        return self._out
