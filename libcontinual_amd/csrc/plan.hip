@@ -44,6 +44,11 @@ struct clhip_plan {
     std::vector<Act> acts;
     size_t ws_bytes, shadow_bytes;
     size_t dz_off;           // scratch for the pre-BN gradient
+    size_t dz_off2;          // its twin: units alternate, so unit i's weight gradient (side stream) may still read one while unit i-1's
+                             // BatchNorm backward (main stream) fills the other
+    hipStream_t side;        // weight-gradient stream (created on first use), with the events that order it against the caller's stream
+    hipEvent_t ev_dz[2], ev_wg[2], ev_end;
+    bool wg_pending[2];
     size_t f_base;           // byte offset of the fp32 region
     size_t f_part, f_bnws;   // float offsets: conv stat partials, bn backward scratch
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
@@ -130,6 +135,7 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     }
     for (size_t i = 1; i < p->acts.size(); ++i) { p->acts[i].dy_off = off; off = align_up(off + p->acts[i].bytes); }
     p->dz_off = off; off = align_up(off + max_z);
+    p->dz_off2 = off; off = align_up(off + max_z);
     p->wg_off = off; off = align_up(off + max_wg);
     p->f_base = off;
     nfloat = (nfloat + 63) / 64 * 64;
@@ -152,7 +158,15 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     return p;
 }
 
-extern "C" void clhip_plan_destroy(clhip_plan* p) { delete p; }
+extern "C" void clhip_plan_destroy(clhip_plan* p) {
+    if (p && p->side) {
+        (void)hipStreamSynchronize(p->side);
+        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(p->ev_dz[k]); (void)hipEventDestroy(p->ev_wg[k]); }
+        (void)hipEventDestroy(p->ev_end);
+        (void)hipStreamDestroy(p->side);
+    }
+    delete p;
+}
 extern "C" size_t clhip_plan_workspace_bytes(const clhip_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" size_t clhip_plan_shadow_bytes(const clhip_plan* p) { return p ? p->shadow_bytes : 0; }
 extern "C" int clhip_plan_feat_dim(const clhip_plan* p) { return p ? p->feat_dim : 0; }
@@ -293,26 +307,61 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const Act& last = p->acts.back();
         TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
     }
-    for (int i = unit_hi - 1; i >= unit_lo; --i) {
+    // The weight gradients hang off the backward chain (BN backward -> dgrad -> next unit) as leaves: they run on a second stream,
+    // so their kernels fill the load / store phases of the chain's kernels instead of queueing behind them.  dz is double-buffered;
+    // events order  BN backward(i) -> wgrad(i)  and  wgrad(i) -> BN backward(i-2) (same dz buffer).  CLHIP_WGRAD_STREAM=0: one stream.
+    static const bool two_streams = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
+    hipStream_t main_s = static_cast<hipStream_t>(stream);
+    if (two_streams && !p->side) {
+        if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
+        for (int k = 0; k < 2; ++k) {
+            (void)hipEventCreateWithFlags(&p->ev_dz[k], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&p->ev_wg[k], hipEventDisableTiming);
+            p->wg_pending[k] = false;
+        }
+        (void)hipEventCreateWithFlags(&p->ev_end, hipEventDisableTiming);
+    }
+    int k = 0;
+    for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
         void* dres = u.d.res >= 0 ? ws + p->acts[u.d.res].dy_off : nullptr;
+        char* dz = ws + (two_streams && k ? p->dz_off2 : p->dz_off);
+        if (two_streams && p->wg_pending[k]) {
+            (void)hipStreamWaitEvent(main_s, p->ev_wg[k], 0);         // the weight gradient of two units ago has finished reading this buffer
+            p->wg_pending[k] = false;
+        }
         if (u.rep_bwd > 0) {
             TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                                 grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                                 grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
                                  reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else {
             TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                             grads + u.d.gamma_off, grads + u.d.beta_off, ws + p->dz_off, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                             grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
                              fr + p->f_bnws, p->dtype, stream));
         }
-        TRY(clhip_conv_wgrad(ws + src.y_off, ws + p->dz_off, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
-                             u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+        void* wg_stream = stream;
+        if (two_streams) {
+            (void)hipEventRecord(p->ev_dz[k], main_s);
+            (void)hipStreamWaitEvent(p->side, p->ev_dz[k], 0);
+            wg_stream = p->side;
+        }
+        TRY(clhip_conv_wgrad(ws + src.y_off, dz, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
+                             u.d.ksize, u.d.stride, u.d.pad, p->dtype, wg_stream));
+        if (two_streams) {
+            (void)hipEventRecord(p->ev_wg[k], p->side);
+            p->wg_pending[k] = true;
+        }
         if (u.d.src != 0) {
-            TRY(clhip_conv_dgrad(ws + p->dz_off, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,
+            TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         }
+    }
+    if (two_streams) {            // the caller's stream owns the gradients again when this call returns (optimizer, all-reduce hooks)
+        (void)hipEventRecord(p->ev_end, p->side);
+        (void)hipStreamWaitEvent(main_s, p->ev_end, 0);
+        p->wg_pending[0] = p->wg_pending[1] = false;
     }
     return CLHIP_OK;
 }
