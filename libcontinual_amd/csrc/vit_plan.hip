@@ -36,6 +36,8 @@ struct clhip_vit {
     std::vector<LayerShadow> sh;
     Layout last;          // configuration of the most recent forward
     bool have_last;
+    hipStream_t side;     // stream of the LoRA weight gradients (leaves of the backward chain), created on first use
+    hipEvent_t ev_q, ev_l;
 };
 
 static void make_layout(const clhip_vit* v, int B, int P, int save, Layout& L) {
@@ -116,7 +118,15 @@ extern "C" clhip_vit* clhip_vit_create(const clhip_vit_desc* desc, int dtype) {
     return v;
 }
 
-extern "C" void clhip_vit_destroy(clhip_vit* v) { delete v; }
+extern "C" void clhip_vit_destroy(clhip_vit* v) {
+    if (v && v->side) {
+        (void)hipStreamSynchronize(v->side);
+        (void)hipEventDestroy(v->ev_q);
+        (void)hipEventDestroy(v->ev_l);
+        (void)hipStreamDestroy(v->side);
+    }
+    delete v;
+}
 extern "C" size_t clhip_vit_shadow_bytes(const clhip_vit* v) { return v ? v->shadow_bytes : 0; }
 extern "C" size_t clhip_vit_workspace_bytes(const clhip_vit* v, int B, int n_prompt, int save) {
     if (!v || B <= 0 || n_prompt < 0 || n_prompt + 1 + v->np > 256) return 0;
@@ -208,6 +218,16 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
     const char* sh = static_cast<const char*>(shadow);
     const int D = d.dim, Hm = d.mlp, M = L.M, N = L.N, B = L.B, dt = v->dtype;
     char* g = ws + L.g;
+    // the lora_B gradients are leaves of the chain: they run on a side stream (ordered by events against the single dqkv buffer)
+    static const bool two_streams = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
+    hipStream_t main_s = static_cast<hipStream_t>(stream);
+    const bool side_on = two_streams && d_lora_b != nullptr;
+    if (side_on && !v->side) {
+        if (hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking) != hipSuccess) { clhip_set_error("clhip_vit_backward: cannot create the side stream"); return CLHIP_EHIP; }
+        (void)hipEventCreateWithFlags(&v->ev_q, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&v->ev_l, hipEventDisableTiming);
+    }
+    bool lora_pending = false;
     TRY(clhip_ln_pool_bwd(dfeat, ws + L.x_in[d.depth], P->norm_w, g, B, N, D, L.P > 0 ? L.P : 1, 1e-6f, dt, stream));
     for (int l = d.depth - 1; l >= 0; --l) {
         const clhip_vit_layer_params& p = P->layers[l];
@@ -220,18 +240,27 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
         TRY(clhip_ln_bwd(ws + L.dtmp, ws + L.x_mid[l], p.ln2_w, st2, st2 + M, g, M, D, dt, stream));
         // attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
         TRY(clhip_gemm_nt(g, sh + s.proj_b, ws + L.dtmp, nullptr, nullptr, nullptr, M, D, D, D, D, D, 0, 0, EPI_NONE, dt, stream));
+        if (lora_pending) { (void)hipStreamWaitEvent(main_s, v->ev_l, 0); lora_pending = false; }     // the previous layer's dB has read dqkv
         TRY(clhip_attn_bwd(ws + L.qkv[l], ws + L.attn_o[l], reinterpret_cast<const float*>(ws + L.lse[l]), ws + L.dtmp, ws + L.dqkv,
                            reinterpret_cast<float*>(ws + L.dsum), B, N, d.heads, D, dt, stream));
         if (d_lora_b) {
             CLHIP_CHECK_ARG(p.lora_a_k && p.lora_a_v && d_lora_b[2 * l] && d_lora_b[2 * l + 1]);
+            void* ls = stream;
+            if (side_on) {
+                (void)hipEventRecord(v->ev_q, main_s);
+                (void)hipStreamWaitEvent(v->side, v->ev_q, 0);
+                ls = v->side;
+            }
             TRY(clhip_lora_grad(ws + L.h1[l], ws + L.dqkv, p.lora_a_k, p.lora_a_v, sh + s.acat, d_lora_b[2 * l], d_lora_b[2 * l + 1], ws + L.lora_ws, M, D,
-                                d.lora_rank, dt, stream));
+                                d.lora_rank, dt, ls));
+            if (side_on) { (void)hipEventRecord(v->ev_l, v->side); lora_pending = true; }
         }
         if (l == 0 && dprompt_tokens == nullptr) break;           // nothing below the first block needs a gradient
         TRY(clhip_gemm_nt(ws + L.dqkv, sh + s.qkv_b, ws + L.dtmp, nullptr, nullptr, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, 0, 0, EPI_NONE, dt, stream));
         TRY(clhip_ln_bwd(ws + L.dtmp, ws + L.x_in[l], p.ln1_w, st1, st1 + M, g, M, D, dt, stream));
     }
     if (dprompt_tokens) TRY(clhip_vit_prompt_grad(g, dprompt_tokens, B, N, L.P, D, dt, stream));
+    if (lora_pending) (void)hipStreamWaitEvent(main_s, v->ev_l, 0);          // the caller's stream owns the gradients again
     return CLHIP_OK;
 }
 
