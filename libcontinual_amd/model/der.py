@@ -55,7 +55,14 @@ class DER(Finetune):
         return 0 if self.out_dim is None else self.out_dim * len(self.convnets)
 
     def _features(self, x):
-        return torch.cat([net(x)["features"] for net in self.convnets], 1)
+        """frozen extractors have no backward: their forwards go to the second stream (ops.TeacherPass) and overlap the trainable one's"""
+        nets = list(self.convnets)
+        frozen = [n for n in nets[:-1] if not n._params[0].requires_grad]
+        if not frozen or len(frozen) != len(nets) - 1 or not torch.is_grad_enabled():
+            return torch.cat([net(x)["features"] for net in nets], 1)
+        old = ops.TeacherPass(x, lambda: [net(x)["features"] for net in frozen])
+        new = nets[-1](x)["features"]
+        return torch.cat(list(old.result()) + [new], 1)
 
     def forward(self, x):
         features = self._features(x)
