@@ -81,3 +81,27 @@ def test_pretrained_checkpoint_key_mapping(tmp_path):
     dst = M.vit_pt_imnet(pretrained=True, model_name="vit_tiny", checkpoint=str(path), **kw)
     for (k, a), (_, b) in zip(src.feat.state_dict().items(), dst.feat.state_dict().items()):
         assert torch.equal(a + 0.5, b), k
+
+
+def test_sinet_parameter_tree_matches_the_reference_names():
+    """SiNet_vit exposes the reference's (timm) parameter names, per-task LoRA pairs and heads included, and nothing of its private
+    executor; the executor's parameters are the same objects (no copies to keep in sync)"""
+    net = M.SiNet_vit(total_sessions=3, rank=4, init_cls=5, embd_dim=128, img_size=32, patch_size=8, depth=2, num_heads=2)
+    names = [n for n, _ in net.named_parameters()]
+    assert not any("_ex" in n or "transformer." in n or "ln_1" in n for n in names)
+    for want in ("image_encoder.cls_token", "image_encoder.pos_embed", "image_encoder.patch_embed.proj.weight", "image_encoder.blocks.1.norm1.weight",
+                 "image_encoder.blocks.0.attn.qkv.bias", "image_encoder.blocks.1.attn.lora_A_k.2.weight", "image_encoder.blocks.0.attn.lora_B_v.0.weight",
+                 "image_encoder.blocks.1.mlp.fc2.weight", "image_encoder.norm.bias", "classifier_pool.2.weight", "classifier_pool_backup.0.bias"):
+        assert want in names, want
+    enc = net.image_encoder
+    assert tuple(enc.blocks[0].attn.lora_A_k[1].weight.shape) == (4, 128) and tuple(enc.blocks[0].attn.lora_B_k[1].weight.shape) == (128, 4)
+    ex = enc._ex
+    assert ex.transformer.blocks[1].mlp.fc1.weight is enc.blocks[1].mlp.fc1.weight
+    assert ex.transformer.blocks[0].ln_1.weight is enc.blocks[0].norm1.weight and ex.pos_embed is enc.pos_embed
+    assert ex.transformer.blocks[0].attn.qkv.weight is not enc.blocks[0].attn.qkv.weight          # the folded base is the executor's own
+    assert ex.block_ln_eps == 1e-6
+    # a timm-style state dict loads by name
+    sd = {k: torch.full_like(v, 0.25) for k, v in enc.state_dict().items() if "lora" not in k}
+    enc.load_timm_state_dict(sd)
+    assert float(enc.blocks[1].attn.proj.weight.mean()) == 0.25 and float(ex.transformer.blocks[1].attn.proj.weight.mean()) == 0.25
+    assert net.numtask == 0 and len(net.classifier_pool) == 3
