@@ -103,5 +103,5 @@ def test_sinet_parameter_tree_matches_the_reference_names():
     # a timm-style state dict loads by name
     sd = {k: torch.full_like(v, 0.25) for k, v in enc.state_dict().items() if "lora" not in k}
     enc.load_timm_state_dict(sd)
-    assert float(enc.blocks[1].attn.proj.weight.mean()) == 0.25 and float(ex.transformer.blocks[1].attn.proj.weight.mean()) == 0.25
+    assert float(enc.blocks[1].attn.proj.weight.detach().mean()) == 0.25 and float(ex.transformer.blocks[1].attn.proj.weight.detach().mean()) == 0.25
     assert net.numtask == 0 and len(net.classifier_pool) == 3
