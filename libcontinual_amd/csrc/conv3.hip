@@ -475,6 +475,107 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv16: 3x3 / stride 1 / pad 1 with 16 input and 16 output channels (ResNet-32 stage 1: 11 of its 33 convolutions, on the
+// largest maps).  The generic implicit-GEMM kernel spent 26 us (forward) / 40 us (dgrad) on [256,32,32,16] -- 2 % of the MFMA
+// peak and 10-20x the 17 MB the layer moves -- because its tiling is built around wide channel counts.  Here the whole
+// weight tensor (16 x 9 x 16 bf16 = 4.6 KB) lives in 20 registers per lane as five ready-made MFMA operands (two taps of 16
+// channels fill one K = 32 step; the 10th half is zero), the pixel patch of a 256-pixel tile sits in 10 KB of LDS at a 32-byte
+// pitch (conflict-free for ds_read_b128), and a 16-pixel x 16-channel output tile costs 5 LDS reads + 5 MFMAs with no barrier
+// after the patch is staged.  Lane (fr, fg) ends with channels 4 fg .. 4 fg + 3 of pixel fr: one 8-byte store, 512 contiguous
+// bytes per wave instruction, no output staging.  MODE as in conv3_kernel (the dgrad weight copy has the same [Cd][9][Cs] layout).
+template <int MODE>
+__global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
+    constexpr int BM = 256, PP = 32;                         // pixels per workgroup, LDS bytes per pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int W = p.W, halo = W + 1;
+    const int half = fg & 1, tsel = fg >> 1;                // which 8 channels / which tap of the pair this lane feeds
+
+    uint4 wreg[5];
+    int sh[5];
+    unsigned bit[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int tap = 2 * ks + tsel;
+        const int r = tap / 3, s_ = tap - 3 * r;
+        wreg[ks] = tap < 9 ? *reinterpret_cast<const uint4*>(p.wt + (size_t)fr * 144 + tap * 16 + half * 8) : make_uint4(0, 0, 0, 0);
+        sh[ks] = (MODE == 0 ? (r - 1) * W + (s_ - 1) : (1 - r) * W + (1 - s_)) * PP;
+        bit[ks] = tap < 9 ? 1u << tap : 0u;
+    }
+    // patch: pixels [m0 - halo, m0 + BM + halo) as 16-byte half rows, plus one zero row for the out-of-image taps
+    const int nchunks = p.np * 2;
+    for (int idx = tid; idx < nchunks; idx += 256) {
+        const int q = idx >> 1, ch = idx & 1;
+        const long long g = (long long)m0 - halo + q;
+        const uint4 v = (g >= 0 && g < p.M) ? *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
+    }
+    if (tid < 2) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    const int zaddr = p.np * PP + half * 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = wave * 64 + i * 16 + fr;
+        const int g = m0 + pl;
+        const unsigned mask = g < p.M ? tap_mask<MODE>(g, p) : 0u;
+        const int base = (pl + halo) * PP + half * 16;
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const uint4 x = ldsq(smem + ((mask & bit[ks]) ? base + sh[ks] : zaddr));
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[ks]), __builtin_bit_cast(bf16x8_t, x), acc[i], 0, 0, 0);
+        }
+    }
+    // D[row = channel fg*4 + e][col = pixel fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = m0 + wave * 64 + i * 16 + fr;
+        if (pix < p.M) {
+            float v0 = acc[i][0], v1 = acc[i][1], v2 = acc[i][2], v3 = acc[i][3];
+            bf16_t* o = p.dst + (size_t)pix * 16 + fg * 4;
+            if (MODE == 1 && p.accumulate) {
+                const uint2 old = *reinterpret_cast<const uint2*>(o);
+                v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+                v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+            }
+            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+    }
+    if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
+        float sv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = m0 + wave * 64 + i * 16 + fr < p.M;
+                const float v = ok ? acc[i][e] : 0.f;
+                s1 += v; s2 = fmaf(v, v, s2);
+            }
+            sv[e] = s1; sv[4 + e] = s2;
+        }
+        row16_sum_n(sv);
+        __syncthreads();                                     // the patch is dead
+        float* red = reinterpret_cast<float*>(smem);         // [4 waves][2][16]
+        if (fr == 0) {
+            *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 16 + fg * 4) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+            *reinterpret_cast<float4*>(red + (wave * 2 + 1) * 16 + fg * 4) = make_float4(sv[4], sv[5], sv[6], sv[7]);
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, cc = tid & 15;
+            const float t = red[(0 * 2 + which) * 16 + cc] + red[(1 * 2 + which) * 16 + cc] + red[(2 * 2 + which) * 16 + cc] + red[(3 * 2 + which) * 16 + cc];
+            if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * 16 + cc, (double)t);
+            else p.stats[((size_t)blockIdx.x * 2 + which) * 16 + cc] = t;
+        }
+    }
+}
+
 template <int WM, int WN, int MODE>
 int launch3(Conv3Params& p, hipStream_t st) {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -520,6 +621,27 @@ Cfg3 pick3(int M, int Cd) {
 }
 
 }  // namespace
+
+bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
+    static const bool off = getenv("CLHIP_NO_CONV16") != nullptr;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == 16 && Cd == 16 && W <= 64 && W >= 2 && H >= 1;
+}
+
+int clhip_conv16_tiles_m(int M) { return (M + 255) / 256; }
+
+int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
+                        hipStream_t st) {
+    Conv3Params p;
+    p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
+    p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
+    p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = 16; p.Cd = 16; p.accumulate = accumulate; p.M = N * H * W;
+    p.np = 256 + 2 * W + 2; p.patch_bytes = (p.np + 1) * 32; p.nbuf = 1; p.debug = 0;
+    const size_t lds = (size_t)p.patch_bytes > 512 ? (size_t)p.patch_bytes : 512;
+    if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, dim3(clhip_conv16_tiles_m(p.M)), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(conv16_kernel<1>, dim3(clhip_conv16_tiles_m(p.M)), dim3(256), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
 
 bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
     return dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && (Cs % 64) == 0 && (Cd % 64) == 0 && W <= 32 && W >= 2 && H >= 1;
