@@ -445,7 +445,7 @@ int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats,
                        int mode, hipStream_t st);
 bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
 int clhip_conv16_tiles_m(int M);
-int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
+int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                         hipStream_t st);
 bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st);
@@ -511,7 +511,7 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
         int tiles_used = clhip_conv16_tiles_m(p.M);
         if (stat_partials && tiles_alloc > tiles_used)
             hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
-        return clhip_conv16_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, 0, 0, st);
+        return clhip_conv16_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, 0, 0, st);
     }
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, C, K, ksize, stride, pad, dtype)) {
         // the caller's partial buffer may hold more tiles than this kernel writes: zero the tail rows
@@ -550,7 +550,7 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))
-        return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, accumulate, 1, st);
+        return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv3_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, st);
     if (!use_v1()) return clhip_conv2_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, p.Hs, p.Ws, K, H, W, C, ksize, stride, pad, accumulate, 1, dtype, st);

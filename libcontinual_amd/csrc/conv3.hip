@@ -576,6 +576,106 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
     }
 }
 
+// conv32: the same scheme for 32 -> 32 channels (ResNet-32 stage 2).  One tap fills a K = 32 step, the 32 output channels are two
+// MFMA row tiles, the weights are 18 operands (72 registers) per lane; the patch pitch is 96 bytes (64 of data), which puts the 16
+// lanes a ds_read_b128 services together on 16 distinct bank quartets.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
+    constexpr int BM = 256, PP = 96;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int W = p.W, halo = W + 1;
+
+    uint4 wreg[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wreg[t][j] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(j * 16 + fr) * 288 + t * 32 + fg * 8);
+    const int nchunks = p.np * 4;
+    for (int idx = tid; idx < nchunks; idx += 256) {
+        const int q = idx >> 2, ch = idx & 3;
+        const long long g = (long long)m0 - halo + q;
+        const uint4 v = (g >= 0 && g < p.M) ? *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
+    }
+    if (tid < 4) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    const int zaddr = p.np * PP + fg * 16;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = wave * 64 + i * 16 + fr;
+        const int g = m0 + pl;
+        const unsigned mask = g < p.M ? tap_mask<MODE>(g, p) : 0u;
+        const int base = (pl + halo) * PP + fg * 16;
+        acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, s_ = t - 3 * r;
+            const int shift = (MODE == 0 ? (r - 1) * W + (s_ - 1) : (1 - r) * W + (1 - s_)) * PP;
+            const uint4 x = ldsq(smem + ((mask & (1u << t)) ? base + shift : zaddr));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[t][j]), __builtin_bit_cast(bf16x8_t, x), acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = m0 + wave * 64 + i * 16 + fr;
+        if (pix < p.M) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                bf16_t* o = p.dst + (size_t)pix * 32 + j * 16 + fg * 4;
+                if (MODE == 1 && p.accumulate) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(o);
+                    v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+                    v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+                }
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+        }
+    }
+    if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
+        float sv[16];                                        // [j][e] sums, then [j][e] sums of squares
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = m0 + wave * 64 + i * 16 + fr < p.M;
+                    const float v = ok ? acc[i][j][e] : 0.f;
+                    s1 += v; s2 = fmaf(v, v, s2);
+                }
+                sv[j * 4 + e] = s1; sv[8 + j * 4 + e] = s2;
+            }
+        row16_sum_n(sv);
+        __syncthreads();                                     // the patch is dead
+        float* red = reinterpret_cast<float*>(smem);         // [4 waves][2][32]
+        if (fr == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 32 + j * 16 + fg * 4) = make_float4(sv[j * 4], sv[j * 4 + 1], sv[j * 4 + 2], sv[j * 4 + 3]);
+                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * 32 + j * 16 + fg * 4) = make_float4(sv[8 + j * 4], sv[9 + j * 4], sv[10 + j * 4], sv[11 + j * 4]);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int which = tid >> 5, cc = tid & 31;
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) t += red[(w2 * 2 + which) * 32 + cc];
+            if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * 32 + cc, (double)t);
+            else p.stats[((size_t)blockIdx.x * 2 + which) * 32 + cc] = t;
+        }
+    }
+}
+
 template <int WM, int WN, int MODE>
 int launch3(Conv3Params& p, hipStream_t st) {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -624,21 +724,27 @@ Cfg3 pick3(int M, int Cd) {
 
 bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
     static const bool off = getenv("CLHIP_NO_CONV16") != nullptr;
-    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == 16 && Cd == 16 && W <= 64 && W >= 2 && H >= 1;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == Cd && (Cs == 16 || Cs == 32) && W <= 64 && W >= 2 && H >= 1;
 }
 
 int clhip_conv16_tiles_m(int M) { return (M + 255) / 256; }
 
-int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
+int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                         hipStream_t st) {
     Conv3Params p;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
-    p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = 16; p.Cd = 16; p.accumulate = accumulate; p.M = N * H * W;
-    p.np = 256 + 2 * W + 2; p.patch_bytes = (p.np + 1) * 32; p.nbuf = 1; p.debug = 0;
-    const size_t lds = (size_t)p.patch_bytes > 512 ? (size_t)p.patch_bytes : 512;
-    if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, dim3(clhip_conv16_tiles_m(p.M)), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(conv16_kernel<1>, dim3(clhip_conv16_tiles_m(p.M)), dim3(256), lds, st, p);
+    p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = C; p.Cd = C; p.accumulate = accumulate; p.M = N * H * W;
+    p.np = 256 + 2 * W + 2; p.patch_bytes = (p.np + 1) * (C == 16 ? 32 : 96); p.nbuf = 1; p.debug = 0;
+    const size_t lds = (size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024;
+    const dim3 grid(clhip_conv16_tiles_m(p.M));
+    if (C == 16) {
+        if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(conv16_kernel<1>, grid, dim3(256), lds, st, p);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL(conv32_kernel<0>, grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(conv32_kernel<1>, grid, dim3(256), lds, st, p);
+    }
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

@@ -70,6 +70,15 @@ CONV_CASES = [
     (2, 7, 5, 64, 64, 3, 1, 1),
     (130, 32, 32, 64, 64, 3, 1, 1),    # 512-pixel tiles (8 waves), ragged last tile
     (70, 16, 16, 128, 256, 3, 1, 1),   # 256x128 tiles
+    # the register-resident-weight kernels for 16 -> 16 and 32 -> 32 channels (conv3.hip conv16 / conv32): tiles spanning several
+    # images, ragged last tile, non-square and non-power-of-two images (division path of the tap masks), one-row images
+    (5, 16, 16, 32, 32, 3, 1, 1),
+    (33, 16, 16, 32, 32, 3, 1, 1),
+    (3, 7, 5, 32, 32, 3, 1, 1),
+    (2, 1, 9, 32, 32, 3, 1, 1),
+    (9, 32, 32, 16, 16, 3, 1, 1),
+    (3, 7, 5, 16, 16, 3, 1, 1),
+    (2, 1, 9, 16, 16, 3, 1, 1),
     # stride-2 3x3: dgrad runs as 4 parity classes visiting only the contributing taps (conv2.hip)
     (4, 16, 16, 64, 128, 3, 2, 1),
     (33, 32, 32, 64, 128, 3, 2, 1),
