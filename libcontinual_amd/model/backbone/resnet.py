@@ -260,6 +260,12 @@ class HipResNet(nn.Module):
         lazily.  Returns True if a re-pack happened."""
         ok = self._flat.device == device and self._stats.device == device and self._nbt.device == device
         if ok:
+            # fast path: the addresses of all parameters and running statistics are what they were after the last (re)pack --
+            # any .to() / dtype change / `.data = ...` moves at least one of them
+            sig = self.__dict__.get("_pack_sig")
+            if sig is not None and sig == self._pointer_signature():
+                return False
+        if ok:
             base = self._flat.data_ptr()
             for (nm, shp, o, is_conv), p in zip(self._layout, self._params):
                 if p.data_ptr() != base + 4 * o or p.device != device or p.dtype != torch.float32:
@@ -272,6 +278,7 @@ class HipResNet(nn.Module):
                     ok = False
                     break
         if ok:
+            self.__dict__["_pack_sig"] = self._pointer_signature()
             return False
         with torch.no_grad():
             flat = torch.zeros(self._nflat, device=device, dtype=torch.float32)
@@ -296,6 +303,11 @@ class HipResNet(nn.Module):
             self._gflat = None
             self._shadow_version = None
         return True
+
+    def _pointer_signature(self):
+        dp = torch.Tensor.data_ptr
+        return (self._flat.data_ptr(), self._stats.data_ptr(), tuple(map(dp, self._params)),
+                tuple(dp(m._buffers[n]) for m, n in self._stat_holders()))
 
     def _stat_holders(self):
         """(module, buffer name) of every running statistic, in `_stat_layout` order -- resolved once: walking
@@ -500,7 +512,7 @@ class HipResNet(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            if k in ("_ws", "_shadow", "_gflat", "_last_state", "_stat_holder_cache", "_grad_view_cache"):
+            if k in ("_ws", "_shadow", "_gflat", "_last_state", "_stat_holder_cache", "_grad_view_cache", "_pack_sig"):
                 new.__dict__[k] = None
             elif k == "_handle":
                 new.__dict__[k] = _PlanHandle()
