@@ -448,6 +448,9 @@ int clhip_conv16_tiles_m(int M);
 int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                         hipStream_t st);
 bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+size_t clhip_wgrad16_ws_bytes(int N);
+int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st);
 int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st);
 size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K);
 static bool use_v3() {
@@ -562,6 +565,7 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
 
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad3_ws_bytes(N, H, W, C, K);
+    if (!use_v1() && use_v3() && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad16_ws_bytes(N);
     return 0;
 }
 
@@ -590,6 +594,8 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* 
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_wgrad3_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, Creal, K, st);
+    if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
+        return clhip_wgrad16_launch(x, dz, dw, static_cast<float*>(ws), N, H, st);
     if (!use_v1()) return clhip_wgrad2_launch(x, dz, dw, N, H, W, C, Creal, K, ksize, stride, pad, dtype, st);
     static const bool no_tr = getenv("CLHIP_WGRAD_NO_TR") != nullptr;
     if (dtype == CLHIP_BF16) {

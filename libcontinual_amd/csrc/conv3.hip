@@ -974,6 +974,72 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad16: dw[o][tap][c] for 16 -> 16 channels on 32-pixel-wide images (ResNet-32 stage 1; the generic kernel took 44 us for a
+// 1.2-GFLOP reduction whose result is 2304 numbers).  One workgroup = one image: the zero-padded 34 x 34 input image and the
+// 32 x 32 output-gradient image sit in LDS (69 KB); an image row is exactly one K = 32 step, both operands are pixel-major
+// columns fetched with transposing reads (a 16-lane group reads 4 pixels x 16 channels and lane i keeps channel i), the 9 taps
+// are constant address offsets into the padded image.  Each of the 4 waves takes 8 rows into 9 accumulator tiles; the waves are
+// summed through LDS and the image's 2304 partial sums go to a slab that wgrad3_reduce_kernel adds up in a fixed order.
+namespace {
+struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; };
+
+__global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
+    constexpr int W = 32, PW = 34, PX = 32;                  // image width, padded width, bytes per pixel (16 bf16)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = p.H;
+    char* xs = smem;                                         // (H + 2) x 34 pixels
+    char* zs = smem + (H + 2) * PW * PX;                     // H x 32 pixels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const size_t img = (size_t)blockIdx.x * H * W;
+    // zero the padded image, then drop the real pixels in; the gradient image is copied as is
+    const int xchunks = (H + 2) * PW * 2;
+    for (int i = tid; i < xchunks; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int chunks = H * W * 2;
+    for (int i = tid; i < chunks; i += 256) {
+        const int pix = i >> 1, half = i & 1, r = pix >> 5, c = pix & 31;
+        *reinterpret_cast<uint4*>(xs + ((r + 1) * PW + c + 1) * PX + half * 16) = *reinterpret_cast<const uint4*>(p.x + (img + pix) * 16 + half * 8);
+        *reinterpret_cast<uint4*>(zs + pix * PX + half * 16) = *reinterpret_cast<const uint4*>(p.dz + (img + pix) * 16 + half * 8);
+    }
+    __syncthreads();
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane (fr, fg) of a transposing read addresses pixel column 8 fg + (fr >> 2) (+4 for the second read), segment fr & 3
+    const int col = fg * 8 + (fr >> 2), seg = (fr & 3) * 8;
+    for (int h = wave; h < H; h += 4) {
+        const uint4 zf = tr8(zs, (h * W + col) * PX + seg, 4 * PX);
+        const int xb = ((h + 1) * PW + col + 1) * PX + seg;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, sx = t - 3 * r;
+            const uint4 xf = tr8(xs, xb + ((r - 1) * PW + (sx - 1)) * PX, 4 * PX);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[t], 0, 0, 0);
+        }
+    }
+    // D[row = out channel fg*4 + e][col = in channel fr]  ->  red[wave][(o*9 + t)*16 + c]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave * 2304 + ((fg * 4 + e) * 9 + t) * 16 + fr] = acc[t][e];
+    __syncthreads();
+    float* out = p.slab + (size_t)blockIdx.x * 2304;
+    for (int i = tid; i < 2304; i += 256) out[i] = red[i] + red[2304 + i] + red[4608 + i] + red[6912 + i];
+}
+}  // namespace
+
+bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    static const bool off = getenv("CLHIP_NO_CONV16") != nullptr;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 16 && Creal == 16 && K == 16 && W == 32 && H >= 1 && H <= 64 && N >= 1;
+}
+
+size_t clhip_wgrad16_ws_bytes(int N) { return (size_t)N * 2304 * sizeof(float); }
+
 bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!(dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C % 64 == 0 && K % 64 == 0 && Creal == C)) return false;
     if (W < 4 || W > 32 || (W & 3)) return false;
@@ -1023,5 +1089,24 @@ int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int
         hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, ws, dw, n4, splits);
         CLHIP_LAUNCH_CHECK();
     }
+    return CLHIP_OK;
+}
+
+int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st) {
+    Wgrad16Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H};
+    size_t lds = (size_t)((H + 2) * 34 + H * 32) * 32;
+    if (lds < 4 * 2304 * sizeof(float)) lds = 4 * 2304 * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            clhip_set_error("wgrad16: cannot reserve %zu bytes of LDS", lds);
+            return CLHIP_EHIP;
+        }
+        attr = lds;
+    }
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(N), dim3(256), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(9), dim3(256), 0, st, ws, dw, (int64_t)576, N);
+    CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
