@@ -254,6 +254,9 @@ def main():
     def run(n):
         train_steps(model, opt, (batches[i % len(batches)] for i in range(n)), reducer, name, meter, dev)
 
+    # the dominant kernel's roofline measurement (HIP events around repeated launches of that kernel alone) runs first: it is
+    # independent of the step, and the GPU enters the timed region at its sustained clocks instead of waking up in it
+    roofline = gemm_roofline(dev, a.dtype, a.batch * (222 if a.workload.startswith("l2p") else 197)) if vit else dominant_kernel_roofline(dev, a.dtype, a.batch)
     from libcontinual_amd.utils import quiesce_gc
     quiesce_gc()          # what Trainer.train_loop does after building a task's optimizer (no 80 ms generation-2 GC stalls mid-epoch)
     run(a.warmup)
@@ -294,7 +297,7 @@ def main():
         "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }
-    out["roofline"] = gemm_roofline(dev, a.dtype, a.batch * (222 if a.workload.startswith("l2p") else 197)) if vit else dominant_kernel_roofline(dev, a.dtype, a.batch)
+    out["roofline"] = roofline
     if not a.no_cpu_baseline and not vit:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps, 128)
     print(json.dumps(out))

@@ -117,8 +117,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = a1[e]; red[threadIdx.x * 16 + 8 + e] = a2[e]; }
     __syncthreads();
-    // channel c, which w: sum over ro
-    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+    // channel c, which w: sum over ro.  Narrow layers have few outputs and many rows per iteration (C = 16: 32 sums of 128
+    // values): all 256 threads take a slice of the rows first (a serial loop of 128 LDS reads was a third of the kernel there)
+    const int nout = 2 * C;
+    if (nout <= 128) {
+        const int nparts = 256 / nout;                       // power of two (C is)
+        const int out = threadIdx.x % nout, prt = threadIdx.x / nout;
+        const int which = out / C, c = out - which * C;
+        const int col = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int q = prt; q < rpi; q += nparts) s += red[(q * cpr + col) * 16 + which * 8 + e];
+        __syncthreads();                                      // everyone has read its slice: red is reused for the partial sums
+        red[prt * nout + out] = s;
+        __syncthreads();
+        if (threadIdx.x < nout) {
+            float t = 0.f;
+            for (int q = 0; q < nparts; ++q) t += red[q * nout + threadIdx.x];
+            if (acc != nullptr) atomicAdd(acc + ((size_t)(blockIdx.x & (rep - 1)) * 2 + which) * C + c, (double)t);
+            else part[((size_t)blockIdx.x * 2 + which) * C + c] = t;
+        }
+        return;
+    }
+    for (int idx = threadIdx.x; idx < nout; idx += 256) {
         int which = idx / C, c = idx - which * C;
         int col = c >> 3, e = c & 7;
         float s = 0.f;
