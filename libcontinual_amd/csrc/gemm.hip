@@ -604,6 +604,29 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
                 return launch_mt<T, EPI>(t, s, false);
             }
         }
+        // short K, wide N (qkv / fc1 / the fc2 activation gradient, K = 768): the last of the 3.5 - 4.6 rounds of 256 x 256 tiles is
+        // poorly filled.  Whole rounds of big tiles run on the leading rows, the remaining rows on the small tiles (qkv forward
+        // 151.7 -> 139.0 us; CLHIP_GEMM_TAIL=0 disables).  Only when the last round is < 160 of 256 tiles: a fuller one costs more as small tiles.
+        static const bool tail_split = !(getenv("CLHIP_GEMM_TAIL") != nullptr && atoi(getenv("CLHIP_GEMM_TAIL")) == 0);
+        if (allow_split && tail_split && !no_split && p.N % 256 == 0 && pick_tile(p.M, p.N) == 8) {
+            const int tn = p.N / 256;
+            const long t256 = (long)((p.M + 255) / 256) * tn;
+            const long full = t256 / 256;
+            const long rest = t256 - full * 256;
+            const int head_rows = (int)(full * 256 / tn) * 256;
+            if (full >= 1 && rest > 0 && rest < 160 && head_rows < p.M) {
+                GemmParams h = p, t = p;
+                h.M = head_rows;
+                if (int rc = launch<T, EPI, 8, 4, 2, 4>(h, s)) return rc;
+                const size_t es = sizeof(T);
+                t.M = p.M - head_rows;
+                t.A = static_cast<const char*>(p.A) + (size_t)head_rows * p.lda * es;
+                t.C = static_cast<char*>(p.C) + (size_t)head_rows * p.ldc * es;
+                if (p.R) t.R = static_cast<const char*>(p.R) + (size_t)head_rows * p.ldr * es;
+                if (p.H) t.H = static_cast<char*>(p.H) + (size_t)head_rows * p.ldh * es;
+                return launch_mt<T, EPI>(t, s, false);
+            }
+        }
         switch (pick_tile(p.M, p.N)) {
             case 8: return launch<T, EPI, 8, 4, 2, 4>(p, s);
             case 5: return launch<T, EPI, 5, 4>(p, s);

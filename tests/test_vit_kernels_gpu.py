@@ -77,6 +77,38 @@ def test_gemm_nt(dt, impl, M, N, K, epi, gemm_impl):
         assert relerr(Hout, pre) < TOL[dt]
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 2304, 64), (25216, 768, 2304), (8192, 4096, 64)])
+@pytest.mark.parametrize("epi", [0, 2, 3, 4])
+def test_gemm_nt_full_size_tilings(M, N, K, epi):
+    """the BASELINE-size shapes take paths small cases never reach: whole rounds of 256 x 256 tiles + a small-tile tail launch
+    with offset A / C / R / H pointers (short K, wide N and narrow N, long K), and the grouped tile rasterisation (N >= 4096)"""
+    A = rnd(M, K, seed=1).to(torch.bfloat16)
+    B = rnd(N, K, scale=1 / math.sqrt(K), seed=2).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    R = rnd(M, N, seed=4).to(torch.bfloat16)
+    Hin = rnd(M, N, seed=5).to(torch.bfloat16)
+    Cc = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    Hout = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    Hp = Hout if epi == 3 else (Hin if epi == 4 else None)
+    call("clhip_gemm_nt", p(A), p(B), p(Cc), p(bias) if epi in (2, 3) else None, p(R) if epi == 2 else None, p(Hp), M, N, K, K, K, N, N, N, epi, CODE["bf16"], st())
+    ref = A.float() @ B.float().T                      # fp32 product of the bf16 operands on the device
+    if epi in (2, 3):
+        ref = ref + bias
+    if epi == 2:
+        ref = ref + R.float()
+    if epi == 3:
+        pre = ref
+        ref = F.gelu(pre)
+        dref = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+        assert relerr(Hout, dref) < TOL["bf16"]
+    if epi == 4:
+        ref = ref * Hin.float()
+    torch.cuda.synchronize()
+    assert relerr(Cc, ref) < TOL["bf16"]
+    # every row panel was written (head launch, tail launch, last ragged tile)
+    assert torch.isfinite(Cc.float()).all() and float(Cc[-1].float().abs().max()) > 0 and float(Cc[21759:21761].float().abs().max() if M > 21761 else 1.0) > 0
+
+
 def attn_ref(qkv, B, N, H, D):
     hd = D // H
     q, k, v = qkv.double().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
