@@ -279,6 +279,68 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         __syncthreads();
     }
 
+    // 256 x 256 bf16 tile: the results leave through LDS.  A lane's accumulators are 4 columns of 16 different rows, so direct
+    // stores (and the H loads of the x H epilogue) touch 16 cache lines per instruction with 32 bytes each -- the GELU epilogue
+    // (two outputs) cost +78 us and the x H epilogue (one extra input) +55 us on top of a 179 us product.  Staged through the
+    // 128 KB the K loop no longer needs (528-byte pitch: conflict-free 8-byte writes per 16-lane group), every global access
+    // of the epilogue is a 16-byte-per-lane, row-contiguous one.
+    if constexpr (sizeof(T) == 2 && MT == 8 && NT == 4 && WM == 2 && WN == 4 && EPI != EPI_BIAS_RES) {
+        constexpr int CP = 528;                                   // LDS bytes per tile row (512 of data)
+        const int rows_ok = min(BM, p.M - m0);                    // BN columns are always complete (N % 256 == 0 for this tiling)
+        auto stage_out = [&](void* dst_base, int ld) {           // LDS tile -> global, 16 chunks of 16 bytes per thread
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cidx = tid + 512 * q, row = cidx >> 5, cc = cidx & 31;
+                if (row < rows_ok)
+                    *reinterpret_cast<uint4*>(static_cast<T*>(dst_base) + (size_t)(m0 + row) * ld + n0 + cc * 8) = *reinterpret_cast<const uint4*>(smem + row * CP + cc * 16);
+            }
+        };
+        if constexpr (EPI == EPI_MUL) {                           // H tile in, coalesced
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cidx = tid + 512 * q, row = cidx >> 5, cc = cidx & 31;
+                if (row < rows_ok)
+                    *reinterpret_cast<uint4*>(smem + row * CP + cc * 16) = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.H) + (size_t)(m0 + row) * p.ldh + n0 + cc * 8);
+            }
+            __syncthreads();
+        }
+        float4 bias4[NT];
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 16 * NT + j * 16 + g * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                char* slot = smem + (wm * 16 * MT + i * 16 + l15) * CP + (wn * 16 * NT + j * 16 + g * 4) * 2;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+                if constexpr (EPI == EPI_BIAS_GELU) {
+                    f2 y0, d0, y1, d1;
+                    gelu_both2((f2){v[0], v[1]}, y0, d0);
+                    gelu_both2((f2){v[2], v[3]}, y1, d1);
+                    v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
+                    if (p.H) {                                            // GELU' leaves directly (a second staged pass would have to keep or recompute it)
+                        const int m = m0 + wm * 16 * MT + i * 16 + l15;
+                        if (m < p.M) {
+                            const float d[4] = {d0.x, d0.y, d1.x, d1.y};
+                            store4<T>(static_cast<T*>(p.H) + (size_t)m * p.ldh + n0 + wn * 16 * NT + j * 16 + g * 4, d);
+                        }
+                    }
+                }
+                if constexpr (EPI == EPI_MUL) {
+                    float h[4];
+                    load4<T>(reinterpret_cast<const T*>(slot), h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= h[e];
+                }
+                store4<T>(reinterpret_cast<T*>(slot), v);
+            }
+        stage_out(p.C, p.ldc);
+        return;
+    }
     // epilogue: lane holds C[m][n .. n+3], m = m0 + wm*16*MT + i*16 + l15, n = n0 + wn*16*NT + j*16 + g*4
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -539,7 +601,8 @@ int gemm_impl() {
 template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launch(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(T);
+    size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(T);
+    if (sizeof(T) == 2 && MT == 8 && NT == 4 && WM == 2 && WN == 4 && smem < 256 * 528) smem = 256 * 528;      // LDS-staged epilogue
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
