@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     // (two outputs) cost +78 us and the x H epilogue (one extra input) +55 us on top of a 179 us product.  Staged through the
     // 128 KB the K loop no longer needs (528-byte pitch: conflict-free 8-byte writes per 16-lane group), every global access
     // of the epilogue is a 16-byte-per-lane, row-contiguous one.
-    if constexpr (sizeof(T) == 2 && MT == 8 && NT == 4 && WM == 2 && WN == 4 && EPI != EPI_BIAS_RES) {
+    if constexpr (sizeof(T) == 2 && MT == 8 && NT == 4 && WM == 2 && WN == 4) {
         constexpr int CP = 528;                                   // LDS bytes per tile row (512 of data)
         const int rows_ok = min(BM, p.M - m0);                    // BN columns are always complete (N % 256 == 0 for this tiling)
         auto stage_out = [&](void* dst_base, int ld) {           // LDS tile -> global, 16 chunks of 16 bytes per thread
@@ -296,17 +296,19 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
                     *reinterpret_cast<uint4*>(static_cast<T*>(dst_base) + (size_t)(m0 + row) * ld + n0 + cc * 8) = *reinterpret_cast<const uint4*>(smem + row * CP + cc * 16);
             }
         };
-        if constexpr (EPI == EPI_MUL) {                           // H tile in, coalesced
+        if constexpr (EPI == EPI_MUL || EPI == EPI_BIAS_RES) {    // the H (or residual) tile comes in the same way, coalesced
+            const T* src = static_cast<const T*>(EPI == EPI_MUL ? p.H : p.R);
+            const int lds_ = EPI == EPI_MUL ? p.ldh : p.ldr;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int cidx = tid + 512 * q, row = cidx >> 5, cc = cidx & 31;
                 if (row < rows_ok)
-                    *reinterpret_cast<uint4*>(smem + row * CP + cc * 16) = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.H) + (size_t)(m0 + row) * p.ldh + n0 + cc * 8);
+                    *reinterpret_cast<uint4*>(smem + row * CP + cc * 16) = *reinterpret_cast<const uint4*>(src + (size_t)(m0 + row) * lds_ + n0 + cc * 8);
             }
             __syncthreads();
         }
         float4 bias4[NT];
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 16 * NT + j * 16 + g * 4);
         }
@@ -316,7 +318,13 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
             for (int j = 0; j < NT; ++j) {
                 char* slot = smem + (wm * 16 * MT + i * 16 + l15) * CP + (wn * 16 * NT + j * 16 + g * 4) * 2;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) { v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w; }
+                if constexpr (EPI == EPI_BIAS_RES) {
+                    float r[4];
+                    load4<T>(reinterpret_cast<const T*>(slot), r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                }
                 if constexpr (EPI == EPI_BIAS_GELU) {
                     f2 y0, d0, y1, d1;
                     gelu_both2((f2){v[0], v[1]}, y0, d0);
