@@ -284,15 +284,18 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     // (two outputs) cost +78 us and the x H epilogue (one extra input) +55 us on top of a 179 us product.  Staged through the
     // 128 KB the K loop no longer needs (528-byte pitch: conflict-free 8-byte writes per 16-lane group), every global access
     // of the epilogue is a 16-byte-per-lane, row-contiguous one.
-    if constexpr (sizeof(T) == 2 && MT == 8 && NT == 4 && WM == 2 && WN == 4) {
-        constexpr int CP = 528;                                   // LDS bytes per tile row (512 of data)
-        const int rows_ok = min(BM, p.M - m0);                    // BN columns are always complete (N % 256 == 0 for this tiling)
+    if (sizeof(T) == 2 && (p.N & 7) == 0) {
+        constexpr int CP = BN * 2 + 16;                           // LDS bytes per tile row: pitch / 4 = 4 (mod 64) for BN = 64, 128, 256
+        constexpr int CPR = BN / 8, NCH = BM * CPR / NTH;         // 16-byte chunks per row / per thread
+        static_assert((BM * CPR) % NTH == 0, "tile chunks must divide among the threads");
+        const int cols_ok = min(BN, p.N - n0);
+        const int rows_ok = min(BM, p.M - m0);
         auto stage_out = [&](void* dst_base, int ld) {           // LDS tile -> global, 16 chunks of 16 bytes per thread
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int cidx = tid + 512 * q, row = cidx >> 5, cc = cidx & 31;
-                if (row < rows_ok)
+            for (int q = 0; q < NCH; ++q) {
+                const int cidx = tid + NTH * q, row = cidx / CPR, cc = cidx - row * CPR;
+                if (row < rows_ok && cc * 8 < cols_ok)
                     *reinterpret_cast<uint4*>(static_cast<T*>(dst_base) + (size_t)(m0 + row) * ld + n0 + cc * 8) = *reinterpret_cast<const uint4*>(smem + row * CP + cc * 16);
             }
         };
@@ -300,9 +303,9 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
             const T* src = static_cast<const T*>(EPI == EPI_MUL ? p.H : p.R);
             const int lds_ = EPI == EPI_MUL ? p.ldh : p.ldr;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int cidx = tid + 512 * q, row = cidx >> 5, cc = cidx & 31;
-                if (row < rows_ok)
+            for (int q = 0; q < NCH; ++q) {
+                const int cidx = tid + NTH * q, row = cidx / CPR, cc = cidx - row * CPR;
+                if (row < rows_ok && cc * 8 < cols_ok)
                     *reinterpret_cast<uint4*>(smem + row * CP + cc * 16) = *reinterpret_cast<const uint4*>(src + (size_t)(m0 + row) * lds_ + n0 + cc * 8);
             }
             __syncthreads();
@@ -310,7 +313,10 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         float4 bias4[NT];
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 16 * NT + j * 16 + g * 4);
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 16 * NT + j * 16 + g * 4;
+                bias4[j] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
                     v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
                     if (p.H) {                                            // GELU' leaves directly (a second staged pass would have to keep or recompute it)
                         const int m = m0 + wm * 16 * MT + i * 16 + l15;
-                        if (m < p.M) {
+                        if (m < p.M && n0 + wn * 16 * NT + j * 16 + g * 4 < p.N) {
                             const float d[4] = {d0.x, d0.y, d1.x, d1.y};
                             store4<T>(static_cast<T*>(p.H) + (size_t)m * p.ldh + n0 + wn * 16 * NT + j * 16 + g * 4, d);
                         }
@@ -610,7 +616,7 @@ template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launc
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     size_t smem = 2 * (size_t)(BM + BN) * BK * sizeof(T);
-    if (sizeof(T) == 2 && MT == 8 && NT == 4 && WM == 2 && WN == 4 && smem < 256 * 528) smem = 256 * 528;      // LDS-staged epilogue
+    if (sizeof(T) == 2 && smem < (size_t)BM * (BN * 2 + 16)) smem = (size_t)BM * (BN * 2 + 16);      // LDS-staged epilogue
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
