@@ -121,15 +121,37 @@ int clhip_bn_bwd(const void* dy, const void* y, const void* z, const float* mean
 int clhip_avgpool_fwd(const void* a, float* feat, int N, int HW, int C, int dtype, void* stream);
 int clhip_avgpool_bwd(const float* dfeat, void* da, int N, int HW, int C, int dtype, void* stream);
 
+/* AvgPool2d(win) + NCHW flatten: feat[n][(c*Ph + ph)*Pw + pw] (fp32), Ph = H/win, Pw = W/win (resnet.py:643, 675-676) */
+int clhip_avgpool_win_fwd(const void* a, float* feat, int N, int H, int W, int C, int win, int dtype, void* stream);
+int clhip_avgpool_win_bwd(const float* dfeat, void* da, int N, int H, int W, int C, int win, int dtype, void* stream);
+
+/* z[M,C] += r[M,C] in place and, when stat_acc != NULL, the per-channel sum / sum of squares of the result added into the fp64
+ * accumulator [replicas][2][C] that clhip_bn_apply_train reads: `out += residual` of BasicBlock2 (resnet.py:615) followed by the
+ * next block's bn1 (:602).  clhip_add_stats_blocks = number of producer workgroups (for sizing `replicas`).                         */
+int clhip_add_stats_blocks(int64_t M, int C);
+int clhip_add_stats(void* z, const void* r, double* stat_acc, int replicas, int64_t M, int C, int dtype, void* stream);
+/* a[n] += b[n] (n % 8 == 0): joins the two gradient paths of a raw sum (autograd's accumulation at `out += residual`) */
+int clhip_add_inplace(void* a, const void* b, int64_t n, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole-backbone plan: a static list of (conv -> BN -> +res -> ReLU) units + global avg-pool, run
  * with ONE call per direction (replaces the per-op dispatch of CifarResNet.forward / ResNet._forward_impl
  * / modified_ResNet.forward, backbone/resnet.py:381-395, 215-223, 549-560, and autograd's backward).  */
+/* bits of clhip_unit_desc.relu.  The last three re-associate pre-activation blocks (ResNet_BIC / BasicBlock2, backbone/resnet.py:589-680:
+ * BN -> ReLU -> conv, the shortcut added to the RAW conv output, BN-free 1x1 shortcut convs) onto the same unit list: a unit is then
+ * conv -> (+ raw sum of unit res-1) -> BatchNorm of the FOLLOWING block -> ReLU.                                                      */
+enum {
+    CLHIP_UNIT_RELU = 1,     /* ReLU after the BatchNorm (+ residual)                                                                 */
+    CLHIP_UNIT_PRE_RES = 2,  /* `res` names a unit whose raw (pre-BatchNorm) sum is added to this conv's output BEFORE the BatchNorm  */
+    CLHIP_UNIT_RAW_SRC = 4,  /* the conv reads the raw sum of activation `src` instead of its normalised output                       */
+    CLHIP_UNIT_NO_BN = 8     /* conv only (gamma/beta/rm/rv offsets ignored); the result is consumed through PRE_RES / RAW_SRC         */
+};
+
 typedef struct {
     int32_t cin, cout, ksize, stride, pad;
     int32_t src;      /* activation index consumed: 0 = network input, i+1 = output of unit i */
     int32_t res;      /* activation index added before the ReLU, or -1 */
-    int32_t relu;
+    int32_t relu;     /* CLHIP_UNIT_* bits (1 = plain ReLU, 0 = none: the values older callers pass) */
     int64_t w_off;    /* element offsets into the flat fp32 parameter / gradient buffers */
     int64_t gamma_off;
     int64_t beta_off;
@@ -140,6 +162,9 @@ typedef struct {
 typedef struct clhip_plan clhip_plan;
 
 clhip_plan* clhip_plan_create(const clhip_unit_desc* units /*host*/, int n_units, int N, int H, int W, int Cin, int dtype);
+/* pool_win > 0: nn.AvgPool2d(pool_win) + flatten of the NCHW result instead of the global pool (ResNet_BIC.forward, resnet.py:675-676;
+ * feat_dim = C * (H/win) * (W/win)) */
+clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units /*host*/, int n_units, int N, int H, int W, int Cin, int dtype, int pool_win);
 void clhip_plan_destroy(clhip_plan*);
 size_t clhip_plan_workspace_bytes(const clhip_plan*);      /* activations + saved tensors + grads + scratch */
 size_t clhip_plan_shadow_bytes(const clhip_plan*);         /* `dtype` copies of the conv weights */

@@ -74,7 +74,13 @@ _PROTOS = {
     "clhip_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "clhip_avgpool_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "clhip_avgpool_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "clhip_avgpool_win_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "clhip_avgpool_win_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "clhip_add_stats_blocks": (_i, [_l, _i]),
+    "clhip_add_stats": (_i, [_p, _p, _p, _i, _l, _i, _i, _p]),
+    "clhip_add_inplace": (_i, [_p, _p, _l, _i, _p]),
     "clhip_plan_create": (_p, [C.POINTER(UnitDesc), _i, _i, _i, _i, _i, _i]),
+    "clhip_plan_create_ex": (_p, [C.POINTER(UnitDesc), _i, _i, _i, _i, _i, _i, _i]),
     "clhip_plan_destroy": (None, [_p]),
     "clhip_plan_workspace_bytes": (_sz, [_p]),
     "clhip_plan_shadow_bytes": (_sz, [_p]),

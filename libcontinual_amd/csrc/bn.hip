@@ -322,6 +322,114 @@ int ew_blocks(int64_t n) {
     return (int)b;
 }
 
+// ------------------------------------------------------------------------------------ pre-activation residual sums
+// ResNet_BIC blocks (core/model/backbone/resnet.py:589-617) add the shortcut to the RAW output of conv2 and normalise the
+// sum in the NEXT block (`out += residual` :615, then `bn1` :602 of the following block / the final `bn` :672): the statistics
+// a BatchNorm needs are those of z + r, which no conv epilogue has seen.  One pass: z <- z + r (in place) and, in training,
+// the per-channel sum / sum of squares of the result into the same fp64 accumulator the conv epilogues feed.
+template <typename T>
+__global__ __launch_bounds__(256) void add_stats_kernel(T* __restrict__ z, const T* __restrict__ r, double* __restrict__ acc, int rep,
+                                                        int64_t M, int C) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [256][16]
+    const int cpr = C >> 3;
+    const int rpi = 256 / cpr;
+    const int cc = threadIdx.x % cpr, ro = threadIdx.x / cpr;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (ro < rpi) {
+        for (int64_t row = (int64_t)blockIdx.x * rpi + ro; row < M; row += (int64_t)gridDim.x * rpi) {
+            const int64_t off = row * C + cc * 8;
+            float a[8], b[8];
+            load8<T>(z + off, a);
+            load8<T>(r + off, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+            store8<T>(z + off, a);
+            if (acc != nullptr) {
+                if (sizeof(T) == 2) {                                    // the statistics of what BatchNorm will read (rounded)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = bf16_to_f32(f32_to_bf16(a[e]));
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a1[e] += a[e]; a2[e] = fmaf(a[e], a[e], a2[e]); }
+            }
+        }
+    }
+    if (acc == nullptr) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = a1[e]; red[threadIdx.x * 16 + 8 + e] = a2[e]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+        const int which = idx / C, c = idx - which * C;
+        const int col = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int q = 0; q < rpi; ++q) s += red[(q * cpr + col) * 16 + which * 8 + e];
+        atomicAdd(acc + ((size_t)(blockIdx.x & (rep - 1)) * 2 + which) * C + c, (double)s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, int64_t nchunks) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        float x[8], y[8];
+        load8<T>(a + i * 8, x);
+        load8<T>(b + i * 8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        store8<T>(a + i * 8, x);
+    }
+}
+
+int add_stats_blocks(int64_t M, int C) {
+    const int rpi = 256 / (C >> 3);
+    int64_t g = ((M + rpi - 1) / rpi + 7) / 8;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------ windowed avg pool
+// nn.AvgPool2d(win) + flatten of the NCHW result (ResNet_BIC.forward, resnet.py:675-676): feat[n][(c*Ph + ph)*Pw + pw]
+template <typename T>
+__global__ void avgpool_win_fwd_kernel(const T* __restrict__ a, float* __restrict__ feat, int N, int H, int W, int C, int win) {
+    const int Ph = H / win, Pw = W / win;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // ((n*Ph + ph)*Pw + pw)*C + c : coalesced along c
+    if (idx >= N * Ph * Pw * C) return;
+    const int c = idx % C;
+    int t = idx / C;
+    const int pw = t % Pw; t /= Pw;
+    const int ph = t % Ph;
+    const int n = t / Ph;
+    float s = 0.f;
+    for (int i = 0; i < win; ++i)
+        for (int j = 0; j < win; ++j) s += Elem<T>::ld(a + (((size_t)n * H + ph * win + i) * W + pw * win + j) * C + c);
+    feat[(size_t)n * C * Ph * Pw + ((size_t)c * Ph + ph) * Pw + pw] = s / (float)(win * win);
+}
+
+template <typename T>
+__global__ void avgpool_win_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ da, int N, int H, int W, int C, int win) {
+    const int Ph = H / win, Pw = W / win;
+    const int64_t nchunks = (int64_t)N * H * W * C / 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float inv = 1.f / (float)(win * win);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int64_t e0 = i * 8;
+        const int c0 = (int)(e0 % C);
+        int64_t t = e0 / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const int ph = h / win, pw = w / win;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (ph < Ph && pw < Pw) ? dfeat[(size_t)n * C * Ph * Pw + ((size_t)(c0 + e) * Ph + ph) * Pw + pw] * inv : 0.f;
+        store8<T>(da + e0, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------ avg pool
 template <typename T>
 __global__ void avgpool_fwd_kernel(const T* __restrict__ a, float* __restrict__ feat, int N, int HW, int C) {
@@ -573,6 +681,51 @@ extern "C" int clhip_avgpool_bwd(const float* dfeat, void* da, int N, int HW, in
     dim3 g(ew_blocks((int64_t)N * HW * C / 8)), b(256);
     if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, dfeat, (bf16_t*)da, N, HW, C);
     else if (dtype == CLHIP_F32) hipLaunchKernelGGL((avgpool_bwd_kernel<float>), g, b, 0, (hipStream_t)stream, dfeat, (float*)da, N, HW, C);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_add_stats_blocks(int64_t M, int C) { return add_stats_blocks(M, C); }
+
+extern "C" int clhip_add_stats(void* z, const void* r, double* stat_acc, int replicas, int64_t M, int C, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(z && r && M > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && 256 % (C >> 3) == 0);
+    CLHIP_CHECK_ARG(stat_acc == nullptr || (replicas >= 1 && (replicas & (replicas - 1)) == 0));
+    dim3 g(add_stats_blocks(M, C)), b(256);
+    const size_t lds = stat_acc ? 256 * 16 * sizeof(float) : 0;
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((add_stats_kernel<bf16_t>), g, b, lds, (hipStream_t)stream, (bf16_t*)z, (const bf16_t*)r, stat_acc, replicas, M, C);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((add_stats_kernel<float>), g, b, lds, (hipStream_t)stream, (float*)z, (const float*)r, stat_acc, replicas, M, C);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_add_inplace(void* a, const void* b_, int64_t n, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(a && b_ && n > 0 && n % 8 == 0);
+    dim3 g(ew_blocks(n / 8)), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((add_inplace_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, (bf16_t*)a, (const bf16_t*)b_, n / 8);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((add_inplace_kernel<float>), g, b, 0, (hipStream_t)stream, (float*)a, (const float*)b_, n / 8);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_avgpool_win_fwd(const void* a, float* feat, int N, int H, int W, int C, int win, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(a && feat && N > 0 && C > 0 && win > 0 && H >= win && W >= win);
+    const int total = N * (H / win) * (W / win) * C;
+    dim3 g((total + 255) / 256), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_win_fwd_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, (const bf16_t*)a, feat, N, H, W, C, win);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((avgpool_win_fwd_kernel<float>), g, b, 0, (hipStream_t)stream, (const float*)a, feat, N, H, W, C, win);
+    else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_avgpool_win_bwd(const float* dfeat, void* da, int N, int H, int W, int C, int win, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dfeat && da && N > 0 && C >= 8 && C % 8 == 0 && win > 0 && H >= win && W >= win);
+    dim3 g(ew_blocks((int64_t)N * H * W * C / 8)), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_win_bwd_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, dfeat, (bf16_t*)da, N, H, W, C, win);
+    else if (dtype == CLHIP_F32) hipLaunchKernelGGL((avgpool_win_bwd_kernel<float>), g, b, 0, (hipStream_t)stream, dfeat, (float*)da, N, H, W, C, win);
     else { CLHIP_CHECK_ARG(!"dtype"); }
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;

@@ -311,6 +311,8 @@ struct TileCfg { int bm, bn; };
 
 // candidate shapes, largest pixel tile first for each channel width
 TileCfg pick_tile(int M, int Cd) {
+    static const char* force = getenv("CLHIP_IGEMM_TILE");      // "bm,bn" (ablation runs)
+    if (force) { int bm = 0, bn = 0; if (sscanf(force, "%d,%d", &bm, &bn) == 2 && bm > 0 && bn > 0 && bn <= Cd) return TileCfg{bm, bn}; }
     int bn = Cd >= 128 ? 128 : (Cd >= 64 ? 64 : (Cd >= 32 ? 32 : 16));
     int gy = (Cd + bn - 1) / bn;
     int cands128[2] = {128, 64};

@@ -4,6 +4,12 @@
 // here allocates or synchronises).  Replaces CifarResNet.forward / ResNet._forward_impl /
 // modified_ResNet.forward (core/model/backbone/resnet.py:381-395, 215-223, 549-560) and the autograd
 // backward the reference trainer triggers with loss.backward() (core/trainer.py:604).
+//
+// Pre-activation networks (ResNet_BIC, resnet.py:589-680: BN -> ReLU -> conv, shortcut added to the RAW conv output, BN-free 1x1
+// shortcut convs) use the same unit list re-associated as  conv -> (+ raw sum of another unit) -> BN of the NEXT block -> ReLU,
+// with three flag bits in `relu` (CLHIP_UNIT_*): PRE_RES adds `res`'s raw sum before the BatchNorm, RAW_SRC convolves the raw
+// sum of `src` instead of its normalised output, NO_BN stops after the conv.  A raw sum consumed that way receives the consumer's
+// gradient through a persistent buffer (`dzr`), added to its own BatchNorm-backward result.
 #include <stdlib.h>
 #include <vector>
 #include <new>
@@ -35,6 +41,9 @@ struct Unit {
     size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([rep][2][cout] each)
     int rep_fwd, rep_bwd;                        // accumulator replicas (power of two): ~64 producer workgroups per replica
     int dx_acc, dres_acc;
+    bool relu, pre_res, raw_src, no_bn;          // decoded CLHIP_UNIT_* bits of d.relu
+    bool has_dzr;                                // this unit's raw sum is consumed raw (PRE_RES / RAW_SRC) by a later unit
+    size_t dzr_off;                              // ... whose gradient contribution lands here (bytes into the workspace)
 };
 }  // namespace
 
@@ -55,16 +64,22 @@ struct clhip_plan {
     size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
     int feat_dim;
+    int pool_win;            // 0: global average pool, else nn.AvgPool2d(pool_win) + NCHW flatten
 };
 
 extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_units, int N, int H, int W, int Cin, int dtype) {
-    if (!units || n_units <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (dtype != CLHIP_BF16 && dtype != CLHIP_F32)) {
+    return clhip_plan_create_ex(units, n_units, N, H, W, Cin, dtype, 0);
+}
+
+extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_units, int N, int H, int W, int Cin, int dtype, int pool_win) {
+    if (!units || n_units <= 0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || pool_win < 0 || (dtype != CLHIP_BF16 && dtype != CLHIP_F32)) {
         clhip_set_error("clhip_plan_create: invalid argument");
         return nullptr;
     }
     clhip_plan* p = new (std::nothrow) clhip_plan();
     if (!p) { clhip_set_error("out of host memory"); return nullptr; }
     p->N = N; p->H = H; p->W = W; p->Cin = Cin; p->dtype = dtype; p->esize = dtype == CLHIP_BF16 ? 2 : 4;
+    p->pool_win = pool_win;
     p->Cin_pad = (Cin + 7) / 8 * 8;
     if (ilog2_exact(p->Cin_pad) < 0) { int c = 8; while (c < Cin) c <<= 1; p->Cin_pad = c; }
     size_t off = 0, sh = 0;
@@ -83,7 +98,11 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     for (int i = 0; i < n_units; ++i) {
         Unit u{};
         u.d = units[i];
-        if (u.d.src < 0 || u.d.src > i || u.d.res > i || (u.d.ksize != 1 && u.d.ksize != 3) || u.d.stride < 1 || u.d.cout % 16) {
+        u.relu = (u.d.relu & CLHIP_UNIT_RELU) != 0; u.pre_res = (u.d.relu & CLHIP_UNIT_PRE_RES) != 0;
+        u.raw_src = (u.d.relu & CLHIP_UNIT_RAW_SRC) != 0; u.no_bn = (u.d.relu & CLHIP_UNIT_NO_BN) != 0;
+        if (u.d.src < 0 || u.d.src > i || u.d.res > i || (u.d.ksize != 1 && u.d.ksize != 3) || u.d.stride < 1 || u.d.cout % 16 ||
+            (u.raw_src && u.d.src < 1) || (u.pre_res && u.d.res < 1) || (u.no_bn && (u.pre_res || u.relu || u.d.res >= 0)) ||
+            (u.d.relu & ~(CLHIP_UNIT_RELU | CLHIP_UNIT_PRE_RES | CLHIP_UNIT_RAW_SRC | CLHIP_UNIT_NO_BN))) {
             clhip_set_error("clhip_plan_create: bad unit %d", i);
             delete p;
             return nullptr;
@@ -120,7 +139,12 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
         nfloat += 4 * (size_t)u.d.cout;
         const bool pow2 = (u.d.cout & (u.d.cout - 1)) == 0;
         u.rep_fwd = (want_acc && pow2) ? replicas(u.tiles) : 0;
+        if (u.pre_res) {            // statistics of the SUM come from clhip_add_stats, always through the accumulator
+            if (!pow2) { clhip_set_error("clhip_plan_create: unit %d: a pre-BatchNorm residual needs a power-of-two channel count", i); delete p; return nullptr; }
+            u.rep_fwd = replicas(clhip_add_stats_blocks(u.M, u.d.cout));
+        }
         u.rep_bwd = (want_acc && pow2) ? replicas(clhip_bn_bwd_blocks(u.M, u.d.cout)) : 0;
+        if (u.no_bn) u.rep_fwd = u.rep_bwd = 0;
         u.a_fwd = ndouble; ndouble += 2 * (size_t)u.d.cout * (u.rep_fwd > 0 ? u.rep_fwd : 1);
         u.a_bwd = ndouble; ndouble += 2 * (size_t)u.d.cout * (u.rep_bwd > 0 ? u.rep_bwd : 1);
         if (u.rep_fwd || u.rep_bwd) p->use_acc = true;
@@ -134,6 +158,21 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
         p->units.push_back(u);
     }
     for (size_t i = 1; i < p->acts.size(); ++i) { p->acts[i].dy_off = off; off = align_up(off + p->acts[i].bytes); }
+    // raw sums consumed raw: exactly one such consumer each (true of every pre-activation ResNet), whose gradient contribution gets
+    // a buffer of its own
+    for (int i = 0; i < n_units; ++i) {
+        const Unit& c = p->units[i];
+        const int targets[2] = {c.pre_res ? c.d.res : 0, c.raw_src ? c.d.src : 0};
+        for (int t : targets) {
+            if (t < 1) continue;
+            Unit& prod = p->units[t - 1];
+            if (prod.has_dzr) { clhip_set_error("clhip_plan_create: the raw output of unit %d has two raw consumers", t - 1); delete p; return nullptr; }
+            prod.has_dzr = true;
+            prod.dzr_off = off; off = align_up(off + p->acts[t].bytes);
+        }
+    }
+    for (int i = 0; i < n_units; ++i)
+        if (p->units[i].no_bn && !p->units[i].has_dzr) { clhip_set_error("clhip_plan_create: unit %d has no BatchNorm and no consumer", i); delete p; return nullptr; }
     p->dz_off = off; off = align_up(off + max_z);
     p->dz_off2 = off; off = align_up(off + max_z);
     p->wg_off = off; off = align_up(off + max_wg);
@@ -146,14 +185,22 @@ extern "C" clhip_plan* clhip_plan_create(const clhip_unit_desc* units, int n_uni
     off = align_up(off + p->acc_bytes);
     p->ws_bytes = off;
     p->shadow_bytes = sh;
-    p->feat_dim = p->units.back().d.cout;
+    {
+        const Act& last = p->acts.back();
+        if (p->units.back().no_bn || (pool_win > 0 && (last.H < pool_win || last.W < pool_win))) {
+            clhip_set_error("clhip_plan_create: the last unit cannot feed the pool");
+            delete p;
+            return nullptr;
+        }
+        p->feat_dim = pool_win > 0 ? last.C * (last.H / pool_win) * (last.W / pool_win) : last.C;
+    }
     // gradient write/accumulate flags: simulate the reverse sweep
     std::vector<char> written(p->acts.size(), 0);
     written.back() = 1;   // pool backward writes the last activation's gradient
     for (int i = n_units - 1; i >= 0; --i) {
         Unit& u = p->units[i];
-        if (u.d.res >= 0) { u.dres_acc = written[u.d.res]; written[u.d.res] = 1; }
-        if (u.d.src != 0) { u.dx_acc = written[u.d.src]; written[u.d.src] = 1; }
+        if (u.d.res >= 0 && !u.pre_res) { u.dres_acc = written[u.d.res]; written[u.d.res] = 1; }
+        if (u.d.src != 0 && !u.raw_src) { u.dx_acc = written[u.d.src]; written[u.d.src] = 1; }
     }
     return p;
 }
@@ -259,18 +306,34 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
+        const char* in = u.raw_src ? ws + p->units[u.d.src - 1].z_off : ws + src.y_off;
+        if (u.no_bn || u.pre_res) {
+            TRY(clhip_conv_fwd(in, sh + u.sh_fwd, ws + u.z_off, nullptr, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            if (u.no_bn) continue;
+            TRY(clhip_add_stats(ws + u.z_off, ws + p->units[u.d.res - 1].z_off, training ? acc + u.a_fwd : nullptr, u.rep_fwd, u.M, u.d.cout, p->dtype, stream));
+            if (training) {
+                TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
+                                         bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, nullptr,
+                                         ws + dst.y_off, u.relu, p->dtype, stream));
+            } else {
+                TRY(clhip_bn_eval_affine(params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnEps, u.d.cout,
+                                         fr + u.f_scale, fr + u.f_shift, stream));
+                TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, nullptr, ws + dst.y_off, u.M, u.d.cout, u.relu, p->dtype, stream));
+            }
+            continue;
+        }
         if (use_acc && u.rep_fwd > 0) {
             // conv epilogue adds the per-channel sums into the fp64 accumulator; BN-apply derives scale / shift on the fly
-            TRY(clhip_conv_fwd_acc(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
+            TRY(clhip_conv_fwd_acc(in, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
                                    u.d.stride, u.d.pad, p->dtype, stream));
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
             TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
                                      bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
-                                     ws + dst.y_off, u.d.relu, p->dtype, stream));
+                                     ws + dst.y_off, u.relu, p->dtype, stream));
             continue;
         }
         float* part = training ? fr + p->f_part : nullptr;
-        TRY(clhip_conv_fwd(ws + src.y_off, sh + u.sh_fwd, ws + u.z_off, part, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
+        TRY(clhip_conv_fwd(in, sh + u.sh_fwd, ws + u.z_off, part, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
                            u.d.stride, u.d.pad, p->dtype, stream));
         if (training) {
             TRY(clhip_bn_stats_finalize(part, u.tiles, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
@@ -281,10 +344,11 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
                                      kBnEps, u.d.cout, fr + u.f_scale, fr + u.f_shift, stream));
         }
         const void* res = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
-        TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, res, ws + dst.y_off, u.M, u.d.cout, u.d.relu, p->dtype, stream));
+        TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, res, ws + dst.y_off, u.M, u.d.cout, u.relu, p->dtype, stream));
     }
     const Act& last = p->acts.back();
-    TRY(clhip_avgpool_fwd(ws + last.y_off, feat, p->N, last.H * last.W, last.C, p->dtype, stream));
+    if (p->pool_win > 0) TRY(clhip_avgpool_win_fwd(ws + last.y_off, feat, p->N, last.H, last.W, last.C, p->pool_win, p->dtype, stream));
+    else TRY(clhip_avgpool_fwd(ws + last.y_off, feat, p->N, last.H * last.W, last.C, p->dtype, stream));
     return CLHIP_OK;
 }
 
@@ -305,7 +369,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     float* fr = reinterpret_cast<float*>(ws + p->f_base);
     if (unit_hi == (int)p->units.size()) {
         const Act& last = p->acts.back();
-        TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
+        if (p->pool_win > 0) TRY(clhip_avgpool_win_bwd(dfeat, ws + last.dy_off, p->N, last.H, last.W, last.C, p->pool_win, p->dtype, stream));
+        else TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
     }
     // The weight gradients hang off the backward chain (BN backward -> dgrad -> next unit) as leaves: they run on a second stream,
     // so their kernels fill the load / store phases of the chain's kernels instead of queueing behind them.  dz is double-buffered;
@@ -326,21 +391,28 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
-        void* dres = u.d.res >= 0 ? ws + p->acts[u.d.res].dy_off : nullptr;
+        void* dres = (u.d.res >= 0 && !u.pre_res) ? ws + p->acts[u.d.res].dy_off : nullptr;
         char* dz = ws + (two_streams && k ? p->dz_off2 : p->dz_off);
+        // pre-activation wiring: the gradient of this unit's sum IS the gradient of the raw sum it added (written straight into that
+        // producer's buffer); a BN-less unit's gradient is whatever its raw consumer left in its own buffer
+        if (u.pre_res) dz = ws + p->units[u.d.res - 1].dzr_off;
+        if (u.no_bn) dz = ws + u.dzr_off;
+        const char* in = u.raw_src ? ws + p->units[u.d.src - 1].z_off : ws + src.y_off;
         if (two_streams && p->wg_pending[k]) {
             (void)hipStreamWaitEvent(main_s, p->ev_wg[k], 0);         // the weight gradient of two units ago has finished reading this buffer
             p->wg_pending[k] = false;
         }
-        if (u.rep_bwd > 0) {
+        if (u.no_bn) {
+        } else if (u.rep_bwd > 0) {
             TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                                 grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                                 grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.relu,
                                  reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else {
             TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                             grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.d.relu,
+                             grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.relu,
                              fr + p->f_bnws, p->dtype, stream));
         }
+        if (u.has_dzr && !u.no_bn) TRY(clhip_add_inplace(dz, ws + u.dzr_off, u.M * u.d.cout, p->dtype, stream));
         // small layers stay on the caller's stream: below ~1 GFLOP the three event calls cost more host time than the overlap wins
         // (ResNet-32 at batch <= 128 is host-bound: 60.5 k img/s on one stream vs 57.1 k on two; ResNet-18 gains from batch 64 up)
         const double wg_flops = 2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout;
@@ -356,13 +428,16 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipStreamWaitEvent(main_s, p->ev_end, 0);
             p->wg_pending[0] = p->wg_pending[1] = false;
         }
-        TRY(clhip_conv_wgrad(ws + src.y_off, dz, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
+        TRY(clhip_conv_wgrad(in, dz, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, wg_stream));
         if (on_side) {
             (void)hipEventRecord(p->ev_wg[k], p->side);
             p->wg_pending[k] = true;
         }
-        if (u.d.src != 0) {
+        if (u.raw_src) {
+            TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + p->units[u.d.src - 1].dzr_off, 0, p->N, u.H, u.W, u.cin_pad, u.d.cout,
+                                 u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+        } else if (u.d.src != 0) {
             TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         }

@@ -25,7 +25,7 @@ import torch.nn as nn
 from ... import _lib
 from ..._lib import call, require_gpu
 
-__all__ = ["HipResNet", "_Scratch", "_ScratchMixin", "cifar_resnet20", "cifar_resnet32", "resnet18", "resnet34", "resnet32_V2",
+__all__ = ["HipResNet", "_Scratch", "_ScratchMixin", "cifar_resnet20", "cifar_resnet32", "cifar_resnet32_V2", "resnet18", "resnet34", "resnet32_V2",
            "CosineLinear", "SplitCosineLinear"]
 
 
@@ -41,12 +41,38 @@ def _dtype_code(dtype):
 
 # ---------------------------------------------------------------------------------------- topology
 class _U:
-    """one conv -> BN -> (+res) -> (ReLU) unit"""
-    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "src", "res", "relu")
+    """one conv -> BN -> (+res) -> (ReLU) unit.  `flags`: extra CLHIP_UNIT_* bits (pre-activation networks); `bn` None = no BN"""
+    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "src", "res", "relu", "flags")
 
-    def __init__(self, conv, bn, cin, cout, k, stride, pad, src, res, relu):
+    def __init__(self, conv, bn, cin, cout, k, stride, pad, src, res, relu, flags=0):
         self.conv, self.bn, self.cin, self.cout, self.k = conv, bn, cin, cout, k
-        self.stride, self.pad, self.src, self.res, self.relu = stride, pad, src, res, relu
+        self.stride, self.pad, self.src, self.res, self.relu, self.flags = stride, pad, src, res, relu, flags
+
+
+_PRE_RES, _RAW_SRC, _NO_BN = 2, 4, 8        # include/clhip.h: CLHIP_UNIT_*
+
+
+def _preact_topology(depth):
+    """ResNet_BIC (resnet.py:619-680): conv1, three stages of BasicBlock2 (:589-617), final bn + ReLU, AvgPool2d(8).  A block is
+    bn1-ReLU-conv1-bn2-ReLU-conv2 (+ shortcut on the raw sums), so every conv is grouped with the BatchNorm that FOLLOWS it:
+    conv1 of the net with layer1.0.bn1, a block's conv1 with its bn2, its conv2 (+ shortcut) with the next block's bn1 (or the
+    final bn); the 1x1 shortcut convs (:652-656) have no BatchNorm and read the raw block input."""
+    n = (depth - 2) // 6
+    spec = [("layer1", 16, 1), ("layer2", 32, 2), ("layer3", 64, 2)]
+    blocks = [(name, b, planes, stride if b == 0 else 1) for name, planes, stride in spec for b in range(n)]
+    units = [_U("conv1", "layer1.0.bn1", 3, 16, 3, 1, 1, 0, -1, True)]
+    cur, inplanes = 1, 16
+    for j, (name, b, planes, stride) in enumerate(blocks):
+        blk = f"{name}.{b}"
+        nxt = f"{blocks[j + 1][0]}.{blocks[j + 1][1]}.bn1" if j + 1 < len(blocks) else "bn"
+        units.append(_U(f"{blk}.conv1", f"{blk}.bn2", inplanes, planes, 3, stride, 1, cur, -1, True))
+        a1, skip = len(units), cur
+        if stride != 1 or inplanes != planes:
+            units.append(_U(f"{blk}.downsample.0", None, inplanes, planes, 1, stride, 0, cur, -1, False, _RAW_SRC | _NO_BN))
+            skip = len(units)
+        units.append(_U(f"{blk}.conv2", nxt, planes, planes, 3, 1, 1, a1, skip, True, _PRE_RES))
+        cur, inplanes = len(units), planes
+    return units
 
 
 def _stage(units, prefix, blocks, cin, cout, stride, src, names, no_last_relu=False):
@@ -97,6 +123,8 @@ def _topology(kind, depth=None, layers=None):
         s = _stage(units, "layer4", layers[3], 256, 512, 2, s, nm)
         extra = [("fc.weight", (20, 512)), ("fc.bias", (20,))]   # unused head the reference keeps (resnet.py:183)
         return units, 512, extra, [(f"layer{i + 1}", layers[i]) for i in range(4)]
+    if kind == "preact":           # ResNet_BIC: resnet.py:619-680
+        return _preact_topology(depth), 256, [], []      # feat_dim = 256 is the reference's constant (:644), right for 64 x 64 inputs
     raise ValueError(kind)
 
 
@@ -180,9 +208,15 @@ class HipResNet(nn.Module):
         #      that, as in the reference, it never receives a gradient and optimizers skip it)
         off = 0
         self._layout = []     # (name, shape, offset, is_conv)
+        self._unit_off = []   # flat offset of each unit's first parameter
+        self._pool_win = 8 if kind == "preact" else 0
+        self._returns_tensor = kind == "preact"      # ResNet_BIC.forward returns the feature tensor, the others a dict
         for u in self._units:
-            for nm, shp, is_conv in ((u.conv + ".weight", (u.cout, u.cin, u.k, u.k), True),
-                                     (u.bn + ".weight", (u.cout,), False), (u.bn + ".bias", (u.cout,), False)):
+            self._unit_off.append(off)
+            tensors = [(u.conv + ".weight", (u.cout, u.cin, u.k, u.k), True)]
+            if u.bn is not None:
+                tensors += [(u.bn + ".weight", (u.cout,), False), (u.bn + ".bias", (u.cout,), False)]
+            for nm, shp, is_conv in tensors:
                 n = math.prod(shp)
                 self._layout.append((nm, shp, off, is_conv))
                 off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
@@ -190,6 +224,8 @@ class HipResNet(nn.Module):
         soff = 0
         self._stat_layout = []
         for u in self._units:
+            if u.bn is None:
+                continue
             for nm in (u.bn + ".running_mean", u.bn + ".running_var"):
                 self._stat_layout.append((nm, (u.cout,), soff))
                 soff += u.cout
@@ -206,7 +242,8 @@ class HipResNet(nn.Module):
         for nm, shp, o in self._stat_layout:
             _attach(self, nm, "buffer", stats[o:o + shp[0]])
         for i, u in enumerate(self._units):
-            _attach(self, u.bn + ".num_batches_tracked", "buffer", nbt[i])
+            if u.bn is not None:
+                _attach(self, u.bn + ".num_batches_tracked", "buffer", nbt[i])
         for nm, shp in extra:
             _attach(self, nm, "param", nn.Parameter(torch.zeros(shp)))
         self.reset_parameters(init)
@@ -296,6 +333,8 @@ class HipResNet(nn.Module):
                 stats[o:o + shp[0]].copy_(m._buffers[bname].to(device=device, dtype=torch.float32))
                 m._buffers[bname] = stats[o:o + shp[0]]
             for i, u in enumerate(self._units):
+                if u.bn is None:
+                    continue
                 m = mods[u.bn]
                 nbt[i] = m._buffers["num_batches_tracked"].to(device)
                 m._buffers["num_batches_tracked"] = nbt[i]
@@ -382,14 +421,16 @@ class HipResNet(nn.Module):
             for i, u in enumerate(self._units):
                 d = descs[i]
                 d.cin, d.cout, d.ksize, d.stride, d.pad = u.cin, u.cout, u.k, u.stride, u.pad
-                d.src, d.res, d.relu = u.src, u.res, int(u.relu)
-                d.w_off, d.gamma_off, d.beta_off = offs[u.conv + ".weight"], offs[u.bn + ".weight"], offs[u.bn + ".bias"]
-                d.rm_off, d.rv_off = soffs[u.bn + ".running_mean"], soffs[u.bn + ".running_var"]
+                d.src, d.res, d.relu = u.src, u.res, int(u.relu) | u.flags
+                d.w_off = offs[u.conv + ".weight"]
+                if u.bn is not None:
+                    d.gamma_off, d.beta_off = offs[u.bn + ".weight"], offs[u.bn + ".bias"]
+                    d.rm_off, d.rv_off = soffs[u.bn + ".running_mean"], soffs[u.bn + ".running_var"]
             L = _lib.lib()
-            p = L.clhip_plan_create(descs, len(self._units), N, H, W, Cin, self._dtype)
+            p = L.clhip_plan_create_ex(descs, len(self._units), N, H, W, Cin, self._dtype, self._pool_win)
             if not p:
                 raise _lib.ClhipError("clhip_plan_create failed: " + L.clhip_last_error().decode())
-            ent = (p, (int(L.clhip_plan_workspace_bytes(p)), int(L.clhip_plan_shadow_bytes(p))))
+            ent = (p, (int(L.clhip_plan_workspace_bytes(p)), int(L.clhip_plan_shadow_bytes(p)), int(L.clhip_plan_feat_dim(p))))
             self._handle.plans[key] = ent
         return ent
 
@@ -409,7 +450,7 @@ class HipResNet(nn.Module):
 
     def _forward_impl(self, x, state):
         plan, ws, training = state["plan"], state["ws"], state["training"]
-        feat = torch.empty(x.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
+        feat = torch.empty(x.shape[0], state["feat_dim"], device=x.device, dtype=torch.float32)
         call("clhip_plan_forward", plan, x.data_ptr(), self._flat.data_ptr(), self._stats.data_ptr(), self._shadow.data_ptr(),
              ws.data_ptr(), feat.data_ptr(), int(training), torch.cuda.current_stream().cuda_stream)
         return feat
@@ -434,8 +475,8 @@ class HipResNet(nn.Module):
             for lo in self._grad_segment_cuts + [0]:
                 call("clhip_plan_backward_range", state["plan"], dfeat.data_ptr(), self._flat.data_ptr(), self._shadow.data_ptr(),
                      state["ws"].data_ptr(), g.data_ptr(), hi, lo, st)
-                end = self._nflat if hi == len(self._units) else self._layout[3 * hi][2]
-                hook(self, self._layout[3 * lo][2], end)
+                end = self._nflat if hi == len(self._units) else self._unit_off[hi]
+                hook(self, self._unit_off[lo], end)
                 hi = lo
         self.attach_grads()
 
@@ -443,7 +484,7 @@ class HipResNet(nn.Module):
         """unit index k such that the parameters of units >= k (the tail of the flat buffer, whose gradients the backward
         produces first) hold at least `frac` of all parameter elements, k as large as possible"""
         for k in range(len(self._units) - 1, 0, -1):
-            if self._nflat - self._layout[3 * k][2] >= frac * self._nflat:
+            if self._nflat - self._unit_off[k] >= frac * self._nflat:
                 return k
         return 0
 
@@ -454,13 +495,13 @@ class HipResNet(nn.Module):
         x = x.contiguous()
         dev = x.device
         self._ensure_flat(dev)
-        plan, (ws_bytes, sh_bytes) = self._plan_for(x)
+        plan, (ws_bytes, sh_bytes, feat_dim) = self._plan_for(x)
         self._prep_weights(plan, sh_bytes, dev)
         if self._ws is None or self._ws.device != dev or self._ws.numel() < ws_bytes:
             self._ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         self._generation += 1
         need_grad = torch.is_grad_enabled() and self._params[0].requires_grad
-        state = dict(plan=plan, ws=self._ws, training=self.training, gen=self._generation, shape=tuple(x.shape))
+        state = dict(plan=plan, ws=self._ws, training=self.training, gen=self._generation, shape=tuple(x.shape), feat_dim=feat_dim)
         self._last_state = state
         if self.training:
             self._nbt.add_(1)
@@ -469,6 +510,8 @@ class HipResNet(nn.Module):
             feats = _BackboneFn.apply(x, self._params[0], self, state)
         else:
             feats = self._forward_impl(x, state)
+        if self._returns_tensor:
+            return feats
         return _Feats(feats, self, state)
 
     def feature(self, x):
@@ -534,6 +577,12 @@ def cifar_resnet20(pretrained=False, **kwargs):
 def cifar_resnet32(pretrained=False, **kwargs):
     """reference factory resnet.py:760-763 (EWC / iCaRL backbone)"""
     return HipResNet("cifar", depth=32, dtype=kwargs.get("dtype"))
+
+
+def cifar_resnet32_V2(pretrained=False, **kwargs):
+    """ResNet_BIC(32) (resnet.py:924-927 `cifar_resnet32_V2`): the pre-activation backbone of the BiC configs; returns the
+    feature TENSOR (AvgPool2d(8) + flatten: 256 features for the 64 x 64 inputs its `feat_dim` is written for)"""
+    return HipResNet("preact", depth=32, dtype=kwargs.get("dtype"))
 
 
 def resnet32_V2(pretrained=False, **kwargs):

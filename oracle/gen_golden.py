@@ -19,7 +19,7 @@ from . import fixtures, ref_shim, scenarios, vit_scenarios
 def reference_namespace():
     resnet = ref_shim.load("core.model.backbone.resnet")
     ns = types.SimpleNamespace()
-    for n in ("cifar_resnet32", "resnet18", "resnet32_V2", "CosineLinear", "SplitCosineLinear"):
+    for n in ("cifar_resnet32", "cifar_resnet32_V2", "resnet18", "resnet32_V2", "CosineLinear", "SplitCosineLinear"):
         setattr(ns, n, getattr(resnet, n))
     ns.EWC = ref_shim.load("core.model.ewc").EWC
     ns.LWF = ref_shim.load("core.model.lwf").LWF
@@ -100,7 +100,7 @@ def main(out_dir=None):
     os.makedirs(out_dir, exist_ok=True)
     ad = scenarios.PluginAdapter(reference_namespace(), "cpu")
     jobs = {}
-    for arch in ("cifar_resnet32", "resnet32_V2", "resnet18"):
+    for arch in ("cifar_resnet32", "resnet32_V2", "resnet18", "cifar_resnet32_V2"):
         jobs[f"backbone_{arch}"] = lambda a=arch: scenarios.scenario_backbone(ad, a)
     jobs["ewc"] = lambda: scenarios.scenario_ewc(ad)
     jobs["lwf_resnet18"] = lambda: scenarios.scenario_lwf(ad)

@@ -7,6 +7,9 @@ a global average pool:
 * ``resnet18``        -- CIFAR stem, reference `core/model/backbone/resnet.py:26-64, 110-246, 259-267`
 * ``resnet32_V2``     -- LUCIR variant without the last ReLU, reference `core/model/backbone/resnet.py:473-576, 769-773`
 
+plus the pre-activation ``cifar_resnet32_V2`` (= ResNet_BIC(32), `resnet.py:589-680, 765-767`), restated block by block in
+`_preact_forward` (its units are BN -> ReLU -> conv with the shortcut added to the raw sums, so it does not fit the list above).
+
 Parameters live in a flat ``dict name -> tensor`` whose names/shapes equal the reference's
 ``named_parameters()`` / buffers, so reference state_dicts load unchanged.
 Arithmetic is torch CPU; backward comes from autograd.
@@ -43,9 +46,55 @@ def _basic_stage(units, prefix, nblocks, cin, cout, stride, src, names, last_no_
     return src
 
 
+PREACT = "cifar_resnet32_V2"
+
+
+def _preact_blocks(depth=32):
+    """[(prefix, inplanes, planes, stride, has_shortcut)] in forward order: resnet.py:638-641, 650-665"""
+    n = (depth - 2) // 6
+    out, inplanes = [], 16
+    for name, planes, stride in (("layer1", 16, 1), ("layer2", 32, 2), ("layer3", 64, 2)):
+        for b in range(n):
+            s = stride if b == 0 else 1
+            out.append((f"{name}.{b}", inplanes, planes, s, s != 1 or inplanes != planes))
+            inplanes = planes
+    return out
+
+
+def _preact_param_shapes():
+    """registration order of ResNet_BIC / BasicBlock2: conv1; per block bn1, conv1, bn2, conv2, downsample.0; final bn"""
+    out = [("conv1.weight", (16, 3, 3, 3))]
+    for blk, cin, planes, s, ds in _preact_blocks():
+        out += [(f"{blk}.bn1.weight", (cin,)), (f"{blk}.bn1.bias", (cin,)), (f"{blk}.conv1.weight", (planes, cin, 3, 3)),
+                (f"{blk}.bn2.weight", (planes,)), (f"{blk}.bn2.bias", (planes,)), (f"{blk}.conv2.weight", (planes, planes, 3, 3))]
+        if ds:
+            out.append((f"{blk}.downsample.0.weight", (planes, cin, 1, 1)))
+    return out + [("bn.weight", (64,)), ("bn.bias", (64,))]
+
+
+def _preact_forward(P, Bf, x, train):
+    """ResNet_BIC.forward (resnet.py:667-678) with BasicBlock2.forward (:601-617) inlined"""
+    def bn(name, t):
+        y = F.batch_norm(t, Bf[name + ".running_mean"], Bf[name + ".running_var"], P[name + ".weight"], P[name + ".bias"], train,
+                         BN_MOMENTUM, BN_EPS)
+        if train:
+            Bf[name + ".num_batches_tracked"] += 1
+        return y
+    s = F.conv2d(x, P["conv1.weight"], None, 1, 1)
+    for blk, cin, planes, stride, ds in _preact_blocks():
+        out = F.conv2d(F.relu(bn(blk + ".bn1", s)), P[blk + ".conv1.weight"], None, stride, 1)
+        out = F.conv2d(F.relu(bn(blk + ".bn2", out)), P[blk + ".conv2.weight"], None, 1, 1)
+        residual = F.conv2d(s, P[blk + ".downsample.0.weight"], None, stride, 0) if ds else s      # the RAW block input
+        s = out + residual
+    y = F.avg_pool2d(F.relu(bn("bn", s)), 8)
+    return y.reshape(y.shape[0], -1)
+
+
 def arch(name):
     """-> (units, feat_dim, extra_params) ; extra_params = [(name, shape)] that exist but are unused."""
     units = []
+    if name == PREACT:
+        return units, 256, []          # feat_dim: resnet.py:644 (64 channels x 2 x 2 windows of a 64 x 64 input)
     if name == "cifar_resnet32":
         # stem conv3x3 3->16 + BN + ReLU (resnet.py:337-338, 382-383); 3 stages x 5 blocks (:341-343)
         units.append(Unit("conv_1_3x3", "bn_1", 3, 16, 3, 1, 1, "input", "stem", None, True))
@@ -79,6 +128,8 @@ def arch(name):
 
 def param_shapes(name):
     """Ordered [(pname, shape)] matching the reference's named_parameters() order."""
+    if name == PREACT:
+        return _preact_param_shapes()
     units, _, extra = arch(name)
     # reference registration order: per block conv_a, bn_a, conv_b, bn_b, downsample
     out = []
@@ -107,6 +158,13 @@ def param_shapes(name):
 
 
 def buffer_shapes(name):
+    if name == PREACT:
+        out = []
+        for pn, shp in _preact_param_shapes():
+            if len(shp) == 1 and pn.endswith(".weight"):
+                b = pn[: -len(".weight")]
+                out += [(b + ".running_mean", shp), (b + ".running_var", shp), (b + ".num_batches_tracked", ())]
+        return out
     units, _, _ = arch(name)
     out = []
     for u in units:
@@ -151,6 +209,8 @@ def init_buffers(name):
 def forward(name, P, Bf, x, train, return_acts=False):
     """Features [B, feat_dim] of NCHW fp32 `x`.  In train mode BN uses batch statistics and updates
     the running stats in `Bf` in place (momentum 0.1, unbiased var) exactly like nn.BatchNorm2d."""
+    if name == PREACT:
+        return _preact_forward(P, Bf, x, train)
     units, feat_dim, _ = arch(name)
     acts = {"input": x}
     for u in units:

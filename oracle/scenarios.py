@@ -122,7 +122,10 @@ def scenario_backbone(adapter, arch, B=4):
     """features / all parameter grads / running stats for one train-mode batch, then eval features."""
     tag = f"bb/{arch}"
     P, Bf = fx.det_backbone_state(arch, tag)
-    x = fx.det_images(tag + "/x", B)
+    x = fx.det_images(tag + "/x", B, size=64 if arch == nets.PREACT else 32)      # ResNet_BIC's feat_dim assumes 64 x 64 inputs
+
+    def feats_of(o):          # ResNet_BIC.forward returns the tensor, the other backbones a dict
+        return o["features"] if isinstance(o, dict) else o
     _, feat_dim, _ = nets.arch(arch)
     cw = fx._t(detrand.uniform(tag + "/cw", (B, feat_dim), -1, 1))
     out = {}
@@ -137,13 +140,13 @@ def scenario_backbone(adapter, arch, B=4):
     else:
         bb = adapter.backbone(arch, P, Bf)
         bb.train()
-        f = bb(adapter.to_dev(x))["features"]
+        f = feats_of(bb(adapter.to_dev(x)))
         (f * adapter.to_dev(cw)).sum().backward()
         grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros(p.shape)) for k, p in bb.named_parameters()}
         bufs = {k: b.detach().cpu() for k, b in bb.named_buffers()}
         bb.eval()
         with torch.no_grad():
-            fe = bb(adapter.to_dev(x))["features"].detach().cpu()
+            fe = feats_of(bb(adapter.to_dev(x))).detach().cpu()
     out["features_train"] = f.detach().cpu().numpy()
     out["features_eval"] = fe.numpy()
     names, rows = fx.summarize(grads)

@@ -309,6 +309,50 @@ def test_avgpool(mode):
     assert (from_nhwc(da) - ref).abs().max() <= tol(mode, ref)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_windowed_avgpool(mode):
+    """nn.AvgPool2d(8) + flatten of ResNet_BIC.forward (resnet.py:675-676) on a 16 x 16 map"""
+    code, tdt = DT[mode]
+    a = quant(rnd((3, 64, 16, 16), 32), tdt)
+    ad = to_nhwc(a, tdt)
+    feat = torch.empty(3, 256, device=DEV)
+    call("clhip_avgpool_win_fwd", ad.data_ptr(), feat.data_ptr(), 3, 16, 16, 64, 8, code, st())
+    ref = torch.nn.functional.avg_pool2d(a, 8).reshape(3, -1)
+    assert torch.allclose(feat.cpu(), ref, rtol=1e-5, atol=1e-6)
+    df = rnd((3, 256), 33)
+    da = torch.empty(3, 16, 16, 64, dtype=tdt, device=DEV)
+    call("clhip_avgpool_win_bwd", df.to(DEV).data_ptr(), da.data_ptr(), 3, 16, 16, 64, 8, code, st())
+    a2 = a.clone().requires_grad_(True)
+    (torch.nn.functional.avg_pool2d(a2, 8).reshape(3, -1) * df).sum().backward()
+    assert (from_nhwc(da) - a2.grad).abs().max() <= tol(mode, a2.grad)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(4, 16, 32, 32), (3, 32, 16, 16), (5, 64, 8, 8), (2, 128, 4, 4)])
+def test_add_stats_and_add_inplace(mode, shape):
+    """`out += residual` of BasicBlock2 (resnet.py:615) + the statistics the next BatchNorm needs, and the gradient join"""
+    code, tdt = DT[mode]
+    N, Cc, H, W = shape
+    M = N * H * W
+    z, r = quant(rnd(shape, 50), tdt), quant(rnd(shape, 51) * 0.7 + 0.3, tdt)
+    zd, rd = to_nhwc(z, tdt), to_nhwc(r, tdt)
+    rep = 4
+    acc = torch.zeros(rep, 2, Cc, dtype=torch.float64, device=DEV)
+    call("clhip_add_stats", zd.data_ptr(), rd.data_ptr(), acc.data_ptr(), rep, M, Cc, code, st())
+    want = quant(z + r, tdt)
+    assert (from_nhwc(zd) - want).abs().max() <= tol(mode, want)
+    got = from_nhwc(zd).double()                      # the statistics are those of the STORED (rounded) sums
+    sums = acc.sum(0).cpu()
+    assert torch.allclose(sums[0], got.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sums[1], (got * got).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    z2 = to_nhwc(z, tdt)
+    call("clhip_add_stats", z2.data_ptr(), rd.data_ptr(), None, 1, M, Cc, code, st())        # eval mode: the sum only
+    assert torch.equal(from_nhwc(z2), from_nhwc(zd))
+    a = to_nhwc(z, tdt)
+    call("clhip_add_inplace", a.data_ptr(), rd.data_ptr(), M * Cc, code, st())
+    assert torch.equal(from_nhwc(a), from_nhwc(zd))
+
+
 # ------------------------------------------------------------------------------------ heads / losses
 def test_linear_and_losses():
     from libcontinual_amd import ops

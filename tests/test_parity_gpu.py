@@ -40,6 +40,9 @@ class ProductNS:
     def resnet32_V2(self, **kw):
         return M.resnet32_V2(dtype=self.dtype)
 
+    def cifar_resnet32_V2(self, **kw):
+        return M.cifar_resnet32_V2(dtype=self.dtype)
+
     def resnet18(self, **kw):
         return M.resnet18(dtype=self.dtype, **kw)
 
@@ -110,6 +113,62 @@ def test_backbone_vs_oracle_random_init(arch, dtype):
     assert [tuple(t.shape[1:]) for t in fm][-1] == (nets.arch(arch)[1], 32 // 2 ** (len(fm) - 1), 32 // 2 ** (len(fm) - 1))
 
 
+@pytest.mark.parametrize("size", [64, 32])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_preactivation_backbone_vs_oracle_random_init(dtype, size):
+    """ResNet_BIC(32) (resnet.py:589-680): BN -> ReLU -> conv blocks, shortcuts on the raw sums, BN-free 1x1 shortcut convs,
+    AvgPool2d(8) + flatten.  64 x 64 inputs = the 256 features its `feat_dim` is written for; 32 x 32 = one pooling window."""
+    arch = "cifar_resnet32_V2"
+    g = torch.Generator().manual_seed(4)
+    P, Bf = nets.init_params(arch, g), nets.init_buffers(arch)
+    x = torch.randn(8, 3, size, size, generator=g)
+    nfeat = 64 * (size // 32) ** 2
+    cw = torch.randn(8, nfeat, generator=g)
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    Bo = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in Bf.items()}
+    f_ref = nets.forward(arch, Pg, Bo, x.double(), True)
+    (f_ref * cw.double()).sum().backward()
+    bb = adapter(dtype).backbone(arch, P, Bf)
+    assert bb.feat_dim == 256 and [n for n, _ in bb.named_parameters()].count("layer2.0.downsample.0.weight") == 1
+    assert sorted(n for n, _ in bb.named_parameters()) == sorted(P) and sum(p.numel() for p in bb.parameters()) == sum(v.numel() for v in P.values())
+    bb.train()
+    f = bb(x.to(DEV))
+    assert isinstance(f, torch.Tensor) and f.shape == (8, nfeat)
+    (f * cw.to(DEV)).sum().backward()
+    ftol = 2e-4 if dtype == "f32" else 6e-2
+    assert relmax(f.detach().cpu(), f_ref.detach()) < ftol
+    worst, dot, n1, n2 = 0.0, 0.0, 0.0, 0.0
+    for n, p in bb.named_parameters():
+        a, b = p.grad.cpu().double().reshape(-1), Pg[n].grad.reshape(-1)
+        worst = max(worst, relnorm(a, b))
+        dot += float(a @ b); n1 += float(a @ a); n2 += float(b @ b)
+    cos = dot / (n1 * n2) ** 0.5
+    if dtype == "f32":
+        assert worst < 2e-2, worst
+    assert cos > (0.9999 if dtype == "f32" else 0.75), cos
+    for n, b in bb.named_buffers():
+        if "running" in n:
+            assert relmax(b.cpu(), Bo[n]) < (1e-4 if dtype == "f32" else 2e-2), n
+        else:
+            assert int(b) == 1
+    bb.eval()
+    with torch.no_grad():
+        fe = bb(x.to(DEV))
+    fe_ref = nets.forward(arch, Pg, Bo, x.double(), False).detach()
+    assert relmax(fe.cpu(), fe_ref) < ftol
+    # a second training step on the same module (persistent raw-gradient buffers, accumulators) and a deep copy
+    import copy
+    bb.train()
+    for p in bb.parameters():
+        p.grad = None
+    twin = copy.deepcopy(bb)
+    f1 = bb(x.to(DEV)); (f1 * cw.to(DEV)).sum().backward()
+    f2 = twin(x.to(DEV)); (f2 * cw.to(DEV)).sum().backward()
+    assert torch.equal(f1, f2)
+    for (n, p), (_, q) in zip(bb.named_parameters(), twin.named_parameters()):
+        assert relnorm(p.grad.cpu(), q.grad.cpu()) < 1e-5, n
+
+
 def test_backbone_intermediate_activations_f32():
     """layer-by-layer: every unit's pre-BN conv output and post-activation against the oracle"""
     arch = "cifar_resnet32"
@@ -129,7 +188,7 @@ def test_backbone_intermediate_activations_f32():
         assert relmax(y, acts[u.dst]) < 1e-4, (i, u.conv)
 
 
-@pytest.mark.parametrize("arch", ["cifar_resnet32", "resnet18", "resnet32_V2"])
+@pytest.mark.parametrize("arch", ["cifar_resnet32", "resnet18", "resnet32_V2", "cifar_resnet32_V2"])
 def test_backbone_golden(golden, arch):
     """fixture = the REFERENCE's own module run in fp64 (oracle/gen_golden.py)"""
     want = golden(f"backbone_{arch}")

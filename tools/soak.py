@@ -15,6 +15,7 @@ total = init + inc * (tasks - 1)
 kw = {"num_class": total, "feat_dim": feat, "init_cls_num": init, "inc_cls_num": inc, "task_num": tasks, "lamda": 100, "K": 2, "lw_mr": 1, "dist": 0.5}
 buf = {"ICarl": {"name": "LinearHerdingBuffer", "kwargs": {"buffer_size": 600, "batch_size": 128}},
        "WA": {"name": "LinearHerdingBuffer", "kwargs": {"buffer_size": 600, "batch_size": 128}},
+       "DER": {"name": "LinearBuffer", "kwargs": {"buffer_size": 600, "batch_size": 128, "strategy": "herding"}},
        "LUCIR": {"name": "LinearBuffer", "kwargs": {"buffer_size": 600, "batch_size": 128, "strategy": "herding"}}}.get(
            method, {"name": "LinearBuffer", "kwargs": {"buffer_size": 0, "batch_size": 128, "strategy": "random"}})
 if method == "WA":
