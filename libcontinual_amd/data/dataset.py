@@ -81,15 +81,15 @@ class ContinualDatasets:
         return self.dataloaders[task_idx] if self.mode == "train" else self.dataloaders[: task_idx + 1]
 
 
-def make_loader(dataset, batch_size, shuffle, num_workers=0, device=None):
+def make_loader(dataset, batch_size, shuffle, num_workers=0, device=None, drop_last=False):
     """the loader of a (per-task or merged) dataset: batches produced on the GPU when the dataset has a resident store, a
     transform pipeline the augment kernels implement and `device` is a HIP device; otherwise torch's DataLoader"""
     if device is not None and torch.device(device).type == "cuda" and hasattr(dataset, "device_store"):
         from .gpu_loader import GpuBatchLoader, gpu_plan
         plan = gpu_plan(dataset.trfms)
         if plan is not None:
-            return GpuBatchLoader(dataset, batch_size, shuffle, device, plan)
-    return DataLoader(dataset, shuffle=shuffle, batch_size=batch_size, drop_last=False, num_workers=num_workers, pin_memory=False)
+            return GpuBatchLoader(dataset, batch_size, shuffle, device, plan, drop_last=drop_last)
+    return DataLoader(dataset, shuffle=shuffle, batch_size=batch_size, drop_last=drop_last, num_workers=num_workers, pin_memory=False)
 
 
 def get_dataloader(config, mode, cls_map=None, device=None):

@@ -9,6 +9,7 @@ from .icarl import ICarl  # noqa: F401
 from .lucir import LUCIR  # noqa: F401
 from .wa import WA  # noqa: F401
 from .der import DER  # noqa: F401
+from .bic import bic, BiasLayer  # noqa: F401
 from .l2p import L2P  # noqa: F401
 from .inflora_opt import InfLoRA_OPT  # noqa: F401
 from .inflora import InfLoRA  # noqa: F401

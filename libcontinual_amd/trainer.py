@@ -171,8 +171,16 @@ class Trainer:
                 model.before_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))
             self.log(f"Trainable Parameters for Task {task_idx} : {count_parameters(model)} / {count_all_parameters(model)}")
             _, _, self.optimizer, self.scheduler = self._init_optim(self.config)
-            quiesce_gc()                                  # model, optimizer and loaders of this task are built: keep them out of later GC passes
             dataloader = self.train_loader.get_loader(task_idx)
+            val_bias_dataloader = None
+            if method_name == "bic":
+                # hard-wired stage-1 recipe and the plugin's own train / validation split (core/trainer.py:297-303)
+                sgd = getattr(self.optim_ns, "SGD", torch.optim.SGD)
+                self.optimizer = sgd(model.get_parameters(self.config), lr=0.1, momentum=0.9, weight_decay=2e-4 * self.task_num / (task_idx + 1))
+                parallel.attach(self.model, self.optimizer, self.reducer)
+                self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[100, 150, 200], gamma=0.1)
+                dataloader, val_bias_dataloader = model.spilt_and_update(dataloader, self.buffer, task_idx, self.config)
+            quiesce_gc()                                  # model, optimizer and loaders of this task are built: keep them out of later GC passes
             from .model.buffer import LinearBuffer, LinearHerdingBuffer
             if isinstance(self.buffer, (LinearBuffer, LinearHerdingBuffer)) and self.buffer.buffer_size > 0 and task_idx > 0:
                 ds = dataloader.dataset                               # rehearsal union at dataset level (:305-322)
@@ -233,14 +241,26 @@ class Trainer:
             if hasattr(model, "after_task"):
                 self.hook_trace.append(("after_task", task_idx, -1))
                 model.after_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))
-            # trainer-side buffer update (:410-418)
-            self.buffer.total_classes += self.init_cls_num if task_idx == 0 else self.inc_cls_num
-            if self.buffer.buffer_size > 0:
+            # trainer-side buffer update (:410-418); BiC re-cuts its split buffer itself in `spilt_and_update`
+            if method_name != "bic":
+                self.buffer.total_classes += self.init_cls_num if task_idx == 0 else self.inc_cls_num
+            if method_name != "bic" and self.buffer.buffer_size > 0:
                 from .model.buffer import herding_update, random_update
                 if self.buffer.strategy == "herding":
                     herding_update(self.train_loader.get_loader(task_idx).dataset, self.buffer, model.backbone, self.device)
                 elif self.buffer.strategy == "random":
                     random_update(self.train_loader.get_loader(task_idx).dataset, self.buffer)
+            if method_name == "bic" and task_idx > 0:
+                # stage 2 (core/trainer.py:420-455): the current task's bias layer on the validation split, the rest frozen
+                for epoch_idx in range(self.config["stage2_epoch"]):
+                    meter = self.stage2_train(epoch_idx, val_bias_dataloader)
+                    self.log(f"Epoch [{epoch_idx}/{self.config['stage2_epoch']}] (stage2)\t|\tLoss: {meter.avg('loss'):.4f} \tAverage Acc: {meter.avg('acc1'):.2f} ")
+                    if (epoch_idx + 1) % self.val_per_epoch == 0 or (epoch_idx + 1) == self.inc_epoch:
+                        test_acc = self._validate(task_idx)
+                        batch_last_acc, per_task_acc = test_acc["avg_acc"], test_acc["per_task_acc"]
+                        best_batch_last_acc = max(batch_last_acc, best_batch_last_acc)
+                        best_task_last_acc = max(np.mean(per_task_acc), best_task_last_acc)
+                        self.log(f" * [Batch] Last Average Acc: {batch_last_acc:.2f} (Best: {best_batch_last_acc:.2f})")
             for test_idx in range(testing_times):
                 test_acc = self._validate(task_idx)
                 batch_last_acc, per_task_acc = test_acc["avg_acc"], test_acc["per_task_acc"]
@@ -286,6 +306,23 @@ class Trainer:
         init_seed(self.config["seed"] + epoch_idx, self.config["deterministic"])
         self.hook_trace.append(("train_epoch", self.task_idx, epoch_idx))
         train_steps(model, self.optimizer, dataloader, self.reducer, self.config["classifier"]["name"], meter, self.device)
+        return meter
+
+    def stage2_train(self, epoch_idx, dataloader):
+        """BiC's second stage (core/trainer.py:534-561): everything in eval mode, `model.stage2` steps its own optimizer"""
+        model = self.model
+        model.eval()
+        for layer in model.bias_layers:
+            layer.train()
+        meter = self.train_meter
+        meter.reset()
+        self.hook_trace.append(("stage2_epoch", self.task_idx, epoch_idx))
+        on_gpu = self.device.type == "cuda"
+        with ops.deferred_metrics(on_gpu):
+            for batch in dataloader:
+                output, acc, loss = model.stage2(batch)
+                meter.update("acc1", 100 * acc)
+                meter.update("loss", loss.detach() if on_gpu else loss.item())
         return meter
 
     def _validate(self, task_idx):

@@ -35,6 +35,8 @@ def reference_namespace():
     utils.get_instance = None
     sys.modules.setdefault("core.utils", utils)
     ns.DER = ref_shim.load("core.model.der").DER
+    ns.bic = ref_shim.load("core.model.bic").bic
+    ns.LinearSpiltBuffer = ref_shim.load("core.model.buffer.linearbuffer").LinearSpiltBuffer
     ns.LinearHerdingBuffer = ref_shim.load("core.model.buffer.linearherdingbuffer").LinearHerdingBuffer
     return ns
 
@@ -109,6 +111,7 @@ def main(out_dir=None):
     jobs["lucir"] = lambda: scenarios.scenario_lucir(ad)
     jobs["wa"] = lambda: scenarios.scenario_wa(ad)
     jobs["der"] = lambda: scenarios.scenario_der(ad)
+    jobs["bic"] = lambda: scenarios.scenario_bic(ad)
 
     def icarl():
         with tempfile.TemporaryDirectory() as d:

@@ -185,6 +185,114 @@ class LWF:
         return _acc(self.network.logits(x, False), y)
 
 
+# --------------------------------------------------------------------------------------------- BiC
+def classwise_split(images, labels, test_size):
+    """bic.py:26-57: per class in ascending label order, positions shuffled with the GLOBAL numpy RNG, the first
+    int(n * (1 - test_size)) (at least one of several) to the train side"""
+    images, labels = np.array(images), np.array(labels)
+    tr_i, tr_l, va_i, va_l = [], [], [], []
+    for c in np.unique(labels):
+        idx = np.where(labels == c)[0]
+        np.random.shuffle(idx)
+        k = int(len(idx) * (1 - test_size))
+        if k == 0 and len(idx) > 1:
+            k = 1
+        tr_i += list(images[idx[:k]]); tr_l += list(labels[idx[:k]])
+        va_i += list(images[idx[k:]]); va_l += list(labels[idx[k:]])
+    return tr_i, va_i, tr_l, va_l
+
+
+class BiC:
+    """reference core/model/bic.py:83-340.  `net` = backbone + full-width head; one (alpha, beta) pair per task applied to that
+    task's logit slice in EVERY pass (bic.py:129 forces the all-layers branch); stage 1: CE over the seen classes, from task 1 on
+    alpha*T^2*KD(T=2) against the bias-corrected previous model + (1-alpha)*CE (:193-217); stage 2: the current task's pair under
+    Adam(1e-3) with the net in eval mode (:219-232, trainer.py:545-547)."""
+
+    def __init__(self, net, init_cls_num, inc_cls_num, task_num):
+        self.network, self.init, self.inc, self.task_num = net, init_cls_num, inc_cls_num, task_num
+        self.alphas = [torch.ones(1, dtype=net.head_w.dtype) for _ in range(task_num)]
+        self.betas = [torch.zeros(1, dtype=net.head_w.dtype) for _ in range(task_num)]
+        self.bias_opt = Adam([q for ab in zip(self.alphas, self.betas) for q in ab], 1e-3)
+        self.seen, self.cur_task, self.old = 0, 0, None
+        self.cls_count = {}
+
+    def before_task(self, task_idx):
+        self.old = self.network.clone(grad=False)                      # bic.py:111-114 (deepcopy, no eval())
+        for q in self.alphas + self.betas:
+            q.requires_grad_(False)                                    # :119-120
+        self.cur_task = task_idx
+        self.seen += self.init if task_idx == 0 else self.inc          # :123
+
+    def after_task(self, task_idx):
+        for i in range(self.task_num):                                 # :170-175
+            self.alphas[i].requires_grad_(i == task_idx); self.betas[i].requires_grad_(i == task_idx)
+
+    def bias_forward(self, logits):
+        outs = []
+        for i in range(self.task_num):                                 # :145-151
+            lo, hi = (0, self.init) if i == 0 else (self.init + (i - 1) * self.inc, self.init + i * self.inc)
+            outs.append(self.alphas[i] * logits[:, lo:hi] + self.betas[i])
+        return torch.cat(outs, dim=1)
+
+    def observe(self, x, y, train=True):
+        p = self.bias_forward(self.network.logits(x, train))
+        ce = F.cross_entropy(p[:, :self.seen], y)
+        pred, acc = _acc(p[:, :self.seen], y)
+        if self.cur_task == 0:
+            return pred, acc, ce                                        # stage1, :180-191
+        T, old = 2.0, self.seen - self.inc
+        alpha = 1.0 * old / self.seen
+        assert 1.0 * self.cur_task / (self.cur_task + 1) == alpha      # :199
+        with torch.no_grad():
+            pre = self.bias_forward(self.old.logits(x, train))          # previous model follows model.train(): quirk a10
+        soft = -torch.mean(torch.sum(torch.softmax(pre[:, :old] / T, dim=1) * torch.log_softmax(p[:, :old] / T, dim=1), dim=1))
+        return pred, acc, alpha * soft * T * T + (1 - alpha) * ce       # :212-215
+
+    def stage2(self, x, y):
+        with torch.no_grad():
+            logits = self.network.logits(x, False)                     # trainer.py:545: model.eval(); the net is frozen (:167-168)
+        p = self.bias_forward(logits)
+        loss = F.cross_entropy(p[:, :self.seen], y)
+        pred, acc = _acc(p[:, :self.seen], y)
+        self.bias_opt.zero_grad(); loss.backward(); self.bias_opt.step()
+        return pred, acc, loss
+
+    def inference(self, x, y):
+        return _acc(self.bias_forward(self.network.logits(x, False))[:, :self.seen], y)
+
+    def split_and_update(self, images, labels, buffer, task_idx, buffer_size):
+        """bic.py:245-340 on plain lists -> (train images, train labels, val images, val labels) of the two loaders' datasets
+        (val lists None for task 0); `buffer` has train_images / train_labels / val_images / val_labels / total_classes"""
+        from collections import Counter
+        ratio = 0.1
+        self.cls_count.update(Counter(labels))
+        tr_i, va_i, tr_l, va_l = classwise_split(images, labels, ratio)
+        train = (tr_i + buffer.train_images, tr_l + buffer.train_labels)
+        val = (None, None)
+        if task_idx > 0:
+            vi, vl = list(buffer.val_images), list(buffer.val_labels)
+            for c in np.unique(va_l):                                   # already grouped by class: appended in the same order
+                pos = np.where(np.array(va_l) == c)[0]
+                vi += list(np.array(va_i)[pos]); vl += list(np.array(va_l)[pos])
+            val = (vi, vl)
+        buffer.train_images += tr_i; buffer.train_labels += tr_l
+        buffer.val_images += va_i; buffer.val_labels += va_l
+        buffer.total_classes += self.init if task_idx == 0 else self.inc
+        total = sum(self.cls_count.values())
+        nt_i, nt_l, nv_i, nv_l = [], [], [], []
+        for c in range(buffer.total_classes):
+            n_val = int(self.cls_count[c] * buffer_size / total * ratio)
+            n_tr = int(self.cls_count[c] * buffer_size / total * (1 - ratio))
+            if n_val == 0 and n_tr > 1:
+                n_val, n_tr = 1, n_tr - 1
+            tp = np.where(np.array(buffer.train_labels) == c)[0][:n_tr]
+            vp = np.where(np.array(buffer.val_labels) == c)[0][:n_val]
+            nt_i += list(np.array(buffer.train_images)[tp]); nt_l += list(np.array(buffer.train_labels)[tp])
+            nv_i += list(np.array(buffer.val_images)[vp]); nv_l += list(np.array(buffer.val_labels)[vp])
+        buffer.train_images, buffer.train_labels, buffer.val_images, buffer.val_labels = nt_i, nt_l, nv_i, nv_l
+        return train + val
+
+
 # ---------------------------------------------------------------------------------------------- WA
 def align_new_rows(w, n_new):
     """wa.py:96-109 / der.py:182-190: scale the last `n_new` rows by mean|old rows| / mean|new rows|; returns (w, gamma)."""
@@ -495,7 +603,7 @@ class Adam:
         self.lr, self.b1, self.b2, self.eps, self.wd = lr, betas[0], betas[1], eps, weight_decay
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
-        self.t = 0
+        self.t = [0] * len(self.params)      # per parameter, advanced only when it has a gradient (torch.optim.Adam's state["step"])
 
     def zero_grad(self):
         for p in self.params:
@@ -503,14 +611,14 @@ class Adam:
 
     @torch.no_grad()
     def step(self):
-        self.t += 1
         for i, p in enumerate(self.params):
             if p.grad is None:
                 continue
+            self.t[i] += 1
             g = p.grad + self.wd * p if self.wd != 0 else p.grad
             self.m[i].mul_(self.b1).add_(g, alpha=1 - self.b1)
             self.v[i].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
-            bc1 = 1 - self.b1 ** self.t
-            bc2 = 1 - self.b2 ** self.t
+            bc1 = 1 - self.b1 ** self.t[i]
+            bc2 = 1 - self.b2 ** self.t[i]
             denom = (self.v[i].sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(self.m[i], denom, value=-self.lr / bc1)

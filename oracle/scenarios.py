@@ -659,6 +659,166 @@ def scenario_der(adapter):
     return out
 
 
+# ----------------------------------------------------------------------------------- scenario: BiC
+BIC_CFG = dict(arch="cifar_resnet32_V2", feat_dim=256, size=64, init=3, inc=3, task_num=3, num_class=9, bs=6, lr=0.02, momentum=0.9,
+               buffer_size=20)
+
+
+class _ListDataset(torch.utils.data.Dataset):
+    """what `spilt_and_update` needs of `dataloader.dataset`: `images` / `labels` lists, deep-copyable, sized"""
+
+    def __init__(self, images, labels):
+        self.images, self.labels = list(images), list(labels)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, i):
+        return {"image": torch.zeros(1), "label": int(self.labels[i])}
+
+
+class _HasDataset:
+    def __init__(self, ds):
+        self.dataset = ds
+
+
+def _ints(v):
+    return np.asarray([int(t) for t in v], np.int64)
+
+
+def _bic_task_lists(t):
+    """(image ids, labels) of task t in a fixed shuffled order; id = 1000 * class + k"""
+    c = BIC_CFG
+    imgs, labs = [], []
+    for j, n in enumerate({0: [12, 12, 12], 1: [10, 12, 14]}[t]):
+        cls = (0 if t == 0 else c["init"]) + j
+        imgs += [cls * 1000 + k for k in range(n)]
+        labs += [cls] * n
+    order = np.random.RandomState(11 + t).permutation(len(labs))
+    return [imgs[i] for i in order], [labs[i] for i in order]
+
+
+def bic_split_plugin(m, ns):
+    """`spilt_and_update` of a plugin-surface `bic` object for two tasks under a seeded numpy RNG -> {task: record}"""
+    c = BIC_CFG
+    buf = ns.LinearSpiltBuffer(c["buffer_size"], "balance_random", 4, 0.1)
+    cfg = {"buffer": {"kwargs": {"buffer_size": c["buffer_size"]}}, "batch_size": 4, "num_workers": 0, "init_cls_num": c["init"],
+           "inc_cls_num": c["inc"], "gpu_input_pipeline": False}
+    m.cls_count = {}
+    split = {}
+    for t in (0, 1):
+        np.random.seed(7 + t)
+        imgs, labs = _bic_task_lists(t)
+        tr, va = m.spilt_and_update(_HasDataset(_ListDataset(imgs, labs)), buf, t, cfg)
+        assert tr.drop_last and tr.batch_size == 4 and (va is None) == (t == 0) and (va is None or (va.batch_size == 100 and not va.drop_last))
+        split[t] = (tr.dataset.images, tr.dataset.labels, va.dataset.images if va is not None else None, va.dataset.labels if va is not None else None,
+                    list(buf.train_images), list(buf.train_labels), list(buf.val_images), list(buf.val_labels))
+    assert buf.total_classes == c["init"] + c["inc"]
+    return split
+
+
+BIC_SPLIT_FIELDS = ("train_i", "train_l", "val_i", "val_l", "buf_ti", "buf_tl", "buf_vi", "buf_vl")
+
+
+def scenario_bic(adapter):
+    """ResNet_BIC(32) on 64 x 64 inputs.  Task 0: 2 steps of CE (weight decay 2e-4 * task_num / 1, core/trainer.py:299-300);
+    after_task; inference.  Task 1: 2 distillation steps against the bias-corrected previous model (its BatchNorm in train mode),
+    after_task, 3 stage-2 steps of the task's bias layer under the plugin's Adam with everything in eval mode, inference.
+    Separately: `spilt_and_update` for two tasks under a seeded numpy RNG (split, loaders' datasets, re-cut buffer)."""
+    c = BIC_CFG
+    tag = "bic"
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    w, b = fx.det_linear(tag + "/head", c["num_class"], c["feat_dim"])
+
+    def batch(name, lo, hi):
+        return fx.det_images(f"{tag}/{name}/x", c["bs"], size=c["size"]), torch.from_numpy(detrand.randint(f"{tag}/{name}/y", (c["bs"],), lo, hi))
+    seen1 = c["init"] + c["inc"]
+    t0 = [batch(f"t0/{i}", 0, c["init"]) for i in range(2)]
+    t1 = [batch(f"t1/{i}", 0, seen1) for i in range(2)]
+    v1 = [batch(f"v1/{i}", 0, seen1) for i in range(3)]
+    probe = batch("probe", 0, seen1)
+    losses, losses2, preds, infer = [], [], [], []
+
+    def wd_of(t):
+        return 2e-4 * c["task_num"] / (t + 1)
+    # ---- the data side, on plain lists
+    split = {}
+    task_lists = _bic_task_lists
+
+    if adapter.kind == "oracle":
+        net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()}, {k: v.clone() for k, v in Bf.items()},
+                     w.clone().requires_grad_(True), b.clone().requires_grad_(True))
+        m = om.BiC(net, c["init"], c["inc"], c["task_num"])
+
+        def run(batches, t):
+            opt = om.SGD(net.parameters(), c["lr"], c["momentum"], wd_of(t))
+            for x, y in batches:
+                pred, acc, loss = m.observe(x, y, True)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item()); preds.append(pred.numpy())
+        m.before_task(0); run(t0, 0); m.after_task(0)
+        infer.append(m.inference(*probe)[0].numpy())
+        m.before_task(1); run(t1, 1); m.after_task(1)
+        teacher_rm = m.old.Bf["bn.running_mean"].clone()
+        for x, y in v1:
+            pred, acc, loss = m.stage2(x, y)
+            losses2.append(loss.item()); preds.append(pred.numpy())
+        infer.append(m.inference(*probe)[0].numpy())
+        bias = torch.stack([torch.cat([m.alphas[i].detach(), m.betas[i].detach()]) for i in range(c["task_num"])])
+        params = dict(net.named_parameters())
+        import types
+        buf = types.SimpleNamespace(train_images=[], train_labels=[], val_images=[], val_labels=[], total_classes=0)
+        m2 = om.BiC(net, c["init"], c["inc"], c["task_num"])
+        for t in (0, 1):
+            np.random.seed(7 + t)
+            imgs, labs = task_lists(t)
+            ti, tl, vi, vl = m2.split_and_update(imgs, labs, buf, t, c["buffer_size"])
+            split[t] = (ti, tl, vi, vl, list(buf.train_images), list(buf.train_labels), list(buf.val_images), list(buf.val_labels))
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.bic(bb, c["num_class"], device=adapter.device, task_num=c["task_num"], init_cls_num=c["init"], inc_cls_num=c["inc"]).to(adapter.device)
+        with torch.no_grad():
+            m.model.classifier.weight.copy_(adapter.to_dev(w)); m.model.classifier.bias.copy_(adapter.to_dev(b))
+
+        def run(batches, t):
+            opt = adapter.sgd_factory(m.get_parameters({}), lr=c["lr"], momentum=c["momentum"], weight_decay=wd_of(t))
+            m.train()
+            for layer in m.bias_layers:
+                layer.eval()
+            for x, y in batches:
+                pred, acc, loss = m.observe(adapter.batch(x, y))
+                opt.zero_grad(); loss.backward(retain_graph=True); opt.step()
+                losses.append(float(loss.item())); preds.append(pred.cpu().numpy())
+
+        def probe_now():
+            m.eval()
+            with torch.no_grad():
+                infer.append(m.inference(adapter.batch(*probe))[0].cpu().numpy())
+        m.before_task(0, None, None, None); run(t0, 0); m.after_task(0, None, None, None); probe_now()
+        m.before_task(1, None, None, None); run(t1, 1); m.after_task(1, None, None, None)
+        teacher_rm = dict(m.previous_model.named_buffers())["backbone.bn.running_mean"].detach().cpu()
+        m.eval()
+        for layer in m.bias_layers:
+            layer.train()
+        for x, y in v1:
+            pred, acc, loss = m.stage2(adapter.batch(x, y))
+            losses2.append(float(loss.item())); preds.append(pred.cpu().numpy())
+        probe_now()
+        bias = torch.stack([torch.cat([layer.alpha.detach().cpu(), layer.beta.detach().cpu()]) for layer in m.bias_layers])
+        params = {k: v.detach().cpu() for k, v in m.model.named_parameters()}
+        split = bic_split_plugin(m, ns)
+    out = dict(losses=np.asarray(losses, np.float64), losses2=np.asarray(losses2, np.float64), preds=np.stack(preds), infer=np.stack(infer),
+               bias=bias.double().numpy(), teacher_rm=teacher_rm.double().numpy())
+    names, rows = fx.summarize(params)
+    out["param_names"], out["param_rows"] = np.asarray(names), rows
+    for t, rec in split.items():
+        for key, v in zip(BIC_SPLIT_FIELDS, rec):
+            if v is not None:
+                out[f"split{t}_{key}"] = _ints(v)
+    return out
+
+
 def F_linear(x, w, b):
     return torch.nn.functional.linear(x, w, b)
 

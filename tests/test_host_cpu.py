@@ -166,3 +166,29 @@ def test_herding_buffer_bookkeeping():
     b.add_data([f"a{i}" for i in range(10)] + [f"b{i}" for i in range(10)], [0] * 10 + [1] * 10)
     b.reduce_old_data(1, 4)              # 20 // 4 = 5 per class, first-k kept
     assert b.labels == [0] * 5 + [1] * 5 and b.images[:2] == ["a0", "a1"] and b.images[5] == "b0"
+
+
+def test_bic_split_and_buffer_recut_match_the_reference(golden):
+    """`bic.spilt_and_update` (bic.py:245-340) runs on the host: 9:1 class-wise split under the global numpy RNG, the two loaders'
+    datasets and the re-cut split buffer, against what the reference's own method produced (tests/golden/bic.npz)"""
+    import numpy as np
+    import libcontinual_amd.model as M
+    from oracle import scenarios as sc
+    want = golden("bic")
+    c = sc.BIC_CFG
+    m = M.bic(M.cifar_resnet32_V2(), c["num_class"], device="cpu", task_num=c["task_num"], init_cls_num=c["init"], inc_cls_num=c["inc"])
+    assert m.model.classifier.in_features == 256 and len(m.bias_layers) == c["task_num"]
+    split = sc.bic_split_plugin(m, M)
+    for t, rec in split.items():
+        for key, v in zip(sc.BIC_SPLIT_FIELDS, rec):
+            if v is not None:
+                np.testing.assert_array_equal(np.asarray([int(q) for q in v]), want[f"split{t}_{key}"], err_msg=f"{t}/{key}")
+    # bias_forward: every task's slice through its own (alpha, beta)
+    import torch
+    with torch.no_grad():
+        for i, layer in enumerate(m.bias_layers):
+            layer.alpha.fill_(1.0 + i); layer.beta.fill_(0.1 * i)
+    z = torch.arange(2 * c["num_class"], dtype=torch.float32).reshape(2, c["num_class"])
+    out = m.bias_forward(z)
+    want_out = torch.cat([(1.0 + i) * z[:, 3 * i:3 * i + 3] + 0.1 * i for i in range(3)], 1)
+    assert torch.allclose(out, want_out)

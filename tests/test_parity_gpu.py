@@ -31,7 +31,8 @@ class ProductNS:
 
     def __init__(self, dtype):
         self.dtype = dtype
-        for n in ("EWC", "LWF", "ICarl", "LUCIR", "WA", "DER", "Finetune", "LinearHerdingBuffer", "CosineLinear", "SplitCosineLinear"):
+        for n in ("EWC", "LWF", "ICarl", "LUCIR", "WA", "DER", "bic", "Finetune", "LinearHerdingBuffer", "LinearSpiltBuffer", "CosineLinear",
+                  "SplitCosineLinear"):
             setattr(self, n, getattr(M, n))
 
     def cifar_resnet32(self, **kw):
@@ -332,6 +333,28 @@ def test_der_golden(golden, monkeypatch):
     assert relmax(got["losses"], want["losses"]) < 5e-2
     assert bool(got["frozen_same"])
     assert relmax(got["rm_frozen"], want["rm_frozen"]) < 3e-2
+
+
+def test_bic_golden(golden):
+    """fixture = the reference's `bic` on its own ResNet_BIC backbone in fp64 (64 x 64 inputs): CE stage, distillation stage against
+    the bias-corrected previous model, the Adam-trained bias layer of stage 2, inference, and the host-side split"""
+    want = golden("bic")
+    got = sc.scenario_bic(adapter("f32"))
+    assert relmax(got["losses"], want["losses"]) < 2e-4
+    assert relmax(got["losses2"], want["losses2"]) < 2e-4
+    np.testing.assert_array_equal(got["preds"], want["preds"])
+    np.testing.assert_array_equal(got["infer"], want["infer"])
+    assert np.abs(got["bias"] - want["bias"]).max() < 2e-5                       # alpha, beta after three Adam steps of 1e-3
+    assert np.array_equal(got["bias"][0], [1.0, 0.0]) and np.array_equal(got["bias"][2], [1.0, 0.0])
+    assert relmax(got["teacher_rm"], want["teacher_rm"]) < 1e-3                   # previous model's BatchNorm ran on batch statistics
+    assert _param_rel(got, want) < 2e-3
+    for k in want:
+        if k.startswith("split"):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    got = sc.scenario_bic(adapter("bf16"))
+    assert relmax(got["losses"], want["losses"]) < 5e-2
+    assert relmax(got["losses2"], want["losses2"]) < 5e-2
+    assert np.abs(got["bias"] - want["bias"]).max() < 2e-3
 
 
 @pytest.mark.parametrize("order", ["zero_forward_backward", "forward_zero_backward"])

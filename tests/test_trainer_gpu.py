@@ -69,6 +69,36 @@ def test_methods_train_end_to_end(method, backbone, extra, monkeypatch):
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_bic_trains_end_to_end(dtype):
+    """BiC through the Trainer: its own SGD recipe and train / validation split (core/trainer.py:297-303), the pre-activation
+    backbone on 64 x 64 images, stage 2 on the validation split after every task but the first (:420-455)"""
+    cfg = Config().get_config_dict()
+    kw = {"num_class": 9, "init_cls_num": 3, "inc_cls_num": 3, "task_num": 3}
+    cfg.update(dict(dataset="synthetic", image_size=64, init_cls_num=3, inc_cls_num=3, task_num=3, epoch=8, init_epoch=8, stage2_epoch=3, batch_size=32,
+                    val_per_epoch=10, testing_times=1, num_workers=0, save_path="", synthetic_per_class=200, synthetic_test_per_class=20, seed=5,
+                    backbone={"name": "cifar_resnet32_V2", "kwargs": {"num_classes": 9, "dtype": dtype, "args": {"dataset": "synthetic"}}},
+                    classifier={"name": "bic", "kwargs": kw},
+                    buffer={"name": "LinearSpiltBuffer", "kwargs": {"buffer_size": 90, "batch_size": 32, "strategy": "balance_random", "val_ratio": 0.1}},
+                    optimizer={"name": "SGD", "kwargs": {"lr": 0.1, "momentum": 0.9, "weight_decay": 2e-4}},
+                    lr_scheduler={"name": "MultiStepLR", "kwargs": {"milestones": [100, 150, 200], "gamma": 0.1}}))
+    tr = Trainer(0, cfg, log=lambda *a, **k: None)
+    out = tr.train_loop()
+    acc = out["acc_table"]
+    assert np.isfinite(acc).all()
+    assert acc[0, 0] > 90.0, acc
+    assert out["batch_last_acc"] > 55.0, acc                      # 9 classes, 90 rehearsal exemplars (80 % observed; chance 11 %)
+    m = tr.model
+    assert m.model.classifier.in_features == 256 and m.seen_cls == 9
+    ab = [(layer.alpha.item(), layer.beta.item()) for layer in m.bias_layers]
+    assert ab[0] == (1.0, 0.0) and ab[1] != (1.0, 0.0) and ab[2] != (1.0, 0.0), ab      # stage 2 trained the layers of tasks 1 and 2 only
+    assert tr.optimizer.param_groups[0]["weight_decay"] == pytest.approx(2e-4 * 3 / 3) and tr.optimizer.param_groups[0]["momentum"] == 0.9
+    assert [e for e in tr.hook_trace if e[0] == "stage2_epoch"] == [("stage2_epoch", t, e) for t in (1, 2) for e in range(3)]
+    assert 0 < len(tr.buffer.train_labels) + len(tr.buffer.val_labels) <= 90 and tr.buffer.total_classes == 9
+    assert len(tr.buffer.val_labels) >= 9                         # at least one validation exemplar per class
+    torch.cuda.synchronize()
+
+
 def vit_cfg(method, dtype):
     cfg = Config().get_config_dict()
     bb_kw = {"pretrained": False, "img_size": 32, "patch_size": 8, "embed_dim": 128, "depth": 2, "num_heads": 2, "dtype": dtype}
