@@ -111,7 +111,12 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
     // offset is row_const + tap_const, so a K-step costs one bit test and one add per 16-byte load instead of
     // re-deriving coordinates (the first version spent ~12 VALU instructions per MFMA on that).
     constexpr bool LINEAR = true;
-    const bool lin = (MODE == 0) || (p.stride == 1);
+    // parity-class tiles of the stride-2 dgrad are linear too: with h + pad = 2a + e (e fixed by the class) the contributing taps are
+    // r = e + 2m and read source row a - m, i.e. "origin a, tap index m" with the same formula as stride 1
+    const bool cls_mode = (MODE == 1) && p.cls_tiles > 0;
+    const int cls_id = cls_mode ? (int)(blockIdx.x / p.cls_tiles) : 0;
+    const int e_h = cls_mode ? (((cls_id >> 1) + p.pad) & 1) : 0, e_w = cls_mode ? (((cls_id & 1) + p.pad) & 1) : 0;
+    const bool lin = (MODE == 0) || (p.stride == 1) || cls_mode;
     long long a_off[AROWS];
     unsigned a_mask[AROWS];
     int a_h0[AROWS], a_w0[AROWS], a_base[AROWS];
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
             int h0, w0, dir;
             if (MODE == 0) { h0 = hd * p.stride - p.pad; w0 = wd * p.stride - p.pad; dir = 1; }
             else { h0 = hd + p.pad; w0 = wd + p.pad; dir = -1; }
+            if (cls_mode) { h0 >>= 1; w0 >>= 1; }
             a_h0[i] = h0; a_w0[i] = w0;
             if (lin) {
                 a_off[i] = ((long long)a_base[i] + (long long)h0 * p.Ws + w0) * p.Cs;
@@ -136,6 +142,10 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
                 for (int r = 0; r < p.ksize; ++r)
                     for (int s2 = 0; s2 < p.ksize; ++s2) {
                         int hs = h0 + dir * r, ws = w0 + dir * s2;
+                        if (cls_mode) {
+                            if (((r - e_h) & 1) || ((s2 - e_w) & 1)) continue;        // this tap never reaches the class
+                            hs = h0 - ((r - e_h) >> 1); ws = w0 - ((s2 - e_w) >> 1);
+                        }
                         if ((unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws) m |= 1u << (r * p.ksize + s2);
                     }
                 a_mask[i] = m;
@@ -162,7 +172,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
         const int s = (p.ksize == 3) ? tap - 3 * r : 0;
         if (lin) {
             const int dir = (MODE == 0) ? 1 : -1;
-            const long long toff = (long long)dir * (r * p.Ws + s) * p.Cs + cs;     // thread-uniform for this K-step
+            const int rr = cls_mode ? ((r - e_h) >> 1) : r, ss = cls_mode ? ((s - e_w) >> 1) : s;
+            const long long toff = (long long)dir * (rr * p.Ws + ss) * p.Cs + cs;   // thread-uniform for this K-step
             const unsigned bit = kvalid ? (1u << tap) : 0u;
 #pragma unroll
             for (int i = 0; i < AROWS; ++i) ra[i] = (a_mask[i] & bit) ? gload2<T>(src + (a_off[i] + toff)) : zero2<T>();
@@ -214,7 +225,13 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
             if (((ph + p.pad - r) & 1) == 0 && ((pw + p.pad - s2) & 1) == 0) tapmask |= 1u << t;
         }
     }
-    auto step_ok = [&](int k) { return p.cls_tiles == 0 || ((tapmask >> ((k * BK2) >> p.log2Cs)) & 1u); };
+    // a 64-element K-step lies inside one tap (Cs >= 64) or spans two (Cs == 32): visited when either can contribute -- the
+    // per-element parity test of the gather zeroes the other one
+    auto step_ok = [&](int k) {
+        if (p.cls_tiles == 0) return true;
+        const int t0 = (k * BK2) >> p.log2Cs, t1 = ((k + 1) * BK2 - 1) >> p.log2Cs;
+        return (((tapmask >> t0) | (tapmask >> (t1 < 9 ? t1 : t0))) & 1u) != 0;
+    };
     auto next_step = [&](int k) { ++k; while (k < nk && !step_ok(k)) ++k; return k; };
     int k = next_step(-1);
     if (k < nk) gload(k);
@@ -383,7 +400,7 @@ int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats,
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.M = N * Hd * Wd; p.K = ksize * ksize * Cs;
     static const bool nocls = getenv("CLHIP_NO_PARITY_DGRAD") != nullptr;
-    p.cls_tiles = (!nocls && mode == 1 && stride == 2 && ksize == 3 && Cs >= 64 && (Hd % 2 == 0) && (Wd % 2 == 0)) ? 1 : 0;
+    p.cls_tiles = (!nocls && mode == 1 && stride == 2 && ksize == 3 && Cs >= 32 && p.log2Cs >= 0 && (Hd % 2 == 0) && (Wd % 2 == 0)) ? 1 : 0;
     if (dtype == CLHIP_BF16) return mode == 0 ? launch2<bf16_t, 0>(p, st) : launch2<bf16_t, 1>(p, st);
     return mode == 0 ? launch2<float, 0>(p, st) : launch2<float, 1>(p, st);
 }

@@ -54,6 +54,7 @@ CONV_CASES = [
     (2, 8, 8, 16, 16, 3, 1, 1),
     (2, 8, 8, 16, 32, 3, 2, 1),
     (2, 8, 8, 16, 32, 1, 2, 0),
+    (5, 32, 32, 16, 32, 3, 2, 1),      # CifarResNet-32 stage 2 entry: parity-class dgrad with a K-step spanning two taps
     (3, 5, 7, 32, 48, 3, 1, 1),        # ragged spatial size, K not a power of two
     (2, 6, 6, 64, 128, 3, 1, 1),
     (1, 4, 4, 256, 512, 3, 2, 1),
