@@ -51,7 +51,7 @@ def _worker(rank, world, port, q):
     head.weight.grad = torch.full_like(head.weight, float(rank + 1))
     with red.overlap(net, fraction=0.5):
         k = bb.grad_cut_for_fraction(0.5)
-        cut = bb._layout[3 * k][2]
+        cut = bb._unit_off[k]
         ok = ok and k > 0 and bb._grad_segment_hook is not None and bb._nflat - cut >= 0.5 * bb._nflat
         bb._grad_segment_hook(bb, cut, bb._nflat)          # "units >= k are done"
         bb._grad_segment_hook(bb, 0, cut)                  # the head of the buffer is left to reduce()

@@ -170,6 +170,29 @@ def test_preactivation_backbone_vs_oracle_random_init(dtype, size):
         assert relnorm(p.grad.cpu(), q.grad.cpu()) < 1e-5, n
 
 
+def test_preactivation_backward_in_ranges_matches_the_whole_backward():
+    """the data-parallel host runs the backward in unit ranges (parallel.GradientReducer): with raw-sum residuals the gradient of a
+    block input crosses a range boundary through the persistent raw-gradient buffers"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+    cw = torch.randn(8, 64, generator=g).to(DEV)
+    bb = M.cifar_resnet32_V2(dtype="f32").to(DEV)
+    bb.train()
+    (bb(x) * cw).sum().backward()
+    whole = [p.grad.clone() for p in bb.parameters()]
+    for cuts in ([17], [30, 22, 11, 3]):                     # inside a block, at shortcut units, several pieces
+        for p in bb.parameters():
+            p.grad = None
+        seen = []
+        bb._grad_segment_cuts, bb._grad_segment_hook = cuts, (lambda mod, lo, hi: seen.append((lo, hi)))
+        (bb(x) * cw).sum().backward()
+        bb._grad_segment_hook, bb._grad_segment_cuts = None, []
+        assert len(seen) == len(cuts) + 1 and seen[0][1] == bb._nflat and seen[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(seen, seen[1:]))             # contiguous ranges, tail of the flat buffer first
+        for p, w in zip(bb.parameters(), whole):
+            assert relnorm(p.grad.cpu(), w.cpu()) < 1e-5
+
+
 def test_backbone_intermediate_activations_f32():
     """layer-by-layer: every unit's pre-BN conv output and post-activation against the oracle"""
     arch = "cifar_resnet32"
