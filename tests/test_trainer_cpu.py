@@ -110,6 +110,63 @@ def test_rehearsal_merge_and_random_buffer():
     assert len(tr.train_loader.get_loader(1).dataset) == 22
 
 
+class TinyBic(TinyMethod):
+    """pure-torch stand-in with BiC's trainer-facing surface (bic.py:83-340); the host-side split is the PRODUCT's method"""
+    spilt_and_update = M.bic.spilt_and_update
+
+    def __init__(self, backbone, feat_dim, num_class, **kwargs):
+        super().__init__(backbone, feat_dim, num_class, **kwargs)
+        self.bias_layers = nn.ModuleList([M.BiasLayer() for _ in range(kwargs["task_num"])])
+        self.bias_opt = torch.optim.Adam(self.bias_layers.parameters(), lr=1e-3)
+        self.cls_count, self.stage2_modes = {}, []
+
+    def observe(self, data):
+        TinyMethod.events.append(("observe_mode", self.training, self.bias_layers[0].training))
+        return super().observe(data)
+
+    def stage2(self, data):
+        self.stage2_modes.append((self.training, self.backbone.training, self.bias_layers[0].training))
+        x, y = data["image"], data["label"]
+        with torch.no_grad():
+            z = self.classifier(self.backbone(x)["features"])[:, : self.seen]
+        loss = nn.functional.cross_entropy(self.bias_layers[0](z), y)
+        self.bias_opt.zero_grad(); loss.backward(); self.bias_opt.step()
+        pred = z.argmax(1)
+        return pred, (pred == y).sum().item() / len(y), loss
+
+
+def test_bic_flow_split_stage1_recipe_and_stage2():
+    """the method named `bic` gets (core/trainer.py:297-303) a hard-wired SGD / MultiStepLR and its own train / validation loaders,
+    keeps the trainer's buffer update away (:410) and, from task 1 on, a second stage on the validation loader between the buffer
+    update and the final evaluations (:420-455) with the model in eval mode and the bias layers in train mode (:545-547)"""
+    TinyMethod.events = []
+    ns = namespace()
+    ns.bic, ns.LinearSpiltBuffer = TinyBic, M.LinearSpiltBuffer
+    cfg = make_cfg(classifier={"name": "bic", "kwargs": {"feat_dim": 16, "num_class": 8, "init_cls_num": 4, "inc_cls_num": 2, "task_num": 3}},
+                   buffer={"name": "LinearSpiltBuffer", "kwargs": {"buffer_size": 40, "batch_size": 8, "strategy": "balance_random", "val_ratio": 0.1}},
+                   stage2_epoch=2, testing_times=1, val_per_epoch=100, synthetic_per_class=10, gpu_input_pipeline=False)
+    tr = T.Trainer(0, cfg, model_namespace=ns, optim_namespace=torch.optim, log=lambda *a, **k: None)
+    seen_opts = []
+    TinyMethod.trainer_opt = lambda self: seen_opts.append((tr.optimizer.param_groups[0]["lr"], tr.optimizer.param_groups[0]["momentum"],
+                                                            tr.optimizer.param_groups[0]["weight_decay"], tr.scheduler.milestones)) or tr.optimizer
+    tr.train_loop()
+    want_wd = [2e-4 * 3 / (t + 1) for t in range(3)]
+    assert [o[:2] for o in seen_opts] == [(0.1, 0.9)] * 3 and np.allclose([o[2] for o in seen_opts], want_wd)
+    assert all(sorted(o[3]) == [100, 150, 200] for o in seen_opts)
+    # order inside a task: stage-1 epochs, [stage-2 epochs], evaluation
+    for t in range(3):
+        ev = [e[0] for e in tr.hook_trace if e[1] == t and e[0] != "before_task"]
+        want = ["train_epoch"] * (1 if t == 0 else 2) + ["after_task"] + (["stage2_epoch"] * 2 if t > 0 else [])
+        assert [e for e in ev if e != "validate"] == want and ev[-1] == "validate", (t, ev)       # (the `epoch + 1 == inc_epoch` validation sits in between)
+    assert all(m == (False, False, True) for m in tr.model.stage2_modes) and len(tr.model.stage2_modes) > 0
+    assert all(e[1] is True for e in TinyMethod.events if e[0] == "observe_mode")                # stage 1 runs under model.train()
+    # the split buffer was filled and re-cut by the plugin alone: 40 * count_c / total = 5 per class -> 3 train + 1 validation (bic.py:317-321)
+    buf = tr.buffer
+    assert buf.total_classes == 8 and len(buf.train_labels) == 24 and len(buf.val_labels) == 8
+    assert sorted(int(v) for v in set(buf.train_labels)) == list(range(8)) and sorted(int(v) for v in buf.val_labels) == list(range(8))
+    assert not hasattr(buf, "images")
+
+
 def test_seed_schedule_reproducible():
     """init_seed(seed + epoch) before every epoch (trainer.py:584): two runs give identical parameters"""
     outs = []
