@@ -308,8 +308,13 @@ int bn_bwd_blocks(int64_t M, int C) {
     int cpr = C >> 3;
     int rpi = 256 / cpr;
     int64_t g = (M + rpi - 1) / rpi;
-    // a few iterations per block; cap so the finalize reduction stays short
-    g = (g + 7) / 8;
+    // up to 8 iterations per block, but small tensors (batch 32, the 8x8 / 4x4 layers) keep 128+ workgroups: with 32 of them the
+    // kernel sat at its latency floor on a mostly idle chip; cap so the finalize reduction stays short
+    static const int forced = getenv("CLHIP_BN_BWD_ITERS") ? atoi(getenv("CLHIP_BN_BWD_ITERS")) : 0;      // ablation runs
+    int64_t iters = forced > 0 ? forced : g / 128;
+    if (iters < 1) iters = 1;
+    if (iters > 8) iters = 8;
+    g = (g + iters - 1) / iters;
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     return (int)g;
