@@ -110,6 +110,10 @@ int clhip_bn_apply_train(const void* z, const double* stat_acc, int replicas, in
 int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
                      float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu, double* acc,
                      int replicas, int dtype, void* stream);
+/* the same for a unit whose ReLU follows the BatchNorm directly (no residual): the ReLU mask is recomputed from z with the forward's
+ * own scale / shift expressions (gamma * invstd, beta - mean * scale), so the activation tensor is not read                          */
+int clhip_bn_bwd_acc_zmask(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           float* dgamma, float* dbeta, void* dz, int64_t M, int C, double* acc, int replicas, int dtype, void* stream);
 /* number of reduction workgroups clhip_bn_bwd / clhip_bn_bwd_acc launch (= producers adding into the accumulator) */
 int clhip_bn_bwd_blocks(int64_t M, int C);
 size_t clhip_bn_bwd_ws_floats(int64_t M, int C);

@@ -83,11 +83,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
 // ------------------------------------------------------------------------------------- backward
 // pass 1: per-channel partial sums of g = dy*mask and g*xhat over a slab of rows.
 // thread layout: cpr = C/8 chunk columns per row, rpi = 256/cpr rows per iteration.
-template <typename T, bool RELU>
+// RELU: 0 none, 1 mask = (y > 0), 2 mask recomputed from z -- units without a residual: y = max(fmaf(z, scale, shift), 0) with the
+// forward's own fp32 scale / shift expressions, so the sign test is bit-identical and the y tensor is not read at all
+template <typename T, int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                             const T* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            double* __restrict__ acc, int rep, int64_t M, int C) {
+                                                            double* __restrict__ acc, int rep, int64_t M, int C,
+                                                            const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float red[];     // [256][16]
     const int cpr = C >> 3;
     const int rpi = 256 / cpr;
@@ -96,19 +99,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
     if (ro < rpi) {
-        float mu[8], is[8];
+        float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { mu[e] = mean[cc * 8 + e]; is[e] = invstd[cc * 8 + e]; }
+        for (int e = 0; e < 8; ++e) {
+            mu[e] = mean[cc * 8 + e]; is[e] = invstd[cc * 8 + e];
+            if (RELU == 2) { sc[e] = gamma[cc * 8 + e] * is[e]; sh[e] = beta[cc * 8 + e] - mu[e] * sc[e]; }
+        }
         for (int64_t r = (int64_t)blockIdx.x * rpi + ro; r < M; r += (int64_t)gridDim.x * rpi) {
             const int64_t off = r * C + cc * 8;
             float g[8], yy[8], zz[8];
             load8<T>(dy + off, g);
             load8<T>(z + off, zz);
-            if (RELU) load8<T>(y + off, yy);
+            if (RELU == 1) load8<T>(y + off, yy);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float gg = g[e];
-                if (RELU) gg = yy[e] > 0.f ? gg : 0.f;
+                if (RELU == 1) gg = yy[e] > 0.f ? gg : 0.f;
+                if (RELU == 2) gg = fmaf(zz[e], sc[e], sh[e]) > 0.f ? gg : 0.f;
                 a1[e] += gg;
                 a2[e] += gg * (zz[e] - mu[e]) * is[e];
             }
@@ -256,12 +263,12 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
     }
 }
 
-template <typename T, bool RELU, int DRES>
+template <typename T, int RELU, int DRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ z,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const double* __restrict__ acc, int rep, double invM,
                                                                float* dgamma, float* dbeta, T* __restrict__ dz, T* __restrict__ dres,
-                                                               int64_t nchunks, int C) {
+                                                               int64_t nchunks, int C, const float* __restrict__ beta = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: mean(g), mean(g * xhat)
     for (int c = threadIdx.x; c < C; c += 256) {
         double s1 = 0.0, s2 = 0.0;
@@ -274,25 +281,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c0 = (int)((i0 * 8) % C);
-    float k0[8], k1[8], gi[8], mu[8], is[8];
+    float k0[8], k1[8], gi[8], mu[8], is[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         k0[e] = coefs[c0 + e];
         k1[e] = coefs[C + c0 + e];
         mu[e] = mean[c0 + e];
         is[e] = invstd[c0 + e];
-        gi[e] = gamma[c0 + e] * is[e];
+        gi[e] = gamma[c0 + e] * is[e];                    // = the forward's scale
+        if (RELU == 2) sh[e] = beta[c0 + e] - mu[e] * gi[e];
     }
     for (int64_t i = i0; i < nchunks; i += stride) {
         float g[8], yy[8], zz[8], o[8], rr[8];
         load8<T>(dy + i * 8, g);
         load8<T>(z + i * 8, zz);
-        if (RELU) load8<T>(y + i * 8, yy);
+        if (RELU == 1) load8<T>(y + i * 8, yy);
         if (DRES == 2) load8<T>(dres + i * 8, rr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float gg = g[e];
-            if (RELU) gg = yy[e] > 0.f ? gg : 0.f;
+            if (RELU == 1) gg = yy[e] > 0.f ? gg : 0.f;
+            if (RELU == 2) gg = fmaf(zz[e], gi[e], sh[e]) > 0.f ? gg : 0.f;
             const float xh = (zz[e] - mu[e]) * is[e];
             o[e] = gi[e] * (gg - k0[e] - xh * k1[e]);
             g[e] = gg;
@@ -563,8 +572,8 @@ static int bn_bwd_t(const void* dy, const void* y, const void* z, const float* m
     float* coef = ws + (size_t)G * 2 * C;
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = 256 * 16 * sizeof(float);
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C, (const float*)nullptr, (const float*)nullptr);
     CLHIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, G, 1.0 / (double)M, C, dgamma, dbeta, coef);
     CLHIP_LAUNCH_CHECK();
@@ -636,12 +645,14 @@ extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int r
 
 template <typename T>
 static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                        float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, int rep, hipStream_t st) {
+                        float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, int rep, hipStream_t st,
+                        const float* beta = nullptr) {        // relu == 2: the mask comes from z, gamma and beta (see bn_bwd_reduce_kernel)
     const int G = bn_bwd_blocks(M, C);
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = 256 * 16 * sizeof(float);
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C);
+    if (relu == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, gamma, beta);
+    else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
     CLHIP_LAUNCH_CHECK();
     const int64_t nch = M * C / 8;
     dim3 g(acc_blocks(nch)), b(256);
@@ -649,9 +660,10 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     T* dzz = (T*)dz; T* dr = (T*)dres;
     const double invM = 1.0 / (double)M;
     int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
-#define BWD_ACC(R, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, lds2, st, dyy, yy, zz, mean, invstd, gamma, acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C)
-    if (relu) { if (mode == 0) BWD_ACC(true, 0); else if (mode == 1) BWD_ACC(true, 1); else BWD_ACC(true, 2); }
-    else { if (mode == 0) BWD_ACC(false, 0); else if (mode == 1) BWD_ACC(false, 1); else BWD_ACC(false, 2); }
+#define BWD_ACC(R, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, lds2, st, dyy, yy, zz, mean, invstd, gamma, acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C, beta)
+    if (relu == 2) { if (mode == 0) BWD_ACC(2, 0); else if (mode == 1) BWD_ACC(2, 1); else BWD_ACC(2, 2); }
+    else if (relu) { if (mode == 0) BWD_ACC(1, 0); else if (mode == 1) BWD_ACC(1, 1); else BWD_ACC(1, 2); }
+    else { if (mode == 0) BWD_ACC(0, 0); else if (mode == 1) BWD_ACC(0, 1); else BWD_ACC(0, 2); }
 #undef BWD_ACC
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
@@ -667,6 +679,18 @@ extern "C" int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, co
         return bn_bwd_acc_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, replicas, (hipStream_t)stream);
     if (dtype == CLHIP_F32)
         return bn_bwd_acc_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, acc, replicas, (hipStream_t)stream);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+extern "C" int clhip_bn_bwd_acc_zmask(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      float* dgamma, float* dbeta, void* dz, int64_t M, int C, double* acc, int replicas, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dy && z && mean && invstd && gamma && beta && dgamma && dbeta && dz && acc && M > 0 && acc_ok(C));
+    CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    if (dtype == CLHIP_BF16)
+        return bn_bwd_acc_t<bf16_t>(dy, nullptr, z, mean, invstd, gamma, dgamma, dbeta, dz, nullptr, 0, M, C, 2, acc, replicas, (hipStream_t)stream, beta);
+    if (dtype == CLHIP_F32)
+        return bn_bwd_acc_t<float>(dy, nullptr, z, mean, invstd, gamma, dgamma, dbeta, dz, nullptr, 0, M, C, 2, acc, replicas, (hipStream_t)stream, beta);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }

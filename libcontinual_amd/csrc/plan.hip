@@ -402,7 +402,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipStreamWaitEvent(main_s, p->ev_wg[k], 0);         // the weight gradient of two units ago has finished reading this buffer
             p->wg_pending[k] = false;
         }
+        static const bool mask_from_y = getenv("CLHIP_BN_MASK_FROM_Y") != nullptr;       // ablation: always read the activation
         if (u.no_bn) {
+        } else if (u.rep_bwd > 0 && u.relu && dres == nullptr && !mask_from_y) {
+            // ReLU straight after the BatchNorm (no residual in between): the mask is recomputed from z, y is not read
+            TRY(clhip_bn_bwd_acc_zmask(ws + dst.dy_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off, params + u.d.beta_off,
+                                       grads + u.d.gamma_off, grads + u.d.beta_off, dz, u.M, u.d.cout,
+                                       reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else if (u.rep_bwd > 0) {
             TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
                                  grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.relu,

@@ -287,6 +287,21 @@ def test_batchnorm_fwd_bwd(shape, mode, relu, res):
     assert (db2.cpu().double() - b64.grad).abs().max() <= 2e-3 * (b64.grad.abs().max() + 1e-9) + 1e-4
     if res:
         assert (from_nhwc(dres2).double() - rr.grad).abs().max() <= tol(mode, rr.grad)
+    if relu and not res:
+        # ReLU right after the BatchNorm: the mask recomputed from z (forward's own scale / shift expressions) is the mask read from y
+        outs = []
+        for variant in ("from_y", "from_z"):
+            bacc.zero_(); dg2.zero_(); db2.zero_()
+            dz3 = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+            if variant == "from_y":
+                call("clhip_bn_bwd_acc", dyd.data_ptr(), y2.data_ptr(), zd.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gd.data_ptr(), dg2.data_ptr(),
+                     db2.data_ptr(), dz3.data_ptr(), None, 0, M, C, 1, bacc.data_ptr(), REP, code, st())
+            else:
+                call("clhip_bn_bwd_acc_zmask", dyd.data_ptr(), zd.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gd.data_ptr(), bd.data_ptr(), dg2.data_ptr(),
+                     db2.data_ptr(), dz3.data_ptr(), M, C, bacc.data_ptr(), REP, code, st())
+            outs.append((from_nhwc(dz3).clone(), dg2.cpu().clone(), db2.cpu().clone()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-5)
     # eval-mode affine
     call("clhip_bn_eval_affine", gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, C, scale.data_ptr(),
          shift.data_ptr(), st())
