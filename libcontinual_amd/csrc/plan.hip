@@ -64,6 +64,7 @@ struct clhip_plan {
     size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
     int feat_dim;
+    bool side_ok;            // some unit's weight gradient is big enough for the side stream to pay (see clhip_plan_backward_range)
     int pool_win;            // 0: global average pool, else nn.AvgPool2d(pool_win) + NCHW flatten
 };
 
@@ -193,6 +194,12 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
             return nullptr;
         }
         p->feat_dim = pool_win > 0 ? last.C * (last.H / pool_win) * (last.W / pool_win) : last.C;
+    }
+    {
+        const double net_flops = 1.0e9 * (getenv("CLHIP_WGRAD_NET_GFLOP") ? atof(getenv("CLHIP_WGRAD_NET_GFLOP")) : 4.0);
+        p->side_ok = false;
+        for (const Unit& u : p->units)
+            if (2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout >= net_flops) p->side_ok = true;
     }
     // gradient write/accumulate flags: simulate the reverse sweep
     std::vector<char> written(p->acts.size(), 0);
@@ -421,8 +428,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         if (u.has_dzr && !u.no_bn) TRY(clhip_add_inplace(dz, ws + u.dzr_off, u.M * u.d.cout, p->dtype, stream));
         // small layers stay on the caller's stream: below ~1 GFLOP the three event calls cost more host time than the overlap wins
         // (ResNet-32 at batch <= 128 is host-bound: 60.5 k img/s on one stream vs 57.1 k on two; ResNet-18 gains from batch 64 up)
+        // A network made of such layers only gets no side stream at all: ResNet-32 at batch 256 (1.2 GFLOP per layer, 7-19 us kernels) ran
+        // 2.08-2.35 ms per EWC step from run to run with its weight gradients on the side stream, 2.200 +- 0.003 ms without -- the same mean,
+        // whereas ResNet-18 (10-19 GFLOP layers; its 1-GFLOP shortcut convs included) gains 10 % reproducibly.  `side_ok` = the plan has a
+        // layer of CLHIP_WGRAD_NET_GFLOP (default 4) GFLOP or more.
         const double wg_flops = 2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout;
-        const bool on_side = two_streams && wg_flops >= 1.0e9;
+        const bool on_side = two_streams && p->side_ok && wg_flops >= 1.0e9;
         void* wg_stream = stream;
         if (on_side) {
             (void)hipEventRecord(p->ev_dz[k], main_s);
