@@ -216,8 +216,17 @@ def gemm_roofline(dev, dtype, M):
     es = 2 if dtype == "bf16" else 4
     alg_bytes = (M * K + N * K + 2 * M * N) * es
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM traffic per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/roofline_pmc_gemm.sh) of this kernel at this shape, committed
+    # under profiles/; null if no matching measurement is on disk
+    traffic, src = None, None
+    pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_roofline_pmc_gemm.json")
+    if os.path.exists(pj):
+        with open(pj) as f:
+            for m in json.load(f):
+                if m.get("shape") == [M, N, K] and m.get("dtype") == dtype:
+                    traffic, src = m["traffic_bytes_per_launch"], "profiles/r01_roofline_pmc_gemm.json (rocprofv3 --pmc, separate passes)"
     return dict(bound="mfma", kernel=f"gemm_nt_kernel<{dtype}, bias+GELU> fc1 @ [{M},768]x[3072,768]^T", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                frac=ach / PEAK_BF16_TFLOPS, traffic=None, launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
+                frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=src, launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
                 hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
 
 
