@@ -443,6 +443,10 @@ bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, 
 int clhip_conv3_tiles_m(int M, int Cd);
 int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, int accumulate,
                        int mode, hipStream_t st);
+bool clhip_conv4_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
+int clhip_conv4_tiles_m(int M, int Cs, int Cd, int W);
+int clhip_conv4_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, int accumulate,
+                       int mode, hipStream_t st);
 bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
 int clhip_conv16_tiles_m(int M);
 int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
@@ -474,6 +478,7 @@ extern "C" int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize
         }
         if (use_v3() && clhip_conv3_supported(H, W, C, K, ksize, stride, pad, CLHIP_BF16)) {
             int t3 = clhip_conv3_tiles_m(M, K);
+            if (clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, CLHIP_BF16)) { int t4 = clhip_conv4_tiles_m(M, C, K, W); if (t4 > t3) t3 = t4; }
             return t3 > t2 ? t3 : t2;
         }
         return t2;
@@ -516,6 +521,13 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
             hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
         return clhip_conv16_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, 0, 0, st);
     }
+    if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype)) {
+        int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
+        int tiles_used = clhip_conv4_tiles_m(p.M, C, K, W);
+        if (stat_partials && tiles_alloc > tiles_used)
+            hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
+        return clhip_conv4_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, K, 0, 0, st);
+    }
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, C, K, ksize, stride, pad, dtype)) {
         // the caller's partial buffer may hold more tiles than this kernel writes: zero the tail rows
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
@@ -554,6 +566,8 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, st);
+    if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv4_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv3_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, st);
     if (!use_v1()) return clhip_conv2_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, p.Hs, p.Ws, K, H, W, C, ksize, stride, pad, accumulate, 1, dtype, st);
