@@ -77,6 +77,17 @@ int clhip_conv_fwd_acc(const void* x, const void* w_fwd, void* z, double* stat_a
                        int ksize, int stride, int pad, int dtype, void* stream);
 int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C, int K,
                      int ksize, int stride, int pad, int dtype, void* stream);
+/* clhip_conv_dgrad whose epilogue also reduces the BatchNorm backward of the layer that PRODUCED the tensor x (the two per-channel
+ * sums of autograd's batch-norm backward, resnet.py:296-316: sum g and sum g * xhat with g = dx * (y_prod > 0), xhat =
+ * (z_prod - mean) * invstd), from the fp32 results before they are rounded: the separate reduction pass over dx and z_prod
+ * (first launch of clhip_bn_bwd_acc) disappears.  Valid when this launch COMPLETES dx (it is the last writer / accumulator).
+ * z_prod, y_prod: [N,H,W,C] pre- / post-activation outputs of the producing layer (y_prod NULL: no ReLU); acc[replicas][2][C] fp64,
+ * zeroed by the caller.  3x3 / stride 1 / pad 1 bf16 layers the fourth-generation kernel covers:
+ * clhip_conv_dgrad_bn_reduce_supported() != 0. */
+int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
+int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod /*nullable*/,
+                               const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C, int K,
+                               int ksize, int stride, int pad, int dtype, void* stream);
 size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* ws, int N, int H, int W, int C, int Creal, int K, int ksize,
                      int stride, int pad, int dtype, void* stream);
@@ -114,6 +125,13 @@ int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* 
  * own scale / shift expressions (gamma * invstd, beta - mean * scale), so the activation tensor is not read                          */
 int clhip_bn_bwd_acc_zmask(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                            float* dgamma, float* dbeta, void* dz, int64_t M, int C, double* acc, int replicas, int dtype, void* stream);
+/* The apply half alone: acc[replicas][2][C] already holds sum g and sum g * xhat -- accumulated by the launch that produced dy
+ * (clhip_conv_dgrad_bn_reduce).  relu: 0 none, 1 mask = (y > 0), 2 mask recomputed from z, gamma, beta (then beta is required and
+ * dres must be NULL).  Same arithmetic as the second launch of clhip_bn_bwd_acc (autograd of nn.BatchNorm2d + ReLU + residual add,
+ * core/model/backbone/resnet.py:296-316). */
+int clhip_bn_bwd_apply_acc(const void* dy, const void* y /*nullable*/, const void* z, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta /*nullable*/, float* dgamma, float* dbeta, void* dz, void* dres /*nullable*/, int dres_accumulate,
+                           int64_t M, int C, int relu, const double* acc, int replicas, int dtype, void* stream);
 /* number of reduction workgroups clhip_bn_bwd / clhip_bn_bwd_acc launch (= producers adding into the accumulator) */
 int clhip_bn_bwd_blocks(int64_t M, int C);
 size_t clhip_bn_bwd_ws_floats(int64_t M, int C);

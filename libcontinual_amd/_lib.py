@@ -65,6 +65,9 @@ _PROTOS = {
     "clhip_bn_bwd_acc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p]),
     "clhip_bn_bwd_acc_zmask": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _i, _p]),
     "clhip_conv_dgrad": (_i, [_p, _p, _p, _i] + [_i] * 9 + [_p]),
+    "clhip_conv_dgrad_bn_reduce_supported": (_i, [_i] * 9),
+    "clhip_conv_dgrad_bn_reduce": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
+    "clhip_bn_bwd_apply_acc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p]),
     "clhip_conv_wgrad_ws_bytes": (_sz, [_i] * 10),
     "clhip_conv_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_bn_stats_finalize": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),

@@ -646,11 +646,12 @@ extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int r
 template <typename T>
 static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                         float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, int rep, hipStream_t st,
-                        const float* beta = nullptr) {        // relu == 2: the mask comes from z, gamma and beta (see bn_bwd_reduce_kernel)
+                        const float* beta = nullptr, bool sums_ready = false) {        // relu == 2: the mask comes from z, gamma and beta (see bn_bwd_reduce_kernel)
     const int G = bn_bwd_blocks(M, C);
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = 256 * 16 * sizeof(float);
-    if (relu == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, gamma, beta);
+    if (sums_ready) { /* the two channel sums were accumulated by the producer of dy (clhip_conv_dgrad_bn_reduce): apply pass only */ }
+    else if (relu == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, gamma, beta);
     else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
     CLHIP_LAUNCH_CHECK();
@@ -691,6 +692,21 @@ extern "C" int clhip_bn_bwd_acc_zmask(const void* dy, const void* z, const float
         return bn_bwd_acc_t<bf16_t>(dy, nullptr, z, mean, invstd, gamma, dgamma, dbeta, dz, nullptr, 0, M, C, 2, acc, replicas, (hipStream_t)stream, beta);
     if (dtype == CLHIP_F32)
         return bn_bwd_acc_t<float>(dy, nullptr, z, mean, invstd, gamma, dgamma, dbeta, dz, nullptr, 0, M, C, 2, acc, replicas, (hipStream_t)stream, beta);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+extern "C" int clhip_bn_bwd_apply_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C,
+                                      int relu, const double* acc, int replicas, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dy && z && mean && invstd && gamma && dgamma && dbeta && dz && acc && M > 0 && acc_ok(C));
+    CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    CLHIP_CHECK_ARG(relu >= 0 && relu <= 2 && (relu != 1 || y) && (relu != 2 || (beta && dres == nullptr)));
+    double* a = const_cast<double*>(acc);
+    if (dtype == CLHIP_BF16)
+        return bn_bwd_acc_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, a, replicas, (hipStream_t)stream, beta, true);
+    if (dtype == CLHIP_F32)
+        return bn_bwd_acc_t<float>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, a, replicas, (hipStream_t)stream, beta, true);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }

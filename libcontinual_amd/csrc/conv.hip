@@ -447,6 +447,9 @@ bool clhip_conv4_supported(int N, int H, int W, int Cs, int Cd, int ksize, int s
 int clhip_conv4_tiles_m(int M, int Cs, int Cd, int W);
 int clhip_conv4_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, int accumulate,
                        int mode, hipStream_t st);
+int clhip_conv4_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd,
+                          int accumulate, int mode, const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep,
+                          hipStream_t st);
 bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
 int clhip_conv16_tiles_m(int M);
 int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
@@ -575,6 +578,22 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     if (dtype == CLHIP_F32) return launch_igemm<float, 1>(p, st);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
+}
+
+extern "C" int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
+    if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
+    return (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
+}
+
+extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod,
+                                          const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C, int K,
+                                          int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(dz && w_dg && dx && z_prod && mean && invstd && acc);
+    CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    CLHIP_CHECK_ARG(clhip_conv_dgrad_bn_reduce_supported(N, H, W, C, K, ksize, stride, pad, dtype));
+    return clhip_conv4_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
+                                 static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {

@@ -49,6 +49,14 @@ struct Conv4Params {
     float* stats;        // per-tile partial rows [tile][2][Cd] or nullptr
     double* stat_acc;    // [stat_rep][2][Cd] fp64 accumulators or nullptr
     int stat_rep;
+    // dgrad only: BatchNorm-backward sums of the layer that PRODUCED the tensor whose gradient this launch completes
+    // (sum g and sum g * xhat per channel, g = dy masked by the ReLU), accumulated from the fp32 results in the epilogue
+    const bf16_t* bn_z;      // [N,H,W,Cd] pre-BatchNorm output of that layer (xhat = (z - mean) * invstd), or nullptr: no reduction
+    const bf16_t* bn_y;      // its post-activation output for the ReLU mask (y > 0), or nullptr: no ReLU
+    const float* bn_mean;
+    const float* bn_invstd;
+    double* bn_acc;          // [bn_rep][2][Cd]
+    int bn_rep;
     int H, W, Cs, Cd, M, accumulate;
     int wshift, hshift;
     int np;              // patch pixels = BM + 2W + 2
@@ -447,16 +455,49 @@ __global__ __launch_bounds__(WM * WN * KG * 64, 2) void conv4_kernel(const Conv4
                 }
             }
         }
-        if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr) && !(DBG(p) & 16)) {
-            // per-channel sum / sum of squares over this wave's 64 pixels (pixels beyond M hold exact zeros), one channel tile at a time
+        const bool fwd_stats = MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr) && !(DBG(p) & 16);
+        const bool bwd_sums = MODE == 1 && p.bn_z != nullptr;
+        if (fwd_stats || bwd_sums) {
+            // Two per-channel sums over this wave's 64 pixels, one channel tile at a time (pixels beyond M hold exact zeros):
+            //   forward: sum z, sum z^2 (BatchNorm batch statistics of THIS layer, from the fp32 accumulators);
+            //   dgrad  : sum g, sum g*z' with g = dy * (y' > 0) -- the BatchNorm-backward reduction of the layer that produced the
+            //            tensor whose gradient dy this launch completes (z', y' = that layer's pre- / post-activation outputs); the
+            //            centred form  sum g * xhat = invstd * (sum g z' - mean * sum g)  is taken once per channel below, so
+            //            no per-channel constant is needed per element.  Replaces one full bn_bwd_reduce pass (2 tensor reads).
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float sv[32];
+                if (MODE == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a = acc[j][0][r], b = acc[j][1][r];
-                    sv[r] = a + b;
-                    sv[16 + r] = fmaf(a, a, b * b);
+                    for (int r = 0; r < 16; ++r) {
+                        const float a = acc[j][0][r], b = acc[j][1][r];
+                        sv[r] = a + b;
+                        sv[16 + r] = fmaf(a, a, b * b);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) sv[r] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int pix = m0 + wm * 64 + i * 32 + l31;
+                        if (pix < p.M) {
+                            const size_t row = (size_t)pix * p.Cd + n0 + wn * 64 + j * 32 + kh * 4;
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + row + g4 * 8);
+                                uint2 yy = make_uint2(0x3f803f80u, 0x3f803f80u);
+                                if (p.bn_y != nullptr) yy = *reinterpret_cast<const uint2*>(p.bn_y + row + g4 * 8);
+                                const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
+                                const float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float g = y4[e] > 0.f ? acc[j][i][4 * g4 + e] : 0.f;
+                                    sv[4 * g4 + e] += g;
+                                    sv[16 + 4 * g4 + e] = fmaf(g, z4[e], sv[16 + 4 * g4 + e]);
+                                }
+                            }
+                        }
+                    }
                 }
                 row16_sum_n(sv);
                 if ((lane & 15) == 0) {
@@ -478,8 +519,18 @@ __global__ __launch_bounds__(WM * WN * KG * 64, 2) void conv4_kernel(const Conv4
 #pragma unroll
                 for (int w2 = 0; w2 < WM * 2; ++w2) t += red[(w2 * 2 + which) * BN + c2];
                 const int mt = item >> p.nt_shift;
-                if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(mt & (p.stat_rep - 1)) * 2 + which) * p.Cd + n0 + c2, (double)t);
-                else p.stats[((size_t)mt * 2 + which) * p.Cd + n0 + c2] = t;
+                if (MODE == 0) {
+                    if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(mt & (p.stat_rep - 1)) * 2 + which) * p.Cd + n0 + c2, (double)t);
+                    else p.stats[((size_t)mt * 2 + which) * p.Cd + n0 + c2] = t;
+                } else {
+                    if (which == 1) {                             // sum g * xhat from sum g z' and sum g
+                        float sg = 0.f;
+#pragma unroll
+                        for (int w2 = 0; w2 < WM * 2; ++w2) sg += red[(w2 * 2 + 0) * BN + c2];
+                        t = p.bn_invstd[n0 + c2] * (t - p.bn_mean[n0 + c2] * sg);
+                    }
+                    atomicAdd(p.bn_acc + ((size_t)(mt & (p.bn_rep - 1)) * 2 + which) * p.Cd + n0 + c2, (double)t);
+                }
             }
             // `red` is rewritten one item later, many barriers from here
         }
@@ -562,9 +613,21 @@ bool clhip_conv4_supported(int N, int H, int W, int Cs, int Cd, int ksize, int s
 
 int clhip_conv4_tiles_m(int M, int Cs, int Cd, int W) { return (M + pick4(M, Cs, Cd, W).wm * 64 - 1) / (pick4(M, Cs, Cd, W).wm * 64); }
 
+int clhip_conv4_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd,
+                          int accumulate, int mode, const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep,
+                          hipStream_t st);
+
 int clhip_conv4_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd,
                        int accumulate, int mode, hipStream_t st) {
+    return clhip_conv4_launch_bn(src, wt, dst, stats, stat_acc, stat_rep, N, H, W, Cs, Cd, accumulate, mode, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+}
+
+int clhip_conv4_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd,
+                          int accumulate, int mode, const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep,
+                          hipStream_t st) {
     Conv4Params p;
+    p.bn_z = static_cast<const bf16_t*>(bn_z); p.bn_y = static_cast<const bf16_t*>(bn_y); p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
+    p.bn_acc = bn_acc; p.bn_rep = bn_rep > 0 ? bn_rep : 1;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;

@@ -44,6 +44,8 @@ struct Unit {
     bool relu, pre_res, raw_src, no_bn;          // decoded CLHIP_UNIT_* bits of d.relu
     bool has_dzr;                                // this unit's raw sum is consumed raw (PRE_RES / RAW_SRC) by a later unit
     size_t dzr_off;                              // ... whose gradient contribution lands here (bytes into the workspace)
+    bool fuse_src_bn;                            // this unit's dgrad completes the gradient of its input activation AND can reduce the
+                                                 // BatchNorm backward of the unit that produced it in its epilogue (clhip_conv_dgrad_bn_reduce)
 };
 }  // namespace
 
@@ -63,6 +65,7 @@ struct clhip_plan {
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
     size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
+    std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
     int feat_dim;
     bool side_ok;            // some unit's weight gradient is big enough for the side stream to pay (see clhip_plan_backward_range)
     int pool_win;            // 0: global average pool, else nn.AvgPool2d(pool_win) + NCHW flatten
@@ -209,6 +212,33 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (u.d.res >= 0 && !u.pre_res) { u.dres_acc = written[u.d.res]; written[u.d.res] = 1; }
         if (u.d.src != 0 && !u.raw_src) { u.dx_acc = written[u.d.src]; written[u.d.src] = 1; }
     }
+    // BatchNorm-backward reduction fused into a dgrad epilogue: unit i's dgrad may reduce for the producer of its input activation
+    // when it is the LAST writer of that activation's gradient in the reverse sweep (= the lowest-index consumer, and it consumes
+    // through its convolution, not through a residual add), the producer is a plain conv -> BN [-> +res] [-> ReLU] unit on the
+    // accumulator path, and the fourth-generation dgrad kernel covers the layer.  Opt-in (CLHIP_BN_FUSE=1): measured on the ResNet-18
+    // step at batch 256 it is time-neutral (2.617 ms fused vs 2.592 ms with the 13 separate reduce passes, profiles/r02_notes.md) -- the
+    // epilogue's 8-byte gathers of z / y and its 16-lane DPP reductions cost what the streaming reduce pass costs.
+    const bool fuse_on = getenv("CLHIP_BN_FUSE") && atoi(getenv("CLHIP_BN_FUSE")) != 0;         // read per plan: tests build both variants
+    p->bwd_sums_ready.assign(p->units.size(), 0);
+    for (int i = 0; i < n_units; ++i) {
+        Unit& u = p->units[i];
+        u.fuse_src_bn = false;
+        if (!fuse_on || u.d.src < 1 || u.raw_src || u.pre_res || u.no_bn) continue;
+        const int a = u.d.src;                      // the activation; produced by unit a - 1
+        const Unit& prod = p->units[a - 1];
+        if (prod.no_bn || prod.pre_res || prod.raw_src || prod.has_dzr || prod.rep_bwd <= 0) continue;
+        bool lowest = true;
+        for (int k = 0; k < n_units; ++k) {
+            if (k == i) continue;
+            const Unit& o = p->units[k];
+            const bool consumes = (o.d.src == a && !o.raw_src) || (o.d.res == a && !o.pre_res);
+            if (consumes && k < i) lowest = false;
+        }
+        if (u.d.res == a) lowest = false;            // the unit's own residual add writes after its dgrad?  (never in these nets; stay safe)
+        if (!lowest) continue;
+        if (!clhip_conv_dgrad_bn_reduce_supported(N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, dtype)) continue;
+        u.fuse_src_bn = true;
+    }
     return p;
 }
 
@@ -305,6 +335,7 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
     TRY(clhip_nchw_to_nhwc(x, ws + p->acts[0].y_off, p->N, p->Cin, p->H, p->W, p->Cin_pad, p->dtype, stream));
     double* acc = reinterpret_cast<double*>(ws + p->acc_off);
     const bool use_acc = training && p->use_acc;
+    std::fill(p->bwd_sums_ready.begin(), p->bwd_sums_ready.end(), 0);
     if (use_acc && hipMemsetAsync(acc, 0, p->acc_bytes, (hipStream_t)stream) != hipSuccess) {
         clhip_set_error("clhip_plan_forward: hipMemsetAsync failed");
         return CLHIP_EHIP;
@@ -411,6 +442,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         }
         static const bool mask_from_y = getenv("CLHIP_BN_MASK_FROM_Y") != nullptr;       // ablation: always read the activation
         if (u.no_bn) {
+        } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
+            // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
+            const bool zmask = u.relu && dres == nullptr && !mask_from_y;
+            TRY(clhip_bn_bwd_apply_acc(ws + dst.dy_off, zmask ? nullptr : ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
+                                       params + u.d.beta_off, grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout,
+                                       zmask ? 2 : (u.relu ? 1 : 0), reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else if (u.rep_bwd > 0 && u.relu && dres == nullptr && !mask_from_y) {
             // ReLU straight after the BatchNorm (no residual in between): the mask is recomputed from z, y is not read
             TRY(clhip_bn_bwd_acc_zmask(ws + dst.dy_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off, params + u.d.beta_off,
@@ -454,6 +491,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         if (u.raw_src) {
             TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + p->units[u.d.src - 1].dzr_off, 0, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+        } else if (u.d.src != 0 && u.fuse_src_bn) {
+            const Unit& prod = p->units[u.d.src - 1];
+            TRY(clhip_conv_dgrad_bn_reduce(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, ws + prod.z_off, prod.relu ? ws + src.y_off : nullptr,
+                                           fr + prod.f_mean, fr + prod.f_invstd, reinterpret_cast<double*>(ws + p->acc_off) + prod.a_bwd, prod.rep_bwd,
+                                           p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            p->bwd_sums_ready[u.d.src - 1] = 1;
         } else if (u.d.src != 0) {
             TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));

@@ -86,7 +86,7 @@ def make_loader(dataset, batch_size, shuffle, num_workers=0, device=None, drop_l
     transform pipeline the augment kernels implement and `device` is a HIP device; otherwise torch's DataLoader"""
     if device is not None and torch.device(device).type == "cuda" and hasattr(dataset, "device_store"):
         from .gpu_loader import GpuBatchLoader, gpu_plan
-        plan = gpu_plan(dataset.trfms)
+        plan = gpu_plan(dataset.trfms, tuple(dataset.store.shape[1:3]) if hasattr(dataset, "store") else None)
         if plan is not None:
             return GpuBatchLoader(dataset, batch_size, shuffle, device, plan, drop_last=drop_last)
     return DataLoader(dataset, shuffle=shuffle, batch_size=batch_size, drop_last=drop_last, num_workers=num_workers, pin_memory=False)

@@ -20,7 +20,7 @@ from .._lib import call
 from . import transforms as T
 
 
-def gpu_plan(trfms):
+def gpu_plan(trfms, store_hw=None):
     """descriptor of a transform pipeline the augment kernels can run, or None (then the CPU DataLoader path is used)"""
     if not isinstance(trfms, T.Compose):
         return None
@@ -41,6 +41,9 @@ def gpu_plan(trfms):
     elif kinds[0] == "RandomResizedCrop":
         if ts[0].size[0] != ts[0].size[1] or ts[0].interp != 2:
             return None
+        if store_hw is not None and max(store_hw) > ts[0].size[0]:
+            return None       # the resize kernel is a plain 2-tap bilinear: fine for up-scaling (32 -> 224), aliased for down-scaling, where PIL
+                              # (the reference's pipeline) widens the filter support -> stay on the CPU pipeline
         plan.update(kind="rrc_flip", size=ts[0].size[0], scale=ts[0].scale, ratio=ts[0].ratio)
     else:
         return None
@@ -85,7 +88,7 @@ class GpuBatchLoader:
     def __init__(self, dataset, batch_size, shuffle, device, plan=None, drop_last=False, rank=0, world=1, num_workers=0):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), bool(shuffle), bool(drop_last)
         self.device, self.rank, self.world, self.num_workers, self.pin_memory = torch.device(device), rank, world, num_workers, False
-        self.plan = plan if plan is not None else gpu_plan(dataset.trfms)
+        self.plan = plan if plan is not None else gpu_plan(dataset.trfms, tuple(dataset.store.shape[1:3]) if hasattr(dataset, "store") else None)
         if self.plan is None:
             raise ValueError("this transform pipeline has no GPU plan")
         if self.device.type != "cuda":
@@ -97,8 +100,10 @@ class GpuBatchLoader:
         return GpuBatchLoader(self.dataset, max(1, self.batch_size // world), self.shuffle, self.device, self.plan, self.drop_last, rank, world)
 
     def _count(self):
+        """samples per rank: the permutation is padded (wrapped around) to a multiple of the world size, like DistributedSampler,
+        so every rank runs the same number of batches -- the per-step gradient all-reduce needs that"""
         n = len(self.dataset.labels)
-        return (n - self.rank + self.world - 1) // self.world if self.world > 1 else n
+        return (n + self.world - 1) // self.world if self.world > 1 else n
 
     def __len__(self):
         n = self._count()
@@ -111,6 +116,9 @@ class GpuBatchLoader:
         n = len(ds.labels)
         order = torch.randperm(n) if self.shuffle else torch.arange(n)
         if self.world > 1:
+            total_padded = (n + self.world - 1) // self.world * self.world
+            if total_padded > n:
+                order = torch.cat([order, order[:total_padded - n]])
             order = order[self.rank::self.world]
         rows = torch.as_tensor(np.asarray(ds.images, dtype=np.int64))[order].to(dev)
         labels = torch.as_tensor(np.asarray(ds.labels, dtype=np.int64))[order].to(dev)

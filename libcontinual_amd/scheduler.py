@@ -1,4 +1,5 @@
-"""Epoch-level LR schedules of the reference (core/scheduler.py:47-124); scalar host math."""
+"""Epoch-level LR schedules of the reference (core/scheduler.py:4-124); scalar host math.  The sequences are pinned against the
+reference's own classes in tests/golden/schedulers.npz (tests/test_host_cpu.py::test_schedulers_match_the_reference)."""
 import math
 
 
@@ -8,8 +9,10 @@ class _Sched:
         for g in optimizer.param_groups:
             g.setdefault("initial_lr", g["lr"])
         self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
-        self.last_epoch = -1
+        # the reference applies lr(0) at construction and then puts last_epoch back to -1 (scheduler.py:19-20), so the first
+        # `step()` of the epoch loop applies lr(0) AGAIN: epochs run at lr(0), lr(0), lr(1), lr(2), ...
         self.step(0)
+        self.last_epoch = -1
 
     def get_lr(self):
         raise NotImplementedError

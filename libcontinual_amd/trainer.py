@@ -95,6 +95,8 @@ class Trainer:
             return torch.device("cpu")
         ids = config.get("device_ids", "auto")
         local = int(os.environ.get("LOCAL_RANK", self.rank))
+        if os.environ.get("CLHIP_SHARED_GPU"):          # test hook (tests/test_dp_two_ranks_gpu.py): every rank on cuda:0, exchange through gloo
+            local, ids = 0, "auto"
         if isinstance(ids, (list, tuple)):
             idx = ids[local]
         elif isinstance(ids, int) and not self.distribute:
@@ -203,8 +205,9 @@ class Trainer:
             n_epoch = self.init_epoch if task_idx == 0 else self.inc_epoch
             for epoch_idx in range(n_epoch):
                 t0 = time()
-                if self.distribute and hasattr(dataloader.sampler, "set_epoch"):
-                    dataloader.sampler.set_epoch(epoch_idx)
+                sampler = getattr(dataloader, "sampler", None)          # the GPU batch loader has none: its shard is cut in __iter__
+                if self.distribute and sampler is not None and hasattr(sampler, "set_epoch"):
+                    sampler.set_epoch(epoch_idx)
                 meter = self._train(epoch_idx, dataloader)
                 acc1, loss = meter.avg("acc1"), meter.avg("loss")
                 if self.distribute:
@@ -228,7 +231,7 @@ class Trainer:
                     self.log(f" * [Batch] Last Average Acc: {batch_last_acc:.2f} (Best: {best_batch_last_acc:.2f})")
                     self.log(f" * Per-Task Acc: {per_task_acc}")
                 if self.config["lr_scheduler"]["name"] == "PatienceSchedule":
-                    self.scheduler.step(meter.avg("loss"))
+                    self.scheduler.step(loss)               # the loss averaged over the ranks: every replica cuts the lr / stops at the same epoch
                     if self.scheduler.get_last_lr() < self.config["lr_scheduler"]["kwargs"]["stopping_lr"]:
                         break
                 else:

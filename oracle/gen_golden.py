@@ -13,7 +13,7 @@ import types
 import numpy as np
 import torch
 
-from . import fixtures, ref_shim, scenarios, vit_scenarios
+from . import fixtures, ref_shim, scenarios, trainer_scenarios, vit_scenarios
 
 
 def reference_namespace():
@@ -105,6 +105,7 @@ def main(out_dir=None):
     for arch in ("cifar_resnet32", "resnet32_V2", "resnet18", "cifar_resnet32_V2"):
         jobs[f"backbone_{arch}"] = lambda a=arch: scenarios.scenario_backbone(ad, a)
     jobs["ewc"] = lambda: scenarios.scenario_ewc(ad)
+    jobs["ewc_fisher"] = lambda: scenarios.scenario_ewc_fisher(ad)
     jobs["lwf_resnet18"] = lambda: scenarios.scenario_lwf(ad)
     jobs["lwf_cifar_resnet32"] = lambda: scenarios.scenario_lwf(ad, dict(arch="cifar_resnet32", feat_dim=64, bs=8))
     jobs["lwf_long"] = lambda: scenarios.scenario_lwf(ad, scenarios.LWF_LONG_CFG)
@@ -129,13 +130,43 @@ def main(out_dir=None):
     jobs["l2p"] = vit_job(vit_scenarios.scenario_l2p)
     jobs["inflora"] = vit_job(vit_scenarios.scenario_inflora)
     jobs["inflora_orig"] = vit_job(vit_scenarios.scenario_inflora_orig)
+    def schedulers():
+        """learning-rate sequences of the reference's own scheduler classes (core/scheduler.py:47-124): value at construction,
+        then after every `step()`"""
+        sc = ref_shim.load("core.scheduler")
+
+        def seq(make, n):
+            o = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+            s_ = make(o)
+            lrs = [o.param_groups[0]["lr"]]
+            for _ in range(n):
+                s_.step()
+                lrs.append(o.param_groups[0]["lr"])
+            return np.asarray(lrs, np.float64)
+        res = {"cosine_K5": seq(lambda o: sc.CosineSchedule(o, K=5), 6), "cosine_K20": seq(lambda o: sc.CosineSchedule(o, K=20), 21),
+               "cosine_K1": seq(lambda o: sc.CosineSchedule(o, K=1), 3), "warmup_2_10": seq(lambda o: sc.CosineAnnealingWarmUp(o, 2, 10), 11),
+               "warmup_3_30": seq(lambda o: sc.CosineAnnealingWarmUp(o, 3, 30), 12)}
+        o = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+        s_ = sc.PatienceSchedule(o, patience=2, factor=2)
+        lrs = []
+        for v in (1.0, 1.0, 1.0, 0.5, 0.6, 0.7, 0.8):
+            s_.step(v)
+            lrs.append(o.param_groups[0]["lr"])
+        res["patience_2_2"] = np.asarray(lrs, np.float64)
+        return res
+    jobs["schedulers"] = schedulers
+    # whole runs of the reference's own Trainer.train_loop, in its own fp32 arithmetic (oracle/trainer_scenarios.py)
+    fp32_jobs = set()
+    for tn in trainer_scenarios.SCENARIOS:
+        jobs[f"trainer_{tn}"] = lambda n=tn: trainer_scenarios.scenario_trainer(n, reference_namespace())
+        fp32_jobs.add(f"trainer_{tn}")
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:
             continue
         torch.manual_seed(0)
         # fp64 run of the reference = the semantic ground truth (see fixtures.use_dtype)
-        with fixtures.use_dtype(torch.float64):
+        with fixtures.use_dtype(torch.float32 if name in fp32_jobs else torch.float64):
             res = fn()
         path = os.path.join(out_dir, name + ".npz")
         np.savez_compressed(path, **res)

@@ -241,6 +241,51 @@ def scenario_ewc(adapter):
     return out
 
 
+def fisher_probe_index(name, numel, k=64):
+    """the element indices of a Fisher tensor the fixtures keep (all of them for small tensors)"""
+    if numel <= k:
+        return np.arange(numel)
+    return np.sort(detrand.randint(f"fisher_probe/{name}", (k,), 0, numel))
+
+
+def scenario_ewc_fisher(adapter):
+    """The Fisher diagonal of EVERY parameter tensor on fixed (deterministic, untrained) weights: before_task(0), then
+    after_task(0) over three batches (the last one ragged) -- ewc.py:147-205 with no optimisation step in front of it, so that a
+    comparison tests the Fisher pass itself (forward, per-sample-batch backward, squared-gradient accumulation, 1/N) and not the
+    drift of a training trajectory.  Kept per tensor: sum, abs-sum, sq-sum and 64 probed elements."""
+    c = EWC_CFG
+    tag = "ewc_fisher"
+    P, Bf = fx.det_backbone_state(c["arch"], tag)
+    w0, b0 = fx.det_linear(tag + "/head0", c["init"], c["feat_dim"])
+    fb = [fx.det_batch(f"{tag}/fisher/{i}", c["bs"] if i < 2 else 5, 0, c["init"]) for i in range(3)]
+    if adapter.kind == "oracle":
+        net = om.Net(c["arch"], {k: v.clone().requires_grad_(True) for k, v in P.items()},
+                     {k: v.clone() for k, v in Bf.items()}, w0.clone().requires_grad_(True), b0.clone().requires_grad_(True))
+        m = om.EWC(net, c["init"], c["inc"], c["lamda"])
+        m.before_task(0, new_rows=(w0, b0))
+        m.after_task(fb, c["bs"])
+        fisher = {k: v.clone() for k, v in m.fisher.items()}
+    else:
+        ns = adapter.ns
+        bb = adapter.backbone(c["arch"], P, Bf)
+        m = ns.EWC(bb, c["feat_dim"], 100, device=adapter.device, init_cls_num=c["init"], inc_cls_num=c["inc"], lamda=c["lamda"]).to(adapter.device)
+        m.before_task(0, None, None, None)
+        with torch.no_grad():
+            m.network.classifier.weight.data[:] = adapter.to_dev(w0)
+            m.network.classifier.bias.data[:] = adapter.to_dev(b0)
+        m.after_task(0, None, ListLoader(fb, c["bs"]), None)
+        fisher = {k: v.detach().cpu().clone() for k, v in m.fisher.items()}
+    names, rows = fx.summarize(fisher)
+    out = {"fisher_names": np.asarray(names), "fisher_rows": rows}
+    probes = []
+    for n in names:
+        a = fisher[n].detach().double().reshape(-1).numpy()
+        idx = fisher_probe_index(n, a.size)
+        probes.append(np.pad(a[idx], (0, 64 - len(idx))))
+    out["fisher_probes"] = np.stack(probes)
+    return out
+
+
 # ----------------------------------------------------------------------------------- scenario: LwF
 LWF_CFG = dict(arch="resnet18", feat_dim=512, init=6, inc=2, bs=4, lr=0.02)
 # a longer trajectory through the same plugin: 6 + 6 steps with momentum, weight decay and a learning-rate drop inside each

@@ -75,6 +75,21 @@ def test_two_ranks_train_in_lockstep_and_match_the_emulation(tmp_path):
     np.testing.assert_allclose(reps[0].backbone._stats.cpu().numpy(), a["rm"], rtol=2e-3, atol=1e-4)
 
 
+def test_trainer_two_ranks_on_the_gpu_loader(tmp_path):
+    """the Trainer itself under data parallelism with the GPU batch loader (no `sampler` attribute; 111 training images in task
+    0, 74 + 21 rehearsal exemplars later: neither a multiple of 2): both ranks run the same number of steps, end with identical
+    parameters, buffers and learning rates (the patience schedule sees the rank-averaged loss)"""
+    r = _launch([os.path.join(ROOT, "tests", "dp_trainer_worker.py"), str(tmp_path)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(tmp_path / "trainer_rank0.npz"), np.load(tmp_path / "trainer_rank1.npz")
+    np.testing.assert_array_equal(a["flat"], b["flat"])
+    np.testing.assert_array_equal(a["head"], b["head"])
+    np.testing.assert_array_equal(a["buffer"], b["buffer"])
+    np.testing.assert_array_equal(a["lr"], b["lr"])
+    np.testing.assert_array_equal(a["acc"], b["acc"])
+    assert len(a["buffer"]) > 0 and np.isfinite(a["flat"]).all()
+
+
 @pytest.mark.parametrize("workload,batch", [("lwf_resnet18_b50_task0", 64), ("icarl_resnet32_b50_task1", 64), ("ewc_resnet32_b50_task1", 64),
                                             ("l2p_vitb16_b10_task1", 8), ("inflora_vitb16_b20_task1", 8)])
 def test_bench_contract_at_two_ranks(workload, batch):

@@ -141,24 +141,33 @@ def test_metrics_and_meter():
     assert m.avg("loss") == 3.0 and m.avg("acc1") == pytest.approx(50.0)
 
 
-def test_schedulers():
+def test_schedulers_match_the_reference():
+    """lr sequences against the reference's own classes (tests/golden/schedulers.npz <- `python -m oracle.gen_golden schedulers`).
+    The reference applies lr(0) at construction and AGAIN at the first step (scheduler.py:19-20 resets last_epoch to -1)."""
+    import os
+    import numpy as np
     from libcontinual_amd.scheduler import CosineAnnealingWarmUp, CosineSchedule, PatienceSchedule
-    import math
-    p = [torch.nn.Parameter(torch.zeros(1))]
-    o = torch.optim.SGD(p, lr=0.1)
-    s = CosineSchedule(o, K=20)
-    s.step(); s.step()
-    assert o.param_groups[0]["lr"] == pytest.approx(0.1 * math.cos(99 * math.pi * 2 / (200 * 19)))
-    o = torch.optim.SGD(p, lr=0.1)
-    s = CosineAnnealingWarmUp(o, 2, 10)
-    assert o.param_groups[0]["lr"] == pytest.approx(0.05)
-    s.step(); s.step()
-    assert o.param_groups[0]["lr"] == pytest.approx(0.1 * 0.5 * (1 + math.cos(math.pi * 2 / 10)))
-    o = torch.optim.SGD(p, lr=0.1)
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedulers.npz"))
+
+    def seq(make, n):
+        o = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+        s = make(o)
+        lrs = [o.param_groups[0]["lr"]]
+        for _ in range(n):
+            s.step()
+            lrs.append(o.param_groups[0]["lr"])
+        return np.asarray(lrs)
+    for key, make in (("cosine_K5", lambda o: CosineSchedule(o, K=5)), ("cosine_K20", lambda o: CosineSchedule(o, K=20)), ("cosine_K1", lambda o: CosineSchedule(o, K=1)),
+                      ("warmup_2_10", lambda o: CosineAnnealingWarmUp(o, 2, 10)), ("warmup_3_30", lambda o: CosineAnnealingWarmUp(o, 3, 30))):
+        np.testing.assert_allclose(seq(make, len(ref[key]) - 1), ref[key], rtol=1e-12, atol=1e-15, err_msg=key)
+    assert ref["cosine_K5"][0] == ref["cosine_K5"][1]                      # the repeated first value
+    o = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
     s = PatienceSchedule(o, patience=2, factor=2)
-    for l in (1.0, 1.0, 1.0):
-        s.step(l)
-    assert o.param_groups[0]["lr"] == pytest.approx(0.05)
+    lrs = []
+    for v in (1.0, 1.0, 1.0, 0.5, 0.6, 0.7, 0.8):
+        s.step(v)
+        lrs.append(o.param_groups[0]["lr"])
+    np.testing.assert_allclose(lrs, ref["patience_2_2"], rtol=1e-12)
 
 
 def test_herding_buffer_bookkeeping():

@@ -520,3 +520,70 @@ def test_conv_fwd_stat_accumulator(mode, shape):
         assert float((acc.sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
         if rep > 1 and tiles >= rep:
             assert (acc.abs().amax(dim=(1, 2)) > 0).all()          # every replica received some workgroups
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64), (4, 8, 8, 128, 256), (6, 4, 4, 512, 512), (3, 12, 20, 64, 128), (32, 8, 8, 64, 64)])
+@pytest.mark.parametrize("relu,accumulate", [(1, 0), (1, 1), (0, 0)])
+def test_dgrad_with_fused_batchnorm_backward_reduction(shape, relu, accumulate):
+    """clhip_conv_dgrad_bn_reduce + clhip_bn_bwd_apply_acc (the dgrad epilogue accumulates sum g and sum g * xhat of the producing
+    layer's BatchNorm backward from its fp32 results) against (a) the unfused pair clhip_conv_dgrad + clhip_bn_bwd_acc and (b) the
+    fp64 math: dx, the two channel sums, dz, dgamma, dbeta, dres.  bf16 only (the fourth-generation kernel's domain); tiles that end
+    inside an image, the K-split configurations (8x8, 4x4 images) and the accumulate path (dx += ...) included."""
+    N, H, W, C, K = shape
+    code, tdt = DT["bf16"]
+    if not _lib.lib().clhip_conv_dgrad_bn_reduce_supported(N, H, W, C, K, 3, 1, 1, code):
+        pytest.skip("layer outside the fused kernel's domain")
+    M = N * H * W
+    dzn = quant(rnd((N, K, H, W), 31, 0.5), tdt)                       # gradient entering the convolution's output
+    wd = quant(rnd((C, 9, K), 32, 0.05), tdt)                          # dgrad weight copy [C][taps][K]
+    zp = quant(rnd((N, C, H, W), 33, 1.5) + 0.2, tdt)                  # producing layer: pre-BN output, post-activation output
+    yp = quant(torch.relu(rnd((N, C, H, W), 34)), tdt) if relu else quant(rnd((N, C, H, W), 34), tdt)
+    old = quant(rnd((N, C, H, W), 35, 0.3), tdt)                       # what an earlier consumer left in dx
+    mean, invstd = rnd((C,), 36) * 0.3, rnd((C,), 37).abs() + 0.5
+    gamma, beta = rnd((C,), 38) * 0.5 + 1.0, rnd((C,), 39) * 0.2
+    d = lambda t: t.to(DEV)
+    dzd, wdd, zpd, ypd = to_nhwc(dzn, tdt), wd.to(tdt).to(DEV).contiguous(), to_nhwc(zp, tdt), to_nhwc(yp, tdt)
+    md, isd, gd, bd = d(mean), d(invstd), d(gamma), d(beta)
+    rep = 4
+
+    def run(fused):
+        dx = to_nhwc(old, tdt).clone() if accumulate else torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+        acc = torch.zeros(rep, 2, C, dtype=torch.float64, device=DEV)
+        dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dzo = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+        if fused:
+            call("clhip_conv_dgrad_bn_reduce", dzd.data_ptr(), wdd.data_ptr(), dx.data_ptr(), accumulate, zpd.data_ptr(), ypd.data_ptr() if relu else None,
+                 md.data_ptr(), isd.data_ptr(), acc.data_ptr(), rep, N, H, W, C, K, 3, 1, 1, code, st())
+            sums = acc.sum(0).cpu()
+            call("clhip_bn_bwd_apply_acc", dx.data_ptr(), ypd.data_ptr() if relu else None, zpd.data_ptr(), md.data_ptr(), isd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                 dgam.data_ptr(), dbet.data_ptr(), dzo.data_ptr(), None, 0, M, C, relu, acc.data_ptr(), rep, code, st())
+        else:
+            call("clhip_conv_dgrad", dzd.data_ptr(), wdd.data_ptr(), dx.data_ptr(), accumulate, N, H, W, C, K, 3, 1, 1, code, st())
+            call("clhip_bn_bwd_acc", dx.data_ptr(), ypd.data_ptr(), zpd.data_ptr(), md.data_ptr(), isd.data_ptr(), gd.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+                 dzo.data_ptr(), None, 0, M, C, relu, acc.data_ptr(), rep, code, st())
+            sums = acc.sum(0).cpu()
+        torch.cuda.synchronize()
+        return from_nhwc(dx).double(), sums, from_nhwc(dzo).double(), dgam.cpu().double(), dbet.cpu().double()
+
+    dx_f, s_f, dz_f, dg_f, db_f = run(True)
+    dx_u, s_u, dz_u, dg_u, db_u = run(False)
+    # fp64 reference of the dgrad: dx[n,c,h,w] = sum_{r,s,o} dz[n,o,h+1-r,w+1-s] * wd[c][3r+s][o]
+    w4 = wd.double().reshape(C, 3, 3, K).permute(3, 0, 1, 2).contiguous()           # [K][C][3][3] = the forward weight of a C -> K convolution
+    dx_ref = F.conv_transpose2d(dzn.double(), w4, padding=1)
+    if accumulate:
+        dx_ref = dx_ref + old.double()
+    assert torch.equal(dx_f, dx_u)                                                   # the stored gradient is the same bf16 tensor either way
+    assert (dx_f - dx_ref).abs().max() <= tol("bf16", dx_ref) * 1.5
+    mask = (yp.double() > 0).double() if relu else torch.ones_like(dx_ref)
+    g = dx_ref * mask
+    xhat = (zp.double() - mean.double().view(1, C, 1, 1)) * invstd.double().view(1, C, 1, 1)
+    s_ref = torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))])
+    scale = torch.stack([g.abs().sum((0, 2, 3)), (g * xhat).abs().sum((0, 2, 3))]) + 1e-9
+    assert ((s_f - s_ref).abs() / scale).max() < 4e-3                                # sums of the fp32 results before rounding
+    assert ((s_u - s_ref).abs() / scale).max() < 4e-3                                # sums of the rounded tensor (unfused pass)
+    gi = (gamma * invstd).double().view(1, C, 1, 1)
+    dz_ref = gi * (g - s_ref[0].view(1, C, 1, 1) / M - xhat * s_ref[1].view(1, C, 1, 1) / M)
+    assert (dz_f - dz_ref).abs().max() <= tol("bf16", dz_ref) * 2.5
+    assert (dz_f - dz_u).abs().max() <= tol("bf16", dz_ref) * 2.5
+    assert (dg_f - s_ref[1]).abs().max() <= 4e-3 * scale[1].max()
+    assert (db_f - s_ref[0]).abs().max() <= 4e-3 * scale[0].max()
