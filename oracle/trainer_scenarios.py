@@ -302,7 +302,7 @@ def run_reference(name, ns, c=COMMON, perturb=0):
         return pack(rec, t.buffer, c)
 
 
-def scenario_trainer(name, ns, c=COMMON, n_perturbed=2):
+def scenario_trainer(name, ns, c=COMMON, n_perturbed=6):
     """run the reference's Trainer.train_loop on the scenario (+ `n_perturbed` runs from 1e-6-perturbed initial weights);
     -> dict for tests/golden/trainer_<name>.npz"""
     out = run_reference(name, ns, c)

@@ -8,10 +8,12 @@ LWF / ICarl classes in fp32 on the CPU; oracle/trainer_scenarios.py): same data,
   drift apart like any two fp32 implementations of a chaotic optimisation -- the fixture holds two more runs of the REFERENCE
   ITSELF from initial weights perturbed by one part in 10^6, and their deviation from the unperturbed reference run is reported
   next to the product's.
-* accuracy (the second half of BASELINE.json's metric): the per-task "Last Average Acc" figures and their mean -- what
-  core/trainer.py:457-520 reports -- against the reference's.  Band: BASELINE's 0.3 points, or the reference's own spread under
-  that perturbation times a stated factor where that is larger (a 1000-image test set: one image is 0.1 point).  All figures
-  go to gpurun_out/accuracy_parity.json (copied to profiles/r02_accuracy_parity.json).
+* accuracy (the second half of BASELINE.json's metric): the final task's "Last Average Acc" and the mean over the tasks -- what
+  core/trainer.py:457-520 reports.  A single pair of runs cannot be compared at 0.3 points here: the reference run against ITSELF
+  from weights moved by 1e-6 lands up to 6 points away on the final-task figure (EWC / LwF forget chaotically; fixtures hold 7
+  reference runs each).  So the test compares DISTRIBUTIONS: 4 product runs (same perturbations) against the 7 reference runs,
+  |difference of the means| <= 0.3 points (BASELINE's band) + 3 standard errors of that difference.  All figures go to
+  gpurun_out/accuracy_parity.json (copied to profiles/r02_accuracy_parity.json).
 """
 import json
 import os
@@ -27,7 +29,7 @@ from oracle import trainer_scenarios as ts                # noqa: E402   (test i
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_product(name, dtype, root):
+def run_product(name, dtype, root, perturb=0):
     import libcontinual_amd.model as M
     from libcontinual_amd.trainer import Trainer
     from libcontinual_amd.utils import init_seed
@@ -39,6 +41,10 @@ def run_product(name, dtype, root):
     tr = Trainer(0, cfg, model_namespace=M, dataloaders=loaders, log=lambda *a, **k: None)
     with fx.use_dtype(torch.float32):
         P, Bf = fx.det_backbone_state(s["arch"], f"trainer/{name}")
+    if perturb:                                            # the same perturbation the fixture's extra reference runs start from
+        from oracle import detrand
+        with fx.use_dtype(torch.float32):
+            P = {k: v * (1.0 + 1e-6 * fx._t(detrand.uniform(f"trainer/{name}/perturb{perturb}/{k}", tuple(v.shape), -1.0, 1.0))) for k, v in P.items()}
     bb = tr.model.backbone if hasattr(tr.model, "backbone") else tr.model.network.backbone
     bb.load_state_dict({**P, **Bf})
     head = (lambda m: m.classifier) if name == "lwf" else (lambda m: m.network.classifier)
@@ -52,9 +58,7 @@ def run_product(name, dtype, root):
 
 # first optimisation steps (before the chaotic amplification of rounding differences sets in): relative loss deviation
 FIRST_STEPS = {"f32": (3, 2e-4), "bf16": (3, 3e-2)}
-# accuracy: BASELINE.json's 0.3 points, or the reference's OWN spread under a 1e-6 perturbation of the initial weights (two extra
-# runs in the fixture) times this factor, whichever is larger
-SPREAD_FACTOR = {"f32": 2.0, "bf16": 3.0}
+N_PRODUCT_RUNS = 4      # unperturbed + 3 perturbed starts
 
 
 @pytest.mark.parametrize("name", ["ewc", "lwf", "icarl"])
@@ -70,19 +74,24 @@ def test_trainer_reproduces_the_reference_run(name, dtype, tmp_path):
     dev = np.abs(got["losses"][:n0] - ref["losses"][:n0]) / np.abs(ref["losses"][:n0])
     ref_dev = np.abs(ref["perturbed_losses_first_epoch"] - ref["losses"][:n0]).max(0) / np.abs(ref["losses"][:n0])     # the reference against itself
     k, tol = FIRST_STEPS[dtype]
-    # ---- accuracy
-    spread_last = float(np.abs(ref["perturbed_batch_last_acc"][:, -1] - ref["batch_last_acc"][-1]).max())
-    spread_avg = float(np.abs(ref["perturbed_overall_avg_acc"] - ref["overall_avg_acc"][0]).max())
-    gap_last = float(got["batch_last_acc"][-1] - ref["batch_last_acc"][-1])
-    gap_avg = float(got["overall_avg_acc"][0] - ref["overall_avg_acc"][0])
-    band_last = max(0.3, SPREAD_FACTOR[dtype] * spread_last)
-    band_avg = max(0.3, SPREAD_FACTOR[dtype] * spread_avg)
+    # ---- accuracy: the product's runs against the reference's runs, as two samples of the chaotic training's distribution
+    prod_last, prod_avg = [float(got["batch_last_acc"][-1])], [float(got["overall_avg_acc"][0])]
+    for q in range(1, N_PRODUCT_RUNS):
+        g2, _ = run_product(name, dtype, str(tmp_path), perturb=q)
+        prod_last.append(float(g2["batch_last_acc"][-1])); prod_avg.append(float(g2["overall_avg_acc"][0]))
+    ref_last = np.concatenate([[ref["batch_last_acc"][-1]], ref["perturbed_batch_last_acc"][:, -1]])
+    ref_avg = np.concatenate([ref["overall_avg_acc"], ref["perturbed_overall_avg_acc"]])
+    R, P = len(ref_last), len(prod_last)
+    se = np.sqrt(1.0 / R + 1.0 / P)
+    gap_last, gap_avg = float(np.mean(prod_last) - ref_last.mean()), float(np.mean(prod_avg) - ref_avg.mean())
+    band_last = 0.3 + 3.0 * se * float(ref_last.std(ddof=1))
+    band_avg = 0.3 + 3.0 * se * float(ref_avg.std(ddof=1))
     report = dict(scenario=name, dtype=dtype, first_steps_loss_rel_dev=dev[:k].tolist(), first_epoch_loss_rel_dev_max=float(dev.max()),
                   reference_self_first_epoch_loss_rel_dev_max=float(ref_dev.max()),
-                  product_batch_last_acc=got["batch_last_acc"].tolist(), reference_batch_last_acc=ref["batch_last_acc"].tolist(),
-                  reference_perturbed_batch_last_acc=ref["perturbed_batch_last_acc"].tolist(),
-                  final_task_gap_points=gap_last, overall_avg_gap_points=gap_avg, reference_self_spread_final_task=spread_last,
-                  reference_self_spread_overall_avg=spread_avg, band_final_task=band_last, band_overall_avg=band_avg,
+                  product_final_task_acc_runs=prod_last, reference_final_task_acc_runs=ref_last.tolist(),
+                  product_overall_avg_acc_runs=prod_avg, reference_overall_avg_acc_runs=ref_avg.tolist(),
+                  mean_gap_final_task_points=gap_last, mean_gap_overall_avg_points=gap_avg, band_final_task=band_last, band_overall_avg=band_avg,
+                  reference_std_final_task=float(ref_last.std(ddof=1)), reference_std_overall_avg=float(ref_avg.std(ddof=1)),
                   product_acc_table=got["acc_table"].tolist(), reference_acc_table=ref["acc_table"].tolist())
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(out, exist_ok=True)
