@@ -34,15 +34,16 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: enough for a timed region of about a second)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 ResNet workloads, 16 L2P, 128 InfLoRA_OPT)")
     ap.add_argument("--workload", default="lwf_resnet18_b50_task0",
                     choices=["lwf_resnet18_b50_task0", "lwf_resnet18_b50_task1", "icarl_resnet32_b50_task1", "ewc_resnet32_b50_task1",
                              "l2p_vitb16_b10_task1", "inflora_vitb16_b20_task1"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' launches (what the PMC passes sample) and print their block")
+    ap.add_argument("--cpu-steps", type=int, default=None, help="steps of the CPU baseline sample (default: 5 ResNet, 1-2 ViT)")
     return ap.parse_args()
 
 
@@ -116,10 +117,27 @@ def synthetic_batch(B, lo, hi, seed, dev, size=32):
     return {"image": x.to(dev), "label": y.to(dev)}
 
 
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(workload, steps, batch):
-    """the CPU oracle (torch CPU fp32, all host cores) running the same step; bounded sample"""
+    """the CPU oracle (torch CPU fp32 restatement of the reference's step, oracle/) on the host's PHYSICAL cores, the GPU line's
+    own batch size; a bounded sample (about 10-30 s of CPU work)"""
+    cores = _physical_cores()
+    torch.set_num_threads(cores)
+    if "vitb16" in workload:
+        return _cpu_baseline_vit(workload, steps, batch, cores)
     from oracle import methods as om, nets
     arch = "resnet18" if "resnet18" in workload else "cifar_resnet32"
+    steps = steps or 5
     torch.manual_seed(0)
     P = {k: v.requires_grad_(True) for k, v in nets.init_params(arch).items()}
     Bf = nets.init_buffers(arch)
@@ -140,52 +158,158 @@ def cpu_baseline(workload, steps, batch):
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
-    return dict(value=batch * steps / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle), 1 warm-up")
+    return dict(value=batch * steps / dt, unit="images/sec", cores=cores, kind="port",
+                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle on {cores} physical cores), 1 warm-up")
 
 
-def dominant_kernel_roofline(dev, dtype, B):
-    """time the dominant kernel family of the ResNet-18 step -- the 3x3 stride-1 implicit-GEMM conv
-    forward at the layer1 shape [B,32,32,64]->64 -- with HIP events on the launch stream and price it
-    against the bf16 MFMA peak; algorithmic FLOPs = 2 * M * (9*Cin) * Cout per launch."""
-    from libcontinual_amd import _lib
-    code = _lib.BF16 if dtype == "bf16" else _lib.F32
-    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
-    N, H, W, C, K = B, 32, 32, 64, 64
-    x = torch.randn(N, H, W, C, device=dev).to(tdt)
-    w = (torch.randn(K, 9, C, device=dev) * 0.05).to(tdt)
-    z = torch.empty(N, H, W, K, device=dev, dtype=tdt)
-    tiles = _lib.lib().clhip_conv_fwd_tiles(N, H, W, C, K, 3, 1, 1)
-    part = torch.empty(tiles, 2, K, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    run = lambda: _lib.call("clhip_conv_fwd", x.data_ptr(), w.data_ptr(), z.data_ptr(), part.data_ptr(), N, H, W, C, K, 3, 1, 1, code, st)
-    for _ in range(5):
+def _cpu_baseline_vit(workload, steps, batch, cores):
+    """ViT-B/16 workloads: the oracle's L2P / InfLoRA_OPT step (oracle/vit.py, restating l2p.py:46-122 / InfLoRA_opt.py:141-369 and
+    backbone/transformer.py) at the full geometry, random weights, fp32"""
+    import numpy as np
+    from oracle import vit as ov
+    cfg, D = ov.VIT_B16, 768
+    g = torch.Generator().manual_seed(0)
+    l2p = workload.startswith("l2p")
+    steps = steps or (2 if l2p else 1)
+
+    def rnd(shape, scale):
+        return (torch.rand(shape, generator=g) * 2 - 1) * scale
+    P = {n: rnd(shp, 0.02 if len(shp) > 1 else 0.01) for n, shp in ov.param_shapes(cfg, 0 if l2p else 10)}
+    for n in P:
+        if n.endswith("ln_1.weight") or n.endswith("ln_2.weight") or n.endswith("norm.weight"):
+            P[n] = torch.ones_like(P[n])
+    x = torch.rand(batch, 3, 224, 224, generator=g) * 2 - 1
+    if l2p:
+        P["prompt.prompt"], P["prompt.prompt_key"] = torch.rand(1, 10, 5, D, generator=g), torch.rand(10, D, generator=g)
+        P["classifier.weight"], P["classifier.bias"] = rnd((100, D), 0.03), torch.zeros(100)
+        m = ov.L2P(P, cfg, 10, 10, 100, 5, 1.0)
+        m.before_task(0); m.after_task(0); m.before_task(1)
+        opt = ov.Adam(m.parameters(), 0.001875)
+        y = torch.randint(10, 20, (batch,), generator=g)
+
+        def step():
+            m.observe(x, y)
+            opt.step()
+    else:
+        from oracle.methods import SGD
+        for t in range(2):
+            P[f"classifier_pool.{t}.weight"], P[f"classifier_pool.{t}.bias"] = rnd((20, D), 0.03), torch.zeros(20)
+        m = ov.InfLoRA(P, cfg, 20, 20, 10, 1.0, 0.95, 10)
+        m.cur_task, m.known, m.apply_lora = 1, 20, True
+        m.trainable = [n for n in P if "lora_B" in n or n.startswith("classifier_pool.1.")]
+        for n, prm in P.items():
+            prm.requires_grad_(n in m.trainable)
+        opt = SGD(m.parameters(), 8e-3, 0.9, 0.0)
+        y = torch.randint(20, 40, (batch,), generator=g)
+
+        def step():
+            _, _, loss = m.observe(x, y)
+            opt.zero_grad(); loss.backward(); opt.step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=batch * steps / dt, unit="images/sec", cores=cores, kind="port",
+                sample=f"{steps} step(s) of batch {batch} ({'L2P' if l2p else 'InfLoRA_OPT'} task-1 step, ViT-B/16 224x224, fp32 torch-CPU oracle on {cores} physical cores), no warm-up")
+
+
+def _time_launches(run, reps, warm=5):
+    """average duration of `run` (which launches on torch's current stream) with HIP events on that stream"""
+    for _ in range(warm):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 50
     e0.record()
     for _ in range(reps):
         run()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * N * H * W * 9 * C * K
-    alg_bytes = (N * H * W * C + N * H * W * K) * (2 if dtype == "bf16" else 4) + w.numel() * w.element_size()
-    ach = flops / (ms * 1e-3) / 1e12
-    # HBM traffic per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/roofline_pmc.sh) of this same kernel / shape,
-    # committed under profiles/; null if no matching measurement is on disk
-    traffic, src = None, None
-    pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_roofline_pmc.json")
-    if os.path.exists(pj):
-        with open(pj) as f:
-            m = json.load(f)
-        if m.get("shape") == [N, H, W, C, K, 3, 1] and m.get("dtype") == dtype:
-            traffic, src = m["traffic_bytes_per_launch"], "profiles/r01_roofline_pmc.json (rocprofv3 --pmc, separate passes)"
-    kname = "conv3_kernel<4,1,0>" if dtype == "bf16" else "conv_igemm2_kernel<float>"
-    return dict(bound="mfma", kernel=kname + " fwd 3x3/s1 + BN-stat epilogue @ [B,32,32,64]x[64,3,3,64]", achieved=ach,
-                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=src,
-                launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
-                hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
+    return e0.elapsed_time(e1) / reps
+
+
+def _profile_lookup(workload, symbol):
+    """in-step average duration of a kernel symbol from the committed rocprofv3 --kernel-trace --stats summary of THIS command
+    (profiles/r02_bench_kernel_stats.json, written by tools/bench_profile.sh); None if absent"""
+    pj = os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.json")
+    if not os.path.exists(pj):
+        return None
+    with open(pj) as f:
+        prof = json.load(f)
+    ent = prof.get(workload, {}).get("kernels", {})
+    hits = [v for k, v in ent.items() if k.startswith(symbol)]
+    if not hits:
+        return None
+    calls = sum(h["calls"] for h in hits)
+    return dict(avg_us=sum(h["avg_us"] * h["calls"] for h in hits) / calls, share_of_kernel_time=sum(h["pct"] for h in hits) / 100.0,
+                source="profiles/r02_bench_kernel_stats.json (rocprofv3 --kernel-trace --stats of bench.py)")
+
+
+def _pmc_lookup(key):
+    pj = os.path.join(ROOT, "profiles", "r02_roofline_pmc.json")
+    if not os.path.exists(pj):
+        return None, None
+    with open(pj) as f:
+        m = json.load(f).get(key)
+    if not m:
+        return None, None
+    return m["traffic_bytes_per_launch"], "profiles/r02_roofline_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)"
+
+
+def conv_rooflines(dev, dtype, B, workload):
+    """The convolution families of the ResNet-18 step, each timed live (HIP events on the launch stream, the kernel alone, layer shapes of
+    the step) and priced against the roofline that bounds it; the first entry is the symbol with the largest share of the step's kernel
+    time in the committed in-step trace -- since round 2 the 3x3 stride-1 weight gradient.  Algorithmic FLOPs = 2 * M * 9 * Cin * Cout;
+    algorithmic bytes = the two tensors read once + the result written once."""
+    from libcontinual_amd import _lib
+    code = _lib.BF16 if dtype == "bf16" else _lib.F32
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    es = 2 if dtype == "bf16" else 4
+    st = torch.cuda.current_stream().cuda_stream
+    L = _lib.lib()
+    out = []
+
+    def entry(kind, symbol, label, N, H, W, C, K, run, flops, alg_bytes, pmc_key):
+        ms = _time_launches(run, 50)
+        ach = flops / (ms * 1e-3) / 1e12
+        t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        traffic, src = _pmc_lookup(pmc_key)
+        e = dict(bound=bound, kernel=label, pmc_key=pmc_key, launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
+                 traffic=traffic, traffic_source=src)
+        if bound == "mfma":
+            e.update(achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
+        else:
+            gbs = alg_bytes / (ms * 1e-3) / 1e9
+            e.update(achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, tflops_algorithmic=ach)
+        ins = _profile_lookup(workload, symbol)
+        if ins is not None:                      # the same symbol inside the step (two streams share the chip): the conservative figure
+            e.update(in_step_launch_ms=ins["avg_us"] * 1e-3, in_step_frac=e["frac"] * ms / (ins["avg_us"] * 1e-3), in_step_share_of_kernel_time=ins["share_of_kernel_time"],
+                     in_step_source=ins["source"])
+        out.append(e)
+
+    r18 = "resnet18" in workload
+    shapes = ((32, 64, "conv4_kernel<4, 1, 1, 32, 32, 0>"), (16, 128, "conv4_kernel<4, 2, 1, 64, 32, 0>")) if r18 else ((8, 64, "conv4_kernel<2, 1, 2, 64, 8, 0>"),)
+    for i, (H, C, sym) in enumerate(shapes):
+        N, W, K = B, H, C
+        M = N * H * W
+        x = torch.randn(N, H, W, C, device=dev).to(tdt)
+        dz = torch.randn(N, H, W, K, device=dev).to(tdt)
+        w = (torch.randn(K, 9, C, device=dev) * 0.05).to(tdt)
+        z = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+        dw = torch.zeros(K, 9, C, device=dev)
+        wsb = L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 3, 1, 1, code)
+        wsbuf = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        acc = torch.zeros(64, 2, K, dtype=torch.float64, device=dev)
+        flops = 2.0 * M * 9 * C * K
+        if i == 0:
+            _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st)
+            entry("wgrad", "conv_wgrad3_kernel", f"conv_wgrad3_kernel + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
+                  N, H, W, C, K,
+                  lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st),
+                  flops, M * (C + K) * es + K * 9 * C * 4, f"wgrad/{N}x{H}x{W}x{C}x{K}")
+        entry("fwd", sym, f"{sym.replace(' ', '')} forward 3x3/s1 + BN-stat epilogue @ [{N},{H},{W},{C}] x [{K},3,3,{C}]", N, H, W, C, K,
+              lambda: _lib.call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z.data_ptr(), acc.data_ptr(), 8, N, H, W, C, K, 3, 1, 1, code, st),
+              flops, M * (C + K) * es + w.numel() * es, f"fwd/{N}x{H}x{W}x{C}x{K}")
+    return out
 
 
 def gemm_roofline(dev, dtype, M):
@@ -235,6 +359,10 @@ def main():
     vit = "vitb16" in a.workload
     if a.batch is None:
         a.batch = 16 if a.workload.startswith("l2p") else (128 if vit else 256)
+    if a.steps is None:               # a timed region of about a second (the ResNet steps take 2-3 ms, the ViT steps 5-16 ms)
+        a.steps = 80 if vit else 400
+    if a.warmup is None:
+        a.warmup = 5 if vit else 20
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("CLHIP_SHARED_GPU") else int(os.environ.get("LOCAL_RANK", "0"))     # test hook: ranks share cuda:0
@@ -265,7 +393,16 @@ def main():
 
     # the dominant kernel's roofline measurement (HIP events around repeated launches of that kernel alone) runs first: it is
     # independent of the step, and the GPU enters the timed region at its sustained clocks instead of waking up in it
-    roofline = gemm_roofline(dev, a.dtype, a.batch * (222 if a.workload.startswith("l2p") else 197)) if vit else dominant_kernel_roofline(dev, a.dtype, a.batch)
+    more = []
+    if vit:
+        roofline = gemm_roofline(dev, a.dtype, a.batch * (222 if a.workload.startswith("l2p") else 197))
+    else:
+        rl = conv_rooflines(dev, a.dtype, a.batch, a.workload)
+        roofline, more = rl[0], rl[1:]
+    if a.roofline_only:               # the launches the PMC passes of tools/bench_profile.py sample
+        if rank == 0:
+            print(json.dumps(dict(roofline=roofline, roofline_more=more)))
+        return
     from libcontinual_amd.utils import quiesce_gc
     quiesce_gc()          # what Trainer.train_loop does after building a task's optimizer (no 80 ms generation-2 GC stalls mid-epoch)
     run(a.warmup)
@@ -307,8 +444,12 @@ def main():
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }
     out["roofline"] = roofline
-    if not a.no_cpu_baseline and not vit:
-        out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps, 128)
+    if more:
+        out["roofline_more"] = more
+    if not a.no_cpu_baseline and world == 1:
+        # the GPU line's own batch for the ResNet workloads; the ViT steps cost 2-3 CPU-seconds per image, so their bounded sample is a
+        # smaller batch (the per-image cost of the CPU path does not depend on it)
+        out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps, min(a.batch, 8) if vit else a.batch)
     print(json.dumps(out))
 
 
