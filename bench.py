@@ -257,7 +257,7 @@ def _pmc_lookup(key):
 def conv_rooflines(dev, dtype, B, workload):
     """The convolution families of the ResNet-18 step, each timed live (HIP events on the launch stream, the kernel alone, layer shapes of
     the step) and priced against the roofline that bounds it; the first entry is the symbol with the largest share of the step's kernel
-    time in the committed in-step trace -- since round 2 the 3x3 stride-1 weight gradient.  Algorithmic FLOPs = 2 * M * 9 * Cin * Cout;
+    time in the committed in-step trace -- since round 2 the 3x3 stride-1 weight gradient (its in-step figure averages the four layer shapes that share the symbol family).  Algorithmic FLOPs = 2 * M * 9 * Cin * Cout;
     algorithmic bytes = the two tensors read once + the result written once."""
     from libcontinual_amd import _lib
     code = _lib.BF16 if dtype == "bf16" else _lib.F32
@@ -280,10 +280,11 @@ def conv_rooflines(dev, dtype, B, workload):
         else:
             gbs = alg_bytes / (ms * 1e-3) / 1e9
             e.update(achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, tflops_algorithmic=ach)
-        ins = _profile_lookup(workload, symbol)
-        if ins is not None:                      # the same symbol inside the step (two streams share the chip): the conservative figure
-            e.update(in_step_launch_ms=ins["avg_us"] * 1e-3, in_step_frac=e["frac"] * ms / (ins["avg_us"] * 1e-3), in_step_share_of_kernel_time=ins["share_of_kernel_time"],
-                     in_step_source=ins["source"])
+        ins = [_profile_lookup(workload, sy) for sy in (symbol if isinstance(symbol, (list, tuple)) else [symbol])]
+        if all(i is not None for i in ins):      # the same symbol(s) inside the step (two streams share the chip): the conservative figure
+            t_in = sum(i["avg_us"] for i in ins) * 1e-3
+            e.update(in_step_launch_ms=t_in, in_step_frac=e["frac"] * ms / t_in, in_step_share_of_kernel_time=sum(i["share_of_kernel_time"] for i in ins),
+                     in_step_source=ins[0]["source"])
         out.append(e)
 
     r18 = "resnet18" in workload
@@ -302,13 +303,27 @@ def conv_rooflines(dev, dtype, B, workload):
         flops = 2.0 * M * 9 * C * K
         if i == 0:
             _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st)
-            entry("wgrad", "conv_wgrad3_kernel", f"conv_wgrad3_kernel + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
+            entry("wgrad", [f"conv_wgrad4_kernel<{W}>", "wgrad3_reduce_kernel"], f"conv_wgrad4_kernel<{W}> + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
                   N, H, W, C, K,
                   lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st),
                   flops, M * (C + K) * es + K * 9 * C * 4, f"wgrad/{N}x{H}x{W}x{C}x{K}")
         entry("fwd", sym, f"{sym.replace(' ', '')} forward 3x3/s1 + BN-stat epilogue @ [{N},{H},{W},{C}] x [{K},3,3,{C}]", N, H, W, C, K,
               lambda: _lib.call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z.data_ptr(), acc.data_ptr(), 8, N, H, W, C, K, 3, 1, 1, code, st),
               flops, M * (C + K) * es + w.numel() * es, f"fwd/{N}x{H}x{W}x{C}x{K}")
+    if r18:
+        # the atomic weight-gradient kernel of the stride-2 / 1x1 / stem layers (one symbol for the three stride-2 3x3 layers and the three
+        # 1x1 shortcuts: its in-step average mixes them), here at the largest of them
+        N, H, W, C, K = B, 32, 32, 64, 128
+        x = torch.randn(N, H, W, C, device=dev).to(tdt)
+        dz = torch.randn(N, H // 2, W // 2, K, device=dev).to(tdt)
+        dw = torch.zeros(K, 9, C, device=dev)
+        M2 = N * (H // 2) * (W // 2)
+        entry("wgrad", "conv_wgrad2_kernel<unsigned short, 2, 2, 4, 4>", f"conv_wgrad2_kernel<bf16,2,2,4,4>: dW of 3x3/s2 @ [{N},{H},{W},{C}] x [{N},{H // 2},{W // 2},{K}] (fp32 atomics)",
+              N, H, W, C, K,
+              lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), None, N, H, W, C, C, K, 3, 2, 1, code, st),
+              2.0 * M2 * 9 * C * K, (N * H * W * C + M2 * K) * es + K * 9 * C * 4, f"wgrad_s2/{N}x{H}x{W}x{C}x{K}")
+    # largest share of the step's kernel time first (committed in-step trace); without a trace, the order above
+    out.sort(key=lambda e: -e.get("in_step_share_of_kernel_time", 0.0))
     return out
 
 

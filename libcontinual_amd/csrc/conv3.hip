@@ -1092,6 +1092,13 @@ int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int
     return CLHIP_OK;
 }
 
+// dw += the `splits` partial blocks of a workspace, fixed order (shared with wgrad4.hip)
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, slab, dw, n4, splits);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
 int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st) {
     Wgrad16Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H};
     size_t lds = (size_t)((H + 2) * 34 + H * 32) * 32;

@@ -416,7 +416,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     static const bool two_streams = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
     hipStream_t main_s = static_cast<hipStream_t>(stream);
     if (two_streams && !p->side) {
-        if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
+        // lowest priority: the weight gradients are off the critical path (nothing waits for them before the optimizer step); when both
+        // queues have workgroups ready the dispatcher should serve the caller's stream (dgrad, BatchNorm backward) first
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        static const bool flat = getenv("CLHIP_SIDE_PRIO") != nullptr && atoi(getenv("CLHIP_SIDE_PRIO")) == 0;
+        const hipError_t e = flat ? hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_lo);
+        if (e != hipSuccess) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
         for (int k = 0; k < 2; ++k) {
             (void)hipEventCreateWithFlags(&p->ev_dz[k], hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&p->ev_wg[k], hipEventDisableTiming);

@@ -1,0 +1,340 @@
+// wgrad4.hip -- weight gradient of the 3x3 / stride 1 / pad 1 layers, bf16, gfx950:  dw[o][tap][c] += sum_p dz[p][o] * x[p @ tap][c].
+//
+// conv_wgrad3_kernel (conv3.hip) keeps a zero-padded input patch in LDS and reads both MFMA operands with transposing LDS reads; what
+// the round-2 measurements said about it (tools/ubench/wgrad_bench, profiles/r02_wgrad4_notes.md): 1.5 us per 64-pixel step even on
+// an idle chip -- the step's global loads are issued at its start, parked in registers and stored to LDS at its end, so every step
+// pays one L2 / HBM round trip, with one workgroup per CU and nothing else to hide it -- and 0.61 fragment reads per MFMA (a wave owns
+// 32 x 16 x 9 outputs), which makes LDS the next limit.  This generation:
+//
+//  * both operands are streamed by LDS-DMA through buffer descriptors (`buffer_load ... lds`, 16 bytes per lane, no staging
+//    registers) into a 3-stage ring TWO 128-pixel steps ahead; waits are counted (s_waitcnt vmcnt(6)), the barrier is the raw
+//    s_barrier.  Zero padding costs nothing: pad slots, halo rows outside the image and pixels behind the tensor's end get an offset
+//    the hardware range check rejects, and the DMA writes zeros there.
+//  * the patch has ONE pad column per row (it is the right neighbour of the row's last pixel and the left neighbour of the next
+//    row's first) and one zero row between images, so a 128-pixel step stages 171-206 patch pixels (wgrad3: 136 per 64).
+//  * a wave owns 64 (out) x 16 (in) x 9 outputs = 36 accumulator tiles, 144 registers: 4 + 9 fragment reads per 36 MFMAs.  Waves
+//    0-3 and 4-7 split the step's four 32-pixel MFMA K-steps; the two halves are summed through LDS at the end (each keeps two
+//    of the four out-channel tiles, so all eight waves store).
+//  * A = the input fragment, B = the gradient fragment: the accumulator then holds four consecutive INPUT channels per lane and the
+//    partial block is written with 16-byte stores.
+//  * workgroups that share a pixel range (the (C/64) x (K/64) tiles of one split) are placed on one XCD, so the second read of a
+//    tensor is an L2 hit.
+//
+// The partial blocks go to the same [split][K][9][C] fp32 workspace as wgrad3's and are summed in a fixed order by
+// wgrad3_reduce_kernel (bitwise reproducible weight gradients).  Replaces the weight-gradient half of nn.Conv2d's backward for the
+// reference ResNets' 3x3 stride-1 layers (core/model/backbone/resnet.py:17-24, 295-298).
+#include <stdlib.h>
+
+#include "common.h"
+
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);      // conv3.hip
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+struct Wgrad4Params {
+    const bf16_t* x;     // [N,H,W,C]
+    const bf16_t* dz;    // [N,H,W,K]
+    float* slab;         // [splits][K][9][C]
+    int N, H, C, K, M;
+    int R, nimg;         // a 128-pixel step = nimg images x R rows x W columns (nimg == 1: R rows of one image, nimg > 1: whole images, R == H)
+    int npatch;          // patch pixels: 1 + rows * (W + 1)
+    int steps_per_split, total_steps;
+    int tiles_c, tiles, splits, xcd_map;
+    unsigned long long* trace;   // CLHIP_ABLATION builds: s_memtime stamps of waves 0 and 4 of workgroup 0 ([2][64])
+};
+
+unsigned long long* g_trace_w4 = nullptr;
+#ifdef CLHIP_ABLATION
+#define STAMP4() do { if (p.trace && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && nstamp < 64) p.trace[(wave >> 2) * 64 + nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP4() do { } while (0)
+#endif
+
+constexpr int SP = 128;                     // pixels per step
+constexpr int P4 = 144;                     // LDS bytes per pixel: 64 channels + one pad slot (4 consecutive pixels fall in disjoint bank ranges)
+constexpr int ZINST = SP * 9 / 64;          // DMA instructions of the gradient tile (18)
+constexpr int NINST = 48, WINST = NINST / 8;// DMA instructions per stage / per wave
+constexpr int STAGE = NINST * 1024;
+constexpr int NST = 2;                    // ring stages (see the LDS note at conv_wgrad4_kernel)
+constexpr int ZBYTES = SP * P4;             // the patch follows the gradient tile
+constexpr int LDS4 = NST * STAGE;           // 98304; the epilogue's exchange rounds need 8 waves x 9 tiles x 64 lanes x 16 bytes = 73728
+constexpr int OOB = 0x40000000;
+
+__device__ __forceinline__ void wg_barrier4() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's LDS reads of the stage that is about to be overwritten
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// two transposing 8-byte reads -> the 8 reduction elements (pixels) of one MFMA operand row; `second` = byte distance of pixels k+4..k+7
+__device__ __forceinline__ bf16x8_t tr8x(const char* base, int addr, int second) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr + second));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return __builtin_bit_cast(bf16x8_t, make_uint4(l.x, l.y, h.x, h.y));
+}
+
+// The LDS-DMA is issued from inline asm ON PURPOSE.  hipcc (ROCm 7.2) knows that a `buffer_load ... lds` builtin writes LDS and puts
+// `s_waitcnt vmcnt(0)` in front of the first ds_read_tr intrinsic that follows one (the intrinsic carries an LDS memory operand which
+// every DMA in flight may alias) -- the ring would be drained every step.  Hidden in asm, the DMA is invisible to that bookkeeping;
+// its completion is waited for by hand (dma_wait<N>: loads return in order) and published by the workgroup barrier.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int IMM>
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, int voffset) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr + IMM), "v"(voffset), "s"(rsrc) : "memory");      // m0 is a reserved register: hipcc re-materialises it before each of its own uses
+}
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int W>
+__global__ __launch_bounds__(512) void conv_wgrad4_kernel(const Wgrad4Params p) {
+    constexpr int PW = W + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, ct = wave & 3;               // K-step half, 16-channel input column
+    int nstamp = 0; (void)nstamp;
+    STAMP4();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int H = p.H, R = p.R;
+
+    // ---- workgroup -> (tile, split): the tiles of one split sit on one XCD (block b runs on XCD b % 8)
+    int tile, split;
+    if (p.xcd_map) { const int b = blockIdx.x, xcd = b & 7, j = b >> 3; tile = j % p.tiles; split = (j / p.tiles) * 8 + xcd; }
+    else { tile = blockIdx.x % p.tiles; split = blockIdx.x / p.tiles; }
+    const int c0 = (tile % p.tiles_c) * 64, o0 = (tile / p.tiles_c) * 64;
+    const int s_beg = split * p.steps_per_split;
+    const int s_end = min(p.total_steps, s_beg + p.steps_per_split);
+    const int nst = s_end - s_beg;
+
+    // ---- fragment addresses.  Reduction element k of a step is pixel (img, row, col) = (k / (RI*W), (k % (RI*W)) / W, k % W); lane
+    //      (fr, fg) feeds k = ks*32 + fg*8 + {0..7}; a transposing read fetches 4 consecutive k of one image row.
+    int zaddr[2], xaddr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = (kg * 2 + u) * 32 + fg * 8 + (fr >> 2);
+        zaddr[u] = k * P4 + (fr & 3) * 8;
+        const int per = R * W;
+        const int img = k / per, rem = k - img * per, rr = rem / W, cc = rem - rr * W;
+        const int j = p.nimg == 1 ? rr + 1 : img * (H + 1) + 1 + rr;
+        // biased to tap (0, 0): the nine taps are the non-negative immediates (r * PW + s) * P4
+        xaddr[u] = ZBYTES + (1 + j * PW + cc - PW - 1) * P4 + (ct * 16 + (fr & 3) * 4) * 2;
+    }
+    constexpr int xsecond = (W >= 8 ? 4 : PW) * P4;       // pixels k+4..k+7: same row, or (4-pixel rows) the next row
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;        // LDS byte address of the ring (low half of the flat address)
+
+    // ---- DMA lanes.  Instruction I = wave * 6 + i of a stage fills LDS bytes [I * 1024, +1024): slot n = I * 64 + lane is
+    //      (pixel n / 9, 16-byte column n % 9); instructions 0-17 (waves 0-2) carry the gradient tile, the rest the patch.
+    const bool zwave = wave < ZINST / WINST;
+    const uintptr_t tb = reinterpret_cast<uintptr_t>(zwave ? p.dz : p.x);
+    u32x4 rs;                                                // raw buffer descriptor: base, stride 0, bytes, DATA_FORMAT = 32 bits
+    rs.x = __builtin_amdgcn_readfirstlane((unsigned)tb); rs.y = __builtin_amdgcn_readfirstlane((unsigned)(tb >> 32) & 0xffffu);
+    rs.z = __builtin_amdgcn_readfirstlane((unsigned)(p.M * (zwave ? p.K : p.C) * 2)); rs.w = 0x00020000u;
+    int prel[WINST];
+    unsigned topm = 0, botm = 0;
+#pragma unroll
+    for (int i = 0; i < WINST; ++i) {
+        const int n = (wave * WINST + i) * 64 + lane;
+        if (zwave) {
+            const int q = n / 9, sub = n - q * 9;
+            prel[i] = sub < 8 ? q * p.K * 2 + sub * 16 : OOB;
+        } else {
+            const int n2 = n - ZINST * 64;
+            const int q = n2 / 9, sub = n2 - q * 9;
+            int v = OOB;
+            if (q >= 1 && q < p.npatch && sub < 8) {
+                const int j = (q - 1) / PW, w = (q - 1) - j * PW;
+                if (w < W) {
+                    if (p.nimg == 1) {
+                        v = ((j - 1) * W + w) * p.C * 2 + sub * 16;
+                        if (j == 0) topm |= 1u << i;
+                        if (j == R + 1) botm |= 1u << i;
+                    } else {
+                        const int img = j / (H + 1), jj = j - img * (H + 1);
+                        if (jj != 0) v = ((img * H + jj - 1) * W + w) * p.C * 2 + sub * 16;
+                    }
+                }
+            }
+            prel[i] = v;
+        }
+    }
+    auto dma = [&](int s, int stage) {
+        const int p0 = s * SP;
+        int base;
+        bool top_ok = true, bot_ok = true;
+        if (zwave) base = (p0 * p.K + o0) * 2;
+        else {
+            base = (p0 * p.C + c0) * 2;
+            if (p.nimg == 1) { const int h0 = (p0 / W) % H; top_ok = h0 > 0; bot_ok = h0 + R < H; }
+        }
+        const unsigned l = lds0 + stage * STAGE + wave * (WINST * 1024);
+        int v[WINST];
+#pragma unroll
+        for (int i = 0; i < WINST; ++i) {
+            v[i] = prel[i] + base;
+            if (((topm >> i) & 1u) && !top_ok) v[i] = OOB;
+            if (((botm >> i) & 1u) && !bot_ok) v[i] = OOB;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        dma16<0>(rs, l, v[0]); dma16<1024>(rs, l, v[1]); dma16<2048>(rs, l, v[2]);
+        dma16<3072>(rs, l, v[3]); dma16<4096>(rs, l, v[4]); dma16<5120>(rs, l, v[5]);
+#else
+        (void)l;
+#endif
+    };
+
+    f32x4 acc[4][9];                                         // [out-channel tile][tap]: D[row = in channel 4 fg + e][col = out channel fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    STAMP4();
+    if (nst > 0) dma(s_beg, 0);
+    STAMP4();
+    int stage = 0;
+    for (int i = 0; i < nst; ++i) {
+        dma_wait<0>();                                               // this wave's part of step i has landed
+        STAMP4();
+        wg_barrier4();                                               // ... everybody's; and the other stage is no longer read
+        STAMP4();
+        if (i + 1 < nst) dma(s_beg + i + 1, stage ^ 1);              // one step (1.5 us of MFMAs) ahead
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8_t zf[4];
+#pragma unroll
+            for (int oi = 0; oi < 4; ++oi) zf[oi] = tr8x(sb, zaddr[u] + oi * 32, 4 * P4);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s2 = t - 3 * r;
+                const bf16x8_t xf = tr8x(sb, xaddr[u] + (r * PW + s2) * P4, xsecond);
+#pragma unroll
+                for (int oi = 0; oi < 4; ++oi) acc[oi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, zf[oi], acc[oi][t], 0, 0, 0);
+            }
+        }
+        stage ^= 1;
+    }
+
+    // ---- the two K-step halves: waves 0-3 keep out-channel tiles 0-1 and hand over 2-3, waves 4-7 the other way round
+    STAMP4();
+    wg_barrier4();
+    STAMP4();
+    f32x4* ex = reinterpret_cast<f32x4*>(smem);              // [wave][9][64], one out-channel tile per round
+    float* out = p.slab + (size_t)split * p.K * 9 * p.C;
+    const int c = c0 + ct * 16 + fg * 4;
+    const int partner = wave ^ 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (kg == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) ex[(wave * 9 + t) * 64 + lane] = acc[2 + h][t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) ex[(wave * 9 + t) * 64 + lane] = acc[h][t];
+        }
+        wg_barrier4();
+        if (kg == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 v = acc[h][t] + ex[(partner * 9 + t) * 64 + lane];
+                *reinterpret_cast<f32x4*>(out + ((size_t)(o0 + h * 16 + fr) * 9 + t) * p.C + c) = v;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 v = acc[2 + h][t] + ex[(partner * 9 + t) * 64 + lane];
+                *reinterpret_cast<f32x4*>(out + ((size_t)(o0 + (2 + h) * 16 + fr) * 9 + t) * p.C + c) = v;
+            }
+        }
+        if (h == 0) wg_barrier4();
+    }
+    STAMP4();
+#ifdef CLHIP_ABLATION
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP4();
+}
+
+bool geometry4(int N, int H, int W, int C, int K, Wgrad4Params& p) {
+    p.N = N; p.H = H; p.C = C; p.K = K; p.M = N * H * W;
+    const int hw = H * W;
+    int rows;
+    if (hw >= SP) {
+        if (SP % W || H % (SP / W)) return false;
+        p.nimg = 1; p.R = SP / W; rows = p.R + 2;
+    } else {
+        if (SP % hw) return false;
+        p.nimg = SP / hw; p.R = H; rows = p.nimg * (H + 1) + 1;
+    }
+    p.npatch = 1 + rows * (W + 1);
+    if ((SP + p.npatch) * 9 > NINST * 64) return false;
+    p.tiles_c = C / 64; p.tiles = (C / 64) * (K / 64);
+    p.total_steps = (p.M + SP - 1) / SP;
+    // 160 workgroups, not 256: inside a training step this kernel runs on the weight-gradient stream beside the dgrad / BatchNorm chain
+    // of the caller's stream, which is the critical path -- a launch that fills every CU (one workgroup each: 96 KB of LDS, 196 VGPRs)
+    // costs the step more than its own 2 us (ResNet-18, batch 256: 2.66 ms per step at 256, 2.55 at 128-160; profiles/r02_wgrad4_notes.md)
+    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 160;
+    static const int min_steps = getenv("CLHIP_WGRAD4_MIN_STEPS") ? atoi(getenv("CLHIP_WGRAD4_MIN_STEPS")) : 2;
+    int splits = (target + p.tiles - 1) / p.tiles;
+    const int max_splits = (p.total_steps + min_steps - 1) / min_steps;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (p.total_steps + splits - 1) / splits;
+    p.splits = (p.total_steps + p.steps_per_split - 1) / p.steps_per_split;
+    p.xcd_map = (p.splits % 8 == 0) ? 1 : 0;
+    return true;
+}
+
+template <int W>
+int launch4(const Wgrad4Params& p, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad4_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess) {
+            clhip_set_error("wgrad4: cannot reserve %d bytes of LDS", LDS4);
+            return CLHIP_EHIP;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad4_kernel<W>, dim3(p.tiles * p.splits), dim3(512), LDS4, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+}  // namespace
+
+bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    static const bool off = getenv("CLHIP_WGRAD4") != nullptr && atoi(getenv("CLHIP_WGRAD4")) == 0;
+    if (off) return false;
+    if (!(dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C % 64 == 0 && K % 64 == 0 && Creal == C && N >= 1 && H >= 1)) return false;
+    if (!(W == 4 || W == 8 || W == 16 || W == 32)) return false;
+    if ((long long)N * H * W * (C > K ? C : K) * 2 >= (1ll << 30)) return false;      // descriptor offsets + the out-of-range marker stay below 2^31
+    Wgrad4Params p;
+    return geometry4(N, H, W, C, K, p);
+}
+
+size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K) {
+    Wgrad4Params p;
+    if (!geometry4(N, H, W, C, K, p)) return 0;
+    return (size_t)p.splits * K * 9 * C * sizeof(float);
+}
+
+int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int K, hipStream_t st) {
+    Wgrad4Params p;
+    if (!geometry4(N, H, W, C, K, p) || ws == nullptr) { clhip_set_error("wgrad4: unsupported geometry or no workspace"); return CLHIP_EINVAL; }
+    p.x = static_cast<const bf16_t*>(x); p.dz = static_cast<const bf16_t*>(dz); p.slab = ws; p.trace = g_trace_w4;
+    int rc;
+    switch (W) {
+        case 4: rc = launch4<4>(p, st); break;
+        case 8: rc = launch4<8>(p, st); break;
+        case 16: rc = launch4<16>(p, st); break;
+        default: rc = launch4<32>(p, st); break;
+    }
+    if (rc != CLHIP_OK) return rc;
+    return clhip_wgrad_reduce_launch(ws, dw, (int64_t)K * 9 * C / 4, p.splits, st);
+}
+
+// phase stamps of workgroup 0 (ablation build only; tools/ubench/wgrad_bench trace)
+extern "C" void clhip_wgrad4_set_trace(unsigned long long* dev_buf) { g_trace_w4 = dev_buf; }

@@ -71,6 +71,11 @@ CONV_CASES = [
     (2, 7, 5, 64, 64, 3, 1, 1),
     (130, 32, 32, 64, 64, 3, 1, 1),    # 512-pixel tiles (8 waves), ragged last tile
     (70, 16, 16, 128, 256, 3, 1, 1),   # 256x128 tiles
+    # step geometries of the LDS-DMA weight-gradient kernel (wgrad4.hip): 16 rows of an 8-wide image, four 4x8 images, two 8x4 images
+    # per 128-pixel step, each with a ragged last step
+    (3, 16, 8, 64, 64, 3, 1, 1),
+    (5, 4, 8, 64, 128, 3, 1, 1),
+    (7, 8, 4, 128, 64, 3, 1, 1),
     # the register-resident-weight kernels for 16 -> 16 and 32 -> 32 channels (conv3.hip conv16 / conv32): tiles spanning several
     # images, ragged last tile, non-square and non-power-of-two images (division path of the tap masks), one-row images
     (5, 16, 16, 32, 32, 3, 1, 1),

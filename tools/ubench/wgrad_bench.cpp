@@ -21,11 +21,14 @@ static uint32_t rng_state = 777;
 static uint32_t irand() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 4; }
 static float urand() { return (irand() & 0xffff) / 32768.0f - 1.0f; }
 
+extern "C" void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
+
 struct Case { const char* name; int N, H, W, C, K; };
 
 int main(int argc, char** argv) {
     const char* filt = argc > 1 ? argv[1] : "";
     const int reps = argc > 2 ? atoi(argv[2]) : 40;
+    const bool trace = argc > 3 && !strcmp(argv[3], "trace");      // phase stamps of workgroup 0 (link against libclhip_abl.so)
     std::vector<Case> cases = {
         {"L1w 256x32x32 64->64", 256, 32, 32, 64, 64},     {"L2w 256x16x16 128->128", 256, 16, 16, 128, 128},
         {"L3w 256x8x8 256->256", 256, 8, 8, 256, 256},     {"L4w 256x4x4 512->512", 256, 4, 4, 512, 512},
@@ -80,6 +83,19 @@ int main(int argc, char** argv) {
             }
             const double err = fabs(h1[e] - a) / (mag * 2e-6 + 1e-6);      // 1 = fp32 accumulation slack over the whole reduction
             if (!(err <= worst)) worst = err;
+        }
+        if (trace) {
+            unsigned long long* dt; CK(hipMalloc(&dt, 128 * 8)); CK(hipMemset(dt, 0, 128 * 8));
+            clhip_wgrad4_set_trace(dt);
+            run(0); CK(hipStreamSynchronize(st));
+            clhip_wgrad4_set_trace(nullptr);
+            std::vector<unsigned long long> ht(128); CK(hipMemcpy(ht.data(), dt, 128 * 8, hipMemcpyDeviceToHost));
+            for (int h = 0; h < 2; ++h) {
+                printf("wave %d stamps (deltas, ticks of the 100 MHz s_memtime counter = 10 ns):", h * 4);
+                for (int i = 1; i < 64 && ht[h * 64 + i]; ++i) printf(" %llu", ht[h * 64 + i] - ht[h * 64 + i - 1]);
+                printf("\n");
+            }
+            hipFree(dt);
         }
         for (int i = 0; i < 5; ++i) run(i % nset);
         CK(hipEventRecord(e0, st));
