@@ -300,6 +300,9 @@ int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
                   int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
 /* tuning knob (bf16): 0 register-staged tiles, 1 LDS-DMA 128x128, 2 LDS-DMA 256x128; -1 = from $CLHIP_GEMM_IMPL (default 0) */
 void clhip_gemm_config(int impl);
+/* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never, 1 where it wins (default: N >= 2048,
+ * >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
+void clhip_gemm5_config(int mode);
 /* softmax(q k^T / sqrt(d)) v per (batch, head) on the packed qkv [B*N, 3D] (column = which*D + head*d + i), out [B*N, D],
  * lse [B,H,N] (nullable in forward-only use); MultiHeadAttention.forward, transformer.py:169-197.  N <= 256, d <= 64. */
 int clhip_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype, void* stream);

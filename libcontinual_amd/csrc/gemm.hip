@@ -727,6 +727,10 @@ template <typename T> int dispatch(int epi, const GemmParams& p, hipStream_t s) 
 
 }  // namespace
 
+bool clhip_gemm5_supported(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype);
+int clhip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
+                       int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st);
+
 extern "C" void clhip_gemm_config(int impl) { g_impl = impl; }
 
 extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
@@ -742,5 +746,7 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
     static const int gm_env = getenv("CLHIP_GEMM_GROUP_M") ? atoi(getenv("CLHIP_GEMM_GROUP_M")) : 0;
     GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, gm_env > 0 ? gm_env : (N >= 4096 ? 4 : 1)};     // wide outputs: 8192^3 991 -> 1046 TFLOP/s; the ViT shapes (N <= 3072) are indifferent
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gemm_impl() == 0 && clhip_gemm5_supported(M, N, K, lda, ldb, ldc, ldr, ldh, dtype))
+        return clhip_gemm5_launch(A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, epilogue, s);
     return dtype == CLHIP_BF16 ? dispatch<bf16_t>(epilogue, p, s) : dispatch<float>(epilogue, p, s);
 }
