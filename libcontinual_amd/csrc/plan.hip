@@ -413,8 +413,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     // The weight gradients hang off the backward chain (BN backward -> dgrad -> next unit) as leaves: they run on a second stream,
     // so their kernels fill the load / store phases of the chain's kernels instead of queueing behind them.  dz is double-buffered;
     // events order  BN backward(i) -> wgrad(i)  and  wgrad(i) -> BN backward(i-2) (same dz buffer).  CLHIP_WGRAD_STREAM=0: one stream.
-    static const bool two_streams = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
+    static const bool two_streams_env = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
     hipStream_t main_s = static_cast<hipStream_t>(stream);
+    // inside a stream capture (trainer.GraphedStep: small, host-bound batches) everything stays on the captured stream: the fork /
+    // join of a second stream gains nothing at those sizes, and ROCm 7.2 crashed in hipStreamEndCapture on it
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(main_s, &cap);
+    const bool two_streams = two_streams_env && cap == hipStreamCaptureStatusNone;
     if (two_streams && !p->side) {
         // lowest priority: the weight gradients are off the critical path (nothing waits for them before the optimizer step); when both
         // queues have workgroups ready the dispatcher should serve the caller's stream (dgrad, BatchNorm backward) first

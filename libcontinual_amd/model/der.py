@@ -40,6 +40,7 @@ class SimpleLinear(HipLinear):
 
 
 class DER(Finetune):
+    cuda_graph_safe = False     # not audited for trainer.GraphedStep
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__(backbone, feat_dim, num_class, **kwargs)
         self.convnets = nn.ModuleList()

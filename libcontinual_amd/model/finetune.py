@@ -9,6 +9,10 @@ from .heads import HipLinear
 
 
 class Finetune(nn.Module):
+    # a training step has no data-dependent host control flow and touches fixed buffers only: trainer.GraphedStep may capture it
+    # (inherited by EWC and LWF; methods with host-side branching per batch leave it False)
+    cuda_graph_safe = True
+
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__()
         self.kwargs = kwargs

@@ -22,6 +22,7 @@ from .finetune import Finetune
 
 
 class InfLoRA(Finetune):
+    cuda_graph_safe = False     # not audited for trainer.GraphedStep
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__(backbone, feat_dim, num_class, **kwargs)
         self._network = backbone

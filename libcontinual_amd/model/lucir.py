@@ -39,6 +39,7 @@ class Model(_ScratchMixin, nn.Module):
 
 
 class LUCIR(Finetune):
+    cuda_graph_safe = False     # not audited for trainer.GraphedStep
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__(backbone, feat_dim, num_class, **kwargs)
         self.kwargs = kwargs

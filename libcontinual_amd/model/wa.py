@@ -59,6 +59,7 @@ class IncrementalModel(nn.Module):
 
 
 class WA(Finetune):
+    cuda_graph_safe = False     # not audited for trainer.GraphedStep
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__(backbone, feat_dim, num_class, **kwargs)
         self.network = IncrementalModel(self.backbone, feat_dim, kwargs["init_cls_num"])

@@ -29,29 +29,127 @@ from .utils import AverageMeter, compute_bwt, compute_frgt, count_all_parameters
 _OBSERVE_DOES_BACKWARD = ("L2P",)      # core/trainer.py:593-596 (subset on the hot path)
 
 
+class GraphedStep:
+    """One training step (observe -> zero_grad -> backward -> step) captured into a HIP graph and replayed.
+
+    At 32 images per GPU a ResNet-32 step is ~250 kernels of 3-8 us each and the host cannot enqueue them as fast as the GPU runs them
+    (eager 1.76 ms per step, replayed 1.34 ms: tools/graph_step.py, profiles/r02_small_batch_notes.md).  The step is already free of host
+    synchronisation (losses and accuracies stay on the device), every buffer it touches has a fixed address (plan workspace, parameter
+    and gradient arenas, momentum), so a capture on the compute stream replays it exactly.  Rules:
+      * the whole loop runs on a stream of its own (see __init__);
+      * the first WARM steps of every (input shapes, learning rates, mode) key run eagerly -- lazy initialisation (kernel attributes,
+        workspaces, the autograd graph's buffers) must not happen inside a capture -- and are REAL steps; the capture itself
+        executes nothing, its first replay is the next real step;
+      * a new key (ragged last batch of an epoch, a scheduler step) captures a new graph; the last few keys are kept;
+      * only single-process runs of methods that declare `cuda_graph_safe` (a step without data-dependent host control flow)."""
+    WARM, KEEP = 2, 4
+
+    def __init__(self, model, optimizer, method_name):
+        self.model, self.optimizer, self.method_name = model, optimizer, method_name
+        self.graphs = {}            # key -> (graph, static inputs, (output, acc, loss))
+        self.seen = {}              # key -> eager steps so far
+        # every step of a graphed loop -- warm-up, capture, replay -- runs on this stream: autograd binds a parameter's gradient
+        # accumulation to the stream of its first backward, and a capture cannot depend on the legacy default stream
+        self.stream = torch.cuda.Stream()
+
+    def _key(self, batch):
+        shapes = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        lrs = tuple((g.get("lr"), g.get("momentum"), g.get("weight_decay")) for g in self.optimizer.param_groups)
+        return shapes, lrs, self.model.training
+
+    def _step(self, batch):
+        if self.method_name in _OBSERVE_DOES_BACKWARD:
+            self.optimizer.zero_grad()
+            out = self.model.observe(batch)
+        else:
+            out = self.model.observe(batch)
+            self.optimizer.zero_grad()
+            out[2].backward()
+        self.optimizer.step()
+        return out
+
+    def __call__(self, batch):
+        key = self._key(batch)
+        ent = self.graphs.get(key)
+        if ent is None:
+            n = self.seen.get(key, 0)
+            if n < self.WARM:
+                self.seen[key] = n + 1
+                return self._step(batch)
+            static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                out = self._step(static)
+            while len(self.graphs) >= self.KEEP:
+                self.graphs.pop(next(iter(self.graphs)))
+            ent = self.graphs[key] = (g, static, out)
+        g, static, out = ent
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                static[k].copy_(v, non_blocking=True)
+        g.replay()
+        output, acc, loss = out
+        # the captured outputs are overwritten by the next replay: hand out copies (two tiny device copies, no synchronisation)
+        acc = ops.Deferred(acc.tensor.clone(), acc.scale) if isinstance(acc, ops.Deferred) else acc
+        return output, acc, loss.detach().clone()
+
+
+def _graph_mode(model, reducer, device):
+    """CLHIP_CUDA_GRAPH = 1: replay where legal; anything else: never.  Opt-in because it only pays when the HOST is the limit: with an
+    otherwise idle host the 32-image ResNet steps are bound by the GPU's own launch cadence (~250 dependent kernels of 3-8 us:
+    eager 1.33 ms, replayed 1.41 ms in bench.py), while a loop that shares its process with a busy loader went 1.76 -> 1.34 ms
+    (tools/graph_step.py; profiles/r02_small_batch_notes.md)"""
+    env = os.environ.get("CLHIP_CUDA_GRAPH")
+    legal = (device is not None and torch.device(device).type == "cuda" and reducer is None and getattr(model, "grad_reducer", None) is None
+             and getattr(model, "cuda_graph_safe", False))
+    if not legal or env != "1":
+        return None
+    return "always"
+
+
 def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=None, device=None):
     """The per-batch hot path (core/trainer.py:585-612): observe -> zero_grad -> backward -> [grad all-reduce]
     -> step -> meters.  Shared by Trainer._train and bench.py so that the benchmark times exactly what
-    training runs.  Loss / accuracy stay on the device (ops.Deferred): no host sync inside the loop."""
+    training runs.  Loss / accuracy stay on the device (ops.Deferred): no host sync inside the loop.
+    Small per-GPU batches of graph-safe methods replay a captured HIP graph of the step (GraphedStep)."""
     on_gpu = device is not None and torch.device(device).type == "cuda"
     import contextlib
     overlap = reducer.overlap(model) if (reducer is not None and hasattr(reducer, "overlap")) else contextlib.nullcontext()
-    with ops.deferred_metrics(on_gpu), overlap:
+    mode = _graph_mode(model, reducer, device)
+    gs = None
+    if mode is not None:
+        gs = getattr(model, "_graphed_step", None)
+        if gs is None or gs.optimizer is not optimizer:
+            gs = model._graphed_step = GraphedStep(model, optimizer, method_name)
+    caller = torch.cuda.current_stream() if gs is not None else None
+    if gs is not None:
+        gs.stream.wait_stream(caller)
+    with ops.deferred_metrics(on_gpu), overlap, (torch.cuda.stream(gs.stream) if gs is not None else contextlib.nullcontext()):
         for b, batch in enumerate(batches):
             batch["batch_id"] = b
-            if method_name in _OBSERVE_DOES_BACKWARD:
-                optimizer.zero_grad()
-                output, acc, loss = model.observe(batch)
+            if gs is not None and (mode == "always" or batch["label"].shape[0] <= GRAPH_MAX_BATCH):
+                gs.stream.wait_stream(caller)                  # loaders that produce their batches on the caller's stream
+                output, acc, loss = gs({k: v for k, v in batch.items() if k != "batch_id"})
             else:
-                output, acc, loss = model.observe(batch)
-                optimizer.zero_grad()
-                loss.backward()
-            if reducer is not None and getattr(model, "grad_reducer", None) is None:
-                reducer.reduce(model)
-            optimizer.step()
+                if method_name in _OBSERVE_DOES_BACKWARD:
+                    optimizer.zero_grad()
+                    output, acc, loss = model.observe(batch)
+                else:
+                    output, acc, loss = model.observe(batch)
+                    optimizer.zero_grad()
+                    loss.backward()
+                if reducer is not None and getattr(model, "grad_reducer", None) is None:
+                    reducer.reduce(model)
+                optimizer.step()
             if meter is not None:
                 meter.update("acc1", 100 * acc)
                 meter.update("loss", loss.detach() if on_gpu else loss.item())
+    if gs is not None:
+        caller.wait_stream(gs.stream)
+
+
+GRAPH_MAX_BATCH = 64      # above this the ResNet steps are GPU-bound and a replay buys nothing (measured: profiles/r02_small_batch_notes.md)
 
 
 class Trainer:

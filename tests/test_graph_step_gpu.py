@@ -1,0 +1,73 @@
+"""trainer.GraphedStep: a captured and replayed training step against the eager enqueue of the same steps (same data, same initial
+state): parameters and losses agree to the run-to-run tolerance of the eager path itself (the atomic weight-gradient kernels of the
+stride-2 / 1x1 layers sum in arrival order), ragged last batches and learning-rate changes capture their own graphs, and methods that
+do not declare `cuda_graph_safe` never replay."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import libcontinual_amd.model as M                     # noqa: E402
+from libcontinual_amd import optim                     # noqa: E402
+from libcontinual_amd import trainer as T              # noqa: E402
+from libcontinual_amd.utils import AverageMeter        # noqa: E402
+
+
+def _make(kind, seed):
+    torch.manual_seed(seed)
+    if kind == "lwf":
+        bb = M.resnet18(args={"dataset": "cifar100"}, dtype="bf16")
+        m = M.LWF(bb, 512, 100, device="cuda", init_cls_num=50, inc_cls_num=5).to("cuda")
+    else:
+        bb = M.cifar_resnet32(dtype="bf16")
+        m = M.EWC(bb, 64, 100, device="cuda", init_cls_num=50, inc_cls_num=5, lamda=100.0).to("cuda")
+    m.before_task(0, None, None, None)
+    m.train()
+    return m
+
+
+def _batches(n, B, last=None):
+    out = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(100 + i)
+        b = B if (last is None or i < n - 1) else last
+        out.append({"image": torch.randn(b, 3, 32, 32, generator=g).cuda(), "label": torch.randint(0, 50, (b,), generator=g).cuda()})
+    return out
+
+
+@pytest.mark.parametrize("kind", ["lwf", "ewc"])
+def test_replayed_steps_match_eager_steps(kind, monkeypatch):
+    name = "LWF" if kind == "lwf" else "EWC"
+    res = []
+    for mode in ("0", "0", "1"):
+        monkeypatch.setenv("CLHIP_CUDA_GRAPH", mode)
+        m = _make(kind, 5)
+        o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+        meter = AverageMeter("train", ["loss", "acc1"])
+        T.train_steps(m, o, _batches(9, 32, last=20), None, name, meter, "cuda")          # 8 full batches + a ragged one
+        for g in o.param_groups:
+            g["lr"] = 0.005                                                               # a scheduler step: new key, new capture
+        T.train_steps(m, o, _batches(6, 32), None, name, meter, "cuda")
+        torch.cuda.synchronize()
+        bb = m.network.backbone if hasattr(m, "network") else m.backbone
+        res.append((bb.flat_parameters()[0].clone(), float(meter.avg("loss")), float(meter.avg("acc1")), getattr(m, "_graphed_step", None)))
+    (p0, l0, a0, g0), (p0b, l0b, a0b, _), (p1, l1, a1, g1) = res
+    assert g0 is None and g1 is not None and len(g1.graphs) >= 2                          # (batch 32, lr .02), (batch 32, lr .005); the ragged batch stays eager (1 < WARM)
+    # the eager path against itself (atomic weight-gradient sums, fp64-atomic BatchNorm statistics, bf16 activations) sets the scale
+    self_p = float((p0 - p0b).abs().max()) / float(p0.abs().max())
+    self_l = abs(l0 - l0b) / abs(l0)
+    dp = float((p0 - p1).abs().max()) / float(p0.abs().max())
+    dl = abs(l0 - l1) / abs(l0)
+    print(f"{kind}: eager vs eager params {self_p:.2e} loss {self_l:.2e}; graphed vs eager params {dp:.2e} loss {dl:.2e}")
+    assert dl <= max(3 * self_l, 5e-3), (l0, l0b, l1)
+    assert dp <= max(3 * self_p, 5e-3), (self_p, dp)
+    assert abs(a0 - a1) <= max(3 * abs(a0 - a0b), 3.0)
+
+
+def test_methods_that_are_not_graph_safe_stay_eager(monkeypatch):
+    monkeypatch.setenv("CLHIP_CUDA_GRAPH", "1")
+    m = _make("lwf", 6)
+    m.cuda_graph_safe = False
+    o = optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9)
+    T.train_steps(m, o, _batches(4, 16), None, "LWF", None, "cuda")
+    assert getattr(m, "_graphed_step", None) is None
