@@ -437,6 +437,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_avg = meter.avg("loss")
+    dp = None
+    if world > 1:            # self-checking record of the process group: one entry per rank, gathered over the collective backend itself
+        mine = dict(rank=rank, local_rank=local, device=torch.cuda.get_device_name(local), pci=torch.cuda.get_device_properties(local).pci_bus_id
+                    if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None, ms_per_step=dt / a.steps * 1e3)
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        dp = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), exchange=reducer.exchange, ranks=every)
     if rank != 0:
         return
     ips = world * a.batch * a.steps / dt
@@ -458,6 +465,8 @@ def main():
         "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }
+    if dp is not None:
+        out["dp"] = dp
     out["roofline"] = roofline
     if more:
         out["roofline_more"] = more

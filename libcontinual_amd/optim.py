@@ -5,7 +5,9 @@
 grad is None are skipped, per-group lr / momentum / weight_decay.  The difference is the launch count:
 all parameters of a HipResNet live in one flat buffer, so a group that holds a whole backbone is updated
 with ONE kernel over the flat range (clhip_sgd_step / clhip_adam_step); any other parameter (heads) is
-one launch per tensor.  `grad_scale` folds the data-parallel 1/world_size (or a clip factor) into the step.
+one launch per tensor.  `grad_scale` folds the data-parallel 1/world_size (or a clip factor) into the step.  After a reduce-scattered exchange
+(parallel.GradientReducer, exchange="reduce_scatter") a backbone carries `_dp_shard`: the step then runs on this rank's slice of the
+flat buffer only, with optimizer state for that slice only, and all-gathers the updated slices.
 """
 import torch
 
@@ -66,6 +68,22 @@ class _FusedBase(torch.optim.Optimizer):
         return g.contiguous().view(-1)
 
 
+def _dp_plan(o):
+    """[(parameter slice, gradient slice, state-key suffix)] of a backbone's flat buffer for this step, and the shard record to publish
+    afterwards (None: the whole buffer, no data-parallel sharding)"""
+    d = getattr(o, "_dp_shard", None)
+    if d is None:
+        return [(o._flat, o._gflat, "")], None
+    o._dp_shard = None                                   # one exchange feeds one step
+    n = o._flat.numel()
+    parts = []
+    if d["hi"] > d["lo"]:
+        parts.append((o._flat[d["lo"]:d["hi"]], d["grad"], "_shard"))
+    if d["prefix"] < n:                                  # the few elements that do not divide: all-reduced, updated on every rank
+        parts.append((o._flat[d["prefix"]:], o._gflat[d["prefix"]:], "_tail"))
+    return parts, d
+
+
 class SGD(_FusedBase):
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
         if dampening != 0 or nesterov:
@@ -78,16 +96,21 @@ class SGD(_FusedBase):
             lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
             whole, rest = self._split(group)
             for o in whole:
-                flat, gflat = o._flat, o._gflat
-                require_gpu(flat)
+                require_gpu(o._flat)
                 st = self.state[o._params[0]]
-                buf = None
-                if mom != 0:
-                    buf = st.get("flat_momentum")
-                    if buf is None or buf.data_ptr() == 0 or buf.numel() != flat.numel() or buf.device != flat.device:
-                        buf = torch.zeros_like(flat)
-                        st["flat_momentum"] = buf
-                ops.sgd_step(flat, gflat, buf, lr, mom, wd, self.grad_scale)
+                parts, shard = _dp_plan(o)
+                for flat, gflat, sfx in parts:
+                    buf = None
+                    if mom != 0:
+                        buf = st.get("flat_momentum" + sfx)
+                        if buf is None or buf.data_ptr() == 0 or buf.numel() != flat.numel() or buf.device != flat.device:
+                            buf = torch.zeros_like(flat)
+                            st["flat_momentum" + sfx] = buf
+                    ops.sgd_step(flat, gflat, buf, lr, mom, wd, self.grad_scale)
+                if shard is not None:
+                    o._dp_shard = shard
+                    shard["reducer"].gather_params(o)
+                    o._dp_shard = None
                 o.mark_params_modified()
             for p in rest:
                 require_gpu(p)
@@ -118,17 +141,27 @@ class Adam(_FusedBase):
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
             whole, rest = self._split(group)
-            items = [(o._params[0], o._flat, o._gflat, o) for o in whole]
-            items += [(p, self._dense(p), self._dense_like(p, p.grad), _owner_of(p)) for p in rest]
-            for key, pd, gd, o in items:
+            items, publish = [], []
+            for o in whole:
+                parts, shard = _dp_plan(o)
+                items += [((o._params[0], sfx), flat, gflat, o) for flat, gflat, sfx in parts]
+                if shard is not None:
+                    publish.append((o, shard))
+            items += [((p, ""), self._dense(p), self._dense_like(p, p.grad), _owner_of(p)) for p in rest]
+            for (key, sfx), pd, gd, o in items:
                 require_gpu(pd)
                 st = self.state[key]
-                if "step" not in st or st["exp_avg"].numel() != pd.numel():
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros(pd.numel(), device=pd.device, dtype=torch.float32)
-                    st["exp_avg_sq"] = torch.zeros(pd.numel(), device=pd.device, dtype=torch.float32)
-                st["step"] += 1
-                ops.adam_step(pd, gd, st["exp_avg"], st["exp_avg_sq"], lr, b1, b2, eps, wd, self.grad_scale, st["step"])
+                if "step" + sfx not in st or st["exp_avg" + sfx].numel() != pd.numel():
+                    st["step" + sfx] = 0
+                    st["exp_avg" + sfx] = torch.zeros(pd.numel(), device=pd.device, dtype=torch.float32)
+                    st["exp_avg_sq" + sfx] = torch.zeros(pd.numel(), device=pd.device, dtype=torch.float32)
+                st["step" + sfx] += 1
+                ops.adam_step(pd, gd, st["exp_avg" + sfx], st["exp_avg_sq" + sfx], lr, b1, b2, eps, wd, self.grad_scale, st["step" + sfx])
                 if o is not None:
                     o.mark_params_modified()
+            for o, shard in publish:
+                o._dp_shard = shard
+                shard["reducer"].gather_params(o)
+                o._dp_shard = None
+                o.mark_params_modified()
         return None

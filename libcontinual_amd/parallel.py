@@ -8,6 +8,13 @@ the head; the mean (1/world) is folded into the fused optimizer step (`grad_scal
 pass.  Terms that are identical on every rank (the EWC penalty gradient) are added before the all-reduce and
 therefore come out exact after the 1/world scaling.  BatchNorm uses per-rank batch statistics (DDP-faithful).
 Fisher accumulation and herding stay on every rank's full copy of the data (single-GPU semantics).
+
+Second exchange (`GradientReducer(exchange="reduce_scatter")` or CLHIP_DP_EXCHANGE=reduce_scatter): the flat
+gradient buffer is reduce-scattered, every rank runs the fused optimizer on ITS 1/world shard of the flat parameter buffer only
+(momentum / Adam moments exist for that shard only), and the updated shards are all-gathered in place over the flat parameter buffer.
+Same bytes on the links as the ring all-reduce, 1/world of the optimizer traffic and state; it gives up the overlap of the exchange
+with the backward, so the all-reduce stays the default and the checked fallback.  The < 4 * world elements that do not divide are
+all-reduced and updated on every rank.
 """
 import os
 
@@ -46,9 +53,13 @@ def _flat_grad_buckets(module):
 class GradientReducer:
     """call `reduce(module)` between loss.backward() and optimizer.step(); set optimizer.grad_scale = 1/world."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, exchange=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.exchange = exchange or os.environ.get("CLHIP_DP_EXCHANGE", "all_reduce")
+        if self.exchange not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"unknown data-parallel exchange {self.exchange!r}")
         self._early = {}          # id(backbone) -> (lowest element offset already handed to an async all-reduce, [works])
 
     # ---- overlap of the exchange with the backward (ResNet-18: 75 % of the parameters sit in layer4, whose gradients are
@@ -62,7 +73,8 @@ class GradientReducer:
         class _Ctx:
             def __enter__(self_c):
                 from .model.backbone.resnet import HipResNet
-                self_c.mods = [m for m in module.modules() if isinstance(m, HipResNet)] if red.world > 1 else []
+                on = red.world > 1 and red.exchange == "all_reduce"       # the sharded exchange needs the whole buffer at once
+                self_c.mods = [m for m in module.modules() if isinstance(m, HipResNet)] if on else []
                 for m in self_c.mods:
                     k = m.grad_cut_for_fraction(fraction)
                     if k > 0:
@@ -84,9 +96,57 @@ class GradientReducer:
         works.append(dist.all_reduce(bb._gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._early[id(bb)] = (lo, works)
 
-    def reduce(self, module):
+    def shard_bounds(self, n):
+        """(elements per rank, length of the divisible prefix) of a flat buffer of n elements: shards are multiples of 4 elements"""
+        per = (n // (4 * self.world)) * 4
+        return per, per * self.world
+
+    def _reduce_rest(self, rest):
+        if rest:
+            flat = torch.cat([p.grad.reshape(-1) for p in rest])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for p in rest:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+
+    def _reduce_scatter(self, module):
+        """sum over ranks of every flat gradient buffer, delivered as this rank's shard: `bb._dp_shard` tells the fused optimizer
+        which slice of the flat PARAMETER buffer to update and how to publish it (gather_params)"""
+        from .model.backbone.resnet import HipResNet
+        buckets, rest = _flat_grad_buckets(module)
+        owners = {m._gflat.data_ptr(): m for m in module.modules() if isinstance(m, HipResNet) and m._gflat is not None}
+        works = []
+        for b in buckets:
+            bb = owners[b.data_ptr()]
+            n = b.numel()
+            per, prefix = self.shard_bounds(n)
+            shard = getattr(bb, "_dp_gshard", None)
+            if shard is None or shard.numel() != per or shard.device != b.device:
+                shard = bb._dp_gshard = torch.empty(per, dtype=b.dtype, device=b.device)
+            if per > 0:
+                works.append(dist.reduce_scatter_tensor(shard, b[:prefix], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if prefix < n:
+                works.append(dist.all_reduce(b[prefix:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            bb._dp_shard = dict(lo=self.rank * per, hi=(self.rank + 1) * per, prefix=prefix, grad=shard, reducer=self)
+        self._reduce_rest(rest)
+        for w in works:
+            w.wait()
+
+    def gather_params(self, bb):
+        """publish this rank's updated shard of the flat parameter buffer to every rank (in place)"""
+        d = bb._dp_shard
+        flat = bb._flat
+        if d["hi"] > d["lo"]:
+            dist.all_gather_into_tensor(flat[:d["prefix"]], flat[d["lo"]:d["hi"]], group=self.group)
+
+    def reduce(self, module, full=False):
+        """`full`: the caller reads the whole summed gradient afterwards (plugins that clip it): always the all-reduce"""
         if self.world == 1:
             return
+        if self.exchange == "reduce_scatter" and not full:
+            return self._reduce_scatter(module)
         buckets, rest = _flat_grad_buckets(module)
         works = []
         from .model.backbone.resnet import HipResNet
@@ -97,14 +157,7 @@ class GradientReducer:
             works += early
             if done_lo > 0:
                 works.append(dist.all_reduce(b[:done_lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        if rest:
-            flat = torch.cat([p.grad.reshape(-1) for p in rest])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            off = 0
-            for p in rest:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        self._reduce_rest(rest)
         for w in works:
             w.wait()
 
@@ -113,7 +166,7 @@ class GradientReducer:
         `observe` (L2P clips its norm there, l2p.py:103-104 -- the clip must see the reduced gradient)"""
         if self.world == 1:
             return
-        self.reduce(module)
+        self.reduce(module, full=True)
         s = 1.0 / self.world
         for p in module.parameters():
             if p.requires_grad and p.grad is not None:

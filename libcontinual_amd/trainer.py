@@ -168,7 +168,7 @@ class Trainer:
             self.rank, self.world = parallel.init_distributed(self.device.type == "cuda")
         else:
             self.world = 1
-        self.reducer = parallel.GradientReducer() if self.distribute else None
+        self.reducer = parallel.GradientReducer(exchange=config.get("dp_exchange")) if self.distribute else None
         self.init_cls_num, self.inc_cls_num, self.task_num = config["init_cls_num"], config["inc_cls_num"], config["task_num"]
         self.model = self._init_model(config)
         if dataloaders is not None:

@@ -33,7 +33,7 @@ def main(out_dir, steps):
     m = make(100 + rank)                               # different initial weights per rank: the broadcast must fix that
     parallel.broadcast_module_state(m)
     opt = optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9, weight_decay=5e-4)
-    red = parallel.GradientReducer()
+    red = parallel.GradientReducer()                   # CLHIP_DP_EXCHANGE picks the exchange (all_reduce | reduce_scatter)
     parallel.attach(m, opt, red)
     m.train()
     train_steps(m, opt, [batch(1000 * rank + i) for i in range(steps)], red, "LWF", None, "cuda")
@@ -41,8 +41,10 @@ def main(out_dir, steps):
     flat = m.backbone.flat_parameters()[0]
     rm = m.backbone._stats.cpu().numpy()
     parallel.broadcast_module_state(m)                 # what the Trainer does before after_task: rank 0's running statistics everywhere
+    st = opt.state[m.backbone._params[0]]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=flat.cpu().numpy(), head=m.classifier.weight.detach().cpu().numpy(),
-             rm=rm, rm_synced=m.backbone._stats.cpu().numpy())
+             rm=rm, rm_synced=m.backbone._stats.cpu().numpy(), momentum_elems=np.array(sum(v.numel() for k, v in st.items() if k.startswith("flat_momentum"))),
+             nflat=np.array(flat.numel()))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -81,6 +81,36 @@ def _worker(rank, world, port, q):
     ok = ok and (not parallel.attach(plain, opt3, red)) and opt3.grad_scale == 0.5
     m = red.mean_scalar(float(rank), "cpu")
     ok = ok and abs(m - 0.5) < 1e-12
+    # ---- the sharded exchange: reduce-scatter -> update of this rank's shard only -> in-place all-gather of the flat parameters
+    rs = parallel.GradientReducer(exchange="reduce_scatter")
+    n = flat.numel()
+    per, prefix = rs.shard_bounds(n)
+    ok = ok and per % 4 == 0 and prefix == per * world and 0 <= n - prefix < 4 * world
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    head.weight.grad = torch.full_like(head.weight, float(rank + 1))
+    flat.copy_(ref)
+    with rs.overlap(net, fraction=0.5):                                   # no early segments in this mode
+        ok = ok and bb._grad_segment_hook is None
+        rs.reduce(net)
+    d = bb._dp_shard
+    total = sum(r + 1 for r in range(world)) * pattern + 5.0 * world
+    ok = ok and d["lo"] == rank * per and d["hi"] == (rank + 1) * per and d["prefix"] == prefix
+    ok = ok and torch.allclose(d["grad"], total[d["lo"]:d["hi"]]) and torch.allclose(gflat[prefix:], total[prefix:])
+    ok = ok and torch.allclose(head.weight.grad * scale, torch.full_like(head.weight, 1.5))            # the head still goes through the small all-reduce
+    # what the fused optimizer does with the record (optim._dp_plan): its slices, then the gather
+    from libcontinual_amd.optim import _dp_plan
+    parts, shard = _dp_plan(bb)
+    ok = ok and shard is d and bb._dp_shard is None and [sfx for _, _, sfx in parts] == (["_shard", "_tail"] if prefix < n else ["_shard"])
+    for pslice, gslice, _ in parts:
+        pslice.sub_(0.1 * scale * gslice)                                  # a plain SGD step on the slices this rank owns
+    bb._dp_shard = shard
+    rs.gather_params(bb)
+    ok = ok and torch.allclose(flat, ref - 0.1 * scale * total, atol=1e-6)  # every rank now holds the full updated buffer
+    # plugins that post-process the whole gradient get the all-reduce whatever the mode
+    sr.grad_reducer = rs
+    sr.w.grad = torch.full((4,), 3.0 * (rank + 1))
+    rs.reduce_mean(sr)
+    ok = ok and torch.allclose(sr.w.grad, torch.full((4,), 4.5))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

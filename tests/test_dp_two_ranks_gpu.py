@@ -26,8 +26,8 @@ def _free_port():
     return p
 
 
-def _launch(script_args, timeout=600):
-    env = dict(os.environ, CLHIP_DIST_BACKEND="gloo", CLHIP_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+def _launch(script_args, timeout=600, **extra):
+    env = dict(os.environ, CLHIP_DIST_BACKEND="gloo", CLHIP_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -75,6 +75,25 @@ def test_two_ranks_train_in_lockstep_and_match_the_emulation(tmp_path):
     np.testing.assert_allclose(reps[0].backbone._stats.cpu().numpy(), a["rm"], rtol=2e-3, atol=1e-4)
 
 
+def test_sharded_exchange_matches_the_all_reduce(tmp_path):
+    """reduce-scatter -> fused SGD on this rank's shard of the flat buffer -> all-gather: same parameters as the all-reduce path
+    (the two collectives sum in a different order: fp32 rounding only), identical on both ranks, half the momentum state per rank"""
+    steps = 3
+    (tmp_path / "ar").mkdir(); (tmp_path / "rs").mkdir()
+    r1 = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path / "ar"), str(steps)])
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path / "rs"), str(steps)], CLHIP_DP_EXCHANGE="reduce_scatter")
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    ar = np.load(tmp_path / "ar" / "rank0.npz")
+    a, b = np.load(tmp_path / "rs" / "rank0.npz"), np.load(tmp_path / "rs" / "rank1.npz")
+    np.testing.assert_array_equal(a["flat"], b["flat"])
+    np.testing.assert_array_equal(a["head"], b["head"])
+    assert np.abs(a["flat"] - ar["flat"]).max() <= 2e-3 * np.abs(ar["flat"]).max()
+    assert np.abs(a["head"] - ar["head"]).max() <= 1e-4
+    n = int(a["nflat"])
+    assert int(ar["momentum_elems"]) == n and n // 2 <= int(a["momentum_elems"]) <= n // 2 + 8
+
+
 def test_trainer_two_ranks_on_the_gpu_loader(tmp_path):
     """the Trainer itself under data parallelism with the GPU batch loader (no `sampler` attribute; 111 training images in task
     0, 74 + 21 rehearsal exemplars later: neither a multiple of 2): both ranks run the same number of steps, end with identical
@@ -104,3 +123,7 @@ def test_bench_contract_at_two_ranks(workload, batch):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * batch and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
     assert abs(out["value"] - 2 * batch * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # the self-checking record of the process group: one entry per rank, the reported time is the maximum over them
+    dp = out["dp"]
+    assert dp["world_size"] == 2 and dp["backend"] == "gloo" and sorted(r_["rank"] for r_ in dp["ranks"]) == [0, 1]
+    assert dp["exchange"] in ("all_reduce", "reduce_scatter")
