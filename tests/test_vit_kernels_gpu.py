@@ -115,7 +115,7 @@ def test_gemm5_every_epilogue(M, N, K, epi):
         _lib.lib().clhip_gemm5_config(-1)
 
 
-@pytest.mark.parametrize("M,N,K", [(25216, 2304, 64), (25216, 768, 2304), (8192, 4096, 64), (25216, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(25216, 2304, 64), (25216, 768, 2304), (8192, 4096, 64), (25216, 3072, 768), (25216, 2304, 768)])
 @pytest.mark.parametrize("epi", [0, 2, 3, 4])
 def test_gemm_nt_full_size_tilings(M, N, K, epi):
     """the BASELINE-size shapes take paths small cases never reach: whole rounds of 256 x 256 tiles + a small-tile tail launch
