@@ -298,8 +298,6 @@ int clhip_herding_select(const float* feats /*[n,D], L2-normalised*/, int n, int
  *   K % 64 == 0, N % 4 == 0.                                                                                    */
 int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                   int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
-/* tuning knob (bf16): 0 register-staged tiles, 1 LDS-DMA 128x128, 2 LDS-DMA 256x128; -1 = from $CLHIP_GEMM_IMPL (default 0) */
-void clhip_gemm_config(int impl);
 /* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never, 1 where it wins (default: N >= 2048,
  * >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
 void clhip_gemm5_config(int mode);

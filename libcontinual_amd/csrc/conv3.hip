@@ -30,8 +30,15 @@ struct Conv3Params {
     int np;              // patch pixels = BM + 2W + 2
     int patch_bytes;     // np*128 rounded up to 256
     int nbuf;            // patch buffers (2 when Cs > 64)
-    int debug;           // perf experiments only (CLHIP_CONV3_DEBUG): 1 = skip weight streaming, 2 = skip MFMA
+    int debug;           // CLHIP_ABLATION builds only (CLHIP_CONV3_DEBUG): 1 = skip weight streaming, 2 = skip MFMA, 4 = skip patch loads, 8 = skip stores
 };
+
+// the production build carries no ablation branches (ABL=1 csrc/build.sh builds libclhip_abl.so with them)
+#ifdef CLHIP_ABLATION
+#define DBG3(p) ((p).debug)
+#else
+#define DBG3(p) 0
+#endif
 
 // 9-bit mask of the taps whose source pixel lies inside the image, for output pixel g (tap t = 3 r + s reads the pixel at
 // (h + dh, w + dw), dh = r - 1 / dw = s - 1 forward, mirrored for dgrad): border rows / columns knock out three taps each.
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
             const int idx = tid + i * NTH;
             const int q = idx >> 3, ch = idx & 7;
             const long long g = (long long)m0 - halo + q;
-            pp[i] = (idx < np8 && g >= 0 && g < p.M && !(p.debug & 4)) ? *reinterpret_cast<const uint4*>(p.src + ((size_t)g * Cs + c * 64 + ch * 8))
+            pp[i] = (idx < np8 && g >= 0 && g < p.M && !(DBG3(p) & 4)) ? *reinterpret_cast<const uint4*>(p.src + ((size_t)g * Cs + c * 64 + ch * 8))
                                                                         : make_uint4(0, 0, 0, 0);
         }
     };
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bool last = (c == nchunk - 1) && (tap == 8);
-            if (!last && !(p.debug & 1)) wload(tap == 8 ? (c + 1) * 64 : (tap + 1) * Cs + c * 64);
+            if (!last && !(DBG3(p) & 1)) wload(tap == 8 ? (c + 1) * 64 : (tap + 1) * Cs + c * 64);
             if (tap == 5 && c + 1 < nchunk) pload(c + 1);
             const char* ws = wst0 + (step & 1) * (BN * PITCH);
             constexpr int R = 0;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
                 for (int i = 0; i < 4; ++i) xf[i] = ldsq(patch0 + xa[i] + ks * 64);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wf[j] = ldsq(ws + waddr[j] + ks * 64);
-                if (!(p.debug & 2))
+                if (!(DBG3(p) & 2))
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
                 __syncthreads();                    // every wave is done with this chunk's patch
                 pstore();
             }
-            if (!last && !(p.debug & 1)) wstore((step + 1) & 1);
+            if (!last && !(DBG3(p) & 1)) wstore((step + 1) & 1);
             __syncthreads();
         }
     }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(Conv3Params p) {
         for (int idx = tid; idx < BM * CPR; idx += NTH) {
             const int pl = idx / CPR, ch = idx - pl * CPR;
             const int pix = m0 + pl, o = n0 + ch * 8;
-            if (pix < p.M && o < p.Cd && !(p.debug & 8))
+            if (pix < p.M && o < p.Cd && !(DBG3(p) & 8))
                 *reinterpret_cast<uint4*>(p.dst + (size_t)pix * p.Cd + o) = *reinterpret_cast<const uint4*>(ot + pl * OPITCH + ch * 16);
         }
         __syncthreads();

@@ -368,249 +368,8 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (bf16): the operand tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no
-// ds_write pass: in the register-staged kernel above the 16-byte LDS stores cost about as many LDS cycles as the
-// fragment reads).  The DMA writes lane-linearly (1 KB per wave-instruction = 8 rows of 128 B), so the XOR swizzle is
-// applied to the per-lane SOURCE chunk; reads use the same swizzled offsets as above.  NST-deep ring, prefetch distance
-// NST-1, counted s_waitcnt vmcnt + raw s_barrier (one per K step).  WM x WN waves, each 64x64.  Rows beyond M / N are
-// clamped to the last valid row (their results are never stored).
-template <int EPI, int WM, int WN, int NST>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(1))) const void gvoid;
-    typedef __attribute__((address_space(3))) void lvoid;
-    constexpr int GM = 64 * WM, GN = 64 * WN, NW = WM * WN;
-    constexpr int A_BYTES = GM * 128, B_BYTES = GN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int AI = (GM / 8) / NW, BI = (GN / 8) / NW, GRP = AI + BI;       // DMA instructions per wave per stage
-    static_assert((GM / 8) % NW == 0 && (GN / 8) % NW == 0, "row groups must divide among the waves");
-    constexpr int PD = NST - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (p.N + GN - 1) / GN;
-    const int nwg = gridDim.x;
-    int wg;
-    {
-        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    const int m0 = tm * GM, n0 = tn * GN;
-    const bf16_t* A = static_cast<const bf16_t*>(p.A);
-    const bf16_t* B = static_cast<const bf16_t*>(p.B);
-    const int lr = lane >> 3, sc = ((lane & 7) ^ lr) * 8;          // row within the 8-row group, swizzled source chunk
-    const bf16_t* asrc[AI];
-    const bf16_t* bsrc[BI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) asrc[i] = A + (size_t)min(m0 + (wave * AI + i) * 8 + lr, p.M - 1) * p.lda + sc;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) bsrc[i] = B + (size_t)min(n0 + (wave * BI + i) * 8 + lr, p.N - 1) * p.ldb + sc;
-    auto dma = [&](int kt) {
-        char* st = smem + (kt % NST) * STAGE;
-        const int ko = kt * BK;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(asrc[i] + ko), (lvoid*)(st + (wave * AI + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < BI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(bsrc[i] + ko), (lvoid*)(st + A_BYTES + (wave * BI + i) * 1024), 16, 0, 0);
-    };
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        a_off[kk] = lds_off<bf16_t>(wm * 64 + l15, g + 4 * kk);
-        b_off[kk] = lds_off<bf16_t>(wn * 64 + l15, g + 4 * kk);
-    }
-    constexpr int ROW16 = 16 * 128;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT = p.K / BK;
-#pragma unroll
-    for (int s_ = 0; s_ < PD; ++s_)
-        if (s_ < KT) dma(s_);
-    for (int kt = 0; kt < KT; ++kt) {
-        const int rem = min(KT, kt + PD) - (kt + 1);              // DMA groups allowed to stay in flight
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GRP) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // stage kt landed for every wave; stage kt-1 is free
-        asm volatile("" ::: "memory");
-        if (kt + PD < KT) dma(kt + PD);
-        const char* As = smem + (kt % NST) * STAGE;
-        const char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            Chunk<bf16_t> fa[4], fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = lds_ld<bf16_t>(Bs, b_off[kk] + j * ROW16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = lds_ld<bf16_t>(As, a_off[kk] + i * ROW16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma<bf16_t>(fb[j], fa[i], acc[i][j]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + g * 4;
-            if (n < p.N) epi_store<bf16_t, EPI>(p, acc[i][j], m, n);
-        }
-    }
-}
-
-template <int EPI, int WM, int WN, int NST> int launch_glds(const GemmParams& p, hipStream_t s) {
-    constexpr int GM = 64 * WM, GN = 64 * WN;
-    const int tiles = ((p.M + GM - 1) / GM) * ((p.N + GN - 1) / GN);
-    const size_t smem = (size_t)NST * (GM + GN) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<EPI, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_glds_kernel<EPI, WM, WN, NST>), dim3(tiles), dim3(WM * WN * 64), smem, s, p);
-    CLHIP_LAUNCH_CHECK();
-    return CLHIP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Ping-pong variant of the LDS-DMA kernel: 256x128 tile, 8 waves (4 x 2, each 64x64), 3-stage ring.  Waves w and w+4 share
-// a SIMD; the two wave groups run the same 4-phase K step { read kk0 | mfma kk0 | read kk1 | mfma kk1 }, one workgroup
-// barrier per phase, with group 1 started one barrier late: in every interval one wave of each SIMD issues its 16 MFMAs
-// while the other fetches its next fragments from LDS, instead of both stalling on LDS at the same time.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(1))) const void gvoid;
-    typedef __attribute__((address_space(3))) void lvoid;
-    constexpr int WM = 4, WN = 2, NST = 3, GM = 256, GN = 128, NW = 8;
-    constexpr int A_BYTES = GM * 128, B_BYTES = GN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int AI = (GM / 8) / NW, BI = (GN / 8) / NW, GRP = AI + BI;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wm = wave & 3, wn = wave >> 2;        // group (wave >> 2) = column half; waves w, w+4 share a SIMD
-    const int grp = wave >> 2;
-    const int tiles_n = (p.N + GN - 1) / GN;
-    const int nwg = gridDim.x;
-    int wg;
-    {
-        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    const int m0 = tm * GM, n0 = tn * GN;
-    const bf16_t* A = static_cast<const bf16_t*>(p.A);
-    const bf16_t* B = static_cast<const bf16_t*>(p.B);
-    const int lr = lane >> 3, sc = ((lane & 7) ^ lr) * 8;
-    const bf16_t* asrc[AI];
-    const bf16_t* bsrc[BI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) asrc[i] = A + (size_t)min(m0 + (wave * AI + i) * 8 + lr, p.M - 1) * p.lda + sc;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) bsrc[i] = B + (size_t)min(n0 + (wave * BI + i) * 8 + lr, p.N - 1) * p.ldb + sc;
-    auto dma = [&](int kt) {
-        char* st = smem + (kt % NST) * STAGE;
-        const int ko = kt * BK;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(asrc[i] + ko), (lvoid*)(st + (wave * AI + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < BI; ++i) __builtin_amdgcn_global_load_lds((gvoid*)(bsrc[i] + ko), (lvoid*)(st + A_BYTES + (wave * BI + i) * 1024), 16, 0, 0);
-    };
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        a_off[kk] = lds_off<bf16_t>(wm * 64 + l15, g + 4 * kk);
-        b_off[kk] = lds_off<bf16_t>(wn * 64 + l15, g + 4 * kk);
-    }
-    constexpr int ROW16 = 16 * 128;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT = p.K / BK;
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-    dma(0);
-    if (KT > 1) { dma(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BARRIER();                                   // stage 0 has landed for every wave
-    if (grp == 1) PP_BARRIER();                     // stagger the second wave group by one phase
-    Chunk<bf16_t> fa[4], fb[4];
-    for (int kt = 0; kt < KT; ++kt) {
-        const char* As = smem + (kt % NST) * STAGE;
-        const char* Bs = As + A_BYTES;
-        // phase 1: fragments of kk = 0 (+ DMA of stage kt+2 into the slot whose last readers finished two phases ago)
-        if (kt + 2 < KT) dma(kt + 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = lds_ld<bf16_t>(Bs, b_off[0] + j * ROW16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_ld<bf16_t>(As, a_off[0] + i * ROW16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        // phase 2
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mma<bf16_t>(fb[j], fa[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        PP_BARRIER();
-        // phase 3: fragments of kk = 1; my share of stage kt+1 must have landed before the barrier that ends this phase
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = lds_ld<bf16_t>(Bs, b_off[1] + j * ROW16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_ld<bf16_t>(As, a_off[1] + i * ROW16);
-        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        // phase 4
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mma<bf16_t>(fb[j], fa[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        PP_BARRIER();
-    }
-    if (grp == 0) PP_BARRIER();                     // every wave executes the same number of barriers
-#undef PP_BARRIER
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + g * 4;
-            if (n < p.N) epi_store<bf16_t, EPI>(p, acc[i][j], m, n);
-        }
-    }
-}
-
-template <int EPI> int launch_pp(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-    const size_t smem = 3 * (size_t)(256 + 128) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(tiles), dim3(512), smem, s, p);
-    CLHIP_LAUNCH_CHECK();
-    return CLHIP_OK;
-}
-
-int g_impl = -1;     // 0 register-staged (default), 1 LDS-DMA 128x128 2-stage, 2 LDS-DMA 256x128 3-stage; env CLHIP_GEMM_IMPL / clhip_gemm_config
-int gemm_impl() {
-    if (g_impl < 0) { const char* e = getenv("CLHIP_GEMM_IMPL"); g_impl = e ? atoi(e) : 0; }
-    return g_impl;
-}
+// The round-1 LDS-DMA experiments (128 x 128 two-stage, 256 x 128 three-stage ring, barrier-staggered ping-pong; none faster than the
+// register-staged kernel above: profiles/r01_gemm_ablation.txt) are gone; their successor is gemm5.hip.
 
 template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launch(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -656,10 +415,6 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
     if constexpr (sizeof(T) == 4) {
         return launch<T, EPI, 4, 4>(p, s);
     } else {
-        const int impl = gemm_impl();
-        if (impl == 1) return launch_glds<EPI, 2, 2, 2>(p, s);
-        if (impl == 2) return launch_glds<EPI, 4, 2, 3>(p, s);
-        if (impl == 3) return launch_pp<EPI>(p, s);
         // Narrow outputs with a long K (the ViT's N = 768 GEMMs, 36 % of an InfLoRA step): 256 x 256 tiles are 30 % faster per
         // tile (891 vs 647 TFLOP/s at K = 3072) but 297 of them on 256 CUs take two rounds.  Run exactly one round of 256 x 256
         // tiles on the leading rows and hand the remaining rows to the small-tile kernels (a second, short launch).
@@ -731,7 +486,6 @@ bool clhip_gemm5_supported(int M, int N, int K, int lda, int ldb, int ldc, int l
 int clhip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                        int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st);
 
-extern "C" void clhip_gemm_config(int impl) { g_impl = impl; }
 
 extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                              int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream) {
@@ -746,7 +500,7 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
     static const int gm_env = getenv("CLHIP_GEMM_GROUP_M") ? atoi(getenv("CLHIP_GEMM_GROUP_M")) : 0;
     GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, gm_env > 0 ? gm_env : (N >= 4096 ? 4 : 1)};     // wide outputs: 8192^3 991 -> 1046 TFLOP/s; the ViT shapes (N <= 3072) are indifferent
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (gemm_impl() == 0 && clhip_gemm5_supported(M, N, K, lda, ldb, ldc, ldr, ldh, dtype))
+    if (clhip_gemm5_supported(M, N, K, lda, ldb, ldc, ldr, ldh, dtype))
         return clhip_gemm5_launch(A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, epilogue, s);
     return dtype == CLHIP_BF16 ? dispatch<bf16_t>(epilogue, p, s) : dispatch<float>(epilogue, p, s);
 }
