@@ -303,7 +303,7 @@ def conv_rooflines(dev, dtype, B, workload):
         flops = 2.0 * M * 9 * C * K
         if i == 0:
             _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st)
-            entry("wgrad", [f"conv_wgrad4_kernel<{W}>", "wgrad3_reduce_kernel"], f"conv_wgrad4_kernel<{W}> + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
+            entry("wgrad", [f"conv_wgrad4_kernel<{W}, 1, 3>", "wgrad3_reduce_kernel"], f"conv_wgrad4_kernel<{W},1,3> + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
                   N, H, W, C, K,
                   lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st),
                   flops, M * (C + K) * es + K * 9 * C * 4, f"wgrad/{N}x{H}x{W}x{C}x{K}")
@@ -311,16 +311,17 @@ def conv_rooflines(dev, dtype, B, workload):
               lambda: _lib.call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z.data_ptr(), acc.data_ptr(), 8, N, H, W, C, K, 3, 1, 1, code, st),
               flops, M * (C + K) * es + w.numel() * es, f"fwd/{N}x{H}x{W}x{C}x{K}")
     if r18:
-        # the atomic weight-gradient kernel of the stride-2 / 1x1 / stem layers (one symbol for the three stride-2 3x3 layers and the three
-        # 1x1 shortcuts: its in-step average mixes them), here at the largest of them
+        # the stride-2 layer entries (3x3 / stride 2), the largest of them
         N, H, W, C, K = B, 32, 32, 64, 128
         x = torch.randn(N, H, W, C, device=dev).to(tdt)
         dz = torch.randn(N, H // 2, W // 2, K, device=dev).to(tdt)
         dw = torch.zeros(K, 9, C, device=dev)
         M2 = N * (H // 2) * (W // 2)
-        entry("wgrad", "conv_wgrad2_kernel<unsigned short, 2, 2, 4, 4>", f"conv_wgrad2_kernel<bf16,2,2,4,4>: dW of 3x3/s2 @ [{N},{H},{W},{C}] x [{N},{H // 2},{W // 2},{K}] (fp32 atomics)",
+        wsb = L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 3, 2, 1, code)
+        wsbuf = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        entry("wgrad", [f"conv_wgrad4_kernel<{W}, 2, 3>"], f"conv_wgrad4_kernel<{W},2,3> + wgrad3_reduce_kernel: dW of 3x3/s2 @ [{N},{H},{W},{C}] x [{N},{H // 2},{W // 2},{K}]",
               N, H, W, C, K,
-              lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), None, N, H, W, C, C, K, 3, 2, 1, code, st),
+              lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 2, 1, code, st),
               2.0 * M2 * 9 * C * K, (N * H * W * C + M2 * K) * es + K * 9 * C * 4, f"wgrad_s2/{N}x{H}x{W}x{C}x{K}")
     # largest share of the step's kernel time first (committed in-step trace); without a trace, the order above
     out.sort(key=lambda e: -e.get("in_step_share_of_kernel_time", 0.0))

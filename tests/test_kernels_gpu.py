@@ -76,6 +76,14 @@ CONV_CASES = [
     (3, 16, 8, 64, 64, 3, 1, 1),
     (5, 4, 8, 64, 128, 3, 1, 1),
     (7, 8, 4, 128, 64, 3, 1, 1),
+    # ... its stride-2 and 1x1 / stride-2 forms (the layer-entry convolutions and shortcuts of ResNet-18), large enough to be picked
+    # (>= 64 steps), with ragged last steps; 16-, 8- and 4-pixel-wide outputs
+    (20, 32, 32, 64, 128, 3, 2, 1),
+    (70, 16, 16, 128, 64, 3, 2, 1),
+    (260, 8, 8, 64, 64, 3, 2, 1),
+    (33, 32, 32, 64, 128, 1, 2, 0),
+    (140, 16, 16, 128, 64, 1, 2, 0),
+    (520, 8, 8, 64, 64, 1, 2, 0),
     # the register-resident-weight kernels for 16 -> 16 and 32 -> 32 channels (conv3.hip conv16 / conv32): tiles spanning several
     # images, ragged last tile, non-square and non-power-of-two images (division path of the tap masks), one-row images
     (5, 16, 16, 32, 32, 3, 1, 1),

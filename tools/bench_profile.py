@@ -72,8 +72,8 @@ def pmc(workload):
     for e in entries:
         lab = e["kernel"]
         key = e["pmc_key"]
-        syms = (("conv_wgrad4_kernel", "wgrad3_reduce_kernel") if key.startswith("wgrad/") else ("conv_wgrad2_kernel<unsigned short, 2, 2, 4, 4>",) if key.startswith("wgrad_s2/")
-                else (re.sub(r",", ", ", lab.split(" ")[0]),))
+        sym0 = re.sub(r",", ", ", lab.split(" ")[0])
+        syms = (sym0, "wgrad3_reduce_kernel") if key.startswith("wgrad") else (sym0,)
         rd = wr = 0.0
         found = []
         for s_ in syms:

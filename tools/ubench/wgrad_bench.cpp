@@ -23,7 +23,7 @@ static float urand() { return (irand() & 0xffff) / 32768.0f - 1.0f; }
 
 extern "C" void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
 
-struct Case { const char* name; int N, H, W, C, K; };
+struct Case { const char* name; int N, H, W, C, K, ks = 3, st = 1; };      // H, W: INPUT size; ks x ks filter, stride st, pad ks / 2
 
 int main(int argc, char** argv) {
     const char* filt = argc > 1 ? argv[1] : "";
@@ -35,12 +35,18 @@ int main(int argc, char** argv) {
         {"S3w 256x8x8 64->64", 256, 8, 8, 64, 64},         {"S3w32 32x8x8 64->64", 32, 8, 8, 64, 64},
         {"L1w32 32x32x32 64->64", 32, 32, 32, 64, 64},     {"X2w 256x16x16 64->128", 256, 16, 16, 64, 128},
         {"odd 3x12x20 64->128", 3, 12, 20, 64, 128},       {"odd2 5x16x16 128->64", 5, 16, 16, 128, 64},
+        {"T2w 256x32x32 64->128 s2", 256, 32, 32, 64, 128, 3, 2},   {"T3w 256x16x16 128->256 s2", 256, 16, 16, 128, 256, 3, 2},
+        {"T4w 256x8x8 256->512 s2", 256, 8, 8, 256, 512, 3, 2},     {"T2w5 5x32x32 64->64 s2", 5, 32, 32, 64, 64, 3, 2},
+        {"T4w7 7x8x8 64->128 s2", 7, 8, 8, 64, 128, 3, 2},
+        {"P2w 256x32x32 64->128 1x1s2", 256, 32, 32, 64, 128, 1, 2}, {"P3w 256x16x16 128->256 1x1s2", 256, 16, 16, 128, 256, 1, 2},
+        {"P4w 256x8x8 256->512 1x1s2", 256, 8, 8, 256, 512, 1, 2},   {"P4w7 7x8x8 64->64 1x1s2", 7, 8, 8, 64, 64, 1, 2},
     };
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Case& cs : cases) {
         if (!strstr(cs.name, filt)) continue;
-        const size_t M = (size_t)cs.N * cs.H * cs.W, nx = M * cs.C, nz = M * cs.K, nw = (size_t)cs.K * 9 * cs.C;
+        const int Ho = cs.H / cs.st, Wo = cs.W / cs.st, pad = cs.ks / 2, T = cs.ks * cs.ks;
+        const size_t M = (size_t)cs.N * Ho * Wo, nx = (size_t)cs.N * cs.H * cs.W * cs.C, nz = M * cs.K, nw = (size_t)cs.K * T * cs.C;
         int nset = (int)((300u << 20) / ((nx + nz) * 2)) + 1; if (nset > 8) nset = 8; if (nset < 2) nset = 2;
         std::vector<uint16_t> hx(nx), hz(nz);
         for (auto& v : hx) v = f2b(urand());
@@ -53,9 +59,9 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(dx[i], hx.data(), nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dz[i], hz.data(), nz * 2, hipMemcpyHostToDevice));
         }
         float* dw; CK(hipMalloc(&dw, nw * 4));
-        const size_t wsb = clhip_conv_wgrad_ws_bytes(cs.N, cs.H, cs.W, cs.C, cs.C, cs.K, 3, 1, 1, CLHIP_BF16);
+        const size_t wsb = clhip_conv_wgrad_ws_bytes(cs.N, cs.H, cs.W, cs.C, cs.C, cs.K, cs.ks, cs.st, pad, CLHIP_BF16);
         void* ws = nullptr; if (wsb) CK(hipMalloc(&ws, wsb));
-        auto run = [&](int set) { return clhip_conv_wgrad(dx[set], dz[set], dw, ws, cs.N, cs.H, cs.W, cs.C, cs.C, cs.K, 3, 1, 1, CLHIP_BF16, st); };
+        auto run = [&](int set) { return clhip_conv_wgrad(dx[set], dz[set], dw, ws, cs.N, cs.H, cs.W, cs.C, cs.C, cs.K, cs.ks, cs.st, pad, CLHIP_BF16, st); };
         bool fail = false;
         for (int pass = 0; pass < 2 && !fail; ++pass) {
             CK(hipMemcpyAsync(dw, h0.data(), nw * 4, hipMemcpyHostToDevice, st));
@@ -71,13 +77,13 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 1024; ++q) {
             size_t e = q < 64 ? (size_t)q * (nw / 64) : irand() % nw;
             if (q == 1023) e = nw - 1;
-            const int c = (int)(e % cs.C), t = (int)((e / cs.C) % 9), o = (int)(e / cs.C / 9), r = t / 3, s = t % 3;
+            const int c = (int)(e % cs.C), t = (int)((e / cs.C) % T), o = (int)(e / cs.C / T), r = t / cs.ks, s = t % cs.ks;
             double a = h0[e], mag = fabs(a);
-            for (int n = 0; n < cs.N; ++n) for (int h = 0; h < cs.H; ++h) {
-                const int hh = h + r - 1; if (hh < 0 || hh >= cs.H) continue;
-                for (int w = 0; w < cs.W; ++w) {
-                    const int ww = w + s - 1; if (ww < 0 || ww >= cs.W) continue;
-                    const double tt = (double)b2f(hz[(((size_t)n * cs.H + h) * cs.W + w) * cs.K + o]) * b2f(hx[(((size_t)n * cs.H + hh) * cs.W + ww) * cs.C + c]);
+            for (int n = 0; n < cs.N; ++n) for (int h = 0; h < Ho; ++h) {
+                const int hh = h * cs.st + r - pad; if (hh < 0 || hh >= cs.H) continue;
+                for (int w = 0; w < Wo; ++w) {
+                    const int ww = w * cs.st + s - pad; if (ww < 0 || ww >= cs.W) continue;
+                    const double tt = (double)b2f(hz[(((size_t)n * Ho + h) * Wo + w) * cs.K + o]) * b2f(hx[(((size_t)n * cs.H + hh) * cs.W + ww) * cs.C + c]);
                     a += tt; mag += fabs(tt);
                 }
             }
@@ -107,7 +113,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < reps; ++i) run(0);
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("%-26s %7.1f us %6.0f TF/s (hot %6.1f us)  ws %.1f MB  err %.2f %s%s\n", cs.name, us, 2.0 * M * 9.0 * cs.C * cs.K / us * 1e-6, ms * 1e3 / reps, wsb / 1048576.0, worst,
+        printf("%-26s %7.1f us %6.0f TF/s (hot %6.1f us)  ws %.1f MB  err %.2f %s%s\n", cs.name, us, 2.0 * M * T * cs.C * cs.K / us * 1e-6, ms * 1e3 / reps, wsb / 1048576.0, worst,
                repro ? "" : " NOT-REPRODUCIBLE", worst > 1.0 ? "  <-- MISMATCH" : "");
         fflush(stdout);
         for (int i = 0; i < nset; ++i) { hipFree(dx[i]); hipFree(dz[i]); }
