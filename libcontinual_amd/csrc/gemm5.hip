@@ -137,21 +137,33 @@ __global__ __launch_bounds__(512) void gemm5_kernel(const Gemm5Params p) {
         const int mt = t / p.nt;
         m0 = mt * BM; n0 = (t - mt * p.nt) * BN;
     };
-    // global slab counter g = k * nslab + s of this workgroup; stage = g % 4
-    auto dma = [&](int g) {
-        const int k = g / nslab, s = g - k * nslab;
+    // global slab counter g = k * nslab + s of this workgroup; stage = g % 4.  The DMA cursor walks the slabs in order (no divisions
+    // in the loop: the tile bases are recomputed once per tile)
+    int d_s = 0, d_k = 0, d_abase = 0, d_bbase = 0;
+    {
         int m0, n0;
-        tile_of(k, m0, n0);
-        const int abase = m0 * p.lda * 2, bbase = n0 * p.ldb * 2, koff = s * (BK * 2);
+        tile_of(0, m0, n0);
+        d_abase = m0 * p.lda * 2; d_bbase = n0 * p.ldb * 2;
+    }
+    auto dma = [&](int g) {                                  // called with g = 0, 1, 2, ... exactly once each
+        const int koff = d_s * (BK * 2);
         char* l = smem + (g & (NST - 1)) * STAGE + wave * 2048;
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lvoid_t*)(l), 16, arel[0] + abase, koff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lvoid_t*)(l + 1024), 16, arel[1] + abase, koff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lvoid_t*)(l + PART), 16, brel[0] + bbase, koff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lvoid_t*)(l + PART + 1024), 16, brel[1] + bbase, koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lvoid_t*)(l), 16, arel[0] + d_abase, koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lvoid_t*)(l + 1024), 16, arel[1] + d_abase, koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lvoid_t*)(l + PART), 16, brel[0] + d_bbase, koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lvoid_t*)(l + PART + 1024), 16, brel[1] + d_bbase, koff, 0, 0);
 #else
-        (void)abase; (void)bbase; (void)koff; (void)l;
+        (void)koff; (void)l;
 #endif
+        if (++d_s == nslab) {
+            d_s = 0; ++d_k;
+            if (d_k < nmy) {
+                int m0, n0;
+                tile_of(d_k, m0, n0);
+                d_abase = m0 * p.lda * 2; d_bbase = n0 * p.ldb * 2;
+            }
+        }
     };
 
     const int gtot = nmy * nslab;
@@ -178,8 +190,7 @@ __global__ __launch_bounds__(512) void gemm5_kernel(const Gemm5Params p) {
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
         if (lag) __builtin_amdgcn_s_barrier();
-        for (int s = 0; s < nslab; ++s, ++g) {
-            // ---- read phase: the 12 fragments of slab g, DMA of slab g + 3 into the stage slab g - 1 has left, wait for slab g + 1
+        for (int s = 0; s < nslab; ++s, ++g) {            // ---- read phase: the 12 fragments of slab g, DMA of slab g + 3 into the stage slab g - 1 has left, wait for slab g + 1
             const char* sb = smem + (g & (NST - 1)) * STAGE;
             bf16x8_t xf[2][4], wf[2][2];
             if (!(DBG5(p) & 4))
