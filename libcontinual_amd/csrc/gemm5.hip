@@ -39,7 +39,7 @@ struct Gemm5Params {
     int M, N, K, lda, ldb, ldc, ldr, ldh;
     int nt, items, ipx;          // n tiles, tiles, tiles per XCD
     unsigned long long* trace;   // CLHIP_ABLATION builds: s_memtime stamps of waves 0 and 4 of workgroup 0 ([2][256])
-    int debug;                   // CLHIP_ABLATION builds: 1 no MFMA, 2 no DMA in the loop, 4 no fragment reads
+    int debug;                   // CLHIP_ABLATION builds: 1 no MFMA, 2 no DMA in the loop, 4 no fragment reads, 8 no C stores
 };
 
 unsigned long long* g_trace5 = nullptr;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm5_kernel(const Gemm5Params p) {
                         unsigned bx = pack_bf16x2(acc[j][i][8 * pr + 4], acc[j][i][8 * pr + 5]), by = pack_bf16x2(acc[j][i][8 * pr + 6], acc[j][i][8 * pr + 7]);
                         auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                         auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                        if (mv) *reinterpret_cast<u32x4*>(crow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                        if (mv && !(DBG5(p) & 8)) *reinterpret_cast<u32x4*>(crow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
                     }
                     if constexpr (EPI == EPI_BIAS_GELU) {
                         unsigned ax = pack_bf16x2(dv[8 * pr + 0], dv[8 * pr + 1]), ay = pack_bf16x2(dv[8 * pr + 2], dv[8 * pr + 3]);

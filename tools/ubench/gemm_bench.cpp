@@ -60,14 +60,14 @@ int main(int argc, char** argv) {
         }
     }
     if (argc > 5 && !strcmp(argv[5], "abl")) {            // ablation build: the loop with pieces removed (results are garbage)
-        for (int mk : {0, 1, 2, 4, 1 | 4, 2 | 4, 1 | 2, 1 | 2 | 4}) {
+        for (int mk : {0, 8, 1, 2, 4, 1 | 2 | 4, 1 | 2 | 4 | 8}) {
             clhip_gemm5_set_debug(mk);
             for (int i = 0; i < 3; ++i) run(i % nset);
             CK(hipEventRecord(e0, st));
             for (int i = 0; i < reps; ++i) run(i % nset);
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms2; CK(hipEventElapsedTime(&ms2, e0, e1));
-            printf("debug %d (%s%s%s): %8.1f us\n", mk, mk & 1 ? "-mfma " : "", mk & 2 ? "-dma " : "", mk & 4 ? "-ldsread " : "", ms2 * 1e3 / reps);
+            printf("debug %d (%s%s%s%s): %8.1f us\n", mk, mk & 1 ? "-mfma " : "", mk & 2 ? "-dma " : "", mk & 4 ? "-ldsread " : "", mk & 8 ? "-store " : "", ms2 * 1e3 / reps);
         }
         clhip_gemm5_set_debug(0);
     }
