@@ -301,6 +301,46 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* __r
         if (c < d.Cpad && k < d.K) Elem<T>::st(wd + ((size_t)c * d.taps + tap) * d.K + k, tile[tx][i]);
     }
 }
+
+// bf16 plans with K % 4 == 0 and Cpad % 4 == 0 (every ResNet here): block = one (tap, 64 out-channels x 64 in-channels) tile, four
+// consecutive elements per lane -- 8-byte stores of both copies instead of 2-byte ones (the 32 x 32 version above moved ResNet-18's
+// 11.2 M weights in 37 us = 2.4 TB/s per training step; this one: profiles/r02_conv4_notes.md)
+__global__ __launch_bounds__(256) void weight_prep_multi64_kernel(const float* __restrict__ params, char* __restrict__ shadow, PrepTable t) {
+    __shared__ float tile[64][65];
+    int u = 0;
+    while (u + 1 < t.n && blockIdx.x >= t.e[u + 1].first_block) ++u;
+    const PrepEntry& d = t.e[u];
+    const int kb = (d.K + 63) / 64, cb = (d.Cpad + 63) / 64;
+    int r = blockIdx.x - d.first_block;
+    const int c0 = (r % cb) * 64; r /= cb;
+    const int k0 = (r % kb) * 64;
+    const int tap = r / kb;
+    const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
+    bf16_t* wf = reinterpret_cast<bf16_t*>(shadow + d.wf_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kk = ty + 16 * i, k = k0 + kk, c = c0 + tx;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < d.K && c < d.Cpad) {
+            const float* src = params + d.w_off + ((size_t)k * d.taps + tap) * d.Creal + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < d.Creal) v[e] = src[e];
+            *reinterpret_cast<uint2*>(wf + ((size_t)k * d.taps + tap) * d.Cpad + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[kk][tx + e] = v[e];
+    }
+    if (d.wd_off < 0) return;
+    __syncthreads();
+    bf16_t* wd = reinterpret_cast<bf16_t*>(shadow + d.wd_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = ty + 16 * i, c = c0 + cc, k = k0 + tx;
+        if (c < d.Cpad && k < d.K)
+            *reinterpret_cast<uint2*>(wd + ((size_t)c * d.taps + tap) * d.K + k) =
+                make_uint2(pack_bf16x2(tile[tx][cc], tile[tx + 1][cc]), pack_bf16x2(tile[tx + 2][cc], tile[tx + 3][cc]));
+    }
+}
 }  // namespace
 
 extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void* shadow, void* stream) {
@@ -311,15 +351,21 @@ extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void*
         PrepTable t;
         t.n = 0;
         unsigned blocks = 0;
+        bool wide = p->dtype == CLHIP_BF16;
+        static const bool no_wide = getenv("CLHIP_PREP_NARROW") != nullptr;
+        for (size_t j = i; j < p->units.size() && j < i + kPrepMax; ++j)
+            wide = wide && !no_wide && p->units[j].d.cout % 4 == 0 && p->units[j].cin_pad % 4 == 0 && p->units[j].sh_fwd % 8 == 0 && p->units[j].sh_dg % 8 == 0;
+        const int tb = wide ? 64 : 32;
         for (; i < p->units.size() && t.n < kPrepMax; ++i) {
             const Unit& u = p->units[i];
             PrepEntry& e = t.e[t.n++];
             e.w_off = u.d.w_off; e.wf_off = (int64_t)u.sh_fwd; e.wd_off = u.d.src != 0 ? (int64_t)u.sh_dg : -1;
             e.K = u.d.cout; e.taps = u.d.ksize * u.d.ksize; e.Creal = u.d.cin; e.Cpad = u.cin_pad;
             e.first_block = blocks;
-            blocks += (unsigned)(e.taps * ((e.K + 31) / 32) * ((e.Cpad + 31) / 32));
+            blocks += (unsigned)(e.taps * ((e.K + tb - 1) / tb) * ((e.Cpad + tb - 1) / tb));
         }
-        if (p->dtype == CLHIP_BF16) hipLaunchKernelGGL(weight_prep_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);
+        if (wide) hipLaunchKernelGGL(weight_prep_multi64_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);
+        else if (p->dtype == CLHIP_BF16) hipLaunchKernelGGL(weight_prep_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);
         else hipLaunchKernelGGL(weight_prep_multi_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);
         CLHIP_LAUNCH_CHECK();
     }
