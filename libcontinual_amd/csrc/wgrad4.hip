@@ -359,8 +359,10 @@ bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ks
     if ((long long)N * H * W * C * 2 >= (1ll << 30) || (long long)N * (H / stride) * (W / stride) * K * 2 >= (1ll << 30)) return false;      // descriptor offsets + the out-of-range marker stay below 2^31
     Wgrad4Params p;
     if (!geometry4(N, H, W, C, K, ksize, stride, p)) return false;
-    // small stride-2 problems stay on the one-launch atomic kernel (5 x 32 x 32: 8.7 us there, 14.4 us here with the reduce launch)
-    return stride == 1 || p.total_steps >= 64;
+    // small stride-2 problems stay on the one-launch atomic kernel (5 x 32 x 32, 20 steps: 8.7 us there, 14.4 us here with the reduce
+    // launch; 256 x 8 x 8 1x1, 32 steps: 16.6 us there, 12.7 us here)
+    static const int min_total = getenv("CLHIP_WGRAD4_MIN_TOTAL") ? atoi(getenv("CLHIP_WGRAD4_MIN_TOTAL")) : 32;
+    return stride == 1 || p.total_steps >= min_total;
 }
 
 size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K, int ksize, int stride) {
