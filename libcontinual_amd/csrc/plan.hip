@@ -533,8 +533,11 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipEventRecord(p->ev_dz[k], main_s);
             (void)hipStreamWaitEvent(p->side, p->ev_dz[k], 0);
             wg_stream = p->side;
-        } else if (two_streams && (p->wg_pending[0] || p->wg_pending[1])) {
+        } else if (two_streams && (p->wg_pending[0] || p->wg_pending[1]) &&
+                   (getenv("CLHIP_WGRAD_ALWAYS_QUEUE") != nullptr ||
+                    clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0)) {
             // this unit's weight gradient shares the partial-sum scratch with the ones in flight on the side stream: queue behind them
+            // (the atomic kernels -- the stem -- use no scratch and run beside the side stream's tail instead of behind it)
             (void)hipEventRecord(p->ev_end, p->side);
             (void)hipStreamWaitEvent(main_s, p->ev_end, 0);
             p->wg_pending[0] = p->wg_pending[1] = false;

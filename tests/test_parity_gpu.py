@@ -317,18 +317,18 @@ def test_icarl_golden(golden, tmp_path):
     assert relmax(got["losses"], want["losses"]) < 5e-3             # 1e-3 observed
     np.testing.assert_array_equal(got["preds"][:2], want["preds"][:2])
     assert _param_rel(got, want) < 2e-2
-    # the greedy herding picks after the first one are near-ties on this synthetic data (class = fixed pattern +
-    # noise): the selection KERNEL is checked for exact equality with the reference's loop on given features in
-    # test_kernels_gpu.py::test_ncm_and_herding_match_reference_math; here (features recomputed after two SGD steps
-    # in fp32) only the well-conditioned parts are pinned: which classes / how many exemplars, the overlap of the
-    # picked sets, the class means, and the NCM decisions.
+    # Herding runs on features recomputed after two SGD steps in fp32: the feature drift against the fp64 reference run shows in the
+    # class means (9e-4 observed, bound 5e-3).  The selection KERNEL is exact on given features (test_kernels_gpu.py::
+    # test_herding_at_benchmark_size, test_ncm_and_herding_match_reference_math); with that drift the picked SETS coincide (24 of 24
+    # observed; the first two picks of one class, a near-tie, swap their order) and the NCM decisions differ only where two class means are at the
+    # same distance to 1e-7 (3 of 16 test points, margins 6e-8).
     np.testing.assert_array_equal(got["buffer_labels0"], want["buffer_labels0"])
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
-    assert len(set(got["chosen0"]) & set(want["chosen0"])) >= 10     # of 24; observed 10-14 (near-tie picks)
-    assert relmax(got["class_means0"], want["class_means0"]) < 2e-2
-    differ = got["ncm_pred0"] != want["ncm_pred0"]                   # NCM decisions may only differ on near-ties
-    assert (got["ncm_margin0"][differ] < 0.05).all(), (got["ncm_margin0"], differ)
-    assert (~differ).mean() >= 0.5
+    assert len(set(got["chosen0"]) & set(want["chosen0"])) >= 22     # of 24
+    assert relmax(got["class_means0"], want["class_means0"]) < 5e-3
+    differ = got["ncm_pred0"] != want["ncm_pred0"]                   # NCM decisions may only differ on exact ties
+    assert (got["ncm_margin0"][differ] < 1e-5).all(), (got["ncm_margin0"], differ)
+    assert (~differ).mean() >= 0.75
     got = sc.scenario_icarl(adapter("bf16"), str(tmp_path / "b"))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 5e-2
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
