@@ -460,6 +460,8 @@ size_t clhip_wgrad16_ws_bytes(int N);
 int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st);
 int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st);
 size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K);
+bool clhip_stem_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
+int clhip_stem_launch(const void* x, const void* w, void* z, double* acc, int rep, int N, int H, int W, int K, hipStream_t st);
 bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K, int ksize, int stride);
 int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int K, int ksize, int stride, hipStream_t st);
@@ -520,6 +522,9 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
     p.M = N * p.Hd * p.Wd; p.K = ksize * ksize * C;
     hipStream_t st = static_cast<hipStream_t>(stream);
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
+    // the stems (<= 8 padded input channels): no LDS, weights in registers; serves the accumulator and the no-statistics forms
+    if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_stem_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_stem_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, K, st);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype)) {
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
         int tiles_used = clhip_conv16_tiles_m(p.M);

@@ -134,7 +134,11 @@ def test_conv_fwd_and_stats(case, mode):
     # eval mode: no statistics requested
     z2 = torch.empty_like(z)
     call("clhip_conv_fwd", xd.data_ptr(), wfd.data_ptr(), z2.data_ptr(), None, N, H, W, cpad, K, k, s, p, code, st())
-    assert torch.equal(z2, z)
+    if mode == "bf16" and cpad == 8 and k == 3 and s == 1:      # the stems: partial-row statistics come from the generic kernel, this call from stem.hip
+        assert (z2.float() - z.float()).abs().max() <= 2 ** -7 * z.float().abs().max()      # one bf16 rounding of a different summation order
+        assert (from_nhwc(z2).double() - ref).abs().max() <= tol(mode, ref)
+    else:
+        assert torch.equal(z2, z)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
@@ -536,7 +540,8 @@ def test_herding_at_benchmark_size(n, D, m):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
-@pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64, 3, 1), (4, 16, 16, 64, 128, 3, 2), (4, 8, 8, 32, 64, 1, 2), (16, 32, 32, 8, 16, 3, 1)])
+@pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64, 3, 1), (4, 16, 16, 64, 128, 3, 2), (4, 8, 8, 32, 64, 1, 2), (16, 32, 32, 8, 16, 3, 1),
+                                   (5, 32, 32, 8, 64, 3, 1), (3, 7, 5, 8, 32, 3, 1), (130, 32, 32, 8, 64, 3, 1)])      # the last three: stem.hip (ragged last tile, odd image, many tiles per wave)
 def test_conv_fwd_stat_accumulator(mode, shape):
     """clhip_conv_fwd_acc: same z as clhip_conv_fwd, per-channel sums of z and z^2 added into a zeroed fp64 [2][K] buffer
     (= the column sums of the partial rows of the partial-buffer entry point)"""
@@ -556,7 +561,15 @@ def test_conv_fwd_stat_accumulator(mode, shape):
         acc = torch.zeros(rep, 2, K, dtype=torch.float64, device=DEV)
         call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z2.data_ptr(), acc.data_ptr(), rep, N, H, W, C, K, ks, stride, pad, code, st())
         torch.cuda.synchronize()
-        assert torch.equal(z1, z2)
+        if mode == "bf16" and C == 8 and ks == 3 and stride == 1:       # stem.hip serves the accumulator form, the generic kernel the partial rows
+            assert (z1.float() - z2.float()).abs().max() <= 2 ** -7 * z1.float().abs().max()
+            xr, wr = x.float().cpu().double().permute(0, 3, 1, 2), w.float().cpu().double().reshape(K, ks, ks, C).permute(0, 3, 1, 2)
+            zr = F.conv2d(xr, wr, None, stride, pad)
+            assert (z2.float().cpu().double().permute(0, 3, 1, 2) - zr).abs().max() <= 2 ** -8 * zr.abs().max() + 1e-6
+            assert float((acc.sum(0)[0].cpu() - zr.sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float(zr.abs().sum(dim=(0, 2, 3)).max())
+            assert float((acc.sum(0)[1].cpu() - (zr * zr).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float((zr * zr).sum(dim=(0, 2, 3)).max())
+        else:
+            assert torch.equal(z1, z2)
         assert float((acc.sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
         if rep > 1 and tiles >= rep:
             assert (acc.abs().amax(dim=(1, 2)) > 0).all()          # every replica received some workgroups
