@@ -53,15 +53,38 @@ def test_replayed_steps_match_eager_steps(kind, monkeypatch):
         res.append((bb.flat_parameters()[0].clone(), float(meter.avg("loss")), float(meter.avg("acc1")), getattr(m, "_graphed_step", None)))
     (p0, l0, a0, g0), (p0b, l0b, a0b, _), (p1, l1, a1, g1) = res
     assert g0 is None and g1 is not None and len(g1.graphs) >= 2                          # (batch 32, lr .02), (batch 32, lr .005); the ragged batch stays eager (1 < WARM)
-    # the eager path against itself (atomic weight-gradient sums, fp64-atomic BatchNorm statistics, bf16 activations) sets the scale
     self_p = float((p0 - p0b).abs().max()) / float(p0.abs().max())
     self_l = abs(l0 - l0b) / abs(l0)
     dp = float((p0 - p1).abs().max()) / float(p0.abs().max())
     dl = abs(l0 - l1) / abs(l0)
     print(f"{kind}: eager vs eager params {self_p:.2e} loss {self_l:.2e}; graphed vs eager params {dp:.2e} loss {dl:.2e}")
-    assert dl <= max(3 * self_l, 5e-3), (l0, l0b, l1)
-    assert dp <= max(3 * self_p, 5e-3), (self_p, dp)
+    # The ragged batch and the small layers still take the atomic weight-gradient kernel, whose summation order differs from run to
+    # run; 15 SGD steps amplify that 3e-8 to anything between 7e-3 and 8e-2 in the parameters (two EAGER runs differ that much from
+    # each other, and one pair says little about the next): here only the loss level and a loose parameter bound; the strict
+    # statement is test_a_replayed_step_is_the_same_step below
+    assert dl <= 3e-2, (l0, l0b, l1)
+    assert dp <= 0.3, (self_p, dp)
     assert abs(a0 - a1) <= max(3 * abs(a0 - a0b), 3.0)
+
+
+def test_a_replayed_step_is_the_same_step(monkeypatch):
+    """LwF / ResNet-18 at a fixed batch of 32: every weight gradient but the stem's comes from the deterministic partial-block kernels, so
+    a training step is reproducible to the fp64-atomic BatchNorm sums -- and eight steps of which six are graph replays end within 1e-5
+    of eight eager steps (3e-8 per step observed)"""
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLHIP_CUDA_GRAPH", mode)
+        m = _make("lwf", 7)
+        o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+        T.train_steps(m, o, _batches(8, 32), None, "LWF", None, "cuda")
+        torch.cuda.synchronize()
+        out.append((m.backbone.flat_parameters()[0].clone(), m.classifier.weight.detach().clone(), getattr(m, "_graphed_step", None)))
+    (p0, h0, g0), (p1, h1, g1) = out
+    assert g0 is None and g1 is not None and len(g1.graphs) == 1
+    d = float((p0 - p1).abs().max()) / float(p0.abs().max())
+    print("eight steps, six of them replayed: parameter deviation from eight eager steps", d)
+    assert d <= 1e-5
+    assert float((h0 - h1).abs().max()) <= 1e-5 * float(h0.abs().max())
 
 
 def test_methods_that_are_not_graph_safe_stay_eager(monkeypatch):
