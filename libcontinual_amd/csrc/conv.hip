@@ -462,6 +462,9 @@ int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int
 size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K);
 bool clhip_stem_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
 int clhip_stem_launch(const void* x, const void* w, void* z, double* acc, int rep, int N, int H, int W, int K, hipStream_t st);
+bool clhip_stem_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+size_t clhip_stem_wgrad_ws_bytes(int N, int H, int W, int Creal, int K);
+int clhip_stem_wgrad_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int Creal, int K, hipStream_t st);
 bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K, int ksize, int stride);
 int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int K, int ksize, int stride, hipStream_t st);
@@ -605,6 +608,7 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
 }
 
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    if (!use_v1() && use_v3() && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_stem_wgrad_ws_bytes(N, H, W, Creal, K);
     if (!use_v1() && use_v3() && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad4_ws_bytes(N, H, W, C, K, ksize, stride);
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad3_ws_bytes(N, H, W, C, K);
     if (!use_v1() && use_v3() && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad16_ws_bytes(N);
@@ -634,6 +638,8 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* 
     dim3 grid(gx, gy, splits);
     hipStream_t st = static_cast<hipStream_t>(stream);
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
+    if (!use_v1() && use_v3() && ws != nullptr && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
+        return clhip_stem_wgrad_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, Creal, K, st);
     if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_wgrad4_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, K, ksize, stride, st);
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))

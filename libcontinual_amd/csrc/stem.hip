@@ -98,7 +98,132 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const StemParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------ weight gradient
+// dw[o][tap][c] += sum_p dz[p][o] * x[p @ tap][c] for the same layers.  The atomic generic kernel took 53 us on ResNet-18's stem -- on
+// the caller's stream, at the very end of the backward, where nothing hides it.  Here every wave walks 32-pixel steps on its own: the
+// step's gradient rows and its im2col rows (9 taps x 8 padded channels, 16 bytes per tap straight from the neighbour pixel) go into
+// the wave's private LDS tiles, both MFMA operands come back through transposing reads (the reduction index is the pixel), and a
+// 16 x 16 x 32 MFMA per (16 output channels, 2 taps) accumulates D[row = output channel][col = (tap, channel)].  Workgroup partials
+// go to a [workgroup][K][9][Creal] slab that wgrad3_reduce_kernel sums in a fixed order: deterministic, like every other weight
+// gradient of the ResNets.
+struct StemWParams { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, W, K, M, Creal, nstep; };
+
+__device__ __forceinline__ bf16x8_t tr8s(const char* base, int addr, int second) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr + second));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return __builtin_bit_cast(bf16x8_t, make_uint4(l.x, l.y, h.x, h.y));
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void wgrad_stem_kernel(const StemWParams p) {
+    constexpr int PZ = KT * 32 + 16, PX = 176;               // LDS pitches: gradient row (16 KT channels), im2col row (10 x 16 B + pad)
+    constexpr int WAVE_LDS = 32 * PZ + 32 * PX;
+    __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_LDS > KT * 16 * 80 * 4 ? 4 * WAVE_LDS : KT * 16 * 80 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int H = p.H, W = p.W, K = p.K;
+    char* zs = smem + wave * WAVE_LDS;
+    char* xs = zs + 32 * PZ;
+    // the tenth tap slot of every im2col row stays zero
+    if (lane < 32) *reinterpret_cast<uint4*>(xs + lane * PX + 144) = make_uint4(0, 0, 0, 0);
+    f32x4 acc[KT][5];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col = fg * 8 + (fr >> 2), seg = (fr & 3) * 8;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    for (int s = gw; s < p.nstep; s += nw) {
+        const int p0 = s * 32;
+        // gradient rows: 32 pixels x 2 KT chunks of 16 bytes
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const int id = lane + 64 * i, px = id / (2 * KT), part = id - px * (2 * KT);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p0 + px < p.M) v = *reinterpret_cast<const uint4*>(p.dz + (size_t)(p0 + px) * K + part * 8);
+            *reinterpret_cast<uint4*>(zs + px * PZ + part * 16) = v;
+        }
+        // im2col rows: 32 pixels x 9 taps
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int id = lane + 64 * i;
+            if (id < 288) {
+                const int px = id / 9, tap = id - px * 9, g = p0 + px;
+                const int w0 = g % W, h0 = (g / W) % H, dr = tap / 3 - 1, ds = tap % 3 - 1;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (g < p.M && (unsigned)(h0 + dr) < (unsigned)H && (unsigned)(w0 + ds) < (unsigned)W)
+                    v = *reinterpret_cast<const uint4*>(p.x + ((size_t)g + dr * W + ds) * 8);
+                *reinterpret_cast<uint4*>(xs + px * PX + tap * 16) = v;
+            }
+        }
+        bf16x8_t zf[KT], xf[5];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) zf[kt] = tr8s(zs, col * PZ + kt * 32 + seg, 4 * PZ);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) xf[j] = tr8s(xs, col * PX + j * 32 + seg, 4 * PX);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[kt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[kt], xf[j], acc[kt][j], 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // the tiles are overwritten by the next step's stores
+    }
+    // D[row = out channel 4 fg + e][col = 16 j + fr = (tap 2 j + fr / 8, channel fr % 8)] -> red[o][80], the four waves in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* q = red + (kt * 16 + fg * 4 + e) * 80 + j * 16 + fr;
+                        *q = w == 0 ? acc[kt][j][e] : *q + acc[kt][j][e];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = p.slab + (size_t)blockIdx.x * K * 9 * p.Creal;
+    for (int i = tid; i < K * 9 * p.Creal; i += 256) {
+        const int c = i % p.Creal, t = (i / p.Creal) % 9, o = i / (p.Creal * 9);
+        out[i] = red[o * 80 + t * 8 + c];
+    }
+}
+
+int stem_wgrad_grid(int M) {
+    const int nstep = (M + 31) / 32;
+    int grid = (nstep + 15) / 16;                            // >= 4 steps per wave
+    if (grid > 256) grid = 256;
+    if (grid < 1) grid = 1;
+    return grid;
+}
+
 }  // namespace
+
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);      // conv3.hip
+
+bool clhip_stem_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    static const bool off = getenv("CLHIP_NO_STEM") != nullptr;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 8 && Creal >= 1 && Creal <= 8 && (K == 16 || K == 32 || K == 64) &&
+           (K * 9 * Creal) % 4 == 0 && N >= 1 && (long long)N * H * W >= 2048;
+}
+
+size_t clhip_stem_wgrad_ws_bytes(int N, int H, int W, int Creal, int K) { return (size_t)stem_wgrad_grid(N * H * W) * K * 9 * Creal * sizeof(float); }
+
+int clhip_stem_wgrad_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int Creal, int K, hipStream_t st) {
+    StemWParams p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, W, K, N * H * W, Creal, (N * H * W + 31) / 32};
+    const int grid = stem_wgrad_grid(p.M);
+    if (K == 16) hipLaunchKernelGGL(wgrad_stem_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+    else if (K == 32) hipLaunchKernelGGL(wgrad_stem_kernel<2>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wgrad_stem_kernel<4>, dim3(grid), dim3(256), 0, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return clhip_wgrad_reduce_launch(ws, dw, (int64_t)K * 9 * Creal / 4, grid, st);
+}
 
 bool clhip_stem_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
     static const bool off = getenv("CLHIP_NO_STEM") != nullptr;

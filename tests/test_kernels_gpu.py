@@ -59,6 +59,8 @@ CONV_CASES = [
     (2, 6, 6, 64, 128, 3, 1, 1),
     (1, 4, 4, 256, 512, 3, 2, 1),
     (4, 16, 16, 3, 16, 3, 1, 1),       # stem: 3 channels padded to 8
+    (9, 32, 32, 3, 64, 3, 1, 1),       # ... large enough for stem.hip's deterministic weight gradient (>= 2048 pixels)
+    (11, 17, 13, 3, 32, 3, 1, 1),      # ... odd image, ragged last 32-pixel step
     (2, 9, 9, 128, 256, 1, 2, 0),
     (64, 32, 32, 16, 16, 3, 1, 1),     # M = 65536 -> the 128-row tile path
     (1, 1, 1, 16, 16, 3, 1, 1),        # single pixel
