@@ -14,8 +14,8 @@ LWF / ICarl classes in fp32 on the CPU; oracle/trainer_scenarios.py): same data,
   reference runs each).  So the test compares DISTRIBUTIONS: 7 product runs (same perturbations) against the 7 reference runs,
   |difference of the means| <= 0.3 points (BASELINE's band) + 3 standard errors of that difference (Welch), two-sided in f32 mode
   (like for like with the reference's arithmetic).  In bf16 mode the bound is ONE-sided (no accuracy lost): in these short
-  under-trained runs (3-4 epochs per task) bf16 training forgets measurably LESS than fp32 -- EWC +2.6 / +3.9, LwF +6.6 / +0.2 points
-  (final-task / overall average, 7 runs against 7, profiles/r02_accuracy_parity.json), iCaRL -0.3 / -0.6 -- while its first steps
+  under-trained runs (3-4 epochs per task) bf16 training forgets measurably LESS than fp32 -- EWC +0.8..+2.6 / +3.6..+3.9, LwF +6.6..+11.6 / +0.2..+1.7 points
+  (final-task / overall average, 7 runs against 7, two test runs; profiles/r02_accuracy_parity.json), iCaRL -0.3..+0.5 / -0.6..+0.9 -- while its first steps
   deviate from the reference by the expected 1e-4 .. 2e-3; the rounding noise acts as a regulariser here.  The gap is reported, not
   hidden: every run's figures go to gpurun_out/accuracy_parity.json (copied to profiles/r02_accuracy_parity.json).
 """
