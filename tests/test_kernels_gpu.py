@@ -84,7 +84,7 @@ CONV_CASES = [
     (70, 16, 16, 128, 64, 3, 2, 1),
     (260, 8, 8, 64, 64, 3, 2, 1),
     (33, 32, 32, 64, 128, 1, 2, 0),
-    (140, 16, 16, 128, 64, 1, 2, 0),
+    (141, 16, 16, 128, 64, 1, 2, 0),      # (>= 8192 output pixels with a ragged last tile: shortcut.hip's input gradient when accumulating)
     (520, 8, 8, 64, 64, 1, 2, 0),
     # the register-resident-weight kernels for 16 -> 16 and 32 -> 32 channels (conv3.hip conv16 / conv32): tiles spanning several
     # images, ragged last tile, non-square and non-power-of-two images (division path of the tap masks), one-row images
@@ -136,7 +136,8 @@ def test_conv_fwd_and_stats(case, mode):
     # eval mode: no statistics requested
     z2 = torch.empty_like(z)
     call("clhip_conv_fwd", xd.data_ptr(), wfd.data_ptr(), z2.data_ptr(), None, N, H, W, cpad, K, k, s, p, code, st())
-    if mode == "bf16" and cpad == 8 and k == 3 and s == 1:      # the stems: partial-row statistics come from the generic kernel, this call from stem.hip
+    special = cpad == 8 and k == 3 and s == 1
+    if mode == "bf16" and special:      # the stems: partial-row statistics come from the generic kernel, this call from stem.hip
         assert (z2.float() - z.float()).abs().max() <= 2 ** -7 * z.float().abs().max()      # one bf16 rounding of a different summation order
         assert (from_nhwc(z2).double() - ref).abs().max() <= tol(mode, ref)
     else:
@@ -543,7 +544,8 @@ def test_herding_at_benchmark_size(n, D, m):
 
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64, 3, 1), (4, 16, 16, 64, 128, 3, 2), (4, 8, 8, 32, 64, 1, 2), (16, 32, 32, 8, 16, 3, 1),
-                                   (5, 32, 32, 8, 64, 3, 1), (3, 7, 5, 8, 32, 3, 1), (130, 32, 32, 8, 64, 3, 1)])      # the last three: stem.hip (ragged last tile, odd image, many tiles per wave)
+                                   (5, 32, 32, 8, 64, 3, 1), (3, 7, 5, 8, 32, 3, 1), (130, 32, 32, 8, 64, 3, 1),        # stem.hip (ragged last tile, odd image, many tiles per wave)
+                                   (6, 16, 16, 64, 128, 1, 2), (5, 8, 8, 128, 256, 1, 2), (3, 4, 4, 256, 512, 1, 2), (7, 6, 10, 64, 64, 1, 2)])      # the shortcuts
 def test_conv_fwd_stat_accumulator(mode, shape):
     """clhip_conv_fwd_acc: same z as clhip_conv_fwd, per-channel sums of z and z^2 added into a zeroed fp64 [2][K] buffer
     (= the column sums of the partial rows of the partial-buffer entry point)"""
@@ -570,10 +572,12 @@ def test_conv_fwd_stat_accumulator(mode, shape):
             assert (z2.float().cpu().double().permute(0, 3, 1, 2) - zr).abs().max() <= 2 ** -8 * zr.abs().max() + 1e-6
             assert float((acc.sum(0)[0].cpu() - zr.sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float(zr.abs().sum(dim=(0, 2, 3)).max())
             assert float((acc.sum(0)[1].cpu() - (zr * zr).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float((zr * zr).sum(dim=(0, 2, 3)).max())
+            assert float((acc.sum(0) - ref).abs().max()) <= 1e-4 * float(ref.abs().max())       # two kernels, two summation orders
         else:
             assert torch.equal(z1, z2)
-        assert float((acc.sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
-        if rep > 1 and tiles >= rep:
+            assert float((acc.sum(0) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        dedicated = mode == "bf16" and C == 8 and ks == 3 and stride == 1
+        if rep > 1 and tiles >= rep and not dedicated:          # (`tiles` counts the generic kernel's workgroups)
             assert (acc.abs().amax(dim=(1, 2)) > 0).all()          # every replica received some workgroups
 
 

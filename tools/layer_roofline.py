@@ -58,12 +58,17 @@ def conv_rows(tag, N, H, W, C, K, ks, stride, count):
     wsbuf = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     fl = 2.0 * N * Ho * Wo * ks * ks * C * K
     act_in, act_out, wb = x.numel() * 2, z.numel() * 2, w.numel() * 2
+    if ks == 1 and stride == 2:
+        act_in //= 4                                                # only every other row and column is touched
     shape = f"{tag} {C}->{K} k{ks} s{stride} {H}x{W} (x{count})"
-    us = timed(lambda: _lib.call("clhip_conv_fwd", x.data_ptr(), w.data_ptr(), z.data_ptr(), part.data_ptr(), N, H, W, Cp, K, ks, stride, pad, code, st))
+    acc = torch.zeros(16, 2, K, device=dev, dtype=torch.float64)    # the entry point the training step uses: sums into fp64 accumulators
+    us = timed(lambda: _lib.call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z.data_ptr(), acc.data_ptr(), 16, N, H, W, Cp, K, ks, stride, pad, code, st))
     row(shape + " fwd", us, fl, act_in + act_out + wb)
     if C >= 16:
-        us = timed(lambda: _lib.call("clhip_conv_dgrad", z.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, N, H, W, Cp, K, ks, stride, pad, code, st))
-        row(shape + " dgrad", us, fl, act_in + act_out + wb)
+        accum = 1 if ks == 1 else 0                                 # the shortcut's input gradient is added to the main branch's, as in the step
+        dx.zero_()
+        us = timed(lambda: _lib.call("clhip_conv_dgrad", z.data_ptr(), wd.data_ptr(), dx.data_ptr(), accum, N, H, W, Cp, K, ks, stride, pad, code, st))
+        row(shape + " dgrad", us, fl, (2 * act_in if accum else act_in) + act_out + wb)
     us = timed(lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), z.data_ptr(), dw.data_ptr(), wsbuf.data_ptr() if wsb else None, N, H, W, Cp, C, K, ks,
                                  stride, pad, code, st))
     row(shape + " wgrad", us, fl, act_in + act_out + dw.numel() * 4)
