@@ -98,26 +98,47 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float a1[8], a2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    // per-channel constants through LDS once per workgroup (behind the reduction scratch): [4][C] mean, invstd, scale, shift
+    float* coef = red + 256 * 16;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = mean[c], is_c = invstd[c];
+        coef[c] = m;
+        coef[C + c] = is_c;
+        if (RELU == 2) { const float sc_c = gamma[c] * is_c; coef[2 * C + c] = sc_c; coef[3 * C + c] = beta[c] - m * sc_c; }
+    }
+    __syncthreads();
     if (ro < rpi) {
         float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            mu[e] = mean[cc * 8 + e]; is[e] = invstd[cc * 8 + e];
-            if (RELU == 2) { sc[e] = gamma[cc * 8 + e] * is[e]; sh[e] = beta[cc * 8 + e] - mu[e] * sc[e]; }
+            mu[e] = coef[cc * 8 + e]; is[e] = coef[C + cc * 8 + e];
+            if (RELU == 2) { sc[e] = coef[2 * C + cc * 8 + e]; sh[e] = coef[3 * C + cc * 8 + e]; }
         }
-        for (int64_t r = (int64_t)blockIdx.x * rpi + ro; r < M; r += (int64_t)gridDim.x * rpi) {
-            const int64_t off = r * C + cc * 8;
-            float g[8], yy[8], zz[8];
-            load8<T>(dy + off, g);
-            load8<T>(z + off, zz);
-            if (RELU == 1) load8<T>(y + off, yy);
+        constexpr int UN = 2;                                  // rows per trip, every load issued before the first use
+        const int64_t rstep = (int64_t)gridDim.x * rpi;
+        for (int64_t r = (int64_t)blockIdx.x * rpi + ro; r < M; r += rstep * UN) {
+            float g[UN][8], yy[UN][8], zz[UN][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float gg = g[e];
-                if (RELU == 1) gg = yy[e] > 0.f ? gg : 0.f;
-                if (RELU == 2) gg = fmaf(zz[e], sc[e], sh[e]) > 0.f ? gg : 0.f;
-                a1[e] += gg;
-                a2[e] += gg * (zz[e] - mu[e]) * is[e];
+            for (int u = 0; u < UN; ++u) {
+                const int64_t ru = r + u * rstep;
+                if (ru < M) {
+                    const int64_t off = ru * C + cc * 8;
+                    load8<T>(dy + off, g[u]);
+                    load8<T>(z + off, zz[u]);
+                    if (RELU == 1) load8<T>(y + off, yy[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (r + u * rstep >= M) break;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float gg = g[u][e];
+                    if (RELU == 1) gg = yy[u][e] > 0.f ? gg : 0.f;
+                    if (RELU == 2) gg = fmaf(zz[u][e], sc[e], sh[e]) > 0.f ? gg : 0.f;
+                    a1[e] += gg;
+                    a2[e] += gg * (zz[u][e] - mu[e]) * is[e];
+                }
             }
         }
     }
@@ -207,6 +228,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// Sums of the fp64 accumulator replicas [rep][2][C] for the consumers' prologues: -> s1 (sum) and s2 (second sum) of channel c for the
+// threads c < C (c + 256 k for wide layers).  Every load of a thread is independent and issued before the first add, and with 2 C < 256
+// the replicas are split over 256 / (2 C) thread groups and combined through LDS: the serial loop this replaces made `rep` (16-32)
+// dependent L2 round trips, ~10 us -- most of the 8 x 8 / 4 x 4 layers' BatchNorm launches (tools/bn_bench.py).
+__device__ inline void sum_strided2(const double* __restrict__ p1, const double* __restrict__ p2, int n, size_t stride, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        double v1[8], v2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool in = r0 + i < n;
+            v1[i] = in ? p1[(size_t)(r0 + i) * stride] : 0.0;
+            v2[i] = in ? p2[(size_t)(r0 + i) * stride] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += v1[i]; s2 += v2[i]; }
+    }
+}
+
+// narrow layers (2 C <= 128): part sums of thread group t / (2 C) into sred[256]; afterwards channel c reads sred[part * 2 C + which * C + c]
+__device__ inline void replica_parts(const double* __restrict__ acc, int rep, int C, double* sred) {
+    const int n2 = 2 * C, parts = 256 / n2;
+    const int col = threadIdx.x % n2, part = threadIdx.x / n2;
+    const int n = (rep - part + parts - 1) / parts;                     // replicas part, part + parts, ...
+    double s = 0.0;
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r0 + i < n ? acc[(size_t)(part + (r0 + i) * parts) * n2 + col] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    sred[threadIdx.x] = s;
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------- accumulator ("acc") variants
 // The per-layer finalize launches (bn_finalize, bn_bwd_finalize: 40 x ~6 us of a 3.3 ms ResNet-18 step) disappear when the
 // producer adds its per-channel sums into a [2][C] fp64 accumulator with hardware fp64 atomics (order-independent to ~1e-16)
@@ -219,9 +276,16 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
                                                              const T* __restrict__ res, T* __restrict__ y, int64_t nchunks, int C) {
     extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: scale, shift
     // block-cooperative finalize: sum the accumulator replicas, derive scale / shift once per workgroup
+    __shared__ double sred[256];
+    const bool narrow = 2 * C <= 128;
+    if (narrow) replica_parts(acc, rep, C, sred);
     for (int c = threadIdx.x; c < C; c += 256) {
+        // (workgroup 0's read-modify-writes: the reads ride with the accumulator loads instead of adding a round trip behind them)
+        const bool upd = blockIdx.x == 0 && rm != nullptr;
+        const float rm_old = upd ? rm[c] : 0.f, rv_old = upd ? rv[c] : 0.f;
         double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < rep; ++r) { s1 += acc[((size_t)r * 2 + 0) * C + c]; s2 += acc[((size_t)r * 2 + 1) * C + c]; }
+        if (narrow) { for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; } }
+        else sum_strided2(acc + c, acc + C + c, rep, 2 * (size_t)C, s1, s2);
         const double mean = s1 * invM;
         double var = s2 * invM - mean * mean;       // the cancellation happens in fp64 ...
         if (var < 0.0) var = 0.0;
@@ -236,30 +300,40 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
             mean_o[c] = (float)mean;
             invstd_o[c] = istd;
             if (rm != nullptr) {
-                rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
-                rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * unbias);
+                rm[c] = (1.f - momentum) * rm_old + momentum * (float)mean;
+                rv[c] = (1.f - momentum) * rv_old + momentum * (float)(var * unbias);
             }
         }
     }
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c0 = (int)((i0 * 8) % C);                                // fixed per thread: the grid stride is a multiple of C/8
+    const int c0 = ((int)i0 & ((C >> 3) - 1)) * 8;                     // fixed per thread: C is a power of two and the grid stride a multiple of C/8
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = coefs[c0 + e]; sh[e] = coefs[C + c0 + e]; }
-    for (int64_t i = i0; i < nchunks; i += stride) {
-        float v[8], r[8];
-        load8<T>(z + i * 8, v);
-        if (RES) load8<T>(res + i * 8, r);
+    // UN chunks per trip, every load issued before the first use: the kernels are a few dependent round trips long on the small layers
+    constexpr int UN = 4;
+    for (int64_t i = i0; i < nchunks; i += stride * UN) {
+        float v[UN][8], r[UN][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float o = fmaf(v[e], sc[e], sh[e]);
-            if (RES) o += r[e];
-            if (RELU) o = fmaxf(o, 0.f);
-            v[e] = o;
+        for (int u = 0; u < UN; ++u) {
+            const int64_t iu = i + u * stride;
+            if (iu < nchunks) { load8<T>(z + iu * 8, v[u]); if (RES) load8<T>(res + iu * 8, r[u]); }
         }
-        store8<T>(y + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t iu = i + u * stride;
+            if (iu >= nchunks) break;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = fmaf(v[u][e], sc[e], sh[e]);
+                if (RES) o += r[u][e];
+                if (RELU) o = fmaxf(o, 0.f);
+                v[u][e] = o;
+            }
+            store8<T>(y + iu * 8, v[u]);
+        }
     }
 }
 
@@ -269,47 +343,73 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
                                                                const float* __restrict__ gamma, const double* __restrict__ acc, int rep, double invM,
                                                                float* dgamma, float* dbeta, T* __restrict__ dz, T* __restrict__ dres,
                                                                int64_t nchunks, int C, const float* __restrict__ beta = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: mean(g), mean(g * xhat)
+    // [6][C]: mean(g), mean(g * xhat), mean, invstd, scale, shift -- every per-channel constant goes through LDS once per workgroup (32
+    // four-byte gathers per thread from the four parameter arrays were most of this kernel's fixed cost on the small layers)
+    extern __shared__ __attribute__((aligned(16))) float coefs[];
+    __shared__ double sred[256];
+    const bool narrow = 2 * C <= 128;
+    if (narrow) replica_parts(acc, rep, C, sred);
     for (int c = threadIdx.x; c < C; c += 256) {
+        const float db_old = blockIdx.x == 0 ? dbeta[c] : 0.f, dg_old = blockIdx.x == 0 ? dgamma[c] : 0.f;      // (read with the accumulator loads, see above)
+        const float m = mean[c], is_c = invstd[c], gi_c = gamma[c] * is_c;                                     // gi = the forward's scale
+        const float sh_c = RELU == 2 ? beta[c] - m * gi_c : 0.f;
         double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < rep; ++r) { s1 += acc[((size_t)r * 2 + 0) * C + c]; s2 += acc[((size_t)r * 2 + 1) * C + c]; }
+        if (narrow) { for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; } }
+        else sum_strided2(acc + c, acc + C + c, rep, 2 * (size_t)C, s1, s2);
         coefs[c] = (float)(s1 * invM);
         coefs[C + c] = (float)(s2 * invM);
-        if (blockIdx.x == 0) { dbeta[c] += (float)s1; dgamma[c] += (float)s2; }
+        coefs[2 * C + c] = m;
+        coefs[3 * C + c] = is_c;
+        coefs[4 * C + c] = gi_c;
+        coefs[5 * C + c] = sh_c;
+        if (blockIdx.x == 0) { dbeta[c] = db_old + (float)s1; dgamma[c] = dg_old + (float)s2; }
     }
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c0 = (int)((i0 * 8) % C);
+    const int c0 = ((int)i0 & ((C >> 3) - 1)) * 8;
     float k0[8], k1[8], gi[8], mu[8], is[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         k0[e] = coefs[c0 + e];
         k1[e] = coefs[C + c0 + e];
-        mu[e] = mean[c0 + e];
-        is[e] = invstd[c0 + e];
-        gi[e] = gamma[c0 + e] * is[e];                    // = the forward's scale
-        if (RELU == 2) sh[e] = beta[c0 + e] - mu[e] * gi[e];
+        mu[e] = coefs[2 * C + c0 + e];
+        is[e] = coefs[3 * C + c0 + e];
+        gi[e] = coefs[4 * C + c0 + e];
+        if (RELU == 2) sh[e] = coefs[5 * C + c0 + e];
     }
-    for (int64_t i = i0; i < nchunks; i += stride) {
-        float g[8], yy[8], zz[8], o[8], rr[8];
-        load8<T>(dy + i * 8, g);
-        load8<T>(z + i * 8, zz);
-        if (RELU == 1) load8<T>(y + i * 8, yy);
-        if (DRES == 2) load8<T>(dres + i * 8, rr);
+    constexpr int UN = sizeof(T) == 2 ? 4 : 2;
+    for (int64_t i = i0; i < nchunks; i += stride * UN) {
+        float g[UN][8], yy[UN][8], zz[UN][8], rr[UN][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float gg = g[e];
-            if (RELU == 1) gg = yy[e] > 0.f ? gg : 0.f;
-            if (RELU == 2) gg = fmaf(zz[e], gi[e], sh[e]) > 0.f ? gg : 0.f;
-            const float xh = (zz[e] - mu[e]) * is[e];
-            o[e] = gi[e] * (gg - k0[e] - xh * k1[e]);
-            g[e] = gg;
-            if (DRES == 2) rr[e] += gg;
+        for (int u = 0; u < UN; ++u) {
+            const int64_t iu = i + u * stride;
+            if (iu < nchunks) {
+                load8<T>(dy + iu * 8, g[u]);
+                load8<T>(z + iu * 8, zz[u]);
+                if (RELU == 1) load8<T>(y + iu * 8, yy[u]);
+                if (DRES == 2) load8<T>(dres + iu * 8, rr[u]);
+            }
         }
-        store8<T>(dz + i * 8, o);
-        if (DRES == 1) store8<T>(dres + i * 8, g);
-        if (DRES == 2) store8<T>(dres + i * 8, rr);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t iu = i + u * stride;
+            if (iu >= nchunks) break;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gg = g[u][e];
+                if (RELU == 1) gg = yy[u][e] > 0.f ? gg : 0.f;
+                if (RELU == 2) gg = fmaf(zz[u][e], gi[e], sh[e]) > 0.f ? gg : 0.f;
+                const float xh = (zz[u][e] - mu[e]) * is[e];
+                o[e] = gi[e] * (gg - k0[e] - xh * k1[e]);
+                g[u][e] = gg;
+                if (DRES == 2) rr[u][e] += gg;
+            }
+            store8<T>(dz + iu * 8, o);
+            if (DRES == 1) store8<T>(dres + iu * 8, g[u]);
+            if (DRES == 2) store8<T>(dres + iu * 8, rr[u]);
+        }
     }
 }
 
@@ -571,7 +671,7 @@ static int bn_bwd_t(const void* dy, const void* y, const void* z, const float* m
     float* part = ws;
     float* coef = ws + (size_t)G * 2 * C;
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
-    size_t lds = 256 * 16 * sizeof(float);
+    size_t lds = (256 * 16 + 4 * (size_t)C) * sizeof(float);
     if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C, (const float*)nullptr, (const float*)nullptr);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, part, (double*)nullptr, 1, M, C, (const float*)nullptr, (const float*)nullptr);
     CLHIP_LAUNCH_CHECK();
@@ -649,7 +749,7 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
                         const float* beta = nullptr, bool sums_ready = false) {        // relu == 2: the mask comes from z, gamma and beta (see bn_bwd_reduce_kernel)
     const int G = bn_bwd_blocks(M, C);
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
-    size_t lds = 256 * 16 * sizeof(float);
+    size_t lds = (256 * 16 + 4 * (size_t)C) * sizeof(float);
     if (sums_ready) { /* the two channel sums were accumulated by the producer of dy (clhip_conv_dgrad_bn_reduce): apply pass only */ }
     else if (relu == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, gamma, beta);
     else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
@@ -657,7 +757,7 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     CLHIP_LAUNCH_CHECK();
     const int64_t nch = M * C / 8;
     dim3 g(acc_blocks(nch)), b(256);
-    const size_t lds2 = 2 * (size_t)C * sizeof(float);
+    const size_t lds2 = 6 * (size_t)C * sizeof(float);
     T* dzz = (T*)dz; T* dr = (T*)dres;
     const double invM = 1.0 / (double)M;
     int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
