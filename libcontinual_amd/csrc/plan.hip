@@ -215,15 +215,20 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     // BatchNorm-backward reduction fused into a dgrad epilogue: unit i's dgrad may reduce for the producer of its input activation
     // when it is the LAST writer of that activation's gradient in the reverse sweep (= the lowest-index consumer, and it consumes
     // through its convolution, not through a residual add), the producer is a plain conv -> BN [-> +res] [-> ReLU] unit on the
-    // accumulator path, and the fourth-generation dgrad kernel covers the layer.  Opt-in (CLHIP_BN_FUSE=1): measured on the ResNet-18
-    // step at batch 256 it is time-neutral (2.617 ms fused vs 2.592 ms with the 13 separate reduce passes, profiles/r02_notes.md) -- the
-    // epilogue's 8-byte gathers of z / y and its 16-lane DPP reductions cost what the streaming reduce pass costs.
-    const bool fuse_on = getenv("CLHIP_BN_FUSE") && atoi(getenv("CLHIP_BN_FUSE")) != 0;         // read per plan: tests build both variants
+    // accumulator path, and the fourth-generation dgrad kernel covers the layer.  On the 32x32 / 16x16 stages of the ResNet-18 step at batch
+    // 256 it is time-neutral to slightly slower (2.617 ms all fused vs 2.592 ms with the 13 separate reduce passes, profiles/r02_conv4_notes.md):
+    // the epilogue's 8-byte gathers of z / y and its 16-lane DPP reductions cost what the streaming reduce pass costs there.
+    // Default: fused for activations of at most 16384 pixels (the 8x8 / 4x4 stages at batch 256, everything at batch 32), where the reduce
+    // pass is a launch at its latency floor (7-9 us) and the epilogue's extra work is small: 2.321 -> 2.305 ms per step.  CLHIP_BN_FUSE=0:
+    // never; =1: every qualifying layer (CLHIP_BN_FUSE_MAX_M bounds the pixels).  Read per plan: tests build both variants.
+    const char* fe = getenv("CLHIP_BN_FUSE");
+    const bool fuse_on = fe == nullptr || atoi(fe) != 0;
+    const long long fuse_max_m = getenv("CLHIP_BN_FUSE_MAX_M") ? atoll(getenv("CLHIP_BN_FUSE_MAX_M")) : (fe == nullptr ? 16384 : (1ll << 62));
     p->bwd_sums_ready.assign(p->units.size(), 0);
     for (int i = 0; i < n_units; ++i) {
         Unit& u = p->units[i];
         u.fuse_src_bn = false;
-        if (!fuse_on || u.d.src < 1 || u.raw_src || u.pre_res || u.no_bn) continue;
+        if (!fuse_on || u.d.src < 1 || u.raw_src || u.pre_res || u.no_bn || (long long)u.M > fuse_max_m) continue;
         const int a = u.d.src;                      // the activation; produced by unit a - 1
         const Unit& prod = p->units[a - 1];
         if (prod.no_bn || prod.pre_res || prod.raw_src || prod.has_dzr || prod.rep_bwd <= 0) continue;

@@ -481,7 +481,7 @@ def test_full_size_properties_bf16():
 @pytest.mark.parametrize("arch,batch", [("resnet18", 64), ("cifar_resnet32", 64)])
 def test_fused_batchnorm_backward_reduction_at_network_level(arch, batch, monkeypatch):
     """The plan with the BatchNorm-backward reductions fused into the dgrad epilogues (13 of ResNet-18's 20 units) against the same plan
-    without it (CLHIP_BN_FUSE=0, the default: separate reduce passes): same weights, same batch, bf16.  Every parameter gradient agrees to the rounding
+    without it (CLHIP_BN_FUSE=0: separate reduce passes everywhere; the default fuses only activations of at most 16384 pixels): same weights, same batch, bf16.  Every parameter gradient agrees to the rounding
     of the sums' inputs (fp32 results in the epilogue vs the bf16-rounded tensor in the separate pass)."""
     grads = {}
     for fuse in ("1", "0"):
