@@ -7,6 +7,8 @@
 // core/model/backbone/resnet.py:296-316; nn.AvgPool2d(8) / AdaptiveAvgPool2d(1), :160, :344.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace {
@@ -743,6 +745,11 @@ extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int r
     return CLHIP_EINVAL;
 }
 
+// one-shot: the next accumulator-path backward apply launch completes this event (taken by the launch; see plan.hip)
+static thread_local hipEvent_t g_bn_stop_event = nullptr;
+void clhip_bn_set_stop_event(hipEvent_t ev) { g_bn_stop_event = ev; }
+hipEvent_t clhip_bn_pending_stop_event() { return g_bn_stop_event; }
+
 template <typename T>
 static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                         float* dbeta, void* dz, void* dres, int dres_acc, int64_t M, int C, int relu, double* acc, int rep, hipStream_t st,
@@ -761,7 +768,11 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     T* dzz = (T*)dz; T* dr = (T*)dres;
     const double invM = 1.0 / (double)M;
     int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
-#define BWD_ACC(R, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, lds2, st, dyy, yy, zz, mean, invstd, gamma, acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C, beta)
+    // (plan.hip: the kernel's own completion signal is the event the weight-gradient stream waits for -- a separate hipEventRecord is a
+    // marker packet in the caller's queue, ~5 us of bubble in front of the dgrad that follows)
+    hipEvent_t stop_ev = g_bn_stop_event;
+    g_bn_stop_event = nullptr;
+#define BWD_ACC(R, D) hipExtLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, (uint32_t)lds2, st, (hipEvent_t) nullptr, stop_ev, 0u, dyy, yy, zz, mean, invstd, gamma, (const double*)acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C, beta)
     if (relu == 2) { if (mode == 0) BWD_ACC(2, 0); else if (mode == 1) BWD_ACC(2, 1); else BWD_ACC(2, 2); }
     else if (relu) { if (mode == 0) BWD_ACC(1, 0); else if (mode == 1) BWD_ACC(1, 1); else BWD_ACC(1, 2); }
     else { if (mode == 0) BWD_ACC(0, 0); else if (mode == 1) BWD_ACC(0, 1); else BWD_ACC(0, 2); }

@@ -16,6 +16,9 @@
 
 #include "common.h"
 
+void clhip_bn_set_stop_event(hipEvent_t ev);          // bn.hip: one-shot completion event of the next accumulator-path backward apply launch
+hipEvent_t clhip_bn_pending_stop_event();
+
 namespace {
 constexpr float kBnMomentum = 0.1f;   // nn.BatchNorm2d defaults used by every reference ResNet
 constexpr float kBnEps = 1e-5f;
@@ -479,12 +482,16 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         static const bool flat = getenv("CLHIP_SIDE_PRIO") != nullptr && atoi(getenv("CLHIP_SIDE_PRIO")) == 0;
         const hipError_t e = flat ? hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_lo);
         if (e != hipSuccess) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
+        // the events order two streams of ONE device: no timing, and no system-scope fence (the default flags make every record a cache
+        // write-back + invalidate in the middle of the caller's stream; CLHIP_EVENT_FLAGS overrides the flag word)
+        static const unsigned ev_flags = getenv("CLHIP_EVENT_FLAGS") ? (unsigned)strtoul(getenv("CLHIP_EVENT_FLAGS"), nullptr, 0)
+                                                                      : (hipEventDisableTiming | hipEventDisableSystemFence);
         for (int k = 0; k < 2; ++k) {
-            (void)hipEventCreateWithFlags(&p->ev_dz[k], hipEventDisableTiming);
-            (void)hipEventCreateWithFlags(&p->ev_wg[k], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&p->ev_dz[k], ev_flags);
+            (void)hipEventCreateWithFlags(&p->ev_wg[k], ev_flags);
             p->wg_pending[k] = false;
         }
-        (void)hipEventCreateWithFlags(&p->ev_end, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&p->ev_end, ev_flags);
     }
     int k = 0;
     for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
@@ -503,6 +510,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             p->wg_pending[k] = false;
         }
         static const bool mask_from_y = getenv("CLHIP_BN_MASK_FROM_Y") != nullptr;       // ablation: always read the activation
+        // the weight gradient goes to the side stream (see below): let the BatchNorm apply launch -- the last writer of dz -- complete the
+        // event itself instead of recording one behind it
+        const double wg_flops = 2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout;
+        const bool on_side = two_streams && p->side_ok && wg_flops >= 1.0e9;
+        static const bool ev_in_launch = getenv("CLHIP_EVENT_RECORD") == nullptr;
+        const bool hook = on_side && ev_in_launch && !u.no_bn && u.rep_bwd > 0 && !u.has_dzr;
+        if (hook) clhip_bn_set_stop_event(p->ev_dz[k]);
         if (u.no_bn) {
         } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
             // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
@@ -531,11 +545,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         // 2.08-2.35 ms per EWC step from run to run with its weight gradients on the side stream, 2.200 +- 0.003 ms without -- the same mean,
         // whereas ResNet-18 (10-19 GFLOP layers; its 1-GFLOP shortcut convs included) gains 10 % reproducibly.  `side_ok` = the plan has a
         // layer of CLHIP_WGRAD_NET_GFLOP (default 4) GFLOP or more.
-        const double wg_flops = 2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout;
-        const bool on_side = two_streams && p->side_ok && wg_flops >= 1.0e9;
         void* wg_stream = stream;
         if (on_side) {
-            (void)hipEventRecord(p->ev_dz[k], main_s);
+            if (!hook || clhip_bn_pending_stop_event() != nullptr) {          // (not taken: a BatchNorm path without the hook)
+                clhip_bn_set_stop_event(nullptr);
+                (void)hipEventRecord(p->ev_dz[k], main_s);
+            }
             (void)hipStreamWaitEvent(p->side, p->ev_dz[k], 0);
             wg_stream = p->side;
         } else if (two_streams && (p->wg_pending[0] || p->wg_pending[1]) &&
