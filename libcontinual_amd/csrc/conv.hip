@@ -463,7 +463,7 @@ size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K);
 bool clhip_stem_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
 int clhip_stem_launch(const void* x, const void* w, void* z, double* acc, int rep, int N, int H, int W, int K, hipStream_t st);
 bool clhip_shortcut_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
-int clhip_shortcut_dgrad(const void* dz, const void* w_dg, void* dx, int N, int H, int W, int C, int K, hipStream_t st);
+int clhip_shortcut_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st);
 bool clhip_stem_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 size_t clhip_stem_wgrad_ws_bytes(int N, int H, int W, int Creal, int K);
 int clhip_stem_wgrad_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int Creal, int K, hipStream_t st);
@@ -580,8 +580,8 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     p.M = N * H * W; p.K = ksize * ksize * K;
     hipStream_t st = static_cast<hipStream_t>(stream);
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
-    if (!use_v1() && use_v3() && accumulate && clhip_shortcut_supported(N, H, W, C, K, ksize, stride, pad, dtype))
-        return clhip_shortcut_dgrad(dz, w_dg, dx, N, H, W, C, K, st);
+    if (!use_v1() && use_v3() && clhip_shortcut_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_shortcut_dgrad(dz, w_dg, dx, accumulate, N, H, W, C, K, st);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype))

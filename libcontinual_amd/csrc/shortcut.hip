@@ -7,8 +7,8 @@
 // fragment (32 input channels x 16 reduction elements: 16 bytes of one row of the dgrad shadow per lane, L1 / L2 resident), B = a pixel
 // fragment (16 bytes of one dz row per lane).  A wave owns 32 pixels x 128 (or 64) channels; D[row = channel][col = pixel] gives every lane 4
 // consecutive channels per group and the half-waves are paired with v_permlane32_swap into 16-byte accesses, as in conv4.hip.  The three
-// quarters of dx this layer does not touch keep what the main branch wrote: the launch needs accumulate != 0 (the residual block's
-// backward always has it), otherwise the caller uses the generic kernel, which also writes the zeros.  The forward of these layers and
+// quarters of dx this layer does not touch keep what the main branch wrote (accumulate) or get zeros from the lane that owns their 2 x 2
+// cell (first writer: in the reverse sweep of a residual block the shortcut comes before the main branch).  The forward of these layers and
 // layer4.0's gradient (4096 pixels x 512 features: each wave would re-read a 64 KB weight panel for 32 pixels) measured slower this way
 // than through the generic kernel and stay there (profiles/r02_layer_roofline.md).
 #include <stdlib.h>
@@ -27,7 +27,7 @@ struct ShortParams {
     int N, H, W, Ho, Wo, R, F, M;        // R reduction length, F features, M = N*Ho*Wo pixels of the small grid
 };
 
-template <int NT>              // NT 32-channel tiles per workgroup (2 or 4)
+template <int NT, bool ACC>    // NT 32-channel tiles per workgroup (2 or 4); ACC: dx += (else dx = , zeros on the three sibling pixels of every 2x2 cell)
 __global__ __launch_bounds__(256) void shortcut_dgrad_kernel(const ShortParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void shortcut_dgrad_kernel(const ShortParams p
     bf16_t* drow = p.dst + pin * p.F + f0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (valid) {
+        if (ACC && valid) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const uint2 old = *reinterpret_cast<const uint2*>(drow + t * 32 + g4 * 8 + kh * 4);
@@ -76,15 +76,29 @@ __global__ __launch_bounds__(256) void shortcut_dgrad_kernel(const ShortParams p
             unsigned bx = pack_bf16x2(acc[t][8 * pr + 4], acc[t][8 * pr + 5]), by = pack_bf16x2(acc[t][8 * pr + 6], acc[t][8 * pr + 7]);
             auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-            if (valid) *reinterpret_cast<u32x4*>(drow + t * 32 + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+            if (valid) {
+                bf16_t* q = drow + t * 32 + pr * 16 + kh * 8;
+                *reinterpret_cast<u32x4*>(q) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                if (!ACC) {
+                    const u32x4 zero{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(q + p.F) = zero;
+                    *reinterpret_cast<u32x4*>(q + (size_t)p.W * p.F) = zero;
+                    *reinterpret_cast<u32x4*>(q + (size_t)(p.W + 1) * p.F) = zero;
+                }
+            }
         }
     }
 }
 
-int launch_short(const ShortParams& p, hipStream_t st) {
+int launch_short(const ShortParams& p, bool accumulate, hipStream_t st) {
     const int gx = (p.M + 127) / 128;
-    if (p.F % 128 == 0) hipLaunchKernelGGL((shortcut_dgrad_kernel<4>), dim3(gx, p.F / 128), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((shortcut_dgrad_kernel<2>), dim3(gx, p.F / 64), dim3(256), 0, st, p);
+    if (p.F % 128 == 0) {
+        if (accumulate) hipLaunchKernelGGL((shortcut_dgrad_kernel<4, true>), dim3(gx, p.F / 128), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((shortcut_dgrad_kernel<4, false>), dim3(gx, p.F / 128), dim3(256), 0, st, p);
+    } else {
+        if (accumulate) hipLaunchKernelGGL((shortcut_dgrad_kernel<2, true>), dim3(gx, p.F / 64), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((shortcut_dgrad_kernel<2, false>), dim3(gx, p.F / 64), dim3(256), 0, st, p);
+    }
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -99,7 +113,7 @@ bool clhip_shortcut_supported(int N, int H, int W, int C, int K, int ksize, int 
            (long long)N * (H / 2) * (W / 2) >= min_px && (long long)N * H * W * (C > K ? C : K) * 2 < (1ll << 31);
 }
 
-int clhip_shortcut_dgrad(const void* dz, const void* w_dg, void* dx, int N, int H, int W, int C, int K, hipStream_t st) {
+int clhip_shortcut_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st) {
     ShortParams p{static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(w_dg), static_cast<bf16_t*>(dx), N, H, W, H / 2, W / 2, K, C, N * (H / 2) * (W / 2)};
-    return launch_short(p, st);
+    return launch_short(p, accumulate != 0, st);
 }

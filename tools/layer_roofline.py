@@ -65,10 +65,9 @@ def conv_rows(tag, N, H, W, C, K, ks, stride, count):
     us = timed(lambda: _lib.call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z.data_ptr(), acc.data_ptr(), 16, N, H, W, Cp, K, ks, stride, pad, code, st))
     row(shape + " fwd", us, fl, act_in + act_out + wb)
     if C >= 16:
-        accum = 1 if ks == 1 else 0                                 # the shortcut's input gradient is added to the main branch's, as in the step
-        dx.zero_()
-        us = timed(lambda: _lib.call("clhip_conv_dgrad", z.data_ptr(), wd.data_ptr(), dx.data_ptr(), accum, N, H, W, Cp, K, ks, stride, pad, code, st))
-        row(shape + " dgrad", us, fl, (2 * act_in if accum else act_in) + act_out + wb)
+        # (the shortcut's input gradient is the FIRST writer of dx in the reverse sweep: it writes all of dx, zeros on the untouched pixels)
+        us = timed(lambda: _lib.call("clhip_conv_dgrad", z.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, N, H, W, Cp, K, ks, stride, pad, code, st))
+        row(shape + " dgrad", us, fl, dx.numel() * 2 + act_out + wb)
     us = timed(lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), z.data_ptr(), dw.data_ptr(), wsbuf.data_ptr() if wsb else None, N, H, W, Cp, C, K, ks,
                                  stride, pad, code, st))
     row(shape + " wgrad", us, fl, act_in + act_out + dw.numel() * 4)
