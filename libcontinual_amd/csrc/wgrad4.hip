@@ -308,10 +308,11 @@ bool geometry_sk(int N, int H, int W, int C, int K, Wgrad4Params& p) {
     if ((SP + p.npatch) * 9 > G::NINST * 64) return false;
     p.tiles_c = C / 64; p.tiles = (C / 64) * (K / 64);
     p.total_steps = (p.M + SP - 1) / SP;
-    // 160 workgroups, not 256: inside a training step this kernel runs on the weight-gradient stream beside the dgrad / BatchNorm chain
+    // 128 workgroups, not 256: inside a training step this kernel runs on the weight-gradient stream beside the dgrad / BatchNorm chain
     // of the caller's stream, which is the critical path -- a launch that fills every CU (one workgroup each: 96 KB of LDS, 196 VGPRs)
-    // costs the step more than its own 2 us (ResNet-18, batch 256: 2.66 ms per step at 256, 2.55 at 128-160; profiles/r02_wgrad4_notes.md)
-    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 160;
+    // costs the step more than its own 2 us (ResNet-18, batch 256: 2.66 ms per step at 256, 2.55 at 128-160; re-swept after the BatchNorm
+    // kernels got shorter: 2.39 at 256, 2.28 at 160, 2.23 at 128-136, 2.26 at 104-112; profiles/r02_wgrad4_notes.md)
+    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 128;
     static const int min_steps = getenv("CLHIP_WGRAD4_MIN_STEPS") ? atoi(getenv("CLHIP_WGRAD4_MIN_STEPS")) : 2;
     int splits = (target + p.tiles - 1) / p.tiles;
     const int max_splits = (p.total_steps + min_steps - 1) / min_steps;
