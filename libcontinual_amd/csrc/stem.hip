@@ -136,29 +136,45 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const StemWParams p) {
         for (int j = 0; j < 5; ++j) acc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int col = fg * 8 + (fr >> 2), seg = (fr & 3) * 8;
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    for (int s = gw; s < p.nstep; s += nw) {
+    // One step = 32 pixels.  The global loads of step s + 1 are issued (into registers) as soon as those of step s have been stored to
+    // LDS, and land while step s is read back and multiplied: a wave no longer pays a full L2 / HBM round trip per step with nothing
+    // else to do (the serial version: 8 steps x ~2 us of the kernel's 37 us at batch 256).
+    uint4 zr[KT], xr[5];
+    auto fetch = [&](int s) {
         const int p0 = s * 32;
         // gradient rows: 32 pixels x 2 KT chunks of 16 bytes
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
             const int id = lane + 64 * i, px = id / (2 * KT), part = id - px * (2 * KT);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p0 + px < p.M) v = *reinterpret_cast<const uint4*>(p.dz + (size_t)(p0 + px) * K + part * 8);
-            *reinterpret_cast<uint4*>(zs + px * PZ + part * 16) = v;
+            zr[i] = make_uint4(0, 0, 0, 0);
+            if (p0 + px < p.M) zr[i] = *reinterpret_cast<const uint4*>(p.dz + (size_t)(p0 + px) * K + part * 8);
         }
         // im2col rows: 32 pixels x 9 taps
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int id = lane + 64 * i;
+            xr[i] = make_uint4(0, 0, 0, 0);
             if (id < 288) {
                 const int px = id / 9, tap = id - px * 9, g = p0 + px;
                 const int w0 = g % W, h0 = (g / W) % H, dr = tap / 3 - 1, ds = tap % 3 - 1;
-                uint4 v = make_uint4(0, 0, 0, 0);
                 if (g < p.M && (unsigned)(h0 + dr) < (unsigned)H && (unsigned)(w0 + ds) < (unsigned)W)
-                    v = *reinterpret_cast<const uint4*>(p.x + ((size_t)g + dr * W + ds) * 8);
-                *reinterpret_cast<uint4*>(xs + px * PX + tap * 16) = v;
+                    xr[i] = *reinterpret_cast<const uint4*>(p.x + ((size_t)g + dr * W + ds) * 8);
             }
         }
+    };
+    if (gw < p.nstep) fetch(gw);
+    for (int s = gw; s < p.nstep; s += nw) {
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const int id = lane + 64 * i, px = id / (2 * KT), part = id - px * (2 * KT);
+            *reinterpret_cast<uint4*>(zs + px * PZ + part * 16) = zr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int id = lane + 64 * i;
+            if (id < 288) { const int px = id / 9, tap = id - px * 9; *reinterpret_cast<uint4*>(xs + px * PX + tap * 16) = xr[i]; }
+        }
+        if (s + nw < p.nstep) fetch(s + nw);
         bf16x8_t zf[KT], xf[5];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) zf[kt] = tr8s(zs, col * PZ + kt * 32 + seg, 4 * PZ);
@@ -198,7 +214,8 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const StemWParams p) {
 int stem_wgrad_grid(int M) {
     const int nstep = (M + 31) / 32;
     int grid = (nstep + 15) / 16;                            // >= 4 steps per wave
-    if (grid > 256) grid = 256;
+    static const int cap = getenv("CLHIP_STEM_WGRAD_GRID") ? atoi(getenv("CLHIP_STEM_WGRAD_GRID")) : 256;
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     return grid;
 }
@@ -234,7 +251,8 @@ int clhip_stem_launch(const void* x, const void* w, void* z, double* acc, int re
     StemParams p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), static_cast<bf16_t*>(z), acc, rep > 0 ? rep : 1, N, H, W, K, N * H * W};
     const int ntile = (p.M + 63) / 64;
     int grid = (ntile + 3) / 4;
-    if (grid > 1024) grid = 1024;
+    static const int cap = getenv("CLHIP_STEM_GRID") ? atoi(getenv("CLHIP_STEM_GRID")) : 512;      // two tiles per wave at batch 256: 17.9 -> 15.9 us (64 features)
+    if (grid > cap) grid = cap;
     if (K == 16) hipLaunchKernelGGL(conv_stem_kernel<1>, dim3(grid), dim3(256), 0, st, p);
     else if (K == 32) hipLaunchKernelGGL(conv_stem_kernel<2>, dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_stem_kernel<4>, dim3(grid), dim3(256), 0, st, p);
