@@ -267,7 +267,7 @@ def conv_rooflines(dev, dtype, B, workload):
     L = _lib.lib()
     out = []
 
-    def entry(kind, symbol, label, N, H, W, C, K, run, flops, alg_bytes, pmc_key):
+    def entry(kind, symbol, label, N, H, W, C, K, run, flops, alg_bytes, pmc_key, full_chip_run=None):
         ms = _time_launches(run, 50)
         ach = flops / (ms * 1e-3) / 1e12
         t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
@@ -280,12 +280,27 @@ def conv_rooflines(dev, dtype, B, workload):
         else:
             gbs = alg_bytes / (ms * 1e-3) / 1e9
             e.update(achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, tflops_algorithmic=ach)
+        if kind == "wgrad":
+            # the in-step grid is 128 workgroups on purpose (half the chip: the launch runs beside the critical chain); the same kernel with
+            # one workgroup per CU, for the kernel-quality reading of the fraction
+            L.clhip_wgrad4_config(256)
+            try:
+                ms_full = _time_launches(full_chip_run(), 50)
+            finally:
+                L.clhip_wgrad4_config(0)
+            e.update(grid_workgroups_in_step=128, full_chip=dict(grid_workgroups=256, launch_ms=ms_full, frac=e["frac"] * ms / ms_full))
         ins = [_profile_lookup(workload, sy) for sy in (symbol if isinstance(symbol, (list, tuple)) else [symbol])]
         if all(i is not None for i in ins):      # the same symbol(s) inside the step (two streams share the chip): the conservative figure
             t_in = sum(i["avg_us"] for i in ins) * 1e-3
             e.update(in_step_launch_ms=t_in, in_step_frac=e["frac"] * ms / t_in, in_step_share_of_kernel_time=sum(i["share_of_kernel_time"] for i in ins),
                      in_step_source=ins[0]["source"])
         out.append(e)
+
+    def wgrad_full(x, dz, dw, N, H, W, C, K, stride):
+        """-> the launch closure under the CURRENT clhip_wgrad4_config (its scratch is sized for it)"""
+        nb = L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 3, stride, 1, code)
+        buf = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        return lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), buf.data_ptr(), N, H, W, C, C, K, 3, stride, 1, code, st)
 
     r18 = "resnet18" in workload
     shapes = ((32, 64, "conv4_kernel<4, 1, 1, 32, 32, 0>"), (16, 128, "conv4_kernel<4, 2, 1, 64, 32, 0>")) if r18 else ((8, 64, "conv4_kernel<2, 1, 2, 64, 8, 0>"),)
@@ -306,7 +321,7 @@ def conv_rooflines(dev, dtype, B, workload):
             entry("wgrad", [f"conv_wgrad4_kernel<{W}, 1, 3>", "wgrad3_reduce_kernel"], f"conv_wgrad4_kernel<{W},1,3> + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
                   N, H, W, C, K,
                   lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st),
-                  flops, M * (C + K) * es + K * 9 * C * 4, f"wgrad/{N}x{H}x{W}x{C}x{K}")
+                  flops, M * (C + K) * es + K * 9 * C * 4, f"wgrad/{N}x{H}x{W}x{C}x{K}", full_chip_run=lambda: wgrad_full(x, dz, dw, N, H, W, C, K, 1))
         entry("fwd", sym, f"{sym.replace(' ', '')} forward 3x3/s1 + BN-stat epilogue @ [{N},{H},{W},{C}] x [{K},3,3,{C}]", N, H, W, C, K,
               lambda: _lib.call("clhip_conv_fwd_acc", x.data_ptr(), w.data_ptr(), z.data_ptr(), acc.data_ptr(), 8, N, H, W, C, K, 3, 1, 1, code, st),
               flops, M * (C + K) * es + w.numel() * es, f"fwd/{N}x{H}x{W}x{C}x{K}")
@@ -322,7 +337,8 @@ def conv_rooflines(dev, dtype, B, workload):
         entry("wgrad", [f"conv_wgrad4_kernel<{W}, 2, 3>"], f"conv_wgrad4_kernel<{W},2,3> + wgrad3_reduce_kernel: dW of 3x3/s2 @ [{N},{H},{W},{C}] x [{N},{H // 2},{W // 2},{K}]",
               N, H, W, C, K,
               lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 2, 1, code, st),
-              2.0 * M2 * 9 * C * K, (N * H * W * C + M2 * K) * es + K * 9 * C * 4, f"wgrad_s2/{N}x{H}x{W}x{C}x{K}")
+              2.0 * M2 * 9 * C * K, (N * H * W * C + M2 * K) * es + K * 9 * C * 4, f"wgrad_s2/{N}x{H}x{W}x{C}x{K}",
+              full_chip_run=lambda: wgrad_full(x, dz, dw, N, H, W, C, K, 2))
     # largest share of the step's kernel time first (committed in-step trace); without a trace, the order above
     out.sort(key=lambda e: -e.get("in_step_share_of_kernel_time", 0.0))
     return out

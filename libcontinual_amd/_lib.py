@@ -122,6 +122,7 @@ _PROTOS = {
     "clhip_augment_rrc_flip": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_gemm5_config": (None, [_i]),
+    "clhip_wgrad4_config": (None, [_i]),
     "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_ln_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),

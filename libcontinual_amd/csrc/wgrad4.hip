@@ -48,6 +48,7 @@ struct Wgrad4Params {
 };
 
 unsigned long long* g_trace_w4 = nullptr;
+int g_target_w4 = 0;                      // clhip_wgrad4_config(): workgroup target of the next launches (0: the in-step default)
 #ifdef CLHIP_ABLATION
 #define STAMP4() do { if (p.trace && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && nstamp < 64) p.trace[(wave >> 2) * 64 + nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -312,7 +313,8 @@ bool geometry_sk(int N, int H, int W, int C, int K, Wgrad4Params& p) {
     // of the caller's stream, which is the critical path -- a launch that fills every CU (one workgroup each: 96 KB of LDS, 196 VGPRs)
     // costs the step more than its own 2 us (ResNet-18, batch 256: 2.66 ms per step at 256, 2.55 at 128-160; re-swept after the BatchNorm
     // kernels got shorter: 2.39 at 256, 2.28 at 160, 2.23 at 128-136, 2.26 at 104-112; profiles/r02_wgrad4_notes.md)
-    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 128;
+    static const int target_env = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 128;
+    const int target = g_target_w4 > 0 ? g_target_w4 : target_env;
     static const int min_steps = getenv("CLHIP_WGRAD4_MIN_STEPS") ? atoi(getenv("CLHIP_WGRAD4_MIN_STEPS")) : 2;
     int splits = (target + p.tiles - 1) / p.tiles;
     const int max_splits = (p.total_steps + min_steps - 1) / min_steps;
@@ -402,4 +404,5 @@ int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int
 }
 
 // phase stamps of workgroup 0 (ablation build only; tools/ubench/wgrad_bench trace)
+extern "C" void clhip_wgrad4_config(int target_workgroups) { g_target_w4 = target_workgroups > 0 ? target_workgroups : 0; }
 extern "C" void clhip_wgrad4_set_trace(unsigned long long* dev_buf) { g_trace_w4 = dev_buf; }
