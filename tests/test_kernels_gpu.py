@@ -542,6 +542,54 @@ def test_herding_at_benchmark_size(n, D, m):
     assert d_got <= 1.25 * d_ref + 1e-6
 
 
+@pytest.mark.parametrize("rep", [1, 2, 8, 16, 32, 64])
+@pytest.mark.parametrize("shape", [(5, 6, 6, 16), (3, 7, 9, 64), (3, 5, 5, 128), (2, 3, 3, 512), (2, 2, 3, 2048)])
+def test_batchnorm_accumulator_replicas(shape, rep):
+    """The consumers of the fp64 accumulators sum the replicas themselves: every replica count the plan can choose (1 .. 64), narrow layers
+    (2 C <= 128: the replicas are split over thread groups and combined through LDS) and wide ones (several channels per thread, more
+    than eight loads per chain), forward (scale / shift / saved statistics / running statistics) and backward (the two means, dgamma /
+    dbeta added ONCE) against fp64."""
+    N, H, W, C = shape
+    code, tdt = DT["bf16"]
+    M = N * H * W
+    z = quant(rnd((N, C, H, W), 40, 2.0) + 0.3, tdt)
+    dy = quant(rnd((N, C, H, W), 41), tdt)
+    gamma, beta = rnd((C,), 42) * 0.5 + 1.0, rnd((C,), 43) * 0.2
+    zd, dyd, gd, bd = to_nhwc(z, tdt), to_nhwc(dy, tdt), gamma.to(DEV), beta.to(DEV)
+    z2 = z.double().permute(0, 2, 3, 1).reshape(M, C)
+    full = torch.stack([z2.sum(0), (z2 * z2).sum(0)])
+    wts = torch.arange(1, rep + 1, dtype=torch.float64)
+    wts = wts / wts.sum()
+    acc = torch.stack([full * f for f in wts]).to(DEV)                              # [rep, 2, C]: the sums split unevenly over the replicas
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    y = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+    call("clhip_bn_apply_train", zd.data_ptr(), acc.data_ptr(), rep, M, C, gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
+         mean.data_ptr(), invstd.data_ptr(), None, y.data_ptr(), 1, code, st())
+    zr = z.double().clone().requires_grad_(True)
+    g64, b64 = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    rm64, rv64 = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    ybn = F.batch_norm(zr, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    yref = F.relu(ybn.detach())
+    assert (from_nhwc(y).double() - yref).abs().max() <= tol("bf16", yref)
+    assert torch.allclose(mean.cpu().double(), z2.mean(0), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rm.cpu().double(), rm64, rtol=1e-5, atol=1e-6) and torch.allclose(rv.cpu().double(), rv64, rtol=1e-4, atol=1e-6)
+    (ybn * (from_nhwc(y) > 0).double()).backward(dy.double())                      # the ReLU mask of the device's stored y, as above
+    for entry in ("pair", "zmask"):
+        bacc = torch.zeros(rep, 2, C, dtype=torch.float64, device=DEV)
+        dg, db = torch.full((C,), 0.5, device=DEV), torch.full((C,), -0.25, device=DEV)      # the launch ADDS to these
+        dz = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+        if entry == "pair":
+            call("clhip_bn_bwd_acc", dyd.data_ptr(), y.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), dg.data_ptr(),
+                 db.data_ptr(), dz.data_ptr(), None, 0, M, C, 1, bacc.data_ptr(), rep, code, st())
+        else:
+            call("clhip_bn_bwd_acc_zmask", dyd.data_ptr(), zd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), dg.data_ptr(),
+                 db.data_ptr(), dz.data_ptr(), M, C, bacc.data_ptr(), rep, code, st())
+        assert (from_nhwc(dz).double() - zr.grad).abs().max() <= tol("bf16", zr.grad) * 2
+        assert (dg.cpu().double() - 0.5 - g64.grad).abs().max() <= 2e-3 * (g64.grad.abs().max() + 1e-9) + 1e-4
+        assert (db.cpu().double() + 0.25 - b64.grad).abs().max() <= 2e-3 * (b64.grad.abs().max() + 1e-9) + 1e-4
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 @pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64, 3, 1), (4, 16, 16, 64, 128, 3, 2), (4, 8, 8, 32, 64, 1, 2), (16, 32, 32, 8, 16, 3, 1),
                                    (5, 32, 32, 8, 64, 3, 1), (3, 7, 5, 8, 32, 3, 1), (130, 32, 32, 8, 64, 3, 1),        # stem.hip (ragged last tile, odd image, many tiles per wave)
