@@ -53,31 +53,49 @@ __global__ void linear_bwd_dx_kernel(const float* __restrict__ dout, const float
     for (int o = 0; o < O; ++o) s = fmaf(dout[(size_t)b * O + o], w[(size_t)o * D + d], s);
     dx[idx] = acc ? dx[idx] + s : s;
 }
-// dw[o][d] (+)= sum_b dout[b][o] x[b][d] ; db[o] (+)= sum_b dout[b][o].  grid.y splits the batch; partial sums
-// are combined with fp32 atomics (dw / db zeroed by the launcher unless accumulating).
-__global__ void linear_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dw,
-                                     float* __restrict__ db, int B, int D, int O, int bchunk) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * D) return;
-    int o = idx / D, d = idx - o * D;
-    int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+// dw[o][d] (+)= sum_b dout[b][o] x[b][d] ; db[o] (+)= sum_b dout[b][o].  One workgroup = one output row o x 64 columns d; its four
+// waves take every fourth batch row (eight independent loads in flight each) and are summed through LDS in a fixed order: no atomics,
+// no zeroing launches, bitwise reproducible (the batch-split atomic version was the last fp32-atomic kernel of the ResNet step).
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dw,
+                                                            float* __restrict__ db, int B, int D, int O, int accumulate) {
+    __shared__ float red[4][64], redb[4];
+    const int dl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl, o = blockIdx.y;
+    const bool in = d < D;
     float s = 0.f, sb = 0.f;
-    for (int b = b0; b < b1; ++b) {
-        float g = dout[(size_t)b * O + o];
-        s = fmaf(g, x[(size_t)b * D + d], s);
-        sb += g;
+    for (int b0 = bg; b0 < B; b0 += 32) {
+        float g[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 4 * u;
+            g[u] = b < B ? dout[(size_t)b * O + o] : 0.f;
+            xv[u] = (b < B && in) ? x[(size_t)b * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s = fmaf(g[u], xv[u], s); sb += g[u]; }
     }
-    atomicAdd(dw + idx, s);
-    if (db != nullptr && d == 0) atomicAdd(db + o, sb);
+    red[bg][dl] = s;
+    if (dl == 0) redb[bg] = sb;
+    __syncthreads();
+    if (bg == 0) {
+        const float t = (red[0][dl] + red[1][dl]) + (red[2][dl] + red[3][dl]);
+        if (in) { float* q = dw + (size_t)o * D + d; *q = accumulate ? *q + t : t; }
+        if (db != nullptr && blockIdx.x == 0 && dl == 0) { const float tb = (redb[0] + redb[1]) + (redb[2] + redb[3]); db[o] = accumulate ? db[o] + tb : tb; }
+    }
 }
 
 // ---------------------------------------------------------------------------- CE on a column slice
-__global__ __launch_bounds__(256) void ce_slice_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B,
+// SINGLE: one workgroup of 16 waves walks all rows and writes (or adds to) the loss and the correct count itself, summed in a fixed
+// order -- no zeroing launches in front, no atomics, a reproducible loss value (batches of at most 512 rows: the training steps).
+template <bool SINGLE>
+__global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_slice_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B,
                                                        int O, int lo, int hi, int pred_lo, int pred_hi, float weight, float* loss_out,
-                                                       float* __restrict__ dlogits, int grad_acc, int64_t* pred, int32_t* correct) {
+                                                       float* __restrict__ dlogits, int grad_acc, int64_t* pred, int32_t* correct, int loss_acc) {
+    __shared__ float wl[16];
+    __shared__ int wc[16];
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
+    float my_loss = 0.f; int my_correct = 0;
+    for (int row = SINGLE ? (int)(threadIdx.x >> 6) : (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); row < B; row += SINGLE ? 16 : B) {
     const float* lr = logits + (size_t)row * O;
     const int y = (int)labels[row];
     // argmax over [pred_lo, pred_hi): first maximal index, as torch.argmax
@@ -108,9 +126,23 @@ __global__ __launch_bounds__(256) void ce_slice_kernel(const float* __restrict__
     }
     if (lane == 0) {
         float li = (y >= lo && y < hi) ? (lse - lr[y]) : 0.f;
-        atomicAdd(loss_out, weight * li / (float)B);
         if (pred) pred[row] = bi;
-        if (correct && bi == y) atomicAdd(correct, 1);
+        if (SINGLE) { my_loss += weight * li / (float)B; my_correct += bi == y ? 1 : 0; }
+        else {
+            atomicAdd(loss_out, weight * li / (float)B);
+            if (correct && bi == y) atomicAdd(correct, 1);
+        }
+    }
+    }
+    if (SINGLE) {
+        if (lane == 0) { wl[threadIdx.x >> 6] = my_loss; wc[threadIdx.x >> 6] = my_correct; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f; int c = 0;
+            for (int w = 0; w < 16; ++w) { t += wl[w]; c += wc[w]; }
+            *loss_out = loss_acc ? *loss_out + t : t;
+            if (correct) *correct = c;
+        }
     }
 }
 
@@ -380,13 +412,7 @@ extern "C" int clhip_linear_bwd(const float* x, const float* w, const float* dou
         hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST, dout, w, dx, B, D, O, 0);
         CLHIP_LAUNCH_CHECK();
     }
-    if (!accumulate) {
-        if (int e = zero_scalar(dw, sizeof(float) * (size_t)O * D, ST)) return e;
-        if (db) { if (int e = zero_scalar(db, sizeof(float) * (size_t)O, ST)) return e; }
-    }
-    int splits = B >= 64 ? 8 : 1;
-    int bchunk = (B + splits - 1) / splits;
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((O * D + 255) / 256, splits), dim3(256), 0, ST, dout, x, dw, db, B, D, O, bchunk);
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((D + 63) / 64, O), dim3(256), 0, ST, dout, x, dw, db, B, D, O, accumulate);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -396,10 +422,16 @@ extern "C" int clhip_ce_window(const float* logits, const int64_t* labels, int B
                                int32_t* correct, void* stream) {
     CLHIP_CHECK_ARG(logits && labels && loss_out && B > 0 && O > 0 && lo >= 0 && hi > lo && hi <= O);
     CLHIP_CHECK_ARG(pred_lo >= 0 && pred_hi > pred_lo && pred_hi <= O);
+    if (B <= 512) {
+        hipLaunchKernelGGL(ce_slice_kernel<true>, dim3(1), dim3(1024), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out,
+                           dlogits, grad_accumulate, pred, correct, loss_accumulate);
+        CLHIP_LAUNCH_CHECK();
+        return CLHIP_OK;
+    }
     if (!loss_accumulate) { if (int e = zero_scalar(loss_out, 4, ST)) return e; }
     if (correct) { if (int e = zero_scalar(correct, 4, ST)) return e; }
-    hipLaunchKernelGGL(ce_slice_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out,
-                       dlogits, grad_accumulate, pred, correct);
+    hipLaunchKernelGGL(ce_slice_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out,
+                       dlogits, grad_accumulate, pred, correct, loss_accumulate);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
