@@ -585,7 +585,11 @@ Cfg4 pick4(int M, int Cs, int Cd, int W) {
     auto tiles = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * (Cd / bn); };
     if (Cd % 128 == 0 && tiles(256, 128) >= 200) return Cfg4{4, 2, 1, 64};
     if (Cd % 128 == 0 && tiles(128, 128) >= 200 && (Cs / 32) % 2 == 0) return Cfg4{2, 2, 2, 32};
-    if (tiles(256, 64) >= 384) return Cfg4{4, 1, 1, 32};
+    if (tiles(256, 64) >= 256) return Cfg4{4, 1, 1, 32};
+    // few pixels (batch <= 128 on the 4x4 stage, <= 32 on the 8x8 one): 64-pixel tiles, the reduction split over four wave groups --
+    // these launches are one item per workgroup long and weight-streaming bound (4x4x512: 30 -> 20 us at batch 32 / 64; sweep of
+    // every configuration at batch 32 ... 256 in profiles/r02_small_batch_notes.md)
+    if (tiles(64, 64) <= 256 && (Cs / 32) % 4 == 0 && W <= 16) return Cfg4{1, 1, 4, 32};
     if (W <= 8 && tiles(128, 64) >= 128 && (Cs / 64) % 2 == 0) return Cfg4{2, 1, 2, 64};
     if ((Cs / 32) % 2 == 0) return Cfg4{2, 1, 2, 32};
     return Cfg4{2, 1, 1, 32};
