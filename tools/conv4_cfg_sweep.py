@@ -1,5 +1,7 @@
+"""conv4 configuration sweep over the four 3x3 / stride-1 layer shapes of ResNet-18 at a given batch:  python tools/conv4_cfg_sweep.py [batch]
+(forward through clhip_conv_fwd_acc and dgrad, every instantiated (WM, WN, KG, CK) through the clhip_conv4_set_cfg tuning hook; first column = pick4's choice)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from libcontinual_amd import _lib
 dev, tdt, code = "cuda", torch.bfloat16, _lib.BF16
