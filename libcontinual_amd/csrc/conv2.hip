@@ -83,7 +83,7 @@ template <typename T> __device__ __forceinline__ f32x4 mma2(const Chunk2<T>& wf,
 // on average instead of 9 with 75 % zero operands (the first version ran these three layers at 90 TFLOP/s).
 __device__ __forceinline__ int map_pixel(const ConvParams2& p, int BM, int row) {
     if (p.cls_tiles == 0) { int pix = blockIdx.x * BM + row; return pix < p.M ? pix : -1; }
-    const int cls = blockIdx.x / p.cls_tiles, tile = blockIdx.x - cls * p.cls_tiles;
+    const int cb = blockIdx.x / p.cls_tiles, cls = 3 - cb, tile = blockIdx.x - cb * p.cls_tiles;      // heaviest class first, see below
     const int h2 = p.Hd >> 1, w2 = p.Wd >> 1;
     const int q = tile * BM + row;
     if (q >= p.N * h2 * w2) return -1;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
     // parity-class tiles of the stride-2 dgrad are linear too: with h + pad = 2a + e (e fixed by the class) the contributing taps are
     // r = e + 2m and read source row a - m, i.e. "origin a, tap index m" with the same formula as stride 1
     const bool cls_mode = (MODE == 1) && p.cls_tiles > 0;
-    const int cls_id = cls_mode ? (int)(blockIdx.x / p.cls_tiles) : 0;
+    const int cls_id = cls_mode ? 3 - (int)(blockIdx.x / p.cls_tiles) : 0;
     const int e_h = cls_mode ? (((cls_id >> 1) + p.pad) & 1) : 0, e_w = cls_mode ? (((cls_id & 1) + p.pad) & 1) : 0;
     const bool lin = (MODE == 0) || (p.stride == 1) || cls_mode;
     long long a_off[AROWS];
@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvParams2 p) {
     // can contribute to this class
     unsigned tapmask = 0x1ff;
     if (p.cls_tiles > 0) {
-        const int cls = blockIdx.x / p.cls_tiles, ph = cls >> 1, pw = cls & 1;
+        // (the class with four taps, (1, 1), gets the lowest block indices: launched first, its tiles -- four times the work of the
+        //  one-tap class's -- do not form the tail of the launch)
+        const int cls = 3 - (int)(blockIdx.x / p.cls_tiles), ph = cls >> 1, pw = cls & 1;
         tapmask = 0;
         for (int t = 0; t < 9; ++t) {
             const int r = t / 3, s2 = t - 3 * r;
