@@ -73,6 +73,8 @@ CONV_CASES = [
     (2, 7, 5, 64, 64, 3, 1, 1),
     (130, 32, 32, 64, 64, 3, 1, 1),    # 512-pixel tiles (8 waves), ragged last tile
     (70, 16, 16, 128, 256, 3, 1, 1),   # 256x128 tiles
+    (70, 8, 8, 256, 256, 3, 1, 1),     # enough pixels for the two-group 128-pixel tiles (fewer take the four-group 64-pixel ones)
+    (130, 4, 4, 512, 512, 3, 1, 1),
     # step geometries of the LDS-DMA weight-gradient kernel (wgrad4.hip): 16 rows of an 8-wide image, four 4x8 images, two 8x4 images
     # per 128-pixel step, each with a ragged last step
     (3, 16, 8, 64, 64, 3, 1, 1),
