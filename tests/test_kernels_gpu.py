@@ -64,6 +64,7 @@ CONV_CASES = [
     (2, 9, 9, 128, 256, 1, 2, 0),
     (64, 32, 32, 16, 16, 3, 1, 1),     # M = 65536 -> the 128-row tile path
     (1, 1, 1, 16, 16, 3, 1, 1),        # single pixel
+    (6, 16, 16, 32, 32, 3, 1, 1),      # CifarResNet-32 stage 2 (32 -> 32 channels, 16-wide images)
     # shapes served by the halo kernel (conv3.hip: 3x3 s1, channels multiple of 64), incl. ragged tiles,
     # tiles spanning several images and every workgroup shape it picks
     (8, 32, 32, 64, 64, 3, 1, 1),
