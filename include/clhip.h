@@ -116,8 +116,15 @@ int clhip_bn_apply(const void* z, const float* scale, const float* shift, const 
 int clhip_bn_apply_train(const void* z, const double* stat_acc, int replicas, int64_t M, int C, const float* gamma, const float* beta, float* rm,
                          float* rv, float momentum, float eps, float* mean, float* invstd, const void* res /*nullable*/, void* y,
                          int relu, int dtype, void* stream);
+/* clhip_bn_apply_train with ReLU that also writes the packed ReLU mask the backward can read instead of y: relu_mask[M * C / 8] bytes,
+ * bit j of byte i = (stored y[8 i + j] > 0).  The mask of `out = F.relu(out + residual)` (resnet.py:316) costs the backward 1/16 of the
+ * bytes of the activation. */
+int clhip_bn_apply_train_mask(const void* z, const double* stat_acc, int replicas, int64_t M, int C, const float* gamma, const float* beta, float* rm,
+                              float* rv, float momentum, float eps, float* mean, float* invstd, const void* res /*nullable*/, void* y,
+                              void* relu_mask, int dtype, void* stream);
 /* clhip_bn_bwd with the two per-channel sums accumulated into acc[replicas][2][C] (fp64 atomics, zeroed by the caller) and
- * consumed directly by the apply pass: no partial buffer, no finalize launch */
+ * consumed directly by the apply pass: no partial buffer, no finalize launch.  relu: 0 none, 1 mask = (y > 0), 3: `y` points to the
+ * packed mask of clhip_bn_apply_train_mask. */
 int clhip_bn_bwd_acc(const void* dy, const void* y, const void* z, const float* mean, const float* invstd, const float* gamma,
                      float* dgamma, float* dbeta, void* dz, void* dres, int dres_accumulate, int64_t M, int C, int relu, double* acc,
                      int replicas, int dtype, void* stream);
@@ -127,7 +134,7 @@ int clhip_bn_bwd_acc_zmask(const void* dy, const void* z, const float* mean, con
                            float* dgamma, float* dbeta, void* dz, int64_t M, int C, double* acc, int replicas, int dtype, void* stream);
 /* The apply half alone: acc[replicas][2][C] already holds sum g and sum g * xhat -- accumulated by the launch that produced dy
  * (clhip_conv_dgrad_bn_reduce).  relu: 0 none, 1 mask = (y > 0), 2 mask recomputed from z, gamma, beta (then beta is required and
- * dres must be NULL).  Same arithmetic as the second launch of clhip_bn_bwd_acc (autograd of nn.BatchNorm2d + ReLU + residual add,
+ * dres must be NULL), 3: `y` points to the packed mask of clhip_bn_apply_train_mask.  Same arithmetic as the second launch of clhip_bn_bwd_acc (autograd of nn.BatchNorm2d + ReLU + residual add,
  * core/model/backbone/resnet.py:296-316). */
 int clhip_bn_bwd_apply_acc(const void* dy, const void* y /*nullable*/, const void* z, const float* mean, const float* invstd, const float* gamma,
                            const float* beta /*nullable*/, float* dgamma, float* dbeta, void* dz, void* dres /*nullable*/, int dres_accumulate,

@@ -62,6 +62,7 @@ _PROTOS = {
     "clhip_conv_fwd": (_i, [_p, _p, _p, _p] + [_i] * 9 + [_p]),
     "clhip_conv_fwd_acc": (_i, [_p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_bn_apply_train": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _i, _p]),
+    "clhip_bn_apply_train_mask": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
     "clhip_bn_bwd_acc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p]),
     "clhip_bn_bwd_acc_zmask": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _i, _i, _p]),
     "clhip_conv_dgrad": (_i, [_p, _p, _p, _i] + [_i] * 9 + [_p]),

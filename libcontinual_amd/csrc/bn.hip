@@ -120,14 +120,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const int64_t rstep = (int64_t)gridDim.x * rpi;
         for (int64_t r = (int64_t)blockIdx.x * rpi + ro; r < M; r += rstep * UN) {
             float g[UN][8], yy[UN][8], zz[UN][8];
+            unsigned mk[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
+                mk[u] = 0;
                 const int64_t ru = r + u * rstep;
                 if (ru < M) {
                     const int64_t off = ru * C + cc * 8;
                     load8<T>(dy + off, g[u]);
                     load8<T>(z + off, zz[u]);
                     if (RELU == 1) load8<T>(y + off, yy[u]);
+                    if (RELU == 3) mk[u] = reinterpret_cast<const unsigned char*>(y)[off >> 3];
                 }
             }
 #pragma unroll
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                     float gg = g[u][e];
                     if (RELU == 1) gg = yy[u][e] > 0.f ? gg : 0.f;
                     if (RELU == 2) gg = fmaf(zz[u][e], sc[e], sh[e]) > 0.f ? gg : 0.f;
+                    if (RELU == 3) gg = (mk[u] >> e) & 1u ? gg : 0.f;
                     a1[e] += gg;
                     a2[e] += gg * (zz[u][e] - mu[e]) * is[e];
                 }
@@ -230,6 +234,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// is the value, as it is stored in T, positive?  (bf16: a positive fp32 below half the smallest bf16 subnormal rounds to +0)
+template <typename T> __device__ __forceinline__ bool stored_positive(float v);
+template <> __device__ __forceinline__ bool stored_positive<float>(float v) { return v > 0.f; }
+template <> __device__ __forceinline__ bool stored_positive<bf16_t>(float v) { return v > 0.f && (pack_bf16x2(v, 0.f) & 0xffffu) != 0u; }
+
 // Sums of the fp64 accumulator replicas [rep][2][C] for the consumers' prologues: -> s1 (sum) and s2 (second sum) of channel c for the
 // threads c < C (c + 256 k for wide layers).  Every load of a thread is independent and issued before the first add, and with 2 C < 256
 // the replicas are split over 256 / (2 C) thread groups and combined through LDS: the serial loop this replaces made `rep` (16-32)
@@ -275,7 +284,8 @@ template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict__ z, const double* __restrict__ acc, int rep, double invM, double unbias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* rm, float* rv,
                                                              float momentum, float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
-                                                             const T* __restrict__ res, T* __restrict__ y, int64_t nchunks, int C) {
+                                                             const T* __restrict__ res, T* __restrict__ y, int64_t nchunks, int C,
+                                                             unsigned char* __restrict__ relu_mask = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: scale, shift
     // block-cooperative finalize: sum the accumulator replicas, derive scale / shift once per workgroup
     __shared__ double sred[256];
@@ -335,6 +345,13 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
                 v[u][e] = o;
             }
             store8<T>(y + iu * 8, v[u]);
+            if (RELU && relu_mask != nullptr) {
+                // bit e = (the STORED y > 0): the backward reads one byte per 8 elements instead of the 16 (32) bytes of y
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m |= (stored_positive<T>(v[u][e]) ? 1u : 0u) << e;
+                relu_mask[iu] = (unsigned char)m;
+            }
         }
     }
 }
@@ -383,13 +400,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
     constexpr int UN = sizeof(T) == 2 ? 4 : 2;
     for (int64_t i = i0; i < nchunks; i += stride * UN) {
         float g[UN][8], yy[UN][8], zz[UN][8], rr[UN][8];
+        unsigned mk[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
+            mk[u] = 0;
             const int64_t iu = i + u * stride;
             if (iu < nchunks) {
                 load8<T>(dy + iu * 8, g[u]);
                 load8<T>(z + iu * 8, zz[u]);
                 if (RELU == 1) load8<T>(y + iu * 8, yy[u]);
+                if (RELU == 3) mk[u] = reinterpret_cast<const unsigned char*>(y)[iu];
                 if (DRES == 2) load8<T>(dres + iu * 8, rr[u]);
             }
         }
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
                 float gg = g[u][e];
                 if (RELU == 1) gg = yy[u][e] > 0.f ? gg : 0.f;
                 if (RELU == 2) gg = fmaf(zz[u][e], gi[e], sh[e]) > 0.f ? gg : 0.f;
+                if (RELU == 3) gg = (mk[u] >> e) & 1u ? gg : 0.f;
                 const float xh = (zz[u][e] - mu[e]) * is[e];
                 o[e] = gi[e] * (gg - k0[e] - xh * k1[e]);
                 g[u][e] = gg;
@@ -718,13 +739,13 @@ static int acc_blocks(int64_t nchunks) {
 
 template <typename T>
 static int bn_apply_train_t(const void* z, const double* acc, int rep, int64_t M, const float* gamma, const float* beta, float* rm, float* rv, float momentum,
-                            float eps, float* mean, float* invstd, const void* res, void* y, int C, int relu, hipStream_t st) {
+                            float eps, float* mean, float* invstd, const void* res, void* y, int C, int relu, hipStream_t st, unsigned char* mask = nullptr) {
     const int64_t nch = M * C / 8;
     dim3 g(acc_blocks(nch)), b(256);
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const double invM = 1.0 / (double)M, unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
     const T* zz = (const T*)z; const T* rr = (const T*)res; T* yy = (T*)y;
-#define APPLY_TRAIN(R, L) hipLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, lds, st, zz, acc, rep, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C)
+#define APPLY_TRAIN(R, L) hipLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, lds, st, zz, acc, rep, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C, mask)
     if (res && relu) APPLY_TRAIN(true, true);
     else if (res) APPLY_TRAIN(true, false);
     else if (relu) APPLY_TRAIN(false, true);
@@ -745,6 +766,18 @@ extern "C" int clhip_bn_apply_train(const void* z, const double* stat_acc, int r
     return CLHIP_EINVAL;
 }
 
+extern "C" int clhip_bn_apply_train_mask(const void* z, const double* stat_acc, int replicas, int64_t M, int C, const float* gamma, const float* beta, float* rm,
+                                         float* rv, float momentum, float eps, float* mean, float* invstd, const void* res, void* y, void* relu_mask,
+                                         int dtype, void* stream) {
+    CLHIP_CHECK_ARG(z && stat_acc && gamma && beta && mean && invstd && y && relu_mask && M > 0 && acc_ok(C));
+    CLHIP_CHECK_ARG((rm == nullptr) == (rv == nullptr) && replicas >= 1 && replicas <= 64);
+    unsigned char* mk = static_cast<unsigned char*>(relu_mask);
+    if (dtype == CLHIP_BF16) return bn_apply_train_t<bf16_t>(z, stat_acc, replicas, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, 1, (hipStream_t)stream, mk);
+    if (dtype == CLHIP_F32) return bn_apply_train_t<float>(z, stat_acc, replicas, M, gamma, beta, rm, rv, momentum, eps, mean, invstd, res, y, C, 1, (hipStream_t)stream, mk);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
 // one-shot: the next accumulator-path backward apply launch completes this event (taken by the launch; see plan.hip)
 static thread_local hipEvent_t g_bn_stop_event = nullptr;
 void clhip_bn_set_stop_event(hipEvent_t ev) { g_bn_stop_event = ev; }
@@ -759,6 +792,7 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     size_t lds = (256 * 16 + 4 * (size_t)C) * sizeof(float);
     if (sums_ready) { /* the two channel sums were accumulated by the producer of dy (clhip_conv_dgrad_bn_reduce): apply pass only */ }
     else if (relu == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, gamma, beta);
+    else if (relu == 3) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 3>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
     else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
     CLHIP_LAUNCH_CHECK();
@@ -774,6 +808,7 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     g_bn_stop_event = nullptr;
 #define BWD_ACC(R, D) hipExtLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, (uint32_t)lds2, st, (hipEvent_t) nullptr, stop_ev, 0u, dyy, yy, zz, mean, invstd, gamma, (const double*)acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C, beta)
     if (relu == 2) { if (mode == 0) BWD_ACC(2, 0); else if (mode == 1) BWD_ACC(2, 1); else BWD_ACC(2, 2); }
+    else if (relu == 3) { if (mode == 0) BWD_ACC(3, 0); else if (mode == 1) BWD_ACC(3, 1); else BWD_ACC(3, 2); }
     else if (relu) { if (mode == 0) BWD_ACC(1, 0); else if (mode == 1) BWD_ACC(1, 1); else BWD_ACC(1, 2); }
     else { if (mode == 0) BWD_ACC(0, 0); else if (mode == 1) BWD_ACC(0, 1); else BWD_ACC(0, 2); }
 #undef BWD_ACC
@@ -812,7 +847,7 @@ extern "C" int clhip_bn_bwd_apply_acc(const void* dy, const void* y, const void*
                                       int relu, const double* acc, int replicas, int dtype, void* stream) {
     CLHIP_CHECK_ARG(dy && z && mean && invstd && gamma && dgamma && dbeta && dz && acc && M > 0 && acc_ok(C));
     CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
-    CLHIP_CHECK_ARG(relu >= 0 && relu <= 2 && (relu != 1 || y) && (relu != 2 || (beta && dres == nullptr)));
+    CLHIP_CHECK_ARG(relu >= 0 && relu <= 3 && ((relu != 1 && relu != 3) || y) && (relu != 2 || (beta && dres == nullptr)));
     double* a = const_cast<double*>(acc);
     if (dtype == CLHIP_BF16)
         return bn_bwd_acc_t<bf16_t>(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, dres, dres_accumulate, M, C, relu, a, replicas, (hipStream_t)stream, beta, true);

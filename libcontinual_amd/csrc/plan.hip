@@ -47,6 +47,7 @@ struct Unit {
     bool relu, pre_res, raw_src, no_bn;          // decoded CLHIP_UNIT_* bits of d.relu
     bool has_dzr;                                // this unit's raw sum is consumed raw (PRE_RES / RAW_SRC) by a later unit
     size_t dzr_off;                              // ... whose gradient contribution lands here (bytes into the workspace)
+    size_t mask_off;                             // packed ReLU mask of a conv -> BN -> +res -> ReLU unit (bytes into the workspace; 0: none)
     bool fuse_src_bn;                            // this unit's dgrad completes the gradient of its input activation AND can reduce the
                                                  // BatchNorm backward of the unit that produced it in its epilogue (clhip_conv_dgrad_bn_reduce)
 };
@@ -151,6 +152,14 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
             u.rep_fwd = replicas(clhip_add_stats_blocks(u.M, u.d.cout));
         }
         u.rep_bwd = (want_acc && pow2) ? replicas(clhip_bn_bwd_blocks(u.M, u.d.cout)) : 0;
+        // conv -> BN -> +residual -> ReLU units: the forward apply also writes one mask bit per element, and the two backward passes read
+        // that instead of the activation (1/16 of its bytes; CLHIP_BN_MASK_BITS=0: read y)
+        static const bool mask_bits = !(getenv("CLHIP_BN_MASK_BITS") && atoi(getenv("CLHIP_BN_MASK_BITS")) == 0);
+        u.mask_off = 0;
+        if (mask_bits && u.relu && u.d.res >= 0 && !u.pre_res && !u.no_bn && !u.raw_src && u.rep_fwd > 0 && u.rep_bwd > 0) {
+            u.mask_off = off;
+            off = align_up(off + (size_t)u.M * u.d.cout / 8);
+        }
         if (u.no_bn) u.rep_fwd = u.rep_bwd = 0;
         u.a_fwd = ndouble; ndouble += 2 * (size_t)u.d.cout * (u.rep_fwd > 0 ? u.rep_fwd : 1);
         u.a_bwd = ndouble; ndouble += 2 * (size_t)u.d.cout * (u.rep_bwd > 0 ? u.rep_bwd : 1);
@@ -419,9 +428,14 @@ extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* pa
             TRY(clhip_conv_fwd_acc(in, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
                                    u.d.stride, u.d.pad, p->dtype, stream));
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
-            TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
-                                     bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
-                                     ws + dst.y_off, u.relu, p->dtype, stream));
+            if (u.mask_off != 0)
+                TRY(clhip_bn_apply_train_mask(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
+                                              bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
+                                              ws + dst.y_off, ws + u.mask_off, p->dtype, stream));
+            else
+                TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
+                                         bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
+                                         ws + dst.y_off, u.relu, p->dtype, stream));
             continue;
         }
         float* part = training ? fr + p->f_part : nullptr;
@@ -521,17 +535,20 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
             // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
             const bool zmask = u.relu && dres == nullptr && !mask_from_y;
-            TRY(clhip_bn_bwd_apply_acc(ws + dst.dy_off, zmask ? nullptr : ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                                       params + u.d.beta_off, grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout,
-                                       zmask ? 2 : (u.relu ? 1 : 0), reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
+            const bool bits = !zmask && u.relu && u.mask_off != 0 && !mask_from_y;
+            TRY(clhip_bn_bwd_apply_acc(ws + dst.dy_off, zmask ? nullptr : (bits ? ws + u.mask_off : ws + dst.y_off), ws + u.z_off, fr + u.f_mean, fr + u.f_invstd,
+                                       params + u.d.gamma_off, params + u.d.beta_off, grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M,
+                                       u.d.cout, zmask ? 2 : (bits ? 3 : (u.relu ? 1 : 0)), reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd,
+                                       p->dtype, stream));
         } else if (u.rep_bwd > 0 && u.relu && dres == nullptr && !mask_from_y) {
             // ReLU straight after the BatchNorm (no residual in between): the mask is recomputed from z, y is not read
             TRY(clhip_bn_bwd_acc_zmask(ws + dst.dy_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off, params + u.d.beta_off,
                                        grads + u.d.gamma_off, grads + u.d.beta_off, dz, u.M, u.d.cout,
                                        reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else if (u.rep_bwd > 0) {
-            TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
-                                 grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, u.relu,
+            const bool bits = u.relu && u.mask_off != 0 && !mask_from_y;
+            TRY(clhip_bn_bwd_acc(ws + dst.dy_off, bits ? ws + u.mask_off : ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
+                                 grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, bits ? 3 : (int)u.relu,
                                  reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else {
             TRY(clhip_bn_bwd(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,

@@ -310,6 +310,31 @@ def test_batchnorm_fwd_bwd(shape, mode, relu, res):
     assert (db2.cpu().double() - b64.grad).abs().max() <= 2e-3 * (b64.grad.abs().max() + 1e-9) + 1e-4
     if res:
         assert (from_nhwc(dres2).double() - rr.grad).abs().max() <= tol(mode, rr.grad)
+    if relu:
+        # the packed ReLU mask (one bit per element, written by the forward apply) gives the backward the same mask as reading y
+        rm3, rv3 = rm0.clone().to(DEV), rv0.clone().to(DEV)
+        y3 = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+        bits = torch.zeros(M * C // 8, dtype=torch.uint8, device=DEV)
+        call("clhip_bn_apply_train_mask", zd.data_ptr(), acc.data_ptr(), REP, M, C, gd.data_ptr(), bd.data_ptr(), rm3.data_ptr(), rv3.data_ptr(), 0.1, 1e-5,
+             mean2.data_ptr(), invstd2.data_ptr(), rd.data_ptr() if res else None, y3.data_ptr(), bits.data_ptr(), code, st())
+        assert torch.equal(y3, y2)
+        want = (y2.reshape(-1, 8).float() > 0).to(torch.int32)
+        want = (want * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(1).to(torch.uint8)
+        assert torch.equal(bits, want)
+        outs = []
+        for code_relu, yptr in ((1, y2), (3, bits)):
+            bacc.zero_()
+            dgm, dbm = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dzm = torch.empty(N, H, W, C, dtype=tdt, device=DEV)
+            drm = torch.empty(N, H, W, C, dtype=tdt, device=DEV) if res else None
+            call("clhip_bn_bwd_acc", dyd.data_ptr(), yptr.data_ptr(), zd.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gd.data_ptr(), dgm.data_ptr(),
+                 dbm.data_ptr(), dzm.data_ptr(), drm.data_ptr() if res else None, 0, M, C, code_relu, bacc.data_ptr(), REP, code, st())
+            torch.cuda.synchronize()
+            outs.append((dzm.clone(), drm.clone() if res else None, dgm.cpu().clone(), dbm.cpu().clone()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        if res:
+            assert torch.equal(outs[0][1], outs[1][1])
+        assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-5) and torch.allclose(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-5)
     if relu and not res:
         # ReLU right after the BatchNorm: the mask recomputed from z (forward's own scale / shift expressions) is the mask read from y
         outs = []
