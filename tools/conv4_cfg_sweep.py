@@ -15,7 +15,7 @@ def timed(fn, reps=40):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-cfgs = [(0,0,0,0), (4,1,1,32), (2,1,1,32), (2,1,1,64), (2,1,2,32), (2,1,2,64), (2,2,1,32), (2,2,2,32), (4,2,1,64), (1,1,4,32), (1,1,4,64), (2,1,4,32), (2,1,4,64), (1,2,2,32), (1,2,4,32)]
+cfgs = [(0,0,0,0), (2,1,4,64), (4,1,1,32), (2,1,1,32), (2,1,1,64), (2,1,2,32), (2,1,2,64), (2,2,1,32), (2,2,2,32), (4,2,1,64), (1,1,4,32), (1,1,4,64), (2,1,4,32), (2,1,4,64), (1,2,2,32), (1,2,4,32)]
 print("batch", B, "cfgs", cfgs)
 for (H, C) in ((32, 64), (16, 128), (8, 256), (4, 512)):
     N, K = B, C
