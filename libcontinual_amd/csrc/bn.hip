@@ -790,6 +790,10 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     const int G = bn_bwd_blocks(M, C);
     const T* dyy = (const T*)dy; const T* yy = (const T*)y; const T* zz = (const T*)z;
     size_t lds = (256 * 16 + 4 * (size_t)C) * sizeof(float);
+    // the one-shot event is taken on entry: if the reduce launch below fails, it is dropped with the call instead of staying armed for an
+    // unrelated later call
+    hipEvent_t stop_ev = g_bn_stop_event;
+    g_bn_stop_event = nullptr;
     if (sums_ready) { /* the two channel sums were accumulated by the producer of dy (clhip_conv_dgrad_bn_reduce): apply pass only */ }
     else if (relu == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, gamma, beta);
     else if (relu == 3) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 3>), dim3(G), dim3(256), lds, st, dyy, yy, zz, mean, invstd, (float*)nullptr, acc, rep, M, C, (const float*)nullptr, (const float*)nullptr);
@@ -804,8 +808,6 @@ static int bn_bwd_acc_t(const void* dy, const void* y, const void* z, const floa
     int mode = dres == nullptr ? 0 : (dres_acc ? 2 : 1);
     // (plan.hip: the kernel's own completion signal is the event the weight-gradient stream waits for -- a separate hipEventRecord is a
     // marker packet in the caller's queue, ~5 us of bubble in front of the dgrad that follows)
-    hipEvent_t stop_ev = g_bn_stop_event;
-    g_bn_stop_event = nullptr;
 #define BWD_ACC(R, D) hipExtLaunchKernelGGL((bn_bwd_apply_acc_kernel<T, R, D>), g, b, (uint32_t)lds2, st, (hipEvent_t) nullptr, stop_ev, 0u, dyy, yy, zz, mean, invstd, gamma, (const double*)acc, rep, invM, dgamma, dbeta, dzz, dr, nch, C, beta)
     if (relu == 2) { if (mode == 0) BWD_ACC(2, 0); else if (mode == 1) BWD_ACC(2, 1); else BWD_ACC(2, 2); }
     else if (relu == 3) { if (mode == 0) BWD_ACC(3, 0); else if (mode == 1) BWD_ACC(3, 1); else BWD_ACC(3, 2); }

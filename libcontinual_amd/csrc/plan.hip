@@ -507,6 +507,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         }
         (void)hipEventCreateWithFlags(&p->ev_end, ev_flags);
     }
+    // whatever path leaves this function (an error return included), no armed one-shot event survives it
+    struct StopEventGuard { ~StopEventGuard() { clhip_bn_set_stop_event(nullptr); } } stop_event_guard;
     int k = 0;
     for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
         const Unit& u = p->units[i];

@@ -32,6 +32,24 @@ def _tag_backbones(params):
 
 class _FusedBase(torch.optim.Optimizer):
     grad_scale = 1.0
+    capture_safe = False        # may trainer.GraphedStep capture step() into a HIP graph?
+
+    def whole_backbones(self):
+        """the backbones this optimizer updates with ONE launch over their flat buffer (and whose `_dp_shard` it therefore honours):
+        every parameter of the backbone in one group, gradients attached to the flat gradient buffer"""
+        out = []
+        for group in self.param_groups:
+            out += self._split(group)[0]
+        return out
+
+    def _check_unconsumed_shards(self, rest):
+        """a reduce-scattered exchange leaves the summed gradient in the rank's shard only; a backbone that reaches the per-tensor
+        path would step on local, un-reduced gradients and the replicas would diverge silently"""
+        for p in rest:
+            o = _owner_of(p)
+            if o is not None and getattr(o, "_dp_shard", None) is not None:
+                raise RuntimeError("a reduce-scattered gradient shard was not consumed: the backbone's parameters are split across "
+                                   "param groups or partly frozen; use the all_reduce exchange (parallel.GradientReducer)")
 
     def _split(self, group):
         """-> (list of (owner) whose full parameter set is in this group with live flat grads, leftover params)"""
@@ -85,6 +103,8 @@ def _dp_plan(o):
 
 
 class SGD(_FusedBase):
+    capture_safe = True         # lr / momentum / weight decay are part of GraphedStep's key; everything else is a device pointer
+
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
         if dampening != 0 or nesterov:
             raise NotImplementedError("dampening / nesterov are not used by the reference configs")
@@ -95,6 +115,7 @@ class SGD(_FusedBase):
         for group in self.param_groups:
             lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
             whole, rest = self._split(group)
+            self._check_unconsumed_shards(rest)
             for o in whole:
                 require_gpu(o._flat)
                 st = self.state[o._params[0]]
@@ -141,6 +162,7 @@ class Adam(_FusedBase):
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
             whole, rest = self._split(group)
+            self._check_unconsumed_shards(rest)
             items, publish = [], []
             for o in whole:
                 parts, shard = _dp_plan(o)

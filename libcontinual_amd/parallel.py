@@ -61,6 +61,7 @@ class GradientReducer:
         if self.exchange not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"unknown data-parallel exchange {self.exchange!r}")
         self._early = {}          # id(backbone) -> (lowest element offset already handed to an async all-reduce, [works])
+        self.optimizer = None     # set by attach(): the sharded exchange needs to know which backbones the optimizer steps as a whole
 
     # ---- overlap of the exchange with the backward (ResNet-18: 75 % of the parameters sit in layer4, whose gradients are
     #      complete after the first quarter of the backward)
@@ -117,9 +118,17 @@ class GradientReducer:
         from .model.backbone.resnet import HipResNet
         buckets, rest = _flat_grad_buckets(module)
         owners = {m._gflat.data_ptr(): m for m in module.modules() if isinstance(m, HipResNet) and m._gflat is not None}
+        # only a backbone the attached optimizer updates with one launch over its flat buffer consumes `_dp_shard`; anything else
+        # (torch.optim fallback, a backbone split across param groups or partly frozen) would step on its LOCAL gradients: those
+        # buckets take the in-place all-reduce instead
+        whole = getattr(self.optimizer, "whole_backbones", None)
+        sharded_ok = {id(o) for o in whole()} if whole is not None else set()
         works = []
         for b in buckets:
             bb = owners[b.data_ptr()]
+            if id(bb) not in sharded_ok:
+                works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                continue
             n = b.numel()
             per, prefix = self.shard_bounds(n)
             shard = getattr(bb, "_dp_gshard", None)
@@ -191,6 +200,8 @@ def attach(model, optimizer, reducer):
     the trainer reduces after backward and the 1/world factor is folded into the fused optimizer step.  Returns True when
     the plugin owns the reduction."""
     own = reducer is not None and bool(getattr(model, "reduces_own_gradients", False))
+    if reducer is not None:
+        reducer.optimizer = optimizer
     if hasattr(model, "grad_reducer") or own:
         model.grad_reducer = reducer if own else None
     if hasattr(optimizer, "grad_scale"):

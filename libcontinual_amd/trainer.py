@@ -46,6 +46,18 @@ class GraphedStep:
 
     def __init__(self, model, optimizer, method_name):
         self.model, self.optimizer, self.method_name = model, optimizer, method_name
+        # the backbones whose flat parameter buffers the captured optimizer launches rewrite: a replay runs those launches on the
+        # device only, so the host-side "weights changed" mark (HipResNet.mark_params_modified, normally set by optimizer.step())
+        # has to be set here after every replay -- otherwise the next eager forward (validation, after_task) would skip the
+        # weight-preparation kernel and read bf16 / re-arranged copies that are one optimizer step stale
+        from .optim import _owner_of
+        owners = {}
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                o = _owner_of(p)
+                if o is not None:
+                    owners[id(o)] = o
+        self.owners = list(owners.values())
         self.graphs = {}            # key -> (graph, static inputs, (output, acc, loss))
         self.seen = {}              # key -> eager steps so far
         # every step of a graphed loop -- warm-up, capture, replay -- runs on this stream: autograd binds a parameter's gradient
@@ -76,7 +88,9 @@ class GraphedStep:
             if n < self.WARM:
                 self.seen[key] = n + 1
                 return self._step(batch)
-            static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            # static inputs live on the device: a host tensor here would put a pageable host-to-device copy inside the capture
+            dev = torch.device("cuda", torch.cuda.current_device())
+            static = {k: (v.to(dev, copy=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
@@ -89,20 +103,25 @@ class GraphedStep:
             if torch.is_tensor(v):
                 static[k].copy_(v, non_blocking=True)
         g.replay()
+        for o in self.owners:
+            o.mark_params_modified()
         output, acc, loss = out
         # the captured outputs are overwritten by the next replay: hand out copies (two tiny device copies, no synchronisation)
         acc = ops.Deferred(acc.tensor.clone(), acc.scale) if isinstance(acc, ops.Deferred) else acc
         return output, acc, loss.detach().clone()
 
 
-def _graph_mode(model, reducer, device):
-    """CLHIP_CUDA_GRAPH = 1: replay where legal; anything else: never.  Opt-in because it only pays when the HOST is the limit: with an
+def _graph_mode(model, reducer, device, optimizer=None):
+    """CLHIP_CUDA_GRAPH = 1: replay where legal; anything else: never.  Legal = single process, a plugin that declares
+    `cuda_graph_safe`, and an optimizer whose step is capture-safe (class attribute `capture_safe`: the fused SGD -- every argument of
+    its launches is a device pointer or a value covered by the graph key; the fused Adam passes its step count by value, torch.optim
+    fallbacks synchronise or allocate).  Opt-in because it only pays when the HOST is the limit: with an
     otherwise idle host the 32-image ResNet steps are bound by the GPU's own launch cadence (~250 dependent kernels of 3-8 us:
     eager 1.33 ms, replayed 1.41 ms in bench.py), while a loop that shares its process with a busy loader went 1.76 -> 1.34 ms
     (tools/graph_step.py; profiles/r02_small_batch_notes.md)"""
     env = os.environ.get("CLHIP_CUDA_GRAPH")
     legal = (device is not None and torch.device(device).type == "cuda" and reducer is None and getattr(model, "grad_reducer", None) is None
-             and getattr(model, "cuda_graph_safe", False))
+             and getattr(model, "cuda_graph_safe", False) and getattr(optimizer, "capture_safe", False))
     if not legal or env != "1":
         return None
     return "always"
@@ -112,11 +131,12 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
     """The per-batch hot path (core/trainer.py:585-612): observe -> zero_grad -> backward -> [grad all-reduce]
     -> step -> meters.  Shared by Trainer._train and bench.py so that the benchmark times exactly what
     training runs.  Loss / accuracy stay on the device (ops.Deferred): no host sync inside the loop.
-    Small per-GPU batches of graph-safe methods replay a captured HIP graph of the step (GraphedStep)."""
+    With CLHIP_CUDA_GRAPH=1, graph-safe methods under the fused SGD replay a captured HIP graph of the step (GraphedStep; opt-in,
+    see _graph_mode)."""
     on_gpu = device is not None and torch.device(device).type == "cuda"
     import contextlib
     overlap = reducer.overlap(model) if (reducer is not None and hasattr(reducer, "overlap")) else contextlib.nullcontext()
-    mode = _graph_mode(model, reducer, device)
+    mode = _graph_mode(model, reducer, device, optimizer)
     gs = None
     if mode is not None:
         gs = getattr(model, "_graphed_step", None)
@@ -128,7 +148,7 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
     with ops.deferred_metrics(on_gpu), overlap, (torch.cuda.stream(gs.stream) if gs is not None else contextlib.nullcontext()):
         for b, batch in enumerate(batches):
             batch["batch_id"] = b
-            if gs is not None and (mode == "always" or batch["label"].shape[0] <= GRAPH_MAX_BATCH):
+            if gs is not None:
                 gs.stream.wait_stream(caller)                  # loaders that produce their batches on the caller's stream
                 output, acc, loss = gs({k: v for k, v in batch.items() if k != "batch_id"})
             else:
@@ -147,9 +167,6 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
                 meter.update("loss", loss.detach() if on_gpu else loss.item())
     if gs is not None:
         caller.wait_stream(gs.stream)
-
-
-GRAPH_MAX_BATCH = 64      # above this the ResNet steps are GPU-bound and a replay buys nothing (measured: profiles/r02_small_batch_notes.md)
 
 
 class Trainer:

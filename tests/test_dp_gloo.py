@@ -82,8 +82,36 @@ def _worker(rank, world, port, q):
     m = red.mean_scalar(float(rank), "cpu")
     ok = ok and abs(m - 0.5) < 1e-12
     # ---- the sharded exchange: reduce-scatter -> update of this rank's shard only -> in-place all-gather of the flat parameters
+    from libcontinual_amd import optim as fused
     rs = parallel.GradientReducer(exchange="reduce_scatter")
     n = flat.numel()
+    # (a) ADVICE r2: an optimizer that does NOT step the backbone as one flat range (torch.optim fallback, or no optimizer attached)
+    #     would step on its local gradients after a reduce-scatter: those buckets take the in-place all-reduce instead
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    bb.attach_grads()
+    parallel.attach(net, torch.optim.SGD(net.parameters(), lr=0.1), rs)
+    rs.reduce(net)
+    ok = ok and getattr(bb, "_dp_shard", None) is None and torch.allclose(gflat * scale, want)
+    # (b) half of the backbone frozen-by-group: split across two param groups -> not "whole" -> all-reduce as well
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    ps = list(bb.parameters())
+    split_opt = fused.SGD([{"params": ps[:10]}, {"params": ps[10:] + list(head.parameters())}], lr=0.1)
+    parallel.attach(net, split_opt, rs)
+    ok = ok and split_opt.whole_backbones() == []
+    rs.reduce(net)
+    ok = ok and getattr(bb, "_dp_shard", None) is None and torch.allclose(gflat * scale, want)
+    # (c) the optimizer refuses a shard record it would not consume (second line of defence)
+    bb._dp_shard = dict(lo=0, hi=4, prefix=4, grad=gflat[:4].clone(), reducer=rs)
+    try:
+        split_opt._check_unconsumed_shards(ps)
+        ok = False
+    except RuntimeError:
+        pass
+    bb._dp_shard = None
+    # (d) the fused optimizer with the whole backbone in one group: the sharded path
+    whole_opt = fused.SGD(net.parameters(), lr=0.1)
+    parallel.attach(net, whole_opt, rs)
+    ok = ok and [id(o) for o in whole_opt.whole_backbones()] == [id(bb)]
     per, prefix = rs.shard_bounds(n)
     ok = ok and per % 4 == 0 and prefix == per * world and 0 <= n - prefix < 4 * world
     gflat.copy_((rank + 1) * pattern + 5.0)

@@ -94,3 +94,45 @@ def test_methods_that_are_not_graph_safe_stay_eager(monkeypatch):
     o = optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9)
     T.train_steps(m, o, _batches(4, 16), None, "LWF", None, "cuda")
     assert getattr(m, "_graphed_step", None) is None
+
+
+def test_evaluation_after_replayed_steps_sees_the_replayed_weights(monkeypatch):
+    """a replay runs the optimizer on the device only, so the host-side "weights changed" mark has to be set after it --
+    otherwise an eager forward that follows replays (validation, after_task) re-uses bf16 weight copies prepared BEFORE them.  Sequence
+    of the failure: evaluate (prep, version recorded) -> replays -> evaluate (prep skipped).  The logits of the second evaluation must
+    equal those of a fresh module holding the same fp32 master parameters."""
+    monkeypatch.setenv("CLHIP_CUDA_GRAPH", "1")
+    m = _make("lwf", 11)
+    o = optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    xe = _batches(1, 32)[0]
+    T.train_steps(m, o, _batches(4, 32), None, "LWF", None, "cuda")           # 2 eager warm-up steps, capture, 2 replays
+    m.eval()
+    with torch.no_grad():
+        f_mid = m.backbone(xe["image"])["features"].clone()                     # eager forward between replays: preps and records the version
+    m.train()
+    T.train_steps(m, o, _batches(5, 32), None, "LWF", None, "cuda")           # replays only (same key)
+    assert len(m._graphed_step.graphs) == 1
+    m.eval()
+    with torch.no_grad():
+        f_after = m.backbone(xe["image"])["features"].clone()
+    # reference: a second backbone object with the same master parameters / running statistics, its copies prepared from scratch
+    ref = M.resnet18(args={"dataset": "cifar100"}, dtype="bf16").to("cuda")
+    ref.load_state_dict(m.backbone.state_dict())
+    ref.eval()
+    with torch.no_grad():
+        f_ref = ref(xe["image"])["features"]
+    torch.cuda.synchronize()
+    assert torch.equal(f_after, f_ref)
+    assert not torch.equal(f_mid, f_after)                                       # (the five steps did move the weights)
+
+
+def test_adam_is_never_captured(monkeypatch):
+    """the fused Adam passes its step count to the kernel by value -- a capture would freeze the bias correction --, so only
+    optimizers that declare `capture_safe` (the fused SGD) may be graphed"""
+    monkeypatch.setenv("CLHIP_CUDA_GRAPH", "1")
+    m = _make("lwf", 12)
+    o = optim.Adam(m.get_parameters({}), lr=1e-3)
+    T.train_steps(m, o, _batches(5, 16), None, "LWF", None, "cuda")
+    assert getattr(m, "_graphed_step", None) is None
+    st = o.state[m.backbone._params[0]]
+    assert st["step"] == 5
