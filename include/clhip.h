@@ -204,6 +204,10 @@ int clhip_plan_prep_weights(clhip_plan*, const float* params, void* shadow, void
  * activations saved in `workspace` for clhip_plan_backward.                                           */
 int clhip_plan_forward(clhip_plan*, const float* x, const float* params, float* bn_stats, const void* shadow,
                        void* workspace, float* feat, int training, void* stream);
+/* the same with nn.BatchNorm2d's `num_batches_tracked += 1` (torch/nn/modules/batchnorm.py, one int64 counter per unit, slot i = unit i;
+ * nullable) folded into the forward's first launch when training != 0 -- no separate host-side add per step */
+int clhip_plan_forward_ex(clhip_plan*, const float* x, const float* params, float* bn_stats, const void* shadow,
+                          void* workspace, float* feat, int training, int64_t* num_batches_tracked, void* stream);
 /* dfeat: fp32 [N, feat_dim]; grads: flat fp32 buffer laid out like params, accumulated into (+=).      */
 int clhip_plan_backward(clhip_plan*, const float* dfeat, const float* params, const void* shadow, void* workspace,
                         float* grads, void* stream);
@@ -305,6 +309,28 @@ int clhip_herding_select(const float* feats /*[n,D], L2-normalised*/, int n, int
  *   K % 64 == 0, N % 4 == 0.                                                                                    */
 int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                   int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
+/* ---- run-time configuration ------------------------------------------------------------------------------------------------
+ * ONE entry point for every dispatch switch, tuning value and micro-benchmark hook of the library (there are no other steering
+ * exports).  `key` is a name from the list below (a leading "CLHIP_" is accepted), `value` its new value as text; value == NULL
+ * returns the switch to its default, which is the environment variable CLHIP_<key> if that is set and the built-in default
+ * otherwise.  Unknown keys fail with CLHIP_EINVAL.  Most switches are read once, at the first launch or plan creation that
+ * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
+ * pin a code path, tools/ to sweep.
+ *   dispatch (0 / 1 unless noted):
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: stride-2 3x3 layers stay on the generic implicit-GEMM kernel), CONV_V1,
+ *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
+ *     WGRAD_NO_TR, GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
+ *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
+ *     activations), BN_FUSE_MAX_M, BN_MASK_BITS, BN_MASK_FROM_Y, BN_ONEPASS, PREP_NARROW,
+ *     WGRAD_STREAM (0: weight gradients on the caller's stream), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD
+ *   tuning values:
+ *     WGRAD_TARGET (workgroups of the weight-gradient kernels), WGRAD_NET_GFLOP, WGRAD4_MIN_STEPS, WGRAD4_MIN_TOTAL, CONV3_CFG "wm,wn",
+ *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_CFG, CONV5_GRID, IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
+ *     STEM_WGRAD_GRID, SHORTCUT_MIN_PIXELS, BN_ACC_CPT, BN_BWD_ITERS
+ *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG,
+ *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE (device address of
+ *     a stamp buffer as a number; ablation builds only) */
+int clhip_config(const char* key, const char* value);
 /* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never, 1 where it wins (default: N >= 2048,
  * >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
 void clhip_gemm5_config(int mode);

@@ -92,6 +92,7 @@ _PROTOS = {
     "clhip_plan_feat_dim": (_i, [_p]),
     "clhip_plan_prep_weights": (_i, [_p, _p, _p, _p]),
     "clhip_plan_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "clhip_plan_forward_ex": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "clhip_plan_backward": (_i, [_p, _p, _p, _p, _p, _p, _p]),
     "clhip_plan_num_units": (_i, [_p]),
     "clhip_plan_backward_range": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
@@ -122,6 +123,7 @@ _PROTOS = {
     "clhip_augment_crop_flip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_augment_rrc_flip": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
+    "clhip_config": (_i, [C.c_char_p, C.c_char_p]),
     "clhip_gemm5_config": (None, [_i]),
     "clhip_wgrad4_config": (None, [_i]),
     "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

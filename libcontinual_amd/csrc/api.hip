@@ -1,4 +1,10 @@
-// api.hip -- error reporting and version of the C ABI (include/clhip.h).
+// api.hip -- error reporting, version and the run-time configuration of the C ABI (include/clhip.h).
+#include <map>
+#include <mutex>
+#include <string>
+#include <string.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -11,4 +17,76 @@ void clhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* clhip_last_error(void) { return g_err; }
-extern "C" int clhip_version(void) { return 100; }
+extern "C" int clhip_version(void) { return 101; }
+
+// ---- configuration: ONE documented entry point (clhip_config) instead of ad-hoc exports and scattered getenv calls.  Every switch
+//      has a name (the table below = the list in include/clhip.h); its value is what clhip_config() last set or, if never set, the
+//      environment variable CLHIP_<NAME> (kept so that an unmodified caller can still be steered from the shell).  Kernels look a
+//      switch up through clhip_cfg(); most look-ups are cached at their first use, so configure BEFORE the first launch / plan.
+namespace {
+const char* const kKeys[] = {
+    // dispatch switches (A/B runs, tests that pin a code path)
+    "ATTN_GENERIC", "BN_FUSE", "BN_FUSE_MAX_M", "BN_MASK_BITS", "BN_MASK_FROM_Y", "BN_PARTIALS", "CE_ROWS", "CONV3G", "CONV4", "CONV_V1",
+    "GEMM5", "GEMM_NO_SPLIT", "GEMM_TAIL", "NO_CONV16", "NO_CONV3", "NO_PARITY_DGRAD", "NO_SHORTCUT", "NO_STEM", "PREP_NARROW", "WGRAD4",
+    "WGRAD_NO_TR", "WGRAD_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "BN_ONEPASS", "WGRAD5", "WGRAD32",
+    // tuning values
+    "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
+    "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
+    "CONV5_CFG", "CONV5_GRID",
+    // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
+    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE",
+};
+std::mutex g_cfg_mu;
+// values are strdup'ed and never freed: look-up sites cache the pointer (a few bytes per clhip_config call, by design)
+std::map<std::string, const char*>& cfg_map() { static std::map<std::string, const char*> m; return m; }
+bool known_key(const char* k) {
+    for (const char* q : kKeys) if (strcmp(q, k) == 0) return true;
+    return false;
+}
+}  // namespace
+
+// hooks that take effect at once (defined next to the kernels they steer)
+void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck);
+void clhip_conv4_enable(int on);
+void clhip_conv4_set_debug(int bits);
+void clhip_conv4_set_trace(unsigned long long* dev_buf);
+void clhip_gemm5_set_debug(int bits);
+void clhip_gemm5_set_trace(unsigned long long* dev_buf);
+void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
+
+const char* clhip_cfg(const char* name) {
+    {
+        std::lock_guard<std::mutex> lk(g_cfg_mu);
+        auto it = cfg_map().find(name);
+        if (it != cfg_map().end()) return it->second;
+    }
+    char env[96];
+    snprintf(env, sizeof(env), "CLHIP_%s", name);
+    return getenv(env);
+}
+
+extern "C" int clhip_config(const char* key, const char* value) {
+    CLHIP_CHECK_ARG(key != nullptr);
+    if (strncmp(key, "CLHIP_", 6) == 0) key += 6;
+    if (!known_key(key)) { clhip_set_error("clhip_config: unknown switch '%s'", key); return CLHIP_EINVAL; }
+    const char* v = value ? value : "";
+    if (strcmp(key, "CONV4_FORCE_CFG") == 0) {
+        int c[4] = {0, 0, 0, 0};
+        if (value && sscanf(value, "%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3]) != 4) { clhip_set_error("clhip_config: CONV4_FORCE_CFG wants \"wm,wn,kg,ck\""); return CLHIP_EINVAL; }
+        clhip_conv4_set_cfg(c[0], c[1], c[2], c[3]);
+        return CLHIP_OK;
+    }
+    if (strcmp(key, "CONV4_ENABLE") == 0) { clhip_conv4_enable(value ? atoi(v) : -1); return CLHIP_OK; }
+    if (strcmp(key, "CONV4_DEBUG") == 0) { clhip_conv4_set_debug(atoi(v)); return CLHIP_OK; }
+    if (strcmp(key, "GEMM5_DEBUG") == 0) { clhip_gemm5_set_debug(atoi(v)); return CLHIP_OK; }
+    if (strcmp(key, "CONV4_TRACE") == 0) { clhip_conv4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
+    if (strcmp(key, "GEMM5_TRACE") == 0) { clhip_gemm5_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
+    if (strcmp(key, "WGRAD4_TRACE") == 0) { clhip_wgrad4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
+    if (value == nullptr) {
+        cfg_map().erase(key);                 // back to the environment's value
+    } else {
+        cfg_map()[key] = strdup(value);
+    }
+    return CLHIP_OK;
+}

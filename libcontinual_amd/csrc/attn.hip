@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(AttnParams p, int
 
 bool force_generic() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("CLHIP_ATTN_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) { const char* e = clhip_cfg("ATTN_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
 

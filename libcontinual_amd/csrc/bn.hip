@@ -442,7 +442,7 @@ int bn_bwd_blocks(int64_t M, int C) {
     int64_t g = (M + rpi - 1) / rpi;
     // up to 8 iterations per block, but small tensors (batch 32, the 8x8 / 4x4 layers) keep 128+ workgroups: with 32 of them the
     // kernel sat at its latency floor on a mostly idle chip; cap so the finalize reduction stays short
-    static const int forced = getenv("CLHIP_BN_BWD_ITERS") ? atoi(getenv("CLHIP_BN_BWD_ITERS")) : 0;      // ablation runs
+    static const int forced = clhip_cfg("BN_BWD_ITERS") ? atoi(clhip_cfg("BN_BWD_ITERS")) : 0;      // ablation runs
     int64_t iters = forced > 0 ? forced : g / 128;
     if (iters < 1) iters = 1;
     if (iters > 8) iters = 8;
@@ -729,7 +729,7 @@ extern "C" int clhip_bn_bwd(const void* dy, const void* y, const void* z, const 
 static bool acc_ok(int C) { return C >= 8 && C <= 2048 && (C & (C - 1)) == 0; }
 // fewer, longer workgroups than the plain elementwise kernels: every workgroup pays the cooperative finalize prologue
 static int acc_blocks(int64_t nchunks) {
-    static const int cpt = getenv("CLHIP_BN_ACC_CPT") ? atoi(getenv("CLHIP_BN_ACC_CPT")) : 8;      // chunks per thread (swept 1..32: 8)
+    static const int cpt = clhip_cfg("BN_ACC_CPT") ? atoi(clhip_cfg("BN_ACC_CPT")) : 8;      // chunks per thread (swept 1..32: 8)
     int64_t b = (nchunks + 256 * cpt - 1) / (256 * cpt);
     if (b < 512) { b = (nchunks + 255) / 256; if (b > 512) b = 512; }      // small layers: fill the chip first
     if (b > 4096) b = 4096;

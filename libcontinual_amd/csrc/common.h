@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 void clhip_set_error(const char* fmt, ...);
+const char* clhip_cfg(const char* name);      // api.hip: value of a configuration switch (clhip_config(), else $CLHIP_<name>), nullptr if unset
 
 #define CLHIP_CHECK_ARG(cond)                                                          \
     do {                                                                               \

@@ -471,11 +471,11 @@ bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ks
 size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K, int ksize, int stride);
 int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int K, int ksize, int stride, hipStream_t st);
 static bool use_v3() {
-    static const bool v = getenv("CLHIP_NO_CONV3") == nullptr;    // A/B switch: halo kernel for 3x3 stride-1 layers
+    static const bool v = clhip_cfg("NO_CONV3") == nullptr;    // A/B switch: halo kernel for 3x3 stride-1 layers
     return v;
 }
 static bool use_v1() {
-    static const bool v = getenv("CLHIP_CONV_V1") != nullptr;     // A/B switch: first-generation kernel
+    static const bool v = clhip_cfg("CONV_V1") != nullptr;     // A/B switch: first-generation kernel
     return v;
 }
 
@@ -651,7 +651,7 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* 
     if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_wgrad16_launch(x, dz, dw, static_cast<float*>(ws), N, H, st);
     if (!use_v1()) return clhip_wgrad2_launch(x, dz, dw, N, H, W, C, Creal, K, ksize, stride, pad, dtype, st);
-    static const bool no_tr = getenv("CLHIP_WGRAD_NO_TR") != nullptr;
+    static const bool no_tr = clhip_cfg("WGRAD_NO_TR") != nullptr;
     if (dtype == CLHIP_BF16) {
         if (no_tr) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);

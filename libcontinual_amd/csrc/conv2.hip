@@ -330,7 +330,7 @@ struct TileCfg { int bm, bn; };
 
 // candidate shapes, largest pixel tile first for each channel width
 TileCfg pick_tile(int M, int Cd) {
-    static const char* force = getenv("CLHIP_IGEMM_TILE");      // "bm,bn" (ablation runs)
+    static const char* force = clhip_cfg("IGEMM_TILE");      // "bm,bn" (ablation runs)
     if (force) { int bm = 0, bn = 0; if (sscanf(force, "%d,%d", &bm, &bn) == 2 && bm > 0 && bn > 0 && bn <= Cd) return TileCfg{bm, bn}; }
     int bn = Cd >= 128 ? 128 : (Cd >= 64 ? 64 : (Cd >= 32 ? 32 : 16));
     int gy = (Cd + bn - 1) / bn;
@@ -401,7 +401,7 @@ int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats,
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.log2Cs = ilog2_exact(Cs); p.Hd = Hd; p.Wd = Wd; p.Cd = Cd;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.M = N * Hd * Wd; p.K = ksize * ksize * Cs;
-    static const bool nocls = getenv("CLHIP_NO_PARITY_DGRAD") != nullptr;
+    static const bool nocls = clhip_cfg("NO_PARITY_DGRAD") != nullptr;
     p.cls_tiles = (!nocls && mode == 1 && stride == 2 && ksize == 3 && Cs >= 32 && p.log2Cs >= 0 && (Hd % 2 == 0) && (Wd % 2 == 0)) ? 1 : 0;
     if (dtype == CLHIP_BF16) return mode == 0 ? launch2<bf16_t, 0>(p, st) : launch2<bf16_t, 1>(p, st);
     return mode == 0 ? launch2<float, 0>(p, st) : launch2<float, 1>(p, st);
@@ -581,8 +581,8 @@ int launch_wgrad_cfg(WgradParams2& p, hipStream_t st) {
     int gx = (p.J + BJ - 1) / BJ, gy = (p.K + BO - 1) / BO;
     int tiles = gx * gy;
     int max_splits = (p.M + 255) / 256;            // >= 4 K-steps per workgroup
-    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 256;     // measured: 256 beats 128 / 512 / 1536 on every stride-2 / 1x1 / stem shape (atomic contention vs parallelism)
-    static const int dbg = getenv("CLHIP_WGRAD_DEBUG") ? atoi(getenv("CLHIP_WGRAD_DEBUG")) : 0;
+    static const int target = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 256;     // measured: 256 beats 128 / 512 / 1536 on every stride-2 / 1x1 / stem shape (atomic contention vs parallelism)
+    static const int dbg = clhip_cfg("WGRAD_DEBUG") ? atoi(clhip_cfg("WGRAD_DEBUG")) : 0;
     p.debug = dbg;
     int splits = (target + tiles - 1) / tiles;
     if (splits > max_splits) splits = max_splits;

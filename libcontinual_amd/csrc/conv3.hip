@@ -689,7 +689,7 @@ int launch3(Conv3Params& p, hipStream_t st) {
     p.np = BM + 2 * p.W + 2;
     p.patch_bytes = ((p.np + 1) * PITCH + 255) / 256 * 256;       // + the zero row
     p.nbuf = 1;
-    static const int gmode = getenv("CLHIP_CONV3G") ? atoi(getenv("CLHIP_CONV3G")) : 0;     // 0: register-staged weights everywhere
+    static const int gmode = clhip_cfg("CONV3G") ? atoi(clhip_cfg("CONV3G")) : 0;     // 0: register-staged weights everywhere
     const bool use_g = gmode == 2 || (gmode == 1 && p.M <= 32768);   // LDS-DMA weight ring: correct, not faster yet (r01 profiles) -> opt-in
     size_t lds = (size_t)p.patch_bytes + (use_g ? 4 * (size_t)BN * 128 : 2 * (size_t)BN * PITCH);
     size_t olds = (size_t)BM * (BN * 2 + 16);
@@ -711,7 +711,7 @@ int launch3(Conv3Params& p, hipStream_t st) {
 
 struct Cfg3 { int wm, wn; };
 Cfg3 pick3(int M, int Cd) {
-    static const char* ov = getenv("CLHIP_CONV3_CFG");       // tuning override "wm,wn"
+    static const char* ov = clhip_cfg("CONV3_CFG");       // tuning override "wm,wn"
     if (ov) { int a = 0, b = 0; if (sscanf(ov, "%d,%d", &a, &b) == 2 && (b == 1 || (b == 2 && Cd >= 128))) return Cfg3{a, b}; }
     // 4-wave workgroups of ~57 KB LDS: two of them share a CU, so one workgroup's patch load / output store
     // overlaps the other's MFMA phase (a single 8-wave workgroup per CU ran load -> compute -> store serially).
@@ -730,7 +730,7 @@ Cfg3 pick3(int M, int Cd) {
 }  // namespace
 
 bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
-    static const bool off = getenv("CLHIP_NO_CONV16") != nullptr;
+    static const bool off = clhip_cfg("NO_CONV16") != nullptr;
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == Cd && (Cs == 16 || Cs == 32) && W <= 64 && W >= 2 && H >= 1;
 }
 
@@ -767,7 +767,7 @@ int clhip_conv3_launch(const void* src, const void* wt, void* dst, float* stats,
     Conv3Params p;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1; p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = Cs; p.Cd = Cd; p.accumulate = accumulate; p.M = N * H * W;
-    static const int dbg = getenv("CLHIP_CONV3_DEBUG") ? atoi(getenv("CLHIP_CONV3_DEBUG")) : 0;
+    static const int dbg = clhip_cfg("CONV3_DEBUG") ? atoi(clhip_cfg("CONV3_DEBUG")) : 0;
     p.debug = dbg;
     Cfg3 c = pick3(p.M, Cd);
 #define L3(a, b) (mode == 0 ? launch3<a, b, 0>(p, st) : launch3<a, b, 1>(p, st))
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
 }  // namespace
 
 bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
-    static const bool off = getenv("CLHIP_NO_CONV16") != nullptr;
+    static const bool off = clhip_cfg("NO_CONV16") != nullptr;
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 16 && Creal == 16 && K == 16 && W == 32 && H >= 1 && H <= 64 && N >= 1;
 }
 
@@ -1062,7 +1062,7 @@ static void wgrad3_geometry(int N, int H, int W, int C, int K, Wgrad3Params& p, 
     p.npatch = p.nimg * (p.R + 2) * (W + 2);
     int tiles = (C / 64) * (K / 64);
     int total_steps = (p.M + 63) / 64;
-    static const int target = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 256;
+    static const int target = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 256;
     splits = (target + tiles - 1) / tiles;
     int max_splits = (total_steps + 7) / 8;              // >= 8 steps per workgroup
     if (splits > max_splits) splits = max_splits;

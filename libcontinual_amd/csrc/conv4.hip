@@ -566,7 +566,7 @@ int launch4(Conv4Params& p, hipStream_t st) {
     const int wave_cap = 8 / (NWG * KG) > 0 ? 8 / (NWG * KG) : 1;           // <= 2 waves per SIMD
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
-    static const int force_grid = getenv("CLHIP_CONV4_GRID") ? atoi(getenv("CLHIP_CONV4_GRID")) : 0;
+    static const int force_grid = clhip_cfg("CONV4_GRID") ? atoi(clhip_cfg("CONV4_GRID")) : 0;
     int grid = 256 * per_cu;
     if (force_grid > 0) grid = force_grid;
     if (KG > 1 || grid > p.n_items) grid = p.n_items;
@@ -579,7 +579,7 @@ int launch4(Conv4Params& p, hipStream_t st) {
 // profiles/r02_conv4_sweep.txt): fill the 256 CUs first, then prefer 8-wave workgroups (staggered read / MFMA phases) and
 // 64-channel slabs (16 MFMAs per wave between two ring barriers).
 Cfg4 pick4(int M, int Cs, int Cd, int W) {
-    static const char* ov = getenv("CLHIP_CONV4_CFG");       // tuning override "wm,wn,kg,ck"
+    static const char* ov = clhip_cfg("CONV4_CFG");       // tuning override "wm,wn,kg,ck"
     if (g_force4[0] > 0) return Cfg4{g_force4[0], g_force4[1], g_force4[2], g_force4[3]};
     if (ov) { Cfg4 c{0, 0, 0, 0}; if (sscanf(ov, "%d,%d,%d,%d", &c.wm, &c.wn, &c.kg, &c.ck) == 4) return c; }
     auto tiles = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * (Cd / bn); };
@@ -606,7 +606,7 @@ bool cfg_ok(const Cfg4& c, int Cs, int Cd) {
 }  // namespace
 
 bool clhip_conv4_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
-    static const bool on = getenv("CLHIP_CONV4") ? atoi(getenv("CLHIP_CONV4")) != 0 : true;
+    static const bool on = clhip_cfg("CONV4") ? atoi(clhip_cfg("CONV4")) != 0 : true;
     if (g_enable4 >= 0 ? g_enable4 == 0 : !on) return false;
     if (!(dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && (Cs % 64) == 0 && (Cd % 64) == 0 && W <= 32 && W >= 2 && H >= 1)) return false;
     // the patch DMA marks rejected slots with a 1 GiB offset: the gathered tensor has to stay well below that
@@ -667,7 +667,7 @@ int clhip_conv4_launch_bn(const void* src, const void* wt, void* dst, float* sta
 }
 
 // ---- tuning hooks (tools/ubench/conv_bench.cpp; not part of include/clhip.h)
-extern "C" void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck) { g_force4[0] = wm; g_force4[1] = wn; g_force4[2] = kg; g_force4[3] = ck; }
-extern "C" void clhip_conv4_enable(int on) { g_enable4 = on; }
-extern "C" void clhip_conv4_set_debug(int bits) { g_debug4 = bits; }
-extern "C" void clhip_conv4_set_trace(unsigned long long* dev_buf) { g_trace4 = dev_buf; }
+void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck) { g_force4[0] = wm; g_force4[1] = wn; g_force4[2] = kg; g_force4[3] = ck; }
+void clhip_conv4_enable(int on) { g_enable4 = on; }
+void clhip_conv4_set_debug(int bits) { g_debug4 = bits; }
+void clhip_conv4_set_trace(unsigned long long* dev_buf) { g_trace4 = dev_buf; }

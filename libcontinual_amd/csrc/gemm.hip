@@ -391,7 +391,7 @@ template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launc
 // CLHIP_GEMM_MT forces 2 (64 x 64), 4, 5 or 8 (256 x 256, 8 waves).
 int pick_tile(int M, int N) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("CLHIP_GEMM_MT"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) { const char* e = clhip_cfg("GEMM_MT"); forced = e ? atoi(e) : 0; }
     if (forced == 2 || forced == 4 || forced == 5 || forced == 8) return forced;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 < 256) return 2;
@@ -418,7 +418,7 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
         // Narrow outputs with a long K (the ViT's N = 768 GEMMs, 36 % of an InfLoRA step): 256 x 256 tiles are 30 % faster per
         // tile (891 vs 647 TFLOP/s at K = 3072) but 297 of them on 256 CUs take two rounds.  Run exactly one round of 256 x 256
         // tiles on the leading rows and hand the remaining rows to the small-tile kernels (a second, short launch).
-        static const bool no_split = getenv("CLHIP_GEMM_NO_SPLIT") != nullptr || getenv("CLHIP_GEMM_MT") != nullptr;
+        static const bool no_split = clhip_cfg("GEMM_NO_SPLIT") != nullptr || clhip_cfg("GEMM_MT") != nullptr;
         if (allow_split && !no_split && p.N % 256 == 0 && p.K >= 2304) {
             const int tn = p.N / 256;
             const long t256 = (long)((p.M + 255) / 256) * tn;
@@ -439,7 +439,7 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
         // short K, wide N (qkv / fc1 / the fc2 activation gradient, K = 768): the last of the 3.5 - 4.6 rounds of 256 x 256 tiles is
         // poorly filled.  Whole rounds of big tiles run on the leading rows, the remaining rows on the small tiles (qkv forward
         // 151.7 -> 139.0 us; CLHIP_GEMM_TAIL=0 disables).  Only when the last round is < 160 of 256 tiles: a fuller one costs more as small tiles.
-        static const bool tail_split = !(getenv("CLHIP_GEMM_TAIL") != nullptr && atoi(getenv("CLHIP_GEMM_TAIL")) == 0);
+        static const bool tail_split = !(clhip_cfg("GEMM_TAIL") != nullptr && atoi(clhip_cfg("GEMM_TAIL")) == 0);
         if (allow_split && tail_split && !no_split && p.N % 256 == 0 && pick_tile(p.M, p.N) == 8) {
             const int tn = p.N / 256;
             const long t256 = (long)((p.M + 255) / 256) * tn;
@@ -497,7 +497,7 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
     if (epilogue == EPI_BIAS_RES) CLHIP_CHECK_ARG(R != nullptr && ldr % 4 == 0);
     if (epilogue == EPI_MUL) CLHIP_CHECK_ARG(H != nullptr);
     if (H) CLHIP_CHECK_ARG(ldh % 4 == 0);
-    static const int gm_env = getenv("CLHIP_GEMM_GROUP_M") ? atoi(getenv("CLHIP_GEMM_GROUP_M")) : 0;
+    static const int gm_env = clhip_cfg("GEMM_GROUP_M") ? atoi(clhip_cfg("GEMM_GROUP_M")) : 0;
     GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, gm_env > 0 ? gm_env : (N >= 4096 ? 4 : 1)};     // wide outputs: 8192^3 991 -> 1046 TFLOP/s; the ViT shapes (N <= 3072) are indifferent
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (clhip_gemm5_supported(M, N, K, lda, ldb, ldc, ldr, ldh, dtype))

@@ -309,7 +309,7 @@ int launch5(const Gemm5Params& p, hipStream_t st) {
         }
         attr = true;
     }
-    static const int force_grid = getenv("CLHIP_GEMM5_GRID") ? atoi(getenv("CLHIP_GEMM5_GRID")) : 0;
+    static const int force_grid = clhip_cfg("GEMM5_GRID") ? atoi(clhip_cfg("GEMM5_GRID")) : 0;
     int grid = force_grid > 0 ? force_grid : 256;
     if (grid > (p.items + 7) / 8 * 8) grid = (p.items + 7) / 8 * 8;
     grid = (grid + 7) / 8 * 8;
@@ -326,7 +326,7 @@ int launch5(const Gemm5Params& p, hipStream_t st) {
 // mode 0 disables it.  CLHIP_GEMM5 / clhip_gemm5_config.
 static int g_mode5 = -1;
 bool clhip_gemm5_supported(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype) {
-    if (g_mode5 < 0) g_mode5 = getenv("CLHIP_GEMM5") ? atoi(getenv("CLHIP_GEMM5")) : 1;
+    if (g_mode5 < 0) g_mode5 = clhip_cfg("GEMM5") ? atoi(clhip_cfg("GEMM5")) : 1;
     if (g_mode5 == 0 || dtype != CLHIP_BF16) return false;
     if (N % 256 != 0 || K % 32 != 0 || K < 128 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldr % 4 != 0 || ldh % 8 != 0) return false;
     if ((long long)M * lda * 2 >= (1ll << 31) || (long long)N * ldb * 2 >= (1ll << 31)) return false;
@@ -355,5 +355,5 @@ int clhip_gemm5_launch(const void* A, const void* B, void* C, const float* bias,
 }
 
 // phase stamps of workgroup 0 (ablation build only; tools/ubench/gemm_bench trace)
-extern "C" void clhip_gemm5_set_trace(unsigned long long* dev_buf) { g_trace5 = dev_buf; }
-extern "C" void clhip_gemm5_set_debug(int bits) { g_debug5 = bits; }
+void clhip_gemm5_set_trace(unsigned long long* dev_buf) { g_trace5 = dev_buf; }
+void clhip_gemm5_set_debug(int bits) { g_debug5 = bits; }

@@ -146,6 +146,102 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_slice_kernel(const flo
     }
 }
 
+
+// ---- the training steps' form (B <= 512 rows, O <= 16 * NC columns): ONE workgroup of 1024 threads = 64 sixteen-lane groups, a group
+// owns rows g, g + 64, ...; a row's logits are loaded ONCE into registers (NC per lane) -- all of a group's rows up front, so the loads
+// of every row are in flight together -- and argmax / max / sum-exp are 16-lane butterflies.  The one-wave-per-row form above walked
+// 16 rows per wave with three dependent passes over memory per row: 40 us for 256 x 50 logits (profiles/r02_bench_kernel_stats_*),
+// this one: profiles/r03_small_kernels.md.  Loss and correct count are still summed in a fixed order (per group over its rows, then a
+// 64-value butterfly): reproducible, no atomics, no zeroing launches.
+template <int NC, int RPG>
+__global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B, int O, int lo, int hi,
+                                                       int pred_lo, int pred_hi, float weight, float* loss_out, float* __restrict__ dlogits, int grad_acc,
+                                                       int64_t* pred, int32_t* correct, int loss_acc) {
+    __shared__ float gl[64];
+    __shared__ int gc[64];
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    float v[RPG][NC];
+    int yy[RPG];
+#pragma unroll
+    for (int i = 0; i < RPG; ++i) {
+        const int row = grp + 64 * i;
+        const bool rv = row < B;
+        yy[i] = rv ? (int)labels[row] : -1;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = l16 + 16 * j;
+            v[i][j] = (rv && c < O) ? logits[(size_t)row * O + c] : 0.f;
+        }
+    }
+    float my_loss = 0.f; int my_correct = 0;
+    const float sc = weight / (float)B;
+#pragma unroll
+    for (int i = 0; i < RPG; ++i) {
+        const int row = grp + 64 * i;
+        if (row >= B) continue;                                   // uniform over the 16-lane group
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = l16 + 16 * j;
+            if (c >= pred_lo && c < pred_hi && v[i][j] > bv) { bv = v[i][j]; bi = c; }      // ascending c: the first maximum stays
+            if (c >= lo && c < hi) mx = fmaxf(mx, v[i][j]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 16); const int oi = __shfl_xor(bi, o, 16);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        }
+        float e[NC], se = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = l16 + 16 * j;
+            e[j] = (c >= lo && c < hi) ? expf(v[i][j] - mx) : 0.f;
+            se += e[j];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
+        const float lse = mx + logf(se);
+        const int y = yy[i];
+        if (dlogits != nullptr) {
+            float* dr = dlogits + (size_t)row * O;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = l16 + 16 * j;
+                if (c >= O) continue;
+                const bool in = c >= lo && c < hi;
+                const float g = in ? sc * (expf(v[i][j] - lse) - (c == y ? 1.f : 0.f)) : 0.f;
+                if (grad_acc) { if (in) dr[c] += g; }
+                else dr[c] = g;
+            }
+        }
+        // the label's logit sits in lane y & 15, register y >> 4
+        float ly = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) if (l16 + 16 * j == y) ly = v[i][j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ly += __shfl_xor(ly, o, 16);
+        if (l16 == 0) {
+            const float li = (y >= lo && y < hi) ? (lse - ly) : 0.f;
+            if (pred) pred[row] = bi;
+            my_loss += weight * li / (float)B;
+            my_correct += bi == y ? 1 : 0;
+        }
+    }
+    if (l16 == 0) { gl[grp] = my_loss; gc[grp] = my_correct; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = gl[threadIdx.x]; int c = gc[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o, 64); c += __shfl_xor(c, o, 64); }
+        if (threadIdx.x == 0) {
+            *loss_out = loss_acc ? *loss_out + t : t;
+            if (correct) *correct = c;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- KD
 __global__ __launch_bounds__(256) void kd_kernel(const float* __restrict__ pred, int ps, const float* __restrict__ soft, int ss, int B,
                                                  int k, float invT, float weight, float* loss_out, float* __restrict__ dpred, int grad_acc) {
@@ -422,6 +518,17 @@ extern "C" int clhip_ce_window(const float* logits, const int64_t* labels, int B
                                int32_t* correct, void* stream) {
     CLHIP_CHECK_ARG(logits && labels && loss_out && B > 0 && O > 0 && lo >= 0 && hi > lo && hi <= O);
     CLHIP_CHECK_ARG(pred_lo >= 0 && pred_hi > pred_lo && pred_hi <= O);
+    static const bool rows_off = clhip_cfg("CE_ROWS") != nullptr && atoi(clhip_cfg("CE_ROWS")) == 0;      // A/B switch: the one-wave-per-row form
+    if (B <= 512 && (O <= 128 || (O <= 256 && B <= 256)) && !rows_off) {      // (16 columns x 8 rows per lane would spill)
+#define CE_ROWS(NC, RPG) hipLaunchKernelGGL((ce_rows_kernel<NC, RPG>), dim3(1), dim3(1024), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out, \
+                                            dlogits, grad_accumulate, pred, correct, loss_accumulate)
+        const int rpg = (B + 63) / 64;
+        if (O <= 128) { if (rpg <= 1) CE_ROWS(8, 1); else if (rpg <= 2) CE_ROWS(8, 2); else if (rpg <= 4) CE_ROWS(8, 4); else CE_ROWS(8, 8); }
+        else { if (rpg <= 1) CE_ROWS(16, 1); else if (rpg <= 2) CE_ROWS(16, 2); else CE_ROWS(16, 4); }
+#undef CE_ROWS
+        CLHIP_LAUNCH_CHECK();
+        return CLHIP_OK;
+    }
     if (B <= 512) {
         hipLaunchKernelGGL(ce_slice_kernel<true>, dim3(1), dim3(1024), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out,
                            dlogits, grad_accumulate, pred, correct, loss_accumulate);

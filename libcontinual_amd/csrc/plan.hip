@@ -100,7 +100,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     // what it costs (measured: +5..9 us per kernel with 1024 producers on ONE accumulator), so a layer gets one replica per
     // ~64 producer workgroups (blockIdx & (rep-1)); the consumers sum the replicas in a block-cooperative prologue.
     // CLHIP_BN_PARTIALS=1 restores the partial-row + finalize path.
-    const bool want_acc = getenv("CLHIP_BN_PARTIALS") == nullptr;
+    const bool want_acc = clhip_cfg("BN_PARTIALS") == nullptr;
     auto replicas = [](int producers) { int r = 1; while (r < 32 && producers > 64 * r) r <<= 1; return r; };
     p->use_acc = false;
     for (int i = 0; i < n_units; ++i) {
@@ -154,7 +154,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         u.rep_bwd = (want_acc && pow2) ? replicas(clhip_bn_bwd_blocks(u.M, u.d.cout)) : 0;
         // conv -> BN -> +residual -> ReLU units: the forward apply also writes one mask bit per element, and the two backward passes read
         // that instead of the activation (1/16 of its bytes; CLHIP_BN_MASK_BITS=0: read y)
-        static const bool mask_bits = !(getenv("CLHIP_BN_MASK_BITS") && atoi(getenv("CLHIP_BN_MASK_BITS")) == 0);
+        static const bool mask_bits = !(clhip_cfg("BN_MASK_BITS") && atoi(clhip_cfg("BN_MASK_BITS")) == 0);
         u.mask_off = 0;
         if (mask_bits && u.relu && u.d.res >= 0 && !u.pre_res && !u.no_bn && !u.raw_src && u.rep_fwd > 0 && u.rep_bwd > 0) {
             u.mask_off = off;
@@ -211,7 +211,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         p->feat_dim = pool_win > 0 ? last.C * (last.H / pool_win) * (last.W / pool_win) : last.C;
     }
     {
-        const double net_flops = 1.0e9 * (getenv("CLHIP_WGRAD_NET_GFLOP") ? atof(getenv("CLHIP_WGRAD_NET_GFLOP")) : 4.0);
+        const double net_flops = 1.0e9 * (clhip_cfg("WGRAD_NET_GFLOP") ? atof(clhip_cfg("WGRAD_NET_GFLOP")) : 4.0);
         p->side_ok = false;
         for (const Unit& u : p->units)
             if (2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout >= net_flops) p->side_ok = true;
@@ -233,9 +233,9 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     // Default: fused for activations of at most 16384 pixels (the 8x8 / 4x4 stages at batch 256, everything at batch 32), where the reduce
     // pass is a launch at its latency floor (7-9 us) and the epilogue's extra work is small: 2.321 -> 2.305 ms per step.  CLHIP_BN_FUSE=0:
     // never; =1: every qualifying layer (CLHIP_BN_FUSE_MAX_M bounds the pixels).  Read per plan: tests build both variants.
-    const char* fe = getenv("CLHIP_BN_FUSE");
+    const char* fe = clhip_cfg("BN_FUSE");
     const bool fuse_on = fe == nullptr || atoi(fe) != 0;
-    const long long fuse_max_m = getenv("CLHIP_BN_FUSE_MAX_M") ? atoll(getenv("CLHIP_BN_FUSE_MAX_M")) : (fe == nullptr ? 16384 : (1ll << 62));
+    const long long fuse_max_m = clhip_cfg("BN_FUSE_MAX_M") ? atoll(clhip_cfg("BN_FUSE_MAX_M")) : (fe == nullptr ? 16384 : (1ll << 62));
     p->bwd_sums_ready.assign(p->units.size(), 0);
     for (int i = 0; i < n_units; ++i) {
         Unit& u = p->units[i];
@@ -369,7 +369,7 @@ extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void*
         t.n = 0;
         unsigned blocks = 0;
         bool wide = p->dtype == CLHIP_BF16;
-        static const bool no_wide = getenv("CLHIP_PREP_NARROW") != nullptr;
+        static const bool no_wide = clhip_cfg("PREP_NARROW") != nullptr;
         for (size_t j = i; j < p->units.size() && j < i + kPrepMax; ++j)
             wide = wide && !no_wide && p->units[j].d.cout % 4 == 0 && p->units[j].cin_pad % 4 == 0 && p->units[j].sh_fwd % 8 == 0 && p->units[j].sh_dg % 8 == 0;
         const int tb = wide ? 64 : 32;
@@ -389,19 +389,67 @@ extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void*
     return CLHIP_OK;
 }
 
+// The first launch of a forward: NCHW fp32 -> NHWC compute dtype (channels zero-padded) and, in the same grid, the two pieces of
+// per-step housekeeping that used to be launches of their own -- zeroing the fp64 BatchNorm accumulators (was a hipMemsetAsync =
+// a fillBufferAligned kernel per step) and `num_batches_tracked += 1` of every BatchNorm (was a torch add<long> kernel per step).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void plan_prologue_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int Cpad, unsigned layout_blocks,
+                                                            uint4* __restrict__ acc, size_t acc_n16, long long* __restrict__ nbt, unsigned long long nbt_mask_lo,
+                                                            unsigned long long nbt_mask_hi, int n_units) {
+    if (blockIdx.x >= layout_blocks) {
+        const size_t i0 = (size_t)(blockIdx.x - layout_blocks) * 256 * 4 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const size_t i = i0 + (size_t)k * 256; if (i < acc_n16) acc[i] = make_uint4(0, 0, 0, 0); }
+        return;
+    }
+    if (nbt != nullptr && blockIdx.x == 0)
+        for (int u = threadIdx.x; u < n_units; u += 256)
+            if ((u < 64 ? (nbt_mask_lo >> u) : (nbt_mask_hi >> (u - 64))) & 1ull) nbt[u] += 1;
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (int64_t)N * HW) return;
+    const int n = (int)(pix / HW), hw = (int)(pix - (int64_t)n * HW);
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? x[((size_t)n * C + c0 + e) * HW + hw] : 0.f;
+        store8<T>(y + pix * Cpad + c0, v);
+    }
+}
+}  // namespace
+
 extern "C" int clhip_plan_forward(clhip_plan* p, const float* x, const float* params, float* bn_stats, const void* shadow,
                                   void* workspace, float* feat, int training, void* stream) {
+    return clhip_plan_forward_ex(p, x, params, bn_stats, shadow, workspace, feat, training, nullptr, stream);
+}
+
+extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float* params, float* bn_stats, const void* shadow,
+                                     void* workspace, float* feat, int training, int64_t* num_batches_tracked, void* stream) {
     CLHIP_CHECK_ARG(p && x && params && bn_stats && shadow && workspace && feat);
+    CLHIP_CHECK_ARG(num_batches_tracked == nullptr || p->units.size() <= 128);
     char* ws = static_cast<char*>(workspace);
     const char* sh = static_cast<const char*>(shadow);
     float* fr = reinterpret_cast<float*>(ws + p->f_base);
-    TRY(clhip_nchw_to_nhwc(x, ws + p->acts[0].y_off, p->N, p->Cin, p->H, p->W, p->Cin_pad, p->dtype, stream));
     double* acc = reinterpret_cast<double*>(ws + p->acc_off);
     const bool use_acc = training && p->use_acc;
     std::fill(p->bwd_sums_ready.begin(), p->bwd_sums_ready.end(), 0);
-    if (use_acc && hipMemsetAsync(acc, 0, p->acc_bytes, (hipStream_t)stream) != hipSuccess) {
-        clhip_set_error("clhip_plan_forward: hipMemsetAsync failed");
-        return CLHIP_EHIP;
+    {
+        const int64_t npix = (int64_t)p->N * p->H * p->W;
+        const unsigned lb = (unsigned)((npix + 255) / 256);
+        const size_t n16 = use_acc ? p->acc_bytes / 16 : 0;                       // acc_bytes is a multiple of 16 (2 * cout doubles per replica, cout % 16 == 0)
+        const unsigned ab = (unsigned)((n16 + 1023) / 1024);
+        unsigned long long mlo = 0, mhi = 0;                                      // units that own a BatchNorm (the counter array has one slot per unit)
+        for (size_t i = 0; i < p->units.size() && i < 128; ++i)
+            if (!p->units[i].no_bn) { if (i < 64) mlo |= 1ull << i; else mhi |= 1ull << (i - 64); }
+        long long* nbt = training ? reinterpret_cast<long long*>(num_batches_tracked) : nullptr;
+        uint4* a16 = reinterpret_cast<uint4*>(acc);
+        if (p->dtype == CLHIP_BF16)
+            hipLaunchKernelGGL(plan_prologue_kernel<bf16_t>, dim3(lb + ab), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<bf16_t*>(ws + p->acts[0].y_off), p->N, p->Cin,
+                               p->H * p->W, p->Cin_pad, lb, a16, n16, nbt, mlo, mhi, (int)p->units.size());
+        else
+            hipLaunchKernelGGL(plan_prologue_kernel<float>, dim3(lb + ab), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<float*>(ws + p->acts[0].y_off), p->N, p->Cin,
+                               p->H * p->W, p->Cin_pad, lb, a16, n16, nbt, mlo, mhi, (int)p->units.size());
+        CLHIP_LAUNCH_CHECK();
     }
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
@@ -481,7 +529,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     // The weight gradients hang off the backward chain (BN backward -> dgrad -> next unit) as leaves: they run on a second stream,
     // so their kernels fill the load / store phases of the chain's kernels instead of queueing behind them.  dz is double-buffered;
     // events order  BN backward(i) -> wgrad(i)  and  wgrad(i) -> BN backward(i-2) (same dz buffer).  CLHIP_WGRAD_STREAM=0: one stream.
-    static const bool two_streams_env = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
+    static const bool two_streams_env = !(clhip_cfg("WGRAD_STREAM") && atoi(clhip_cfg("WGRAD_STREAM")) == 0);
     hipStream_t main_s = static_cast<hipStream_t>(stream);
     // inside a stream capture (trainer.GraphedStep: small, host-bound batches) everything stays on the captured stream: the fork /
     // join of a second stream gains nothing at those sizes, and ROCm 7.2 crashed in hipStreamEndCapture on it
@@ -493,12 +541,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         // queues have workgroups ready the dispatcher should serve the caller's stream (dgrad, BatchNorm backward) first
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        static const bool flat = getenv("CLHIP_SIDE_PRIO") != nullptr && atoi(getenv("CLHIP_SIDE_PRIO")) == 0;
+        static const bool flat = clhip_cfg("SIDE_PRIO") != nullptr && atoi(clhip_cfg("SIDE_PRIO")) == 0;
         const hipError_t e = flat ? hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_lo);
         if (e != hipSuccess) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
         // the events order two streams of ONE device: no timing, and no system-scope fence (the default flags make every record a cache
         // write-back + invalidate in the middle of the caller's stream; CLHIP_EVENT_FLAGS overrides the flag word)
-        static const unsigned ev_flags = getenv("CLHIP_EVENT_FLAGS") ? (unsigned)strtoul(getenv("CLHIP_EVENT_FLAGS"), nullptr, 0)
+        static const unsigned ev_flags = clhip_cfg("EVENT_FLAGS") ? (unsigned)strtoul(clhip_cfg("EVENT_FLAGS"), nullptr, 0)
                                                                       : (hipEventDisableTiming | hipEventDisableSystemFence);
         for (int k = 0; k < 2; ++k) {
             (void)hipEventCreateWithFlags(&p->ev_dz[k], ev_flags);
@@ -525,12 +573,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipStreamWaitEvent(main_s, p->ev_wg[k], 0);         // the weight gradient of two units ago has finished reading this buffer
             p->wg_pending[k] = false;
         }
-        static const bool mask_from_y = getenv("CLHIP_BN_MASK_FROM_Y") != nullptr;       // ablation: always read the activation
+        static const bool mask_from_y = clhip_cfg("BN_MASK_FROM_Y") != nullptr;       // ablation: always read the activation
         // the weight gradient goes to the side stream (see below): let the BatchNorm apply launch -- the last writer of dz -- complete the
         // event itself instead of recording one behind it
         const double wg_flops = 2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout;
         const bool on_side = two_streams && p->side_ok && wg_flops >= 1.0e9;
-        static const bool ev_in_launch = getenv("CLHIP_EVENT_RECORD") == nullptr;
+        static const bool ev_in_launch = clhip_cfg("EVENT_RECORD") == nullptr;
         const bool hook = on_side && ev_in_launch && !u.no_bn && u.rep_bwd > 0 && !u.has_dzr;
         if (hook) clhip_bn_set_stop_event(p->ev_dz[k]);
         if (u.no_bn) {
@@ -573,7 +621,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipStreamWaitEvent(p->side, p->ev_dz[k], 0);
             wg_stream = p->side;
         } else if (two_streams && (p->wg_pending[0] || p->wg_pending[1]) &&
-                   (getenv("CLHIP_WGRAD_ALWAYS_QUEUE") != nullptr ||
+                   (clhip_cfg("WGRAD_ALWAYS_QUEUE") != nullptr ||
                     clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0)) {
             // this unit's weight gradient shares the partial-sum scratch with the ones in flight on the side stream: queue behind them
             // (the atomic kernels -- the stem -- use no scratch and run beside the side stream's tail instead of behind it)

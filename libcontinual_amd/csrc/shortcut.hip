@@ -107,8 +107,8 @@ int launch_short(const ShortParams& p, bool accumulate, hipStream_t st) {
 
 // 1x1, stride 2, pad 0, even image, bf16, channel counts multiples of 64, at least 8192 output pixels (CLHIP_SHORTCUT_MIN_PIXELS)
 bool clhip_shortcut_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
-    static const bool off = getenv("CLHIP_NO_SHORTCUT") != nullptr;
-    static const long long min_px = getenv("CLHIP_SHORTCUT_MIN_PIXELS") ? atoll(getenv("CLHIP_SHORTCUT_MIN_PIXELS")) : 8192;
+    static const bool off = clhip_cfg("NO_SHORTCUT") != nullptr;
+    static const long long min_px = clhip_cfg("SHORTCUT_MIN_PIXELS") ? atoll(clhip_cfg("SHORTCUT_MIN_PIXELS")) : 8192;
     return !off && dtype == CLHIP_BF16 && ksize == 1 && stride == 2 && pad == 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0 && K % 64 == 0 && N >= 1 &&
            (long long)N * (H / 2) * (W / 2) >= min_px && (long long)N * H * W * (C > K ? C : K) * 2 < (1ll << 31);
 }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const StemWParams p) {
 int stem_wgrad_grid(int M) {
     const int nstep = (M + 31) / 32;
     int grid = (nstep + 15) / 16;                            // >= 4 steps per wave
-    static const int cap = getenv("CLHIP_STEM_WGRAD_GRID") ? atoi(getenv("CLHIP_STEM_WGRAD_GRID")) : 256;
+    static const int cap = clhip_cfg("STEM_WGRAD_GRID") ? atoi(clhip_cfg("STEM_WGRAD_GRID")) : 256;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     return grid;
@@ -225,7 +225,7 @@ int stem_wgrad_grid(int M) {
 int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);      // conv3.hip
 
 bool clhip_stem_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
-    static const bool off = getenv("CLHIP_NO_STEM") != nullptr;
+    static const bool off = clhip_cfg("NO_STEM") != nullptr;
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 8 && Creal >= 1 && Creal <= 8 && (K == 16 || K == 32 || K == 64) &&
            (K * 9 * Creal) % 4 == 0 && N >= 1 && (long long)N * H * W >= 2048;
 }
@@ -243,7 +243,7 @@ int clhip_stem_wgrad_launch(const void* x, const void* dz, float* dw, float* ws,
 }
 
 bool clhip_stem_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
-    static const bool off = getenv("CLHIP_NO_STEM") != nullptr;
+    static const bool off = clhip_cfg("NO_STEM") != nullptr;
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 8 && (K == 16 || K == 32 || K == 64) && N >= 1 && H >= 1 && W >= 1;
 }
 
@@ -251,7 +251,7 @@ int clhip_stem_launch(const void* x, const void* w, void* z, double* acc, int re
     StemParams p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), static_cast<bf16_t*>(z), acc, rep > 0 ? rep : 1, N, H, W, K, N * H * W};
     const int ntile = (p.M + 63) / 64;
     int grid = (ntile + 3) / 4;
-    static const int cap = getenv("CLHIP_STEM_GRID") ? atoi(getenv("CLHIP_STEM_GRID")) : 512;      // two tiles per wave at batch 256: 17.9 -> 15.9 us (64 features)
+    static const int cap = clhip_cfg("STEM_GRID") ? atoi(clhip_cfg("STEM_GRID")) : 512;      // two tiles per wave at batch 256: 17.9 -> 15.9 us (64 features)
     if (grid > cap) grid = cap;
     if (K == 16) hipLaunchKernelGGL(conv_stem_kernel<1>, dim3(grid), dim3(256), 0, st, p);
     else if (K == 32) hipLaunchKernelGGL(conv_stem_kernel<2>, dim3(grid), dim3(256), 0, st, p);

@@ -219,7 +219,7 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
     const int D = d.dim, Hm = d.mlp, M = L.M, N = L.N, B = L.B, dt = v->dtype;
     char* g = ws + L.g;
     // the lora_B gradients are leaves of the chain: they run on a side stream (ordered by events against the single dqkv buffer)
-    static const bool two_streams = !(getenv("CLHIP_WGRAD_STREAM") && atoi(getenv("CLHIP_WGRAD_STREAM")) == 0);
+    static const bool two_streams = !(clhip_cfg("WGRAD_STREAM") && atoi(clhip_cfg("WGRAD_STREAM")) == 0);
     hipStream_t main_s = static_cast<hipStream_t>(stream);
     const bool side_on = two_streams && d_lora_b != nullptr;
     if (side_on && !v->side) {

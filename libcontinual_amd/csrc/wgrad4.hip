@@ -313,9 +313,9 @@ bool geometry_sk(int N, int H, int W, int C, int K, Wgrad4Params& p) {
     // of the caller's stream, which is the critical path -- a launch that fills every CU (one workgroup each: 96 KB of LDS, 196 VGPRs)
     // costs the step more than its own 2 us (ResNet-18, batch 256: 2.66 ms per step at 256, 2.55 at 128-160; re-swept after the BatchNorm
     // kernels got shorter: 2.39 at 256, 2.28 at 160, 2.23 at 128-136, 2.26 at 104-112; profiles/r02_wgrad4_notes.md)
-    static const int target_env = getenv("CLHIP_WGRAD_TARGET") ? atoi(getenv("CLHIP_WGRAD_TARGET")) : 128;
+    static const int target_env = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 128;
     const int target = g_target_w4 > 0 ? g_target_w4 : target_env;
-    static const int min_steps = getenv("CLHIP_WGRAD4_MIN_STEPS") ? atoi(getenv("CLHIP_WGRAD4_MIN_STEPS")) : 2;
+    static const int min_steps = clhip_cfg("WGRAD4_MIN_STEPS") ? atoi(clhip_cfg("WGRAD4_MIN_STEPS")) : 2;
     int splits = (target + p.tiles - 1) / p.tiles;
     const int max_splits = (p.total_steps + min_steps - 1) / min_steps;
     if (splits > max_splits) splits = max_splits;
@@ -352,8 +352,8 @@ int launch4(const Wgrad4Params& p, hipStream_t st) {
 }  // namespace
 
 bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
-    static const bool off = getenv("CLHIP_WGRAD4") != nullptr && atoi(getenv("CLHIP_WGRAD4")) == 0;
-    static const bool s1_only = getenv("CLHIP_WGRAD4") != nullptr && atoi(getenv("CLHIP_WGRAD4")) == 2;       // A/B switch: the stride-1 layers only
+    static const bool off = clhip_cfg("WGRAD4") != nullptr && atoi(clhip_cfg("WGRAD4")) == 0;
+    static const bool s1_only = clhip_cfg("WGRAD4") != nullptr && atoi(clhip_cfg("WGRAD4")) == 2;       // A/B switch: the stride-1 layers only
     if (off) return false;
     if (!(dtype == CLHIP_BF16 && C % 64 == 0 && K % 64 == 0 && Creal == C && N >= 1 && H >= 1)) return false;
     if (!((ksize == 3 && pad == 1 && (stride == 1 || stride == 2)) || (ksize == 1 && pad == 0 && stride == 2))) return false;
@@ -364,7 +364,7 @@ bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ks
     if (!geometry4(N, H, W, C, K, ksize, stride, p)) return false;
     // small stride-2 problems stay on the one-launch atomic kernel (5 x 32 x 32, 20 steps: 8.7 us there, 14.4 us here with the reduce
     // launch; 256 x 8 x 8 1x1, 32 steps: 16.6 us there, 12.7 us here)
-    static const int min_total = getenv("CLHIP_WGRAD4_MIN_TOTAL") ? atoi(getenv("CLHIP_WGRAD4_MIN_TOTAL")) : 32;
+    static const int min_total = clhip_cfg("WGRAD4_MIN_TOTAL") ? atoi(clhip_cfg("WGRAD4_MIN_TOTAL")) : 32;
     return stride == 1 || p.total_steps >= min_total;
 }
 
@@ -405,4 +405,4 @@ int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int
 
 // phase stamps of workgroup 0 (ablation build only; tools/ubench/wgrad_bench trace)
 extern "C" void clhip_wgrad4_config(int target_workgroups) { g_target_w4 = target_workgroups > 0 ? target_workgroups : 0; }
-extern "C" void clhip_wgrad4_set_trace(unsigned long long* dev_buf) { g_trace_w4 = dev_buf; }
+void clhip_wgrad4_set_trace(unsigned long long* dev_buf) { g_trace_w4 = dev_buf; }

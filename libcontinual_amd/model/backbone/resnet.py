@@ -469,8 +469,10 @@ class HipResNet(nn.Module):
     def _forward_impl(self, x, state):
         plan, ws, training = state["plan"], state["ws"], state["training"]
         feat = torch.empty(x.shape[0], state["feat_dim"], device=x.device, dtype=torch.float32)
-        call("clhip_plan_forward", plan, x.data_ptr(), self._flat.data_ptr(), self._stats.data_ptr(), self._shadow.data_ptr(),
-             ws.data_ptr(), feat.data_ptr(), int(training), torch.cuda.current_stream().cuda_stream)
+        # num_batches_tracked += 1 rides on the forward's first launch (it was a torch add kernel per step)
+        call("clhip_plan_forward_ex", plan, x.data_ptr(), self._flat.data_ptr(), self._stats.data_ptr(), self._shadow.data_ptr(),
+             ws.data_ptr(), feat.data_ptr(), int(training), self._nbt.data_ptr() if training else None,
+             torch.cuda.current_stream().cuda_stream)
         return feat
 
     def _backward_impl(self, dfeat, state):
@@ -521,8 +523,6 @@ class HipResNet(nn.Module):
         need_grad = torch.is_grad_enabled() and self._params[0].requires_grad
         state = dict(plan=plan, ws=self._ws, training=self.training, gen=self._generation, shape=tuple(x.shape), feat_dim=feat_dim)
         self._last_state = state
-        if self.training:
-            self._nbt.add_(1)
         if need_grad:
             self.flat_parameters()
             feats = _BackboneFn.apply(x, self._params[0], self, state)

@@ -29,6 +29,21 @@ from .utils import AverageMeter, compute_bwt, compute_frgt, count_all_parameters
 _OBSERVE_DOES_BACKWARD = ("L2P",)      # core/trainer.py:593-596 (subset on the hot path)
 
 
+_UNIT_GRADS = {}
+
+
+def _backward(loss):
+    """loss.backward() (core/trainer.py:604) with the root gradient taken from a cached device scalar: autograd otherwise materialises
+    `ones_like(loss)` with a fill kernel on every step"""
+    if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+        one = _UNIT_GRADS.get(loss.device)
+        if one is None:
+            one = _UNIT_GRADS[loss.device] = torch.ones((), device=loss.device, dtype=torch.float32)
+        torch.autograd.backward(loss, grad_tensors=one)
+    else:
+        loss.backward()
+
+
 class GraphedStep:
     """One training step (observe -> zero_grad -> backward -> step) captured into a HIP graph and replayed.
 
@@ -76,7 +91,7 @@ class GraphedStep:
         else:
             out = self.model.observe(batch)
             self.optimizer.zero_grad()
-            out[2].backward()
+            _backward(out[2])
         self.optimizer.step()
         return out
 
@@ -158,7 +173,7 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
                 else:
                     output, acc, loss = model.observe(batch)
                     optimizer.zero_grad()
-                    loss.backward()
+                    _backward(loss)
                 if reducer is not None and getattr(model, "grad_reducer", None) is None:
                     reducer.reduce(model)
                 optimizer.step()

@@ -30,6 +30,24 @@ def test_library_exports_every_header_symbol():
     assert _lib.lib().clhip_bn_bwd_ws_floats(1024, 64) > 0
 
 
+def test_library_exports_nothing_outside_the_header():
+    """the product's behaviour has to be a function of include/clhip.h -- every unmangled `clhip_*` export of the shared
+    library is declared there (tuning and ablation hooks included: they go through clhip_config)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    c_abi = {e for e in exported if e.startswith("clhip_")}
+    assert c_abi == set(_lib.header_symbols()), c_abi ^ set(_lib.header_symbols())
+
+
+def test_clhip_config_round_trip(monkeypatch):
+    L = _lib.lib()
+    assert L.clhip_config(b"NO_SUCH_SWITCH", b"1") == -1 and b"unknown switch" in L.clhip_last_error()
+    assert L.clhip_config(b"BN_ACC_CPT", b"4") == 0 and L.clhip_config(b"CLHIP_BN_ACC_CPT", None) == 0      # prefix accepted, NULL = default
+    assert L.clhip_config(b"CONV4_FORCE_CFG", b"nonsense") == -1
+    assert L.clhip_config(b"CONV4_FORCE_CFG", None) == 0
+
+
 def test_invalid_arguments_return_error_codes_not_exceptions():
     L = _lib.lib()
     rc = L.clhip_conv_fwd(None, None, None, None, 1, 4, 4, 16, 16, 3, 1, 1, 0, None)

@@ -451,6 +451,57 @@ def test_linear_and_losses():
     assert torch.equal(pred.cpu(), lg.detach()[:, :52].argmax(1))
 
 
+@pytest.mark.parametrize("B,O,lo,hi,plo,phi", [(1, 10, 0, 10, 0, 10), (37, 55, 50, 55, 0, 55), (64, 100, 0, 100, 0, 100), (200, 100, 50, 100, 0, 100),
+                                               (256, 50, 0, 50, 0, 50), (256, 130, 0, 130, 10, 120), (300, 100, 95, 100, 0, 100), (512, 60, 0, 60, 0, 60),
+                                               (256, 200, 180, 200, 0, 200), (300, 200, 0, 200, 0, 200), (600, 55, 0, 55, 0, 55), (7, 300, 0, 300, 0, 300)])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_ce_window_all_forms(B, O, lo, hi, plo, phi, acc):
+    """clhip_ce_window in every dispatch form -- the 16-lane-group kernel of the training steps (B <= 512, O <= 256: ce_rows_kernel), the
+    one-wave-per-row single-workgroup form (wider rows) and the multi-workgroup atomic form (B > 512) -- against fp64 math: loss, its
+    gradient (overwrite and accumulate), first-maximum argmax inside the prediction window with ties, the correct count; the two
+    fixed-order forms are bitwise reproducible."""
+    g = torch.Generator().manual_seed(B * 1000 + O)
+    logits = (torch.randn(B, O, generator=g) * 3).round_(decimals=1)          # one decimal: plenty of exact ties for the argmax
+    y = torch.randint(lo, hi, (B,), generator=g)
+    if B > 3:
+        y[1] = (lo - 1) % O if lo > 0 else y[1]                                # a label outside the loss window contributes no loss term
+    old = torch.randn(B, O, generator=g)
+    w = 0.7
+    ld, yd = logits.to(DEV), y.to(DEV)
+
+    def run():
+        loss = torch.full((1,), 2.5, device=DEV)
+        dl = old.to(DEV).clone()
+        pred = torch.empty(B, dtype=torch.int64, device=DEV)
+        corr = torch.full((1,), -7, dtype=torch.int32, device=DEV)
+        call("clhip_ce_window", ld.data_ptr(), yd.data_ptr(), B, O, lo, hi, plo, phi, w, loss.data_ptr(), acc, dl.data_ptr(), acc, pred.data_ptr(),
+             corr.data_ptr(), st())
+        torch.cuda.synchronize()
+        return loss.cpu(), dl.cpu(), pred.cpu(), corr.cpu()
+
+    loss, dl, pred, corr = run()
+    L = logits.double()
+    lse = torch.logsumexp(L[:, lo:hi], dim=1)
+    inwin = (y >= lo) & (y < hi)
+    li = torch.where(inwin, lse - L[torch.arange(B), y], torch.zeros(B, dtype=torch.float64))
+    want_loss = w * li.sum() / B + (2.5 if acc else 0.0)
+    assert abs(loss.item() - want_loss.item()) <= 2e-5 * max(1.0, abs(want_loss.item()))
+    gref = torch.zeros(B, O, dtype=torch.float64)
+    onehot = torch.zeros(B, O, dtype=torch.float64)
+    onehot[torch.arange(B), y] = 1.0
+    gref[:, lo:hi] = (w / B) * (torch.softmax(L[:, lo:hi], dim=1) - onehot[:, lo:hi])
+    want_g = gref + old.double() if acc else gref
+    if acc:
+        want_g[:, :lo] = old[:, :lo].double(); want_g[:, hi:] = old[:, hi:].double()
+    assert (dl.double() - want_g).abs().max() <= 1e-6
+    want_pred = L[:, plo:phi].argmax(1) + plo                                   # torch.argmax: first maximal index
+    assert torch.equal(pred, want_pred)
+    assert corr.item() == int((want_pred == y).sum())
+    if B <= 512:
+        loss2, dl2, pred2, corr2 = run()
+        assert torch.equal(loss, loss2) and torch.equal(dl, dl2)
+
+
 def test_lucir_head_and_losses():
     from libcontinual_amd import ops
     B, D, O, nold, K = 24, 64, 12, 9, 2

@@ -588,3 +588,20 @@ def test_bf16_loss_trajectory_against_f32_mode_over_50_steps():
     assert dev[:3].max() < 5e-3                               # the first steps: bf16 rounding of one forward
     assert dev.max() < max(3 * self_dev.max(), 2e-2), (dev.max(), self_dev.max())
     assert abs(eb - ea) < max(3 * abs(ea2 - ea), 2e-2 * ea)
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "cifar_resnet32"])
+def test_num_batches_tracked_counts_training_forwards_only(arch):
+    """nn.BatchNorm2d increments `num_batches_tracked` once per training-mode forward (torch/nn/modules/batchnorm.py) and never in eval
+    mode; here the increment rides on the plan's first launch (clhip_plan_forward_ex) instead of a torch kernel per step"""
+    bb = (M.resnet18(args={"dataset": "cifar100"}, dtype="bf16") if arch == "resnet18" else M.cifar_resnet32(dtype="bf16")).to(DEV)
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    bb.train()
+    for _ in range(3):
+        bb(x)
+    bb.eval()
+    with torch.no_grad():
+        bb(x)
+    torch.cuda.synchronize()
+    counters = {k: int(v) for k, v in bb.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert len(counters) >= 20 and set(counters.values()) == {3}, counters

@@ -15,10 +15,13 @@
 #include <string>
 #include "clhip.h"
 
-extern "C" void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck);
-extern "C" void clhip_conv4_enable(int on);
-extern "C" void clhip_conv4_set_debug(int bits);
-extern "C" void clhip_conv4_set_trace(unsigned long long* dev_buf);
+// tuning / ablation hooks go through the library's one configuration entry point (include/clhip.h: clhip_config)
+static void cfg_int(const char* key, long long v) { char b[32]; snprintf(b, sizeof(b), "%lld", v); clhip_config(key, b); }
+static void cfg_ptr(const char* key, const void* ptr) { char b[32]; snprintf(b, sizeof(b), "%llu", (unsigned long long)(uintptr_t)ptr); clhip_config(key, b); }
+static void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck) { char b[64]; snprintf(b, sizeof(b), "%d,%d,%d,%d", wm, wn, kg, ck); clhip_config("CONV4_FORCE_CFG", b); }
+static void clhip_conv4_enable(int on) { cfg_int("CONV4_ENABLE", on); }
+static void clhip_conv4_set_debug(int bits) { cfg_int("CONV4_DEBUG", bits); }
+static void clhip_conv4_set_trace(unsigned long long* d) { cfg_ptr("CONV4_TRACE", d); }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 

@@ -9,8 +9,11 @@
 #include <math.h>
 #include <vector>
 #include "clhip.h"
-extern "C" void clhip_gemm5_set_trace(unsigned long long* dev_buf);
-extern "C" void clhip_gemm5_set_debug(int bits);
+// tuning / ablation hooks go through the library's one configuration entry point (include/clhip.h: clhip_config)
+static void cfg_int(const char* key, long long v) { char b[32]; snprintf(b, sizeof(b), "%lld", v); clhip_config(key, b); }
+static void cfg_ptr(const char* key, const void* ptr) { char b[32]; snprintf(b, sizeof(b), "%llu", (unsigned long long)(uintptr_t)ptr); clhip_config(key, b); }
+static void clhip_gemm5_set_trace(unsigned long long* d) { cfg_ptr("GEMM5_TRACE", d); }
+static void clhip_gemm5_set_debug(int bits) { cfg_int("GEMM5_DEBUG", bits); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 static uint16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float b2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }

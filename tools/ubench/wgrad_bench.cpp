@@ -21,7 +21,10 @@ static uint32_t rng_state = 777;
 static uint32_t irand() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 4; }
 static float urand() { return (irand() & 0xffff) / 32768.0f - 1.0f; }
 
-extern "C" void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
+// tuning / ablation hooks go through the library's one configuration entry point (include/clhip.h: clhip_config)
+static void cfg_int(const char* key, long long v) { char b[32]; snprintf(b, sizeof(b), "%lld", v); clhip_config(key, b); }
+static void cfg_ptr(const char* key, const void* ptr) { char b[32]; snprintf(b, sizeof(b), "%llu", (unsigned long long)(uintptr_t)ptr); clhip_config(key, b); }
+static void clhip_wgrad4_set_trace(unsigned long long* d) { cfg_ptr("WGRAD4_TRACE", d); }
 
 struct Case { const char* name; int N, H, W, C, K, ks = 3, st = 1; };      // H, W: INPUT size; ks x ks filter, stride st, pad ks / 2
 
