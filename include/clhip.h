@@ -317,7 +317,7 @@ int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
  * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
  * pin a code path, tools/ to sweep.
  *   dispatch (0 / 1 unless noted):
- *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: stride-2 3x3 layers stay on the generic implicit-GEMM kernel), CONV_V1,
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
  *     WGRAD_NO_TR, GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
@@ -325,7 +325,7 @@ int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD
  *   tuning values:
  *     WGRAD_TARGET (workgroups of the weight-gradient kernels), WGRAD_NET_GFLOP, WGRAD4_MIN_STEPS, WGRAD4_MIN_TOTAL, CONV3_CFG "wm,wn",
- *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_CFG, CONV5_GRID, IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
+ *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
  *     STEM_WGRAD_GRID, SHORTCUT_MIN_PIXELS, BN_ACC_CPT, BN_BWD_ITERS
  *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG,
  *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE (device address of

@@ -32,7 +32,7 @@ const char* const kKeys[] = {
     // tuning values
     "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
-    "CONV5_CFG", "CONV5_GRID",
+    "CONV5_MIN_TILES", "CONV5_GRID",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
     "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE",
 };
@@ -53,6 +53,8 @@ void clhip_conv4_set_trace(unsigned long long* dev_buf);
 void clhip_gemm5_set_debug(int bits);
 void clhip_gemm5_set_trace(unsigned long long* dev_buf);
 void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
+void clhip_conv5_enable(int on);
+void clhip_conv5_min_tiles(int n);
 
 const char* clhip_cfg(const char* name) {
     {
@@ -82,6 +84,8 @@ extern "C" int clhip_config(const char* key, const char* value) {
     if (strcmp(key, "CONV4_TRACE") == 0) { clhip_conv4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "GEMM5_TRACE") == 0) { clhip_gemm5_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "WGRAD4_TRACE") == 0) { clhip_wgrad4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
+    if (strcmp(key, "CONV5") == 0) clhip_conv5_enable(value ? atoi(v) : -1);                   // immediate AND recorded below
+    if (strcmp(key, "CONV5_MIN_TILES") == 0) clhip_conv5_min_tiles(value ? atoi(v) : -1);
     std::lock_guard<std::mutex> lk(g_cfg_mu);
     if (value == nullptr) {
         cfg_map().erase(key);                 // back to the environment's value

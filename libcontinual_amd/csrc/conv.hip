@@ -470,6 +470,8 @@ int clhip_stem_wgrad_launch(const void* x, const void* dz, float* dw, float* ws,
 bool clhip_wgrad4_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K, int ksize, int stride);
 int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int K, int ksize, int stride, hipStream_t st);
+bool clhip_conv5_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv5.hip
+int clhip_conv5_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, hipStream_t st);
 static bool use_v3() {
     static const bool v = clhip_cfg("NO_CONV3") == nullptr;    // A/B switch: halo kernel for 3x3 stride-1 layers
     return v;
@@ -537,6 +539,9 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
             hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
         return clhip_conv16_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, 0, 0, st);
     }
+    // 64 -> 64 channels on large activations: the weight-stationary kernel (statistics through the accumulators only)
+    if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_conv5_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype)) {
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
         int tiles_used = clhip_conv4_tiles_m(p.M, C, K, W);
@@ -584,6 +589,8 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
         return clhip_shortcut_dgrad(dz, w_dg, dx, accumulate, N, H, W, C, K, st);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, st);
+    if (!use_v1() && use_v3() && clhip_conv5_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv5_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv4_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, K, C, ksize, stride, pad, dtype))

@@ -172,6 +172,61 @@ def test_conv_dgrad(case, mode):
     assert (from_nhwc(dx2).double() - ref2).abs().max() <= tol(mode, ref2) * 1.5
 
 
+CONV5_CASES = [(8, 32, 32), (3, 5, 7), (130, 32, 32), (33, 16, 16), (20, 8, 8), (70, 4, 4), (9, 1, 9), (2, 13, 2), (260, 32, 32)]
+
+
+@pytest.mark.parametrize("shape", CONV5_CASES)
+def test_weight_stationary_conv5(shape):
+    """conv5.hip (64 -> 64 channels, 3x3 / s1, weights resident in registers) forced onto small problems (CONV5_MIN_TILES = 1) against
+    the fp64 convolution and against conv4.hip on the same operands: forward + the fp64 BatchNorm accumulators, dgrad, dgrad with
+    accumulation; ragged last tiles, tiles spanning images, non-power-of-two images (division path of the tap masks), one-row and
+    two-column images, and the benchmark size (260 images: more tiles than workgroups, four per workgroup)."""
+    N, H, W = shape
+    case = (N, H, W, 64, 64, 3, 1, 1)
+    L = _lib.lib()
+    code, tdt = DT["bf16"]
+    x, w, xd, wfd, _, _, cpad = conv_setup(case, "bf16", seed=21)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    rep = 4
+    outs = {}
+    try:
+        for which in ("conv5", "conv4"):
+            assert L.clhip_config(b"CONV5", b"1" if which == "conv5" else b"0") == 0
+            assert L.clhip_config(b"CONV5_MIN_TILES", b"1") == 0
+            z = torch.full((N, H, W, 64), float("nan"), dtype=tdt, device=DEV)
+            acc = torch.zeros(rep, 2, 64, dtype=torch.float64, device=DEV)
+            call("clhip_conv_fwd_acc", xd.data_ptr(), wfd.data_ptr(), z.data_ptr(), acc.data_ptr(), rep, N, H, W, 64, 64, 3, 1, 1, code, st())
+            # dgrad: gradient dz [N,K,H,W], weight copy [C][R][S][K]
+            wq = quant(rnd((64, 64, 3, 3), 5, 1.0 / 24.0), tdt)
+            dz = quant(rnd((N, 64, H, W), 6), tdt)
+            wdg = wq.permute(1, 2, 3, 0).contiguous().to(tdt).to(DEV)
+            dzd = to_nhwc(dz, tdt)
+            dx = torch.full((N, H, W, 64), float("nan"), dtype=tdt, device=DEV)
+            call("clhip_conv_dgrad", dzd.data_ptr(), wdg.data_ptr(), dx.data_ptr(), 0, N, H, W, 64, 64, 3, 1, 1, code, st())
+            base = quant(rnd((N, 64, H, W), 7), tdt)
+            dx2 = to_nhwc(base, tdt)
+            call("clhip_conv_dgrad", dzd.data_ptr(), wdg.data_ptr(), dx2.data_ptr(), 1, N, H, W, 64, 64, 3, 1, 1, code, st())
+            torch.cuda.synchronize()
+            outs[which] = (z.clone(), acc.sum(0).cpu(), dx.clone(), dx2.clone())
+    finally:
+        L.clhip_config(b"CONV5", None)
+        L.clhip_config(b"CONV5_MIN_TILES", None)
+    z5, s5, dx5, dxa5 = outs["conv5"]
+    z4, s4, dx4, dxa4 = outs["conv4"]
+    assert (from_nhwc(z5).double() - ref).abs().max() <= tol("bf16", ref)
+    r1, r2 = ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))
+    assert (s5[0] - r1).abs().max() <= 1e-4 * (ref.abs().sum(dim=(0, 2, 3)).max() + 1e-30)
+    assert (s5[1] - r2).abs().max() <= 1e-4 * (r2.max() + 1e-30)
+    xr = torch.zeros(N, 64, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wq.double(), None, 1, 1).backward(dz.double())
+    assert (from_nhwc(dx5).double() - xr.grad).abs().max() <= tol("bf16", xr.grad)
+    ref2 = xr.grad + base.double()
+    assert (from_nhwc(dxa5).double() - ref2).abs().max() <= tol("bf16", ref2) * 1.5
+    # the two kernels sum the same 576 products per output in fp32 in different orders: they agree to the final bf16 rounding
+    for a, b, r in ((z5, z4, ref), (dx5, dx4, xr.grad), (dxa5, dxa4, ref2)):
+        assert (a.float() - b.float()).abs().max() <= 2 ** -7 * float(r.abs().max())
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_wgrad(case, mode):

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
         {"L1f32 32x32x32 64->64", 32, 32, 32, 64, 64, 0},   {"odd 3x12x20 64->128", 3, 12, 20, 64, 128, 0},
     };
     std::vector<Cfg> cfgs = {
-        {0, 0, 0, 0, 0}, {1, 0, 0, 0, 0},
+        {0, 0, 0, 0, 0}, {1, 0, 0, 0, 0}, {2, 0, 0, 0, 0},       // on = 2: the weight-stationary kernel (conv5.hip) where it applies
         {1, 4, 1, 1, 32}, {1, 4, 1, 1, 64}, {1, 2, 1, 1, 32}, {1, 2, 1, 1, 64}, {1, 2, 2, 1, 32}, {1, 2, 2, 1, 64}, {1, 4, 2, 1, 32}, {1, 4, 2, 1, 64},
         {1, 2, 1, 2, 32}, {1, 2, 1, 2, 64}, {1, 1, 2, 2, 32}, {1, 2, 2, 2, 32}, {1, 1, 1, 4, 32}, {1, 1, 1, 4, 64}, {1, 2, 1, 4, 32}, {1, 2, 1, 4, 64}, {1, 1, 2, 4, 32},
     };
@@ -98,7 +98,10 @@ int main(int argc, char** argv) {
         }
         if (one) { cfgs.clear(); cfgs.push_back(Cfg{acfg[0] > 0 ? 1 : 0, acfg[0], acfg[1], acfg[2], acfg[3]}); }
         for (const Cfg& cf : cfgs) {
-            clhip_conv4_enable(cf.on);
+            clhip_conv4_enable(cf.on ? 1 : 0);
+            clhip_config("CONV5", cf.on == 2 ? "1" : "0");
+            clhip_config("CONV5_MIN_TILES", "1");
+            if (cf.on == 2 && !(Cs == 64 && Cd == 64)) continue;
             clhip_conv4_set_cfg(cf.wm, cf.wn, cf.kg, cf.ck);
             if (cf.wm > 0) {
                 if (Cd % (cf.wn * 64) || Cs % cf.ck || (Cs / cf.ck) % cf.kg) continue;
