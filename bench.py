@@ -4,8 +4,12 @@ Workload (BASELINE.json configs[1]): LwF, ResNet-18 with the CIFAR stem, CIFAR-1
 epoch step = forward + fused CE + backward + fused SGD on a synthetic batch already resident in HBM
 ([B,3,32,32] fp32 normalised images, labels in [0,50)).  One "step" = one pass of the inner loop
 (`libcontinual_amd.trainer.train_steps`, the same function the Trainer runs) over one batch.
-N > 1: one process per GPU (torchrun), per-GPU batch fixed (weak scaling), one all-reduce of the flat gradient
-buffer over RCCL per step, 1/world folded into the SGD kernel.
+N > 1: one process per GPU (torchrun), one all-reduce of the flat gradient buffer over RCCL per step (tail of the buffer overlapped
+with the backward), 1/world folded into the SGD kernel.  `--scaling weak` (default, what the driver runs): per-GPU batch fixed;
+`--scaling strong`: the GLOBAL batch is fixed (256 by default, `--batch` = global) and every rank takes batch // N -- the reference's own
+per-rank batch rule (core/trainer.py:229-241) and SURVEY.md section 8(d)'s first series.  With N > 1 the line carries a `dp` object:
+backend, exchange, and per rank the step time plus a breakdown measured in a separate instrumented pass AFTER the timed region
+(backward, exposed exchange = what the stream still waits for once the backward is done, optimizer, the bucket's all-reduce alone).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, timed live with HIP events) and
 `cpu_baseline` (the CPU oracle of the same step on the host cores, bounded sample) objects.
@@ -36,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: enough for a timed region of about a second)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 ResNet workloads, 16 L2P, 128 InfLoRA_OPT)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling) or GLOBAL batch (strong scaling); default: 256 ResNet workloads, 16 L2P, 128 InfLoRA_OPT")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: per-GPU batch fixed as N grows; strong: global batch fixed, per-GPU batch = batch // N")
     ap.add_argument("--workload", default="lwf_resnet18_b50_task0",
                     choices=["lwf_resnet18_b50_task0", "lwf_resnet18_b50_task1", "icarl_resnet32_b50_task1", "ewc_resnet32_b50_task1",
                              "l2p_vitb16_b10_task1", "inflora_vitb16_b20_task1"])
@@ -229,8 +234,11 @@ def _time_launches(run, reps, warm=5):
 def _profile_lookup(workload, symbol):
     """in-step average duration of a kernel symbol from the committed rocprofv3 --kernel-trace --stats summary of THIS command
     (profiles/r02_bench_kernel_stats.json, written by tools/bench_profile.sh); None if absent"""
-    pj = os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.json")
-    if not os.path.exists(pj):
+    for name in ("r03_bench_kernel_stats.json", "r02_bench_kernel_stats.json"):
+        pj = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pj):
+            break
+    else:
         return None
     with open(pj) as f:
         prof = json.load(f)
@@ -239,19 +247,20 @@ def _profile_lookup(workload, symbol):
     if not hits:
         return None
     calls = sum(h["calls"] for h in hits)
-    return dict(avg_us=sum(h["avg_us"] * h["calls"] for h in hits) / calls, share_of_kernel_time=sum(h["pct"] for h in hits) / 100.0,
-                source="profiles/r02_bench_kernel_stats.json (rocprofv3 --kernel-trace --stats of bench.py)")
+    return dict(avg_us=sum(h["avg_us"] * h["calls"] for h in hits) / calls, share_of_kernel_time=sum(h["pct"] for h in hits) / 100.0, calls=calls,
+                source=f"profiles/{name} (rocprofv3 --kernel-trace --stats of bench.py)")
 
 
 def _pmc_lookup(key):
-    pj = os.path.join(ROOT, "profiles", "r02_roofline_pmc.json")
-    if not os.path.exists(pj):
-        return None, None
-    with open(pj) as f:
-        m = json.load(f).get(key)
-    if not m:
-        return None, None
-    return m["traffic_bytes_per_launch"], "profiles/r02_roofline_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)"
+    for name in ("r03_roofline_pmc.json", "r02_roofline_pmc.json"):
+        pj = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pj):
+            continue
+        with open(pj) as f:
+            m = json.load(f).get(key)
+        if m:
+            return m["traffic_bytes_per_launch"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)"
+    return None, None
 
 
 def conv_rooflines(dev, dtype, B, workload):
@@ -292,8 +301,10 @@ def conv_rooflines(dev, dtype, B, workload):
         ins = [_profile_lookup(workload, sy) for sy in (symbol if isinstance(symbol, (list, tuple)) else [symbol])]
         if all(i is not None for i in ins):      # the same symbol(s) inside the step (two streams share the chip): the conservative figure
             t_in = sum(i["avg_us"] for i in ins) * 1e-3
-            e.update(in_step_launch_ms=t_in, in_step_frac=e["frac"] * ms / t_in, in_step_share_of_kernel_time=sum(i["share_of_kernel_time"] for i in ins),
-                     in_step_source=ins[0]["source"])
+            # a helper symbol shared with other kernels (the partial-block reduce runs once behind EVERY weight-gradient launch of the step)
+            # counts with the launches it has behind THIS entry's first symbol only
+            share = ins[0]["share_of_kernel_time"] + sum(i["share_of_kernel_time"] * min(1.0, ins[0]["calls"] / i["calls"]) for i in ins[1:])
+            e.update(in_step_launch_ms=t_in, in_step_frac=e["frac"] * ms / t_in, in_step_share_of_kernel_time=share, in_step_source=ins[0]["source"])
         out.append(e)
 
     def wgrad_full(x, dz, dw, N, H, W, C, K, stride):
@@ -334,7 +345,7 @@ def conv_rooflines(dev, dtype, B, workload):
         M2 = N * (H // 2) * (W // 2)
         wsb = L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 3, 2, 1, code)
         wsbuf = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-        entry("wgrad", [f"conv_wgrad4_kernel<{W}, 2, 3>"], f"conv_wgrad4_kernel<{W},2,3> + wgrad3_reduce_kernel: dW of 3x3/s2 @ [{N},{H},{W},{C}] x [{N},{H // 2},{W // 2},{K}]",
+        entry("wgrad", [f"conv_wgrad4_kernel<{W}, 2, 3>", "wgrad3_reduce_kernel"], f"conv_wgrad4_kernel<{W},2,3> + wgrad3_reduce_kernel: dW of 3x3/s2 @ [{N},{H},{W},{C}] x [{N},{H // 2},{W // 2},{K}]",
               N, H, W, C, K,
               lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 2, 1, code, st),
               2.0 * M2 * 9 * C * K, (N * H * W * C + M2 * K) * es + K * 9 * C * 4, f"wgrad_s2/{N}x{H}x{W}x{C}x{K}",
@@ -386,6 +397,59 @@ def gemm_roofline(dev, dtype, M):
                 hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
 
 
+def dp_breakdown(model, opt, reducer, batches, method_name, dev, steps=12):
+    """Where a data-parallel step spends its time, measured in an instrumented pass OUTSIDE the timed region (events on the compute stream
+    around the pieces of trainer.train_steps' loop body, overlap context on): `backward_ms` (loss.backward(), the early tail of the flat
+    gradient buffer already handed to the collective inside it), `exchange_exposed_ms` (reducer.reduce(): what is still being waited
+    for once the backward is done -- 0 would be a fully hidden exchange), `optimizer_ms`, and the gradient bucket's all-reduce ALONE
+    (`allreduce_alone_ms`, `bucket_mb`, `busbw_gbs` = 2 (N-1)/N x bytes / time: the ring's per-link rate) -- so a SCALE record says by
+    itself whether a scaling loss is the links, a missing overlap, or the per-rank step."""
+    import contextlib
+    import torch.distributed as dist
+    from libcontinual_amd import ops
+    from libcontinual_amd.trainer import _OBSERVE_DOES_BACKWARD, _backward
+    if method_name in _OBSERVE_DOES_BACKWARD or getattr(model, "grad_reducer", None) is not None:
+        return {}                                                   # the plugin reduces inside observe: no separable pieces
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    overlap = reducer.overlap(model) if hasattr(reducer, "overlap") else contextlib.nullcontext()
+    with ops.deferred_metrics(True), overlap:
+        for i in range(steps):
+            _, _, loss = model.observe(dict(batches[i % len(batches)]))
+            opt.zero_grad()
+            ev[i][0].record()
+            _backward(loss)
+            ev[i][1].record()
+            reducer.reduce(model)
+            ev[i][2].record()
+            opt.step()
+            ev[i][3].record()
+    torch.cuda.synchronize()
+    use = ev[2:]                                                    # the first steps re-warm the collective
+    mean = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in use) / len(use)
+    out = dict(backward_ms=mean(0, 1), exchange_exposed_ms=mean(1, 2), optimizer_ms=mean(2, 3))
+    from libcontinual_amd.parallel import _flat_grad_buckets
+    buckets, _ = _flat_grad_buckets(model)
+    if buckets:
+        b = max(buckets, key=lambda t: t.numel())
+        scratch = torch.empty_like(b)
+        for _ in range(3):
+            dist.all_reduce(scratch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0.record()
+        reps = 10
+        for _ in range(reps):
+            dist.all_reduce(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = b.numel() * 4
+        w = dist.get_world_size()
+        out.update(allreduce_alone_ms=ms, bucket_mb=nbytes / 1e6, busbw_gbs=2.0 * (w - 1) / w * nbytes / (ms * 1e-3) / 1e9)
+    return out
+
+
 def main():
     a = parse()
     vit = "vitb16" in a.workload
@@ -397,6 +461,10 @@ def main():
         a.warmup = 5 if vit else 20
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    global_batch = a.batch * world if a.scaling == "weak" else a.batch
+    if a.scaling == "strong":
+        assert a.batch % world == 0, f"--scaling strong: the global batch {a.batch} does not divide over {world} ranks"
+        a.batch = a.batch // world                         # per-rank batch = batch_size // n_gpu (core/trainer.py:229-241)
     local = 0 if os.environ.get("CLHIP_SHARED_GPU") else int(os.environ.get("LOCAL_RANK", "0"))     # test hook: ranks share cuda:0
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
@@ -458,6 +526,7 @@ def main():
     if world > 1:            # self-checking record of the process group: one entry per rank, gathered over the collective backend itself
         mine = dict(rank=rank, local_rank=local, device=torch.cuda.get_device_name(local), pci=torch.cuda.get_device_properties(local).pci_bus_id
                     if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None, ms_per_step=dt / a.steps * 1e3)
+        mine.update(dp_breakdown(model, opt, reducer, batches, name, dev))
         every = [None] * world
         dist.all_gather_object(every, mine)
         dp = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), exchange=reducer.exchange, ranks=every)
@@ -475,10 +544,10 @@ def main():
                    "images/sec/node (task-0 epoch), CIFAR-100 B50-5x10" if a.workload.endswith("task0") else
                    "images/sec/node (task>=1 step), CIFAR-100 B50-5x10"),
         "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": a.workload, "method": name, "backbone": "vit_base_patch16_224" if vit else arch, "per_gpu_batch": a.batch,
-                   "global_batch": a.batch * world, "image": "3x224x224" if vit else "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused " + type(opt).__name__, "final_loss": loss_avg},
+                   "global_batch": global_batch, "image": "3x224x224" if vit else "3x32x32", "parallelism": f"dp{world}", "optimizer": "fused " + type(opt).__name__, "final_loss": loss_avg},
         "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }

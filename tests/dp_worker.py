@@ -28,7 +28,8 @@ def batch(seed, B=16):
 
 
 def main(out_dir, steps):
-    torch.cuda.set_device(0)
+    # every rank on cuda:0 under the shared-GPU test hook (gloo); one GPU per rank otherwise (RCCL: tests/test_dp_rccl_gpu.py)
+    torch.cuda.set_device(0 if os.environ.get("CLHIP_SHARED_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
     rank, world = parallel.init_distributed(True)
     m = make(100 + rank)                               # different initial weights per rank: the broadcast must fix that
     parallel.broadcast_module_state(m)

@@ -127,3 +127,20 @@ def test_bench_contract_at_two_ranks(workload, batch):
     dp = out["dp"]
     assert dp["world_size"] == 2 and dp["backend"] == "gloo" and sorted(r_["rank"] for r_ in dp["ranks"]) == [0, 1]
     assert dp["exchange"] in ("all_reduce", "reduce_scatter")
+
+
+def test_bench_strong_scaling_and_step_breakdown_at_two_ranks():
+    """`--scaling strong`: the GLOBAL batch is fixed and every rank takes batch // N (core/trainer.py:229-241); the `dp` object carries
+    the per-rank breakdown of the step (backward, exposed exchange, optimizer, the bucket's all-reduce alone) that makes a SCALE record
+    self-diagnosing"""
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--scaling", "strong", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 64 and out["config"]["per_gpu_batch"] == 32
+    assert abs(out["value"] - 64 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]          # whole-job images per second
+    for rk in out["dp"]["ranks"]:
+        for key in ("backward_ms", "exchange_exposed_ms", "optimizer_ms", "allreduce_alone_ms", "bucket_mb", "busbw_gbs"):
+            assert key in rk and rk[key] > 0, (key, rk)
+        assert abs(rk["bucket_mb"] - 44.7) < 0.2                                                      # ResNet-18's flat gradient buffer
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "65", "--scaling", "strong", "--no-cpu-baseline"])
+    assert r.returncode != 0 and "does not divide" in r.stderr
