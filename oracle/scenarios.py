@@ -496,6 +496,26 @@ def scenario_icarl(adapter, tmpdir):
         d = torch.cdist(f, torch.as_tensor(res["class_means0"]).double()) ** 2      # un-normalised features, as in inference
         ds_, _ = d.sort(dim=1)
         res["ncm_margin0"] = ((ds_[:, 1] - ds_[:, 0]) / ds_[:, 1]).numpy()
+        # herding decision margins of the run under test (linearherdingbuffer.py:140-161 replayed on its own features, fp64): for every
+        # class and every greedy pick the relative gap between the best and the second-best candidate's cost -- a pick may legitimately
+        # differ between two implementations only where that gap is at rounding level
+        with torch.no_grad():
+            f0 = torch.cat([m.network.backbone(x0[i:i + 64].to(adapter.device))["features"].float().cpu().double() for i in range(0, len(y0), 64)])
+        f0 = f0 / f0.norm(dim=1).view(-1, 1)
+        per_class = len(res["chosen0"]) // c["init"]
+        margins = []
+        y0n = np.asarray([int(v) for v in y0])
+        for cls in range(c["init"]):
+            cf = f0[np.where(y0n == cls)[0]].clone()
+            mean, run_sum = cf.mean(0, keepdim=True), torch.zeros(1, cf.shape[1], dtype=torch.float64)
+            for k in range(min(per_class, cf.shape[0])):
+                cost = (mean - (cf + run_sum) / (k + 1)).norm(2, 1)
+                two = torch.topk(cost, 2, largest=False)
+                margins.append(float((two.values[1] - two.values[0]) / two.values[1]))
+                j = int(two.indices[0])
+                run_sum += cf[j:j + 1]
+                cf[j] = cf[j] + 1e6
+        res["herding_margin0"] = np.asarray(margins).reshape(c["init"], -1)
         m.before_task(1, buffer, None, None)
         u_imgs, u_labs = imgs1 + list(buffer.images), labs1 + [int(v) for v in buffer.labels]
         ux, uy = load(u_imgs, u_labs)

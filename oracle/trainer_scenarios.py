@@ -38,6 +38,29 @@ SCENARIOS = {
 }
 
 
+# ---- round 3: LOW-VARIANCE accuracy scenarios.  The three scenarios above are short, under-trained runs: the reference
+# against ITSELF from 1e-6-perturbed weights spreads 1.8-4.1 points on the final accuracy, so they cannot resolve BASELINE.json's
+# +-0.3-point band.  These train every task to convergence (learning rate decayed to 1e-3 of its start), on well-separated classes, and
+# are scored on >= 100 test images per class over ALL seen classes (`avg_acc`, core/trainer.py:715-720) -- the reference's own spread
+# over 10 runs is recorded in the fixture and has to be <= 0.3 points (std) for the scenario to be used as a gate.  `acc_icarl11` has the
+# B50-5x10 shape: half of the classes in task 0, ten increments, rehearsal buffer + herding + NCM, exemplars read back from PNG files.
+ACC_COMMON = dict(COMMON, train_per_class=60, test_per_class=100, lr=0.05, signal=0.6, noise=1.0)
+ACC_SCENARIOS = {
+    "acc_ewc": dict(method="EWC", arch="cifar_resnet32", feat_dim=64, kwargs=dict(lamda=100.0), buffer=None,
+                    common=dict(ACC_COMMON, init=10, inc=5, tasks=4, init_epoch=12, epoch=10, milestones=[6, 9, 11], gamma=0.1)),
+    "acc_lwf": dict(method="LWF", arch="resnet18", feat_dim=512, kwargs=dict(), buffer=None,
+                    common=dict(ACC_COMMON, init=10, inc=5, tasks=4, init_epoch=12, epoch=10, milestones=[6, 9, 11], gamma=0.1)),
+    "acc_icarl11": dict(method="ICarl", arch="cifar_resnet32", feat_dim=64, kwargs=dict(), png=True,
+                        buffer=("LinearHerdingBuffer", dict(buffer_size=200, batch_size=32)),
+                        common=dict(ACC_COMMON, init=20, inc=2, tasks=11, train_per_class=50, init_epoch=12, epoch=8, milestones=[5, 7], gamma=0.1)),
+}
+SCENARIOS.update(ACC_SCENARIOS)
+
+
+def common_of(name):
+    return SCENARIOS[name].get("common", COMMON)
+
+
 def num_classes(c=COMMON):
     return c["init"] + c["inc"] * (c["tasks"] - 1)
 
@@ -84,7 +107,7 @@ def make_store(tag, c=COMMON):
         pat = np.stack([coef[ch, 0] * np.sin(2 * np.pi * (coef[ch, 1] * 2 * xx + coef[ch, 2] * 2 * yy)) +
                         coef[ch, 3] * np.cos(2 * np.pi * (coef[ch, 4] * 3 * xx - coef[ch, 5] * 3 * yy)) for ch in range(3)])
         noise = detrand.uniform(f"{tag}/noise{cls}", (n_tr + n_te, 3, 32, 32), -1.0, 1.0)
-        x = 0.55 * pat[None] + 1.1 * noise
+        x = c.get("signal", 0.55) * pat[None] + c.get("noise", 1.1) * noise
         base = sum(r.shape[0] for r in rows)
         rows.append(x.astype(np.float32))
         idx_tr += list(range(base, base + n_tr)); labels_tr += [cls] * n_tr
@@ -122,7 +145,8 @@ def make_png_loaders(root, tag, c=COMMON):
             mode = "train" if k < c["train_per_class"] else "test"
             d = os.path.join(root, mode, f"{cls:03d}")
             os.makedirs(d, exist_ok=True)
-            a = np.clip((0.5 + 0.11 * pat + 0.22 * noise[k]) * 255.0, 0, 255).astype(np.uint8)
+            ks, kn = (0.2 * c["signal"], 0.2 * c["noise"]) if "signal" in c else (0.11, 0.22)
+            a = np.clip((0.5 + ks * pat + kn * noise[k]) * 255.0, 0, 255).astype(np.uint8)
             rel = os.path.join(f"{cls:03d}", f"{k}.png")
             Image.fromarray(a).save(os.path.join(root, mode, rel))
             lists[mode][0].append(rel); lists[mode][1].append(cls)
@@ -279,7 +303,7 @@ class Recorder:
 
 
 def reference_head(name):
-    if name == "lwf":
+    if SCENARIOS[name]["method"] == "LWF":
         return lambda m: m.classifier
     return lambda m: m.network.classifier
 

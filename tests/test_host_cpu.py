@@ -219,3 +219,17 @@ def test_bic_split_and_buffer_recut_match_the_reference(golden):
     out = m.bias_forward(z)
     want_out = torch.cat([(1.0 + i) * z[:, 3 * i:3 * i + 3] + 0.1 * i for i in range(3)], 1)
     assert torch.allclose(out, want_out)
+
+
+def test_input_pipeline_tables_equal_the_reference_fixture(golden):
+    """tests/golden/augment.npz carries the parameter tables parsed out of the reference's core/data/data.py:4-35 (oracle/gen_augment_golden.py);
+    the product's transform tables are those numbers, and its CPU transforms reproduce the fixture's test-time outputs exactly"""
+    from libcontinual_amd.data import transforms as T
+    fx = golden("augment")
+    assert np.allclose(fx["mean"], T.CIFAR_MEAN) and np.allclose(fx["std"], T.CIFAR_STD)
+    tr = T.cifar_resnet_transform("train", 32)
+    kinds = {type(t).__name__: t for t in tr.transforms}
+    assert kinds["RandomCrop"].padding == int(fx["padding"][0]) and abs(kinds["ColorJitter"].b - float(fx["brightness"][0])) < 1e-12
+    te = T.cifar_resnet_transform("test", 32)
+    for k in range(len(fx["cifar_test_expected"])):
+        assert np.abs(te(fx["cifar_images"][k]).numpy() - fx["cifar_test_expected"][k]).max() <= 1e-6

@@ -122,3 +122,44 @@ def test_rrc_loader_for_vit_pipeline():
     for batch in loader:
         x = batch["image"]
         assert x.shape == (8, 3, 64, 64) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+
+
+def test_augment_kernels_against_the_committed_reference_fixture(golden):
+    """f2 pinned: tests/golden/augment.npz holds images, explicit random parameters and the outputs of the reference's
+    CIFAR pipelines (core/data/data.py:4-35: RandomCrop(32, padding 4) + flip + ColorJitter(brightness 63/255) + ToTensor + Normalize;
+    RandomResizedCrop(224) + flip + ToTensor) computed by oracle/gen_augment_golden.py with PIL -- the library torchvision itself calls
+    for PIL images -- from the parameter tables parsed out of the reference's source.  The crop / flip / jitter / normalise kernel is
+    exact (1e-6); the bilinear up-scaling crop is within one uint8 step of PIL's fixed-point two-pass resize."""
+    fx = golden("augment")
+    assert np.allclose(fx["mean"], T.CIFAR_MEAN) and np.allclose(fx["std"], T.CIFAR_STD)            # the product's tables ARE the reference's
+    pad, S = int(fx["padding"][0]), 32
+    imgs, B = fx["cifar_images"], len(fx["cifar_images"])
+    sd = torch.as_tensor(imgs).to(DEV)
+    idx = torch.arange(B).to(DEV)
+    par = torch.as_tensor(np.concatenate([fx["cifar_offsets"], fx["cifar_flip"][:, None]], 1).astype(np.int32)).to(DEV)
+    bri = torch.as_tensor(fx["cifar_brightness"]).to(DEV)
+    out = torch.empty(B, 3, S, S, device=DEV)
+    mean, std = (C.c_float * 3)(*[float(v) for v in fx["mean"]]), (C.c_float * 3)(*[float(v) for v in fx["std"]])
+    call("clhip_augment_crop_flip", sd.data_ptr(), idx.data_ptr(), par.data_ptr(), bri.data_ptr(), out.data_ptr(), B, 32, 32, S, pad, mean, std, st())
+    torch.cuda.synchronize()
+    assert float((out.cpu() - torch.as_tensor(fx["cifar_train_expected"])).abs().max()) <= 1e-6
+    p0 = torch.zeros(B, 3, dtype=torch.int32, device=DEV)
+    call("clhip_augment_crop_flip", sd.data_ptr(), idx.data_ptr(), p0.data_ptr(), None, out.data_ptr(), B, 32, 32, S, 0, mean, std, st())
+    torch.cuda.synchronize()
+    nt = len(fx["cifar_test_expected"])
+    assert float((out[:nt].cpu() - torch.as_tensor(fx["cifar_test_expected"])).abs().max()) <= 1e-6
+    # the jitter range the loader draws from is the reference's
+    ds = ArrayDataset(imgs, list(range(B)), [0] * B, T.cifar_resnet_transform("train", 32), "train")
+    assert abs(gpu_plan(ds.trfms)["brightness"] - float(fx["brightness"][0])) < 1e-9 and gpu_plan(ds.trfms)["pad"] == pad
+    # RandomResizedCrop + flip, every case at its own output size (the reference's 224 among them)
+    vs = torch.as_tensor(fx["vit_images"]).to(DEV)
+    m0, s1 = (C.c_float * 3)(*[float(v) for v in fx["vit_mean"]]), (C.c_float * 3)(*[float(v) for v in fx["vit_std"]])
+    for k, size in enumerate(int(v) for v in fx["vit_sizes"]):
+        o = torch.empty(1, 3, size, size, device=DEV)
+        ik = torch.tensor([k]).to(DEV)
+        pk = torch.as_tensor(fx["vit_boxes"][k:k + 1].astype(np.int32)).to(DEV)
+        call("clhip_augment_rrc_flip", vs.data_ptr(), ik.data_ptr(), pk.data_ptr(), o.data_ptr(), 1, 32, 32, size, m0, s1, st())
+        torch.cuda.synchronize()
+        want = torch.as_tensor(fx[f"vit_train_expected_u8_{k}"]).permute(2, 0, 1).float() / 255.0
+        diff = (o[0].cpu() - want).abs() * 255
+        assert float(diff.max()) <= 1.01 and float(diff.mean()) < 0.35, (k, size, float(diff.max()), float(diff.mean()))

@@ -65,40 +65,59 @@ def relmax(a, b):
 @pytest.mark.parametrize("arch", ["cifar_resnet32", "resnet18", "resnet32_V2"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_backbone_vs_oracle_random_init(arch, dtype):
-    """well-conditioned case: reference-distribution random init, batch 16"""
+    """reference-distribution random init against the fp64 oracle: batch 16 in the f32 mode, batch 64 in bf16 (a
+    per-layer relative L2 norm at batch >= 64, not a cosine).
+
+    What a bf16 bound can be.  The parameter gradient of a random-init ReLU network is ill-conditioned: the fp64 ORACLE ITSELF,
+    evaluated on conv weights and an input that were merely rounded to bf16, lands 0.25 (ResNet-18) / 0.40 (the two 33-layer
+    ResNet-32s) away from its own unrounded gradient in relative L2 norm (0.24 / 0.35 per-layer median, 0.31-0.73 worst layer).
+    That operand-rounding yardstick is computed HERE, on the same weights and batch, and the bf16 mode -- which also rounds every
+    activation and activation gradient -- is held to a multiple of it: whole gradient <= 1.45 x (1.29-1.34 observed over batch 16 /
+    64 / 128 and the three backbones), per-layer median <= 1.5 x (1.27-1.36), worst layer <= 1.7 x the yardstick's worst layer
+    (1.26-1.48).  Forward features <= 6e-2 of fp64 (2.0e-2 .. 4.1e-2 observed).  The arithmetic itself is pinned kernel by kernel
+    in test_kernels_gpu.py (2^-7 of the output magnitude) and the wiring by the f32 run of this very test (per layer <= 2e-2)."""
+    B = 16 if dtype == "f32" else 64
     g = torch.Generator().manual_seed(3)
     P = nets.init_params(arch, g)
     Bf = nets.init_buffers(arch)
-    x = torch.randn(16, 3, 32, 32, generator=g)
-    cw = torch.randn(16, nets.arch(arch)[1], generator=g)
-    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
-    Bo = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in Bf.items()}
-    f_ref = nets.forward(arch, Pg, Bo, x.double(), True)
-    (f_ref * cw.double()).sum().backward()
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    cw = torch.randn(B, nets.arch(arch)[1], generator=g)
+
+    def oracle(Pin, xin):
+        Pg_ = {k: v.double().requires_grad_(True) for k, v in Pin.items()}
+        Bo_ = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in Bf.items()}
+        f_ = nets.forward(arch, Pg_, Bo_, xin.double(), True)
+        (f_ * cw.double()).sum().backward()
+        return f_, Pg_, Bo_
+    f_ref, Pg, Bo = oracle(P, x)
     bb = adapter(dtype).backbone(arch, P, Bf)
     bb.train()
     f = bb(x.to(DEV))["features"]
     (f * cw.to(DEV)).sum().backward()
-    # f32: forward agrees to fp32 rounding; gradients to ~1e-3 -- ReLU masks of the handful of activations that sit
-    # within 1e-7 of zero flip between two fp32 evaluations (measured with tools/diag_backbone.py: top layers 1e-6,
-    # stem 1e-3).  bf16: forward features within 6e-2 of fp64 on this 33-layer random-init net (0.2-0.3 % per layer,
-    # amplified by the untrained net's sensitivity); the gradient is then evaluated at a perturbed point (5 % of the
-    # masks differ), so only its direction is asserted here -- the bf16 arithmetic itself is pinned kernel by kernel
-    # in test_kernels_gpu.py and the wiring by the f32 run of this very test.
     ftol = 2e-4 if dtype == "f32" else 6e-2
     assert relmax(f.detach().cpu(), f_ref.detach()) < ftol
-    worst, dot, n1, n2 = 0.0, 0.0, 0.0, 0.0
+    rels, a_all, b_all = {}, [], []
     for n, p in bb.named_parameters():
         if n.startswith("fc."):
             assert p.grad is None
             continue
         a, b = p.grad.cpu().double().reshape(-1), Pg[n].grad.reshape(-1)
-        worst = max(worst, relnorm(a, b))
-        dot += float(a @ b); n1 += float(a @ a); n2 += float(b @ b)
-    cos = dot / (n1 * n2) ** 0.5
+        rels[n] = relnorm(a, b)
+        a_all.append(a); b_all.append(b)
+    whole = relnorm(torch.cat(a_all), torch.cat(b_all))
     if dtype == "f32":
-        assert worst < 2e-2, worst
-    assert cos > (0.9999 if dtype == "f32" else 0.75), cos
+        # gradients to ~1e-3: ReLU masks of the handful of activations within 1e-7 of zero flip between two fp32 evaluations
+        assert max(rels.values()) < 2e-2 and whole < 1e-2, (max(rels.values()), whole)
+    else:
+        rb = lambda t: t.to(torch.bfloat16).float()
+        _, Py, _ = oracle({k: (rb(v) if v.dim() == 4 else v) for k, v in P.items()}, rb(x))
+        yard = {n: relnorm(Py[n].grad.reshape(-1), Pg[n].grad.reshape(-1)) for n in rels}
+        yard_whole = relnorm(torch.cat([Py[n].grad.reshape(-1) for n in rels]), torch.cat(b_all))
+        med, ymed = float(np.median(list(rels.values()))), float(np.median(list(yard.values())))
+        print(f"{arch} bf16 B={B}: whole {whole:.3f} (yardstick {yard_whole:.3f}), per-layer median {med:.3f} ({ymed:.3f}), worst {max(rels.values()):.3f} ({max(yard.values()):.3f})")
+        assert whole <= 1.45 * yard_whole, (whole, yard_whole)
+        assert med <= 1.5 * ymed, (med, ymed)
+        assert max(rels.values()) <= 1.7 * max(yard.values()), (max(rels.values()), max(yard.values()))
     for n, b in bb.named_buffers():
         if "running" in n:
             assert relmax(b.cpu(), Bo[n]) < (1e-4 if dtype == "f32" else 2e-2), n
@@ -138,15 +157,25 @@ def test_preactivation_backbone_vs_oracle_random_init(dtype, size):
     (f * cw.to(DEV)).sum().backward()
     ftol = 2e-4 if dtype == "f32" else 6e-2
     assert relmax(f.detach().cpu(), f_ref.detach()) < ftol
-    worst, dot, n1, n2 = 0.0, 0.0, 0.0, 0.0
-    for n, p in bb.named_parameters():
-        a, b = p.grad.cpu().double().reshape(-1), Pg[n].grad.reshape(-1)
-        worst = max(worst, relnorm(a, b))
-        dot += float(a @ b); n1 += float(a @ a); n2 += float(b @ b)
-    cos = dot / (n1 * n2) ** 0.5
+    rels = {n: relnorm(p.grad.cpu().double().reshape(-1), Pg[n].grad.reshape(-1)) for n, p in bb.named_parameters()}
+    names = sorted(rels)
+    named = dict(bb.named_parameters())
+    whole = relnorm(torch.cat([named[n].grad.cpu().double().reshape(-1) for n in names]), torch.cat([Pg[n].grad.reshape(-1) for n in names]))
     if dtype == "f32":
-        assert worst < 2e-2, worst
-    assert cos > (0.9999 if dtype == "f32" else 0.75), cos
+        assert max(rels.values()) < 2e-2 and whole < 1e-2, (max(rels.values()), whole)
+    else:
+        # bf16: against the operand-rounding yardstick of the oracle itself (see test_backbone_vs_oracle_random_init)
+        rb = lambda t: t.to(torch.bfloat16).float()
+        Py = {k: (rb(v) if v.dim() == 4 else v).double().requires_grad_(True) for k, v in P.items()}
+        By = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in Bf.items()}
+        (nets.forward(arch, Py, By, rb(x).double(), True) * cw.double()).sum().backward()
+        yard_whole = relnorm(torch.cat([Py[n].grad.reshape(-1) for n in names]), torch.cat([Pg[n].grad.reshape(-1) for n in names]))
+        yard = {n: relnorm(Py[n].grad.reshape(-1), Pg[n].grad.reshape(-1)) for n in names}
+        med, ymed = float(np.median(list(rels.values()))), float(np.median(list(yard.values())))
+        print(f"{arch} {size}px bf16: whole {whole:.3f} (yardstick {yard_whole:.3f}), per-layer median {med:.3f} ({ymed:.3f}), worst {max(rels.values()):.3f} ({max(yard.values()):.3f})")
+        assert whole <= 1.6 * yard_whole, (whole, yard_whole)
+        assert med <= 1.6 * ymed, (med, ymed)
+        assert max(rels.values()) <= 2.0 * max(yard.values()), (max(rels.values()), max(yard.values()))
     for n, b in bb.named_buffers():
         if "running" in n:
             assert relmax(b.cpu(), Bo[n]) < (1e-4 if dtype == "f32" else 2e-2), n
@@ -261,7 +290,11 @@ def test_ewc_fisher_all_rows_golden(golden, monkeypatch):
     for dt in ("f32", "bf16"):
         dev = fisher_deviation(sc.scenario_ewc_fisher(adapter(dt)), want)
         worst = max(dev.items(), key=lambda kv: max(kv[1]))
-        assert max(max(v) for v in dev.values()) < 2e-3, (dt, worst)
+        # SURVEY section 8(d) wrote 1e-3 before anything was measured.  The reference's OWN arithmetic run in fp32 on the CPU (the oracle
+        # restatement, bit-for-bit the reference in fp64) deviates from the fp64 fixture by 2.83e-3 in its worst tensor and 1.28e-3
+        # in the median (tests/test_oracle_golden.py::test_ewc_fisher_all_rows, re-measured in round 3): 1e-3 is below what ANY
+        # single-precision evaluation of getFisher attains, the product (1.3e-3 / 4e-4 worst tensor) is inside the fp32 floor
+        assert max(max(v) for v in dev.values()) < 2e-3, (dt, worst, "CPU fp32 oracle's own figure: worst tensor 2.83e-3, median 1.28e-3")
     orig = M.EWC.__init__
 
     def init_bf16_fisher(self, *a, **kw):
@@ -324,11 +357,22 @@ def test_icarl_golden(golden, tmp_path):
     # same distance to 1e-7 (3 of 16 test points, margins 6e-8).
     np.testing.assert_array_equal(got["buffer_labels0"], want["buffer_labels0"])
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
-    assert len(set(got["chosen0"]) & set(want["chosen0"])) >= 22     # of 24
     assert relmax(got["class_means0"], want["class_means0"]) < 5e-3
-    differ = got["ncm_pred0"] != want["ncm_pred0"]                   # NCM decisions may only differ on exact ties
-    assert (got["ncm_margin0"][differ] < 1e-5).all(), (got["ncm_margin0"], differ)
-    assert (~differ).mean() >= 0.75
+    # the slack is bounded by DECISION MARGINS, not by counts.  Herding: the fixture holds, for every class and every
+    # greedy pick of the reference's own run, the relative gap between its best and second-best candidate (herding_margin0; smallest
+    # gaps of this scenario: 0.7 %, 1.2 %, 1.7 %).  The product's pick sequence of a class may leave the reference's only AT a pick
+    # whose gap is below 2 % -- four times the 5e-3 bound on the feature drift that can flip it -- and is identical before it.
+    per = len(want["chosen0"]) // 4
+    for cls in range(4):
+        g, w = list(got["chosen0"][cls * per:(cls + 1) * per]), list(want["chosen0"][cls * per:(cls + 1) * per])
+        if g != w:
+            k = next(i for i in range(per) if g[i] != w[i])
+            assert want["herding_margin0"][cls, k] < 2e-2, (cls, k, g, w, want["herding_margin0"][cls])
+    assert len(set(got["chosen0"]) & set(want["chosen0"])) >= 22     # (and the sets still nearly coincide: 24 of 24 observed)
+    # NCM: decisions may differ only where the two nearest class means are equidistant to rounding (relative gap < 1e-5 in BOTH runs'
+    # own margins; this scenario's untrained features put 3 of 16 test points on such ties, gaps 6e-8)
+    differ = got["ncm_pred0"] != want["ncm_pred0"]
+    assert (got["ncm_margin0"][differ] < 1e-5).all() and (want["ncm_margin0"][differ] < 1e-5).all(), (got["ncm_margin0"], want["ncm_margin0"], differ)
     got = sc.scenario_icarl(adapter("bf16"), str(tmp_path / "b"))
     assert relmax(got["losses"][:2], want["losses"][:2]) < 5e-2
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
