@@ -737,6 +737,11 @@ static int acc_blocks(int64_t nchunks) {
     return (int)b;
 }
 
+// one-shot: the next accumulator-path FORWARD apply launch completes this event (plan.hip forks the shortcut branch off it: the kernel's
+// own completion signal instead of a marker packet in the caller's queue)
+static thread_local hipEvent_t g_bn_fwd_stop_event = nullptr;
+void clhip_bn_set_fwd_stop_event(hipEvent_t ev) { g_bn_fwd_stop_event = ev; }
+
 template <typename T>
 static int bn_apply_train_t(const void* z, const double* acc, int rep, int64_t M, const float* gamma, const float* beta, float* rm, float* rv, float momentum,
                             float eps, float* mean, float* invstd, const void* res, void* y, int C, int relu, hipStream_t st, unsigned char* mask = nullptr) {
@@ -745,7 +750,9 @@ static int bn_apply_train_t(const void* z, const double* acc, int rep, int64_t M
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const double invM = 1.0 / (double)M, unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
     const T* zz = (const T*)z; const T* rr = (const T*)res; T* yy = (T*)y;
-#define APPLY_TRAIN(R, L) hipLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, lds, st, zz, acc, rep, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C, mask)
+    hipEvent_t stop_ev = g_bn_fwd_stop_event;
+    g_bn_fwd_stop_event = nullptr;
+#define APPLY_TRAIN(R, L) hipExtLaunchKernelGGL((bn_apply_train_kernel<T, R, L>), g, b, (uint32_t)lds, st, (hipEvent_t) nullptr, stop_ev, 0u, zz, acc, rep, invM, unbias, gamma, beta, rm, rv, momentum, eps, mean, invstd, rr, yy, nch, C, mask)
     if (res && relu) APPLY_TRAIN(true, true);
     else if (res) APPLY_TRAIN(true, false);
     else if (relu) APPLY_TRAIN(false, true);

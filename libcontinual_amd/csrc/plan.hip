@@ -18,6 +18,7 @@
 
 void clhip_bn_set_stop_event(hipEvent_t ev);          // bn.hip: one-shot completion event of the next accumulator-path backward apply launch
 hipEvent_t clhip_bn_pending_stop_event();
+void clhip_bn_set_fwd_stop_event(hipEvent_t ev);      // ... of the next accumulator-path forward apply launch
 
 namespace {
 constexpr float kBnMomentum = 0.1f;   // nn.BatchNorm2d defaults used by every reference ResNet
@@ -48,6 +49,10 @@ struct Unit {
     bool has_dzr;                                // this unit's raw sum is consumed raw (PRE_RES / RAW_SRC) by a later unit
     size_t dzr_off;                              // ... whose gradient contribution lands here (bytes into the workspace)
     size_t mask_off;                             // packed ReLU mask of a conv -> BN -> +res -> ReLU unit (bytes into the workspace; 0: none)
+    int branch;                                  // >= 0: a shortcut unit (1x1 conv -> BN, consumed only as the residual of a later unit) that runs on
+                                                 // the plan's branch stream beside the block's main path; value = its slot in the event arrays
+    int forks;                                   // >= 0: this unit's forward BatchNorm launch completes ev_fork[forks] (its activation feeds a branch unit)
+    int joins;                                   // >= 0: this unit adds the output of branch unit slot `joins` as its residual
     bool fuse_src_bn;                            // this unit's dgrad completes the gradient of its input activation AND can reduce the
                                                  // BatchNorm backward of the unit that produced it in its epilogue (clhip_conv_dgrad_bn_reduce)
 };
@@ -64,6 +69,18 @@ struct clhip_plan {
     hipStream_t side;        // weight-gradient stream (created on first use), with the events that order it against the caller's stream
     hipEvent_t ev_dz[2], ev_wg[2], ev_end;
     bool wg_pending[2];
+    // branch stream: the 1x1 shortcut convolution + BatchNorm of a down-sampling block is independent of the block's first 3x3 unit in
+    // the forward, and its BatchNorm backward / input gradient / weight gradient are independent of that unit's in the backward: small
+    // launches that do not fill the chip, run beside the main path instead of in front of it
+    static constexpr int kMaxBranch = 8;
+    hipStream_t br;
+    hipEvent_t ev_fork[kMaxBranch], ev_join[kMaxBranch], ev_bfork[kMaxBranch], ev_bjoin[kMaxBranch];
+    int n_branch;
+    int br_act;              // backward: activation whose gradient the branch stream is writing (-1: none); ev_bjoin[br_slot] orders it
+    int br_slot;
+    hipEvent_t ev_br_end;
+    hipEvent_t bfork_ev[kMaxBranch];   // backward: the event that completes when the consumer's BatchNorm backward has written this branch's dy
+    size_t wg_off2;          // weight-gradient scratch of the branch stream
     size_t f_base;           // byte offset of the fp32 region
     size_t f_part, f_bnws;   // float offsets: conv stat partials, bn backward scratch
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
@@ -173,6 +190,30 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (wg > max_wg) max_wg = wg;
         p->units.push_back(u);
     }
+    // shortcut branches: unit b is a branch when it is a plain 1x1 conv -> BN without ReLU on the accumulator path whose activation has exactly
+    // one consumer, which takes it as a (post-BatchNorm) residual, and whose input is the activation of an earlier plain unit
+    p->n_branch = 0; p->br = nullptr; p->br_act = -1; p->br_slot = -1;
+    size_t max_wg2 = 0;
+    for (auto& u : p->units) { u.branch = u.forks = u.joins = -1; }
+    static const bool branch_off = clhip_cfg("BRANCH_STREAM") != nullptr && atoi(clhip_cfg("BRANCH_STREAM")) == 0;
+    for (int b = 0; b < n_units && !branch_off; ++b) {
+        Unit& u = p->units[b];
+        if (u.d.ksize != 1 || u.relu || u.pre_res || u.raw_src || u.no_bn || u.d.res >= 0 || u.rep_fwd <= 0 || u.rep_bwd <= 0 || u.d.src < 1) continue;
+        if (p->n_branch >= clhip_plan::kMaxBranch) break;
+        int consumer = -1, n_cons = 0;
+        for (int k = 0; k < n_units; ++k) {
+            const Unit& o = p->units[k];
+            if (o.d.src == b + 1) n_cons += 2;                                   // consumed through a convolution: not a pure shortcut
+            if (o.d.res == b + 1) { ++n_cons; consumer = k; }
+        }
+        if (n_cons != 1 || consumer <= b || p->units[consumer].pre_res || p->units[consumer].rep_fwd <= 0 || p->units[consumer].rep_bwd <= 0) continue;
+        Unit& prod = p->units[u.d.src - 1];
+        if (prod.no_bn || prod.rep_fwd <= 0 || prod.forks >= 0 || p->units[consumer].joins >= 0) continue;
+        u.branch = p->n_branch; prod.forks = p->n_branch; p->units[consumer].joins = p->n_branch;
+        ++p->n_branch;
+        size_t wg = clhip_conv_wgrad_ws_bytes(N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, dtype);
+        if (wg > max_wg2) max_wg2 = wg;
+    }
     for (size_t i = 1; i < p->acts.size(); ++i) { p->acts[i].dy_off = off; off = align_up(off + p->acts[i].bytes); }
     // raw sums consumed raw: exactly one such consumer each (true of every pre-activation ResNet), whose gradient contribution gets
     // a buffer of its own
@@ -192,6 +233,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     p->dz_off = off; off = align_up(off + max_z);
     p->dz_off2 = off; off = align_up(off + max_z);
     p->wg_off = off; off = align_up(off + max_wg);
+    p->wg_off2 = off; off = align_up(off + max_wg2);
     p->f_base = off;
     nfloat = (nfloat + 63) / 64 * 64;
     p->f_part = nfloat; nfloat += (max_part + 63) / 64 * 64;
@@ -266,6 +308,12 @@ extern "C" void clhip_plan_destroy(clhip_plan* p) {
         (void)hipEventDestroy(p->ev_end);
         (void)hipStreamDestroy(p->side);
     }
+    if (p && p->br) {
+        (void)hipStreamSynchronize(p->br);
+        for (int k = 0; k < clhip_plan::kMaxBranch; ++k) { (void)hipEventDestroy(p->ev_fork[k]); (void)hipEventDestroy(p->ev_join[k]); (void)hipEventDestroy(p->ev_bfork[k]); (void)hipEventDestroy(p->ev_bjoin[k]); }
+        (void)hipEventDestroy(p->ev_br_end);
+        (void)hipStreamDestroy(p->br);
+    }
     delete p;
 }
 extern "C" size_t clhip_plan_workspace_bytes(const clhip_plan* p) { return p ? p->ws_bytes : 0; }
@@ -277,6 +325,29 @@ extern "C" int clhip_plan_feat_dim(const clhip_plan* p) { return p ? p->feat_dim
         int e_ = (call);     \
         if (e_) return e_;   \
     } while (0)
+
+// the branch stream and its events, created on first use; false inside a stream capture or when extra streams are switched off
+static bool branch_stream_on(clhip_plan* p, hipStream_t main_s) {
+    // like the weight-gradient stream, only networks with layers big enough for the overlap to beat the host cost of the event calls
+    if (p->n_branch == 0 || !p->side_ok) return false;
+    static const bool streams_off = clhip_cfg("WGRAD_STREAM") && atoi(clhip_cfg("WGRAD_STREAM")) == 0;
+    if (streams_off) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(main_s, &cap);
+    if (cap != hipStreamCaptureStatusNone) return false;
+    if (!p->br) {
+        if (hipStreamCreateWithFlags(&p->br, hipStreamNonBlocking) != hipSuccess) { p->br = nullptr; p->n_branch = 0; return false; }
+        static const unsigned ev_flags = clhip_cfg("EVENT_FLAGS") ? (unsigned)strtoul(clhip_cfg("EVENT_FLAGS"), nullptr, 0)
+                                                                  : (hipEventDisableTiming | hipEventDisableSystemFence);
+        for (int k = 0; k < clhip_plan::kMaxBranch; ++k) {
+            (void)hipEventCreateWithFlags(&p->ev_fork[k], ev_flags); (void)hipEventCreateWithFlags(&p->ev_join[k], ev_flags);
+            (void)hipEventCreateWithFlags(&p->ev_bfork[k], ev_flags); (void)hipEventCreateWithFlags(&p->ev_bjoin[k], ev_flags);
+            p->bfork_ev[k] = nullptr;
+        }
+        (void)hipEventCreateWithFlags(&p->ev_br_end, ev_flags);
+    }
+    return true;
+}
 
 // All conv weights of the backbone in ONE launch (the per-conv launches were 20 x 6.7 us of a 3.5 ms ResNet-18 step):
 // the per-conv descriptors travel by value in the kernel arguments, a block finds its conv by a short uniform scan.
@@ -451,6 +522,14 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                                p->H * p->W, p->Cin_pad, lb, a16, n16, nbt, mlo, mhi, (int)p->units.size());
         CLHIP_LAUNCH_CHECK();
     }
+    // shortcut branches run on their own stream in the training forward (accumulator path only)
+    // BRANCH_STREAM: 0 off, 1 both directions, 2 forward only (default), 3 backward only.  Measured on the ResNet-18 step at batch 256 (two
+    // alternating runs each on one box, ms per step): off 2.157 / 2.153, forward only 2.148 / 2.144, both 2.160 / 2.163, backward only 2.197 /
+    // 2.205 -- in the backward the chip is already shared with the weight-gradient stream and a third stream only adds contention and
+    // barrier packets; in the forward nothing else runs beside the chain (profiles/r03_step_notes.md)
+    static const int br_mode_f = clhip_cfg("BRANCH_STREAM") ? atoi(clhip_cfg("BRANCH_STREAM")) : 2;
+    const bool br_on = use_acc && (br_mode_f == 1 || br_mode_f == 2) && branch_stream_on(p, (hipStream_t)stream);
+    struct FwdStopGuard { ~FwdStopGuard() { clhip_bn_set_fwd_stop_event(nullptr); } } fwd_stop_guard;
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
@@ -473,17 +552,26 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
         }
         if (use_acc && u.rep_fwd > 0) {
             // conv epilogue adds the per-channel sums into the fp64 accumulator; BN-apply derives scale / shift on the fly
+            void* us = stream;                                   // the stream this unit's two launches go to
+            const bool on_br = br_on && u.branch >= 0;
+            if (on_br) {                                         // shortcut branch: starts when its input activation is complete (ev_fork)
+                (void)hipStreamWaitEvent(p->br, p->ev_fork[u.branch], 0);
+                us = p->br;
+            }
             TRY(clhip_conv_fwd_acc(in, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
-                                   u.d.stride, u.d.pad, p->dtype, stream));
+                                   u.d.stride, u.d.pad, p->dtype, us));
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
+            if (br_on && u.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)stream, p->ev_join[u.joins], 0);      // the residual comes from the branch stream
+            if (br_on && u.forks >= 0) clhip_bn_set_fwd_stop_event(p->ev_fork[u.forks]);                           // this launch's completion starts the branch
             if (u.mask_off != 0)
                 TRY(clhip_bn_apply_train_mask(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
                                               bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
-                                              ws + dst.y_off, ws + u.mask_off, p->dtype, stream));
+                                              ws + dst.y_off, ws + u.mask_off, p->dtype, us));
             else
                 TRY(clhip_bn_apply_train(ws + u.z_off, acc + u.a_fwd, u.rep_fwd, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
                                          bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, res_,
-                                         ws + dst.y_off, u.relu, p->dtype, stream));
+                                         ws + dst.y_off, u.relu, p->dtype, us));
+            if (on_br) (void)hipEventRecord(p->ev_join[u.branch], p->br);
             continue;
         }
         float* part = training ? fr + p->f_part : nullptr;
@@ -557,6 +645,14 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     }
     // whatever path leaves this function (an error return included), no armed one-shot event survives it
     struct StopEventGuard { ~StopEventGuard() { clhip_bn_set_stop_event(nullptr); } } stop_event_guard;
+    static const int br_mode_b = clhip_cfg("BRANCH_STREAM") ? atoi(clhip_cfg("BRANCH_STREAM")) : 2;
+    const bool br_on = two_streams && (br_mode_b == 1 || br_mode_b == 3) && branch_stream_on(p, main_s);
+    bool br_used = false;
+    p->br_act = -1;
+    auto join_branch = [&]() {          // the caller's stream is about to touch the activation gradient the branch stream is writing
+        (void)hipStreamWaitEvent(main_s, p->ev_bjoin[p->br_slot], 0);
+        p->br_act = -1;
+    };
     int k = 0;
     for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
         const Unit& u = p->units[i];
@@ -564,6 +660,29 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const Act& dst = p->acts[i + 1];
         void* dres = (u.d.res >= 0 && !u.pre_res) ? ws + p->acts[u.d.res].dy_off : nullptr;
         char* dz = ws + (two_streams && k ? p->dz_off2 : p->dz_off);
+        if (br_on && u.branch >= 0 && p->bfork_ev[u.branch] != nullptr) {
+            // ---- shortcut branch (1x1 conv -> BN, its activation consumed as a residual only): BatchNorm backward, input gradient and weight
+            //      gradient on the branch stream, beside the main path's next unit (which shares nothing with it but the gradient of their
+            //      common input activation: this branch writes it first, the main path joins before it accumulates)
+            const int slot = u.branch;
+            (void)hipStreamWaitEvent(p->br, p->bfork_ev[slot], 0);            // its dy = the residual gradient written by the consumer's BatchNorm backward
+            p->bfork_ev[slot] = nullptr;
+            if (p->wg_pending[k]) { (void)hipStreamWaitEvent(p->br, p->ev_wg[k], 0); p->wg_pending[k] = false; }      // the last reader of this dz buffer
+            if (p->br_act >= 0) join_branch();                                 // (two branches never overlap: keep the bookkeeping single-slot)
+            TRY(clhip_bn_bwd_acc(ws + dst.dy_off, ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
+                                 grads + u.d.gamma_off, grads + u.d.beta_off, dz, nullptr, 0, u.M, u.d.cout, 0,
+                                 reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, p->br));
+            TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, p->br));
+            (void)hipEventRecord(p->ev_bjoin[slot], p->br);
+            p->br_act = u.d.src; p->br_slot = slot;
+            TRY(clhip_conv_wgrad(ws + src.y_off, dz, grads + u.d.w_off, ws + p->wg_off2, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
+                                 u.d.ksize, u.d.stride, u.d.pad, p->dtype, p->br));
+            (void)hipEventRecord(p->ev_wg[k], p->br);                          // ... of this dz buffer is now on the branch stream
+            p->wg_pending[k] = true;
+            br_used = true;
+            continue;
+        }
+        if (p->br_act >= 0 && i + 1 == p->br_act) join_branch();             // this unit's BatchNorm backward reads the gradient the branch is writing
         // pre-activation wiring: the gradient of this unit's sum IS the gradient of the raw sum it added (written straight into that
         // producer's buffer); a BN-less unit's gradient is whatever its raw consumer left in its own buffer
         if (u.pre_res) dz = ws + p->units[u.d.res - 1].dzr_off;
@@ -606,6 +725,16 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                              fr + p->f_bnws, p->dtype, stream));
         }
         if (u.has_dzr && !u.no_bn) TRY(clhip_add_inplace(dz, ws + u.dzr_off, u.M * u.d.cout, p->dtype, stream));
+        bool dz_event_recorded = false;
+        if (br_on && u.joins >= 0 && !u.pre_res && dres != nullptr) {
+            // the residual gradient this BatchNorm backward wrote is the dy of a shortcut branch: the branch may start as soon as THIS launch
+            // is complete -- the launch's own completion event when it carries one, an event recorded behind it otherwise
+            if (hook && clhip_bn_pending_stop_event() == nullptr) p->bfork_ev[u.joins] = p->ev_dz[k];
+            else {
+                if (on_side) { clhip_bn_set_stop_event(nullptr); (void)hipEventRecord(p->ev_dz[k], main_s); dz_event_recorded = true; p->bfork_ev[u.joins] = p->ev_dz[k]; }
+                else { (void)hipEventRecord(p->ev_bfork[u.joins], main_s); p->bfork_ev[u.joins] = p->ev_bfork[u.joins]; }
+            }
+        }
         // small layers stay on the caller's stream: below ~1 GFLOP the three event calls cost more host time than the overlap wins
         // (ResNet-32 at batch <= 128 is host-bound: 60.5 k img/s on one stream vs 57.1 k on two; ResNet-18 gains from batch 64 up)
         // A network made of such layers only gets no side stream at all: ResNet-32 at batch 256 (1.2 GFLOP per layer, 7-19 us kernels) ran
@@ -614,7 +743,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         // layer of CLHIP_WGRAD_NET_GFLOP (default 4) GFLOP or more.
         void* wg_stream = stream;
         if (on_side) {
-            if (!hook || clhip_bn_pending_stop_event() != nullptr) {          // (not taken: a BatchNorm path without the hook)
+            if (!dz_event_recorded && (!hook || clhip_bn_pending_stop_event() != nullptr)) {          // (not taken: a BatchNorm path without the hook)
                 clhip_bn_set_stop_event(nullptr);
                 (void)hipEventRecord(p->ev_dz[k], main_s);
             }
@@ -635,6 +764,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipEventRecord(p->ev_wg[k], p->side);
             p->wg_pending[k] = true;
         }
+        if (p->br_act >= 0 && u.d.src == p->br_act && !u.raw_src) join_branch();      // this unit's dgrad accumulates into the gradient the branch wrote first
         if (u.raw_src) {
             TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + p->units[u.d.src - 1].dzr_off, 0, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
@@ -649,6 +779,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         }
     }
+    if (br_used) {                                                     // ... and everything the branch stream wrote
+        (void)hipEventRecord(p->ev_br_end, p->br);
+        (void)hipStreamWaitEvent(main_s, p->ev_br_end, 0);
+        p->br_act = -1;
+    }
+    for (int q = 0; q < clhip_plan::kMaxBranch && br_on; ++q) p->bfork_ev[q] = nullptr;      // (a consumer whose branch unit lies outside this range)
     if (two_streams && (p->wg_pending[0] || p->wg_pending[1])) {      // the caller's stream owns the gradients again when this call returns
         (void)hipEventRecord(p->ev_end, p->side);
         (void)hipStreamWaitEvent(main_s, p->ev_end, 0);

@@ -44,15 +44,22 @@ SCENARIOS = {
 # are scored on >= 100 test images per class over ALL seen classes (`avg_acc`, core/trainer.py:715-720) -- the reference's own spread
 # over 10 runs is recorded in the fixture and has to be <= 0.3 points (std) for the scenario to be used as a gate.  `acc_icarl11` has the
 # B50-5x10 shape: half of the classes in task 0, ten increments, rehearsal buffer + herding + NCM, exemplars read back from PNG files.
-ACC_COMMON = dict(COMMON, train_per_class=60, test_per_class=100, lr=0.05, signal=0.6, noise=1.0)
+ACC_COMMON = dict(COMMON, train_per_class=60, test_per_class=100, lr=0.05)
 ACC_SCENARIOS = {
-    "acc_ewc": dict(method="EWC", arch="cifar_resnet32", feat_dim=64, kwargs=dict(lamda=100.0), buffer=None,
-                    common=dict(ACC_COMMON, init=10, inc=5, tasks=4, init_epoch=12, epoch=10, milestones=[6, 9, 11], gamma=0.1)),
-    "acc_lwf": dict(method="LWF", arch="resnet18", feat_dim=512, kwargs=dict(), buffer=None,
-                    common=dict(ACC_COMMON, init=10, inc=5, tasks=4, init_epoch=12, epoch=10, milestones=[6, 9, 11], gamma=0.1)),
+    # iCaRL / CifarResNet-32, the B50-5x10 SHAPE: 20 + 10 x 2 classes, 11 tasks.  Scenario design (reference runs only, 4 each, from
+    # 1e-6-perturbed starts; final / overall average accuracy, mean +- std): signal 1.0 / noise 0.8: 99.87 +- 0.15 / 99.97 +- 0.03;
+    # signal 0.6 / noise 1.0: 99.28 +- 0.57 / 99.78 +- 0.11 -- the harder the data, the wider the reference's own spread.
     "acc_icarl11": dict(method="ICarl", arch="cifar_resnet32", feat_dim=64, kwargs=dict(), png=True,
                         buffer=("LinearHerdingBuffer", dict(buffer_size=200, batch_size=32)),
-                        common=dict(ACC_COMMON, init=20, inc=2, tasks=11, train_per_class=50, init_epoch=12, epoch=8, milestones=[5, 7], gamma=0.1)),
+                        common=dict(ACC_COMMON, init=20, inc=2, tasks=11, train_per_class=50, init_epoch=12, epoch=8, milestones=[5, 7], gamma=0.1,
+                                    signal=0.8, noise=0.9)),
+    # LwF / ResNet-18 (BASELINE configs[1]).  WITHOUT rehearsal the reference's own class-incremental accuracy is chaotic: trained to
+    # convergence on four tasks (10 + 3 x 5 classes) its final average accuracy over four 1e-6-perturbed runs was 25.6 / 36.7 / 39.9 / 43.7
+    # (std 7.8 points; EWC the same way: 28.2 / 40.8 / 27.4 / 4.9, std 14.9) -- the new logits are trained on their own slice and their
+    # calibration against the old ones is arbitrary.  What IS reproducible is the accuracy after task 0 (plain training of the benchmarked
+    # step: no teacher, no forgetting) -- the gated quantity of this scenario; the two-task final figure is recorded and compared loosely.
+    "acc_lwf": dict(method="LWF", arch="resnet18", feat_dim=512, kwargs=dict(), buffer=None,
+                    common=dict(ACC_COMMON, init=20, inc=5, tasks=2, init_epoch=12, epoch=6, milestones=[6, 9, 11], gamma=0.1, signal=0.45, noise=1.0)),
 }
 SCENARIOS.update(ACC_SCENARIOS)
 

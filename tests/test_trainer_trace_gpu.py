@@ -38,7 +38,7 @@ def run_product(name, dtype, root, perturb=0):
     from libcontinual_amd.trainer import Trainer
     from libcontinual_amd.utils import init_seed
     from oracle import fixtures as fx
-    c, s = ts.COMMON, ts.SCENARIOS[name]
+    c, s = ts.common_of(name), ts.SCENARIOS[name]
     cfg = ts.trainer_config(name, c, gpu_input_pipeline=False)
     cfg["backbone"]["kwargs"]["dtype"] = dtype
     loaders = ts.loaders_for(name, root, c)
@@ -51,7 +51,7 @@ def run_product(name, dtype, root, perturb=0):
             P = {k: v * (1.0 + 1e-6 * fx._t(detrand.uniform(f"trainer/{name}/perturb{perturb}/{k}", tuple(v.shape), -1.0, 1.0))) for k, v in P.items()}
     bb = tr.model.backbone if hasattr(tr.model, "backbone") else tr.model.network.backbone
     bb.load_state_dict({**P, **Bf})
-    head = (lambda m: m.classifier) if name == "lwf" else (lambda m: m.network.classifier)
+    head = (lambda m: m.classifier) if s["method"] == "LWF" else (lambda m: m.network.classifier)
     rec = ts.Recorder(name, tr, tr.model, head, lambda l: float(l.detach().float().item()) if torch.is_tensor(l) else float(l))
     init_seed(c["seed"], True)
     tr.train_loop()
@@ -63,6 +63,11 @@ def run_product(name, dtype, root, perturb=0):
 # first optimisation steps (before the chaotic amplification of rounding differences sets in): relative loss deviation
 FIRST_STEPS = {"f32": (3, 2e-4), "bf16": (3, 3e-2)}
 N_PRODUCT_RUNS = 7      # unperturbed + the 6 perturbed starts of the fixture
+# Round 3: the +-0.3-point accuracy gate lives in tests/test_accuracy_parity_gpu.py, on scenarios whose reference spread can resolve it
+# (LwF, iCaRL in the B50-5x10 shape).  Here the distribution comparison stays for EWC only -- the one method without such a scenario: the
+# reference's EWC, trained to convergence, spreads 15 points (std over its own 1e-6-perturbed runs; oracle/trainer_scenarios.py), so the
+# loose band of this short scenario is all that can honestly be asserted about its accuracy.
+DISTRIBUTION_RUNS = {"ewc": N_PRODUCT_RUNS, "lwf": 1, "icarl": 1}
 
 
 @pytest.mark.parametrize("name", ["ewc", "lwf", "icarl"])
@@ -80,12 +85,17 @@ def test_trainer_reproduces_the_reference_run(name, dtype, tmp_path):
     k, tol = FIRST_STEPS[dtype]
     # ---- accuracy: the product's runs against the reference's runs, as two samples of the chaotic training's distribution
     prod_last, prod_avg = [float(got["batch_last_acc"][-1])], [float(got["overall_avg_acc"][0])]
-    for q in range(1, N_PRODUCT_RUNS):
+    for q in range(1, DISTRIBUTION_RUNS[name]):
         g2, _ = run_product(name, dtype, str(tmp_path), perturb=q)
         prod_last.append(float(g2["batch_last_acc"][-1])); prod_avg.append(float(g2["overall_avg_acc"][0]))
     ref_last = np.concatenate([[ref["batch_last_acc"][-1]], ref["perturbed_batch_last_acc"][:, -1]])
     ref_avg = np.concatenate([ref["overall_avg_acc"], ref["perturbed_overall_avg_acc"]])
     R, P = len(ref_last), len(prod_last)
+    if P == 1:                                              # trace + first steps only (accuracy: tests/test_accuracy_parity_gpu.py)
+        assert dev[:k].max() < tol, (dev[:k], tol)
+        if "buffer_labels" in ref.files:
+            assert sorted(got["buffer_labels"].tolist()) == sorted(ref["buffer_labels"].tolist())
+        return
     gap_last, gap_avg = float(np.mean(prod_last) - ref_last.mean()), float(np.mean(prod_avg) - ref_avg.mean())
     # standard error of the difference of two means (Welch): each sample with its own variance
     band_last = 0.3 + 3.0 * float(np.sqrt(ref_last.var(ddof=1) / R + np.var(prod_last, ddof=1) / P))
