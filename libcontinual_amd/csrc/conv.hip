@@ -437,7 +437,11 @@ int check_conv(int N, int H, int W, int C, int K, int ksize, int stride, int pad
 int clhip_conv2_tiles_m(int M, int Cd);
 int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
                        int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st);
-int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
+bool clhip_wgrad32_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
+size_t clhip_wgrad32_ws_bytes(int N);
+int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st);
+size_t clhip_wgrad2_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad);
+int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
                         int pad, int dtype, hipStream_t st);
 bool clhip_conv3_supported(int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);
 int clhip_conv3_tiles_m(int M, int Cd);
@@ -623,6 +627,8 @@ extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Crea
     if (!use_v1() && use_v3() && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad4_ws_bytes(N, H, W, C, K, ksize, stride);
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad3_ws_bytes(N, H, W, C, K);
     if (!use_v1() && use_v3() && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad16_ws_bytes(N);
+    if (!use_v1() && use_v3() && clhip_wgrad32_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad32_ws_bytes(N);
+    if (!use_v1()) return clhip_wgrad2_ws_bytes(N, H, W, C, Creal, K, ksize, stride, pad);      // the generic kernel's deterministic form
     return 0;
 }
 
@@ -657,7 +663,9 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* 
         return clhip_wgrad3_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, Creal, K, st);
     if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_wgrad16_launch(x, dz, dw, static_cast<float*>(ws), N, H, st);
-    if (!use_v1()) return clhip_wgrad2_launch(x, dz, dw, N, H, W, C, Creal, K, ksize, stride, pad, dtype, st);
+    if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad32_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
+        return clhip_wgrad32_launch(x, dz, dw, static_cast<float*>(ws), N, H, st);
+    if (!use_v1()) return clhip_wgrad2_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, Creal, K, ksize, stride, pad, dtype, st);
     static const bool no_tr = clhip_cfg("WGRAD_NO_TR") != nullptr;
     if (dtype == CLHIP_BF16) {
         if (no_tr) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, p);

@@ -16,6 +16,8 @@
 
 #include "common.h"
 
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);      // conv3.hip
+
 namespace {
 
 constexpr int BK2 = 64;
@@ -419,6 +421,8 @@ struct WgradParams2 {
     const void* x; const void* dz; float* dw;
     int N, H, W, C, log2C, Creal, Ho, Wo, lgHo, lgWo, K, ksize, stride, pad;
     int M, J, pix_per_split, debug;
+    float* slab;              // deterministic form: [split][K][taps][Creal] fp32 partial blocks (plain stores, summed in a fixed order afterwards); nullptr: atomics
+    int64_t slab_stride;
 };
 
 template <typename T>
@@ -562,10 +566,37 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradParams2 p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int o = o0 + (wo_ * MT + i) * 16 + fg * 4 + e;
-                if (o < p.K && !(p.debug & 8)) atomicAdd(p.dw + ((size_t)o * taps + tp) * p.Creal + c, acc[i][j][e]);
+                if (o < p.K && !(p.debug & 8)) {
+                    const size_t at = ((size_t)o * taps + tp) * p.Creal + c;
+                    // every (o, tap, c) belongs to exactly one (blockIdx.x, blockIdx.y) tile, and every split's tiles run (empty ones
+                    // store zeros): the slab is fully written, no zeroing launch
+                    if (p.slab != nullptr) p.slab[(size_t)blockIdx.z * p.slab_stride + at] = acc[i][j][e];
+                    else atomicAdd(p.dw + at, acc[i][j][e]);
+                }
             }
         }
     }
+}
+
+// tile and split geometry of a launch: BO output channels x 128 (tap, channel) columns per workgroup, the pixel range cut into splits
+struct Wgrad2Geo { int bo, gx, gy, splits, pps; };
+Wgrad2Geo wgrad2_geometry(int M, int J, int K, bool deterministic) {
+    Wgrad2Geo g;
+    g.bo = K >= 128 ? 128 : (K >= 64 ? 64 : (K >= 32 ? 32 : 16));
+    g.gx = (J + 127) / 128; g.gy = (K + g.bo - 1) / g.bo;
+    const int tiles = g.gx * g.gy;
+    const int max_splits = (M + 255) / 256;            // >= 4 K-steps per workgroup
+    static const int target = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 256;     // measured: 256 beats 128 / 512 / 1536 on every stride-2 / 1x1 / stem shape (atomic contention vs parallelism)
+    int splits = (target + tiles - 1) / tiles;
+    // the deterministic form writes one partial block per split and reads them all back: fewer, longer splits (at most 64)
+    if (deterministic && splits > 64) splits = 64;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int pps = (M + splits - 1) / splits;
+    pps = (pps + 63) / 64 * 64;
+    g.splits = (M + pps - 1) / pps;
+    g.pps = pps;
+    return g;
 }
 
 template <typename T, int WO, int WJ, int MT, int NT>
@@ -578,21 +609,13 @@ int launch_wgrad_cfg(WgradParams2& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    int gx = (p.J + BJ - 1) / BJ, gy = (p.K + BO - 1) / BO;
-    int tiles = gx * gy;
-    int max_splits = (p.M + 255) / 256;            // >= 4 K-steps per workgroup
-    static const int target = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 256;     // measured: 256 beats 128 / 512 / 1536 on every stride-2 / 1x1 / stem shape (atomic contention vs parallelism)
+    const Wgrad2Geo g = wgrad2_geometry(p.M, p.J, p.K, p.slab != nullptr);
     static const int dbg = clhip_cfg("WGRAD_DEBUG") ? atoi(clhip_cfg("WGRAD_DEBUG")) : 0;
     p.debug = dbg;
-    int splits = (target + tiles - 1) / tiles;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int pps = (p.M + splits - 1) / splits;
-    pps = (pps + 63) / 64 * 64;
-    splits = (p.M + pps - 1) / pps;
-    p.pix_per_split = pps;
-    hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256), lds, st, p);
+    p.pix_per_split = g.pps;
+    hipLaunchKernelGGL(kern, dim3(g.gx, g.gy, g.splits), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
+    if (p.slab != nullptr) return clhip_wgrad_reduce_launch(p.slab, p.dw, p.slab_stride / 4, g.splits, st);
     return CLHIP_OK;
 }
 
@@ -606,7 +629,20 @@ int launch_wgrad2(WgradParams2& p, hipStream_t st) {
 
 }  // namespace
 
-int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
+// bytes of partial-block scratch the deterministic form needs (0: the element count is not a multiple of 4 -- the reduce works on float4 --
+// or the slab would exceed 64 MB: such layers keep the atomic form)
+size_t clhip_wgrad2_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad) {
+    static const bool off = clhip_cfg("WGRAD2_ATOMIC") != nullptr && atoi(clhip_cfg("WGRAD2_ATOMIC")) != 0;
+    if (off) return 0;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int64_t n = (int64_t)K * ksize * ksize * Creal;
+    if (n % 4 != 0) return 0;
+    const Wgrad2Geo g = wgrad2_geometry(N * Ho * Wo, ksize * ksize * C, K, true);
+    const size_t bytes = (size_t)g.splits * n * sizeof(float);
+    return bytes <= ((size_t)64 << 20) ? bytes : 0;
+}
+
+int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
                         int pad, int dtype, hipStream_t st) {
     WgradParams2 p;
     p.x = x; p.dz = dz; p.dw = dw;
@@ -615,6 +651,10 @@ int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, int N, int H, 
     p.lgHo = ilog2_exact(p.Ho); p.lgWo = ilog2_exact(p.Wo);
     p.K = K; p.ksize = ksize; p.stride = stride; p.pad = pad;
     p.M = N * p.Ho * p.Wo; p.J = ksize * ksize * C;
+    // with scratch from the caller: per-split partial blocks + the fixed-order reduce (bitwise reproducible); without: fp32 atomics
+    const bool det = ws != nullptr && clhip_wgrad2_ws_bytes(N, H, W, C, Creal, K, ksize, stride, pad) > 0;
+    p.slab = det ? ws : nullptr;
+    p.slab_stride = (int64_t)K * ksize * ksize * Creal;
     if (dtype == CLHIP_BF16) return launch_wgrad2<bf16_t>(p, st);
     return launch_wgrad2<float>(p, st);
 }

@@ -1040,6 +1040,116 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad32: dw[o][tap][c] for 32 -> 32 channels on 16-pixel-wide images (ResNet-32 stage 2: nine launches per step, until round 3 on the
+// generic kernel's fp32 atomics -- the largest symbol of both ResNet-32 workloads, and not reproducible).  A per-image sibling of
+// wgrad16 was measured at 30.7 us in round 2: an image's 9216 partial sums are more bytes than the image.  Here the OUTPUT channels are
+// split over two workgroups (blockIdx.x = 16-channel out tile) and a workgroup walks a GROUP of images (N / 64 of them, so that ~128
+// workgroups exist and the partial blocks total 128 x 18 KB): the zero-padded 18 x 18 x 32 input image and its 16 x 16 x 16 slice of the
+// gradient sit in LDS, two image rows are one K = 32 step, both operands come from transposing reads, the taps are constant offsets.
+// Wave w owns in-channel tile (w & 1) and taps {0..4} / {5..8} (w >> 1) over ALL K steps -- no cross-wave sum -- and the next image's
+// global loads are in flight while the current one is multiplied.  Partial blocks + wgrad3_reduce_kernel: bitwise reproducible.
+namespace {
+struct Wgrad32Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; };
+
+__global__ __launch_bounds__(256) void wgrad32_kernel(Wgrad32Params p) {
+    constexpr int W = 16, PW = 18, PX = 64, PZ = 32;          // image width, padded width, bytes per input pixel (32 bf16), per gradient pixel (this tile's 16)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = p.H, HW = H * W;
+    char* xs = smem;                                          // (H + 2) x 18 pixels
+    char* zs = smem + (H + 2) * PW * PX;                      // H x 16 pixels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ot = blockIdx.x, grp = blockIdx.y;
+    const int it = wave & 1, th = wave >> 1;                  // in-channel tile, tap half
+    const int n_beg = grp * p.img_per_group, n_end = min(p.N, n_beg + p.img_per_group);
+    // zero the padded image once: only its interior is rewritten per image
+    for (int i = tid; i < (H + 2) * PW * 4; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
+    const int nx = HW * 4, nz = HW * 2;                       // 16-byte chunks per image: input (4 per pixel), gradient slice (2 per pixel)
+    uint4 rx[4], rz[2];
+    auto gload = [&](int n) {
+        const size_t base = (size_t)n * HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            rx[i] = q < nx ? *reinterpret_cast<const uint4*>(p.x + (base + (q >> 2)) * 32 + (q & 3) * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i;
+            rz[i] = q < nz ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            if (q < nx) { const int px = q >> 2; *reinterpret_cast<uint4*>(xs + ((px / W + 1) * PW + (px % W) + 1) * PX + (q & 3) * 16) = rx[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i;
+            if (q < nz) *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = rz[i];
+        }
+    };
+    f32x4 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane (fr, fg) of a transposing read: reduction element 8 fg + (fr >> 2) (+4 for the second read) = pixel (row h0 + (fg >> 1),
+    // column 8 (fg & 1) + (fr >> 2)), 8-byte segment fr & 3 of the 16-channel tile
+    const int prow = fg >> 1, pcol = (fg & 1) * 8 + (fr >> 2), seg = (fr & 3) * 8;
+    const int t0 = th * 5, nt = th == 0 ? 5 : 4;
+    if (n_beg < n_end) gload(n_beg);
+    for (int n = n_beg; n < n_end; ++n) {
+        __syncthreads();                                      // the previous image's reads are done (first pass: the zero fill)
+        sstore();
+        __syncthreads();
+        if (n + 1 < n_end) gload(n + 1);
+        for (int h0 = 0; h0 < H; h0 += 2) {
+            const uint4 zf = tr8(zs, ((h0 + prow) * W + pcol) * PZ + seg, 4 * PZ);
+            const int xb = ((h0 + prow) * PW + pcol) * PX + it * 32 + seg;       // padded coordinates: tap (r, s) adds r rows, s columns
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                if (q < nt) {
+                    const int t = t0 + q, r = t / 3, sx = t - 3 * r;
+                    const uint4 xf = tr8(xs, xb + (r * PW + sx) * PX, 4 * PX);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[row = out channel fg*4 + e][col = in channel fr]  ->  slab[grp][o][tap][c]
+    float* out = p.slab + (size_t)grp * 9216;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (q < nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[((ot * 16 + fg * 4 + e) * 9 + t0 + q) * 32 + it * 16 + fr] = acc[q][e];
+}
+
+int wgrad32_groups(int N) { const int ipg = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1); return (N + ipg - 1) / ipg; }
+}  // namespace
+
+bool clhip_wgrad32_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    static const bool off = clhip_cfg("WGRAD32") != nullptr && atoi(clhip_cfg("WGRAD32")) == 0;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 32 && Creal == 32 && K == 32 && W == 16 && H >= 2 && H <= 32 && (H & 1) == 0 && N >= 1;
+}
+
+size_t clhip_wgrad32_ws_bytes(int N) { return (size_t)wgrad32_groups(N) * 9216 * sizeof(float); }
+
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);
+
+int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st) {
+    const int groups = wgrad32_groups(N);
+    Wgrad32Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, (N + groups - 1) / groups};
+    // (groups was derived from the same images-per-group rule: recompute the per-group count exactly)
+    p.img_per_group = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1);
+    const size_t lds = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
+    hipLaunchKernelGGL(wgrad32_kernel, dim3(2, groups), dim3(256), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return clhip_wgrad_reduce_launch(ws, dw, 2304, groups, st);
+}
+
 bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     static const bool off = clhip_cfg("NO_CONV16") != nullptr;
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 16 && Creal == 16 && K == 16 && W == 32 && H >= 1 && H <= 64 && N >= 1;
