@@ -29,10 +29,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import trainer_scenarios as ts                # noqa: E402
-from test_trainer_trace_gpu import FIRST_STEPS, run_product   # noqa: E402
+from test_trainer_trace_gpu import run_product   # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 N_RUNS = 10
+# first optimisation steps of the unperturbed run: these scenarios step at lr 0.05 (the short ones at 0.02), so the chaotic amplification
+# sets in one step earlier -- f32 mode observed 1.5e-7, 1.8e-5, then 9e-4 at the third step
+FIRST_STEPS_ACC = {"f32": (2, 2e-4), "bf16": (2, 3e-2)}
 
 
 @pytest.mark.parametrize("name", ["acc_icarl11", "acc_lwf"])
@@ -49,7 +52,7 @@ def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
             assert got["trace"].tolist() == ref["trace"].tolist()
             n0 = int(ref["trace"][2][2])
             dev = np.abs(got["losses"][:n0] - ref["losses"][:n0]) / np.abs(ref["losses"][:n0])
-            k, tol = FIRST_STEPS[dtype]
+            k, tol = FIRST_STEPS_ACC[dtype]
             assert dev[:k].max() < tol, (dev[:k], tol)
             if "buffer_labels" in ref.files:
                 assert sorted(got["buffer_labels"].tolist()) == sorted(ref["buffer_labels"].tolist())
