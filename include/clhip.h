@@ -319,7 +319,7 @@ int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
  *   dispatch (0 / 1 unless noted):
  *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
- *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
+ *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
  *     activations), BN_FUSE_MAX_M, BN_MASK_BITS, BN_MASK_FROM_Y, BN_ONEPASS, PREP_NARROW,
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), BRANCH_STREAM (shortcut branches on a third stream: 0 never, 1 forward and backward, 2 forward only = default, 3 backward only), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD

@@ -568,6 +568,9 @@ __global__ void avgpool_win_bwd_kernel(const float* __restrict__ dfeat, T* __res
 }
 
 // ------------------------------------------------------------------------------------ avg pool
+// one thread per (image, channel); the pixel loop issues 8 independent loads per trip (the one-load-per-trip version was a chain of HW
+// dependent L2 round trips: 20 us for the 256 x 8x8 x 64 map of CifarResNet-32, profiles/r03_bench_kernel_stats_ewc_resnet32_b50_task1.txt),
+// summed in pixel order, so the result does not depend on the unrolling
 template <typename T>
 __global__ void avgpool_fwd_kernel(const T* __restrict__ a, float* __restrict__ feat, int N, int HW, int C) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -575,7 +578,15 @@ __global__ void avgpool_fwd_kernel(const T* __restrict__ a, float* __restrict__ 
     int n = idx / C, c = idx - n * C;
     const T* p = a + (size_t)n * HW * C + c;
     float s = 0.f;
-    for (int i = 0; i < HW; ++i) s += Elem<T>::ld(p + (size_t)i * C);
+    int i = 0;
+    for (; i + 8 <= HW; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = Elem<T>::ld(p + (size_t)(i + q) * C);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; i < HW; ++i) s += Elem<T>::ld(p + (size_t)i * C);
     feat[idx] = s / (float)HW;
 }
 

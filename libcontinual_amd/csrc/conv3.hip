@@ -1201,16 +1201,78 @@ int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int
     }
     hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(C / 64, K / 64, splits), dim3(512), lds, st, p);
     CLHIP_LAUNCH_CHECK();
-    if (ws != nullptr) {
-        int64_t n4 = (int64_t)K * 9 * C / 4;
-        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, ws, dw, n4, splits);
-        CLHIP_LAUNCH_CHECK();
-    }
+    if (ws != nullptr) return clhip_wgrad_reduce_launch(ws, dw, (int64_t)K * 9 * C / 4, splits, st);
     return CLHIP_OK;
 }
 
-// dw += the `splits` partial blocks of a workspace, fixed order (shared with wgrad4.hip)
+// ---- deferred reduces.  Every partial-block weight-gradient kernel ends with "dw += sum of my slab".  On CifarResNet-32 those are 33
+// launches of ~5 us per step (the largest symbol of its profile once the atomics were gone: 8.9 % of kernel time,
+// profiles/r03_bench_kernel_stats_ewc_resnet32_b50_task1.txt).  A caller that gives every layer its OWN scratch (plan.hip, networks
+// without a weight-gradient stream) can collect the reduces and run them as ONE launch: clhip_wgrad_defer_begin() makes
+// clhip_wgrad_reduce_launch() record its arguments instead of launching, clhip_wgrad_defer_flush() sums all recorded slabs -- same
+// fixed order per element, so the results are bit-identical to the per-layer launches.
+namespace {
+constexpr int kDeferMax = 40;
+struct ReduceEntry { const float* slab; float* dw; long long n4; int splits; unsigned first_block; };
+struct ReduceTable { int n; ReduceEntry e[kDeferMax]; };
+thread_local ReduceTable g_defer;
+thread_local bool g_defer_on = false;
+
+__global__ __launch_bounds__(256) void wgrad_multi_reduce_kernel(ReduceTable t) {
+    __shared__ float4 part[4][64];
+    int u = 0;
+    while (u + 1 < t.n && blockIdx.x >= t.e[u + 1].first_block) ++u;
+    const ReduceEntry& d = t.e[u];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)(blockIdx.x - d.first_block) * 64 + lane;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < d.n4) {                                      // (the body of wgrad3_reduce_kernel: same grouping, same order)
+        const int per = (d.splits + 3) / 4;
+        const int s0 = grp * per, s1 = min(d.splits, s0 + per);
+        const float4* base = reinterpret_cast<const float4*>(d.slab) + i;
+        int s = s0;
+        for (; s + 8 <= s1; s += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(s + q) * d.n4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+        }
+        for (; s < s1; ++s) { const float4 v = base[(size_t)s * d.n4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    }
+    part[grp][lane] = a;
+    __syncthreads();
+    if (grp == 0 && i < d.n4) {
+        float4 o = reinterpret_cast<const float4*>(d.dw)[i];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const float4 v = part[g][lane]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        reinterpret_cast<float4*>(d.dw)[i] = o;
+    }
+}
+}  // namespace
+
+void clhip_wgrad_defer_begin() { g_defer.n = 0; g_defer_on = true; }
+void clhip_wgrad_defer_abort() { g_defer.n = 0; g_defer_on = false; }
+void clhip_wgrad_defer_pause(bool paused) { g_defer_on = !paused; }      // a launch on another stream reduces on its own
+
+int clhip_wgrad_defer_flush(hipStream_t st, bool end) {
+    if (end) g_defer_on = false;
+    if (g_defer.n == 0) return CLHIP_OK;
+    unsigned blocks = 0;
+    for (int k = 0; k < g_defer.n; ++k) { g_defer.e[k].first_block = blocks; blocks += (unsigned)((g_defer.e[k].n4 + 63) / 64); }
+    hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3(blocks), dim3(256), 0, st, g_defer);
+    g_defer.n = 0;
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+// dw += the `splits` partial blocks of a workspace, fixed order (shared with wgrad4.hip, stem.hip, conv2.hip)
 int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st) {
+    if (g_defer_on) {
+        if (g_defer.n == kDeferMax) { if (int e = clhip_wgrad_defer_flush(st, false)) return e; }
+        g_defer.e[g_defer.n++] = ReduceEntry{slab, dw, (long long)n4, splits, 0u};
+        return CLHIP_OK;
+    }
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, slab, dw, n4, splits);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
@@ -1230,7 +1292,5 @@ int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, in
     }
     hipLaunchKernelGGL(wgrad16_kernel, dim3(N), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(9), dim3(256), 0, st, ws, dw, (int64_t)576, N);
-    CLHIP_LAUNCH_CHECK();
-    return CLHIP_OK;
+    return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N, st);
 }

@@ -153,6 +153,28 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_slice_kernel(const flo
 // 16 rows per wave with three dependent passes over memory per row: 40 us for 256 x 50 logits (profiles/r02_bench_kernel_stats_*),
 // this one: profiles/r03_small_kernels.md.  Loss and correct count are still summed in a fixed order (per group over its rows, then a
 // 64-value butterfly): reproducible, no atomics, no zeroing launches.
+// 16-lane (one DPP row) butterflies without the LDS crossbar: quad_perm xor 1, xor 2, row_half_mirror, row_mirror (common.h: row16_sum)
+__device__ __forceinline__ float dpp_f(float v, int ctrl) {
+    return ctrl == 0 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true))
+         : ctrl == 1 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true))
+         : ctrl == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true))
+                     : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int dpp_i(int v, int ctrl) {
+    return ctrl == 0 ? __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true) : ctrl == 1 ? __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true)
+         : ctrl == 2 ? __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v = fmaxf(v, dpp_f(v, c));
+    return v;
+}
+__device__ __forceinline__ int row16_min_i(int v) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v = min(v, dpp_i(v, c));
+    return v;
+}
+
 template <int NC, int RPG>
 __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B, int O, int lo, int hi,
                                                        int pred_lo, int pred_hi, float weight, float* loss_out, float* __restrict__ dlogits, int grad_acc,
@@ -187,12 +209,10 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
             if (c >= pred_lo && c < pred_hi && v[i][j] > bv) { bv = v[i][j]; bi = c; }      // ascending c: the first maximum stays
             if (c >= lo && c < hi) mx = fmaxf(mx, v[i][j]);
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 16); const int oi = __shfl_xor(bi, o, 16);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-        }
+        // first maximal index of the prediction window: the row maximum, then the smallest index that attains it
+        const float bmax = row16_max(bv);
+        bi = row16_min_i(bv == bmax ? bi : 0x7fffffff);
+        mx = row16_max(mx);
         float e[NC], se = 0.f;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
@@ -200,8 +220,7 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
             e[j] = (c >= lo && c < hi) ? expf(v[i][j] - mx) : 0.f;
             se += e[j];
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
+        se = row16_sum(se);
         const float lse = mx + logf(se);
         const int y = yy[i];
         if (dlogits != nullptr) {
@@ -220,8 +239,7 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
         float ly = 0.f;
 #pragma unroll
         for (int j = 0; j < NC; ++j) if (l16 + 16 * j == y) ly = v[i][j];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ly += __shfl_xor(ly, o, 16);
+        ly = row16_sum(ly);
         if (l16 == 0) {
             const float li = (y >= lo && y < hi) ? (lse - ly) : 0.f;
             if (pred) pred[row] = bi;

@@ -19,6 +19,10 @@
 void clhip_bn_set_stop_event(hipEvent_t ev);          // bn.hip: one-shot completion event of the next accumulator-path backward apply launch
 hipEvent_t clhip_bn_pending_stop_event();
 void clhip_bn_set_fwd_stop_event(hipEvent_t ev);      // ... of the next accumulator-path forward apply launch
+void clhip_wgrad_defer_begin();                        // conv3.hip: collect the partial-block reduces of the weight-gradient launches ...
+int clhip_wgrad_defer_flush(hipStream_t st, bool end);  // ... and run them as one launch
+void clhip_wgrad_defer_abort();
+void clhip_wgrad_defer_pause(bool paused);
 
 namespace {
 constexpr float kBnMomentum = 0.1f;   // nn.BatchNorm2d defaults used by every reference ResNet
@@ -53,6 +57,7 @@ struct Unit {
                                                  // the plan's branch stream beside the block's main path; value = its slot in the event arrays
     int forks;                                   // >= 0: this unit's forward BatchNorm launch completes ev_fork[forks] (its activation feeds a branch unit)
     int joins;                                   // >= 0: this unit adds the output of branch unit slot `joins` as its residual
+    size_t wg_own;                               // this unit's own weight-gradient scratch (plans that defer the reduces), else the shared one
     bool fuse_src_bn;                            // this unit's dgrad completes the gradient of its input activation AND can reduce the
                                                  // BatchNorm backward of the unit that produced it in its epilogue (clhip_conv_dgrad_bn_reduce)
 };
@@ -81,6 +86,8 @@ struct clhip_plan {
     hipEvent_t ev_br_end;
     hipEvent_t bfork_ev[kMaxBranch];   // backward: the event that completes when the consumer's BatchNorm backward has written this branch's dy
     size_t wg_off2;          // weight-gradient scratch of the branch stream
+    bool defer_reduce;       // every unit has its own scratch and the "dw += slab" reduces of a backward run as ONE launch at its end
+    int defer_side;          // > 0 (plans WITH a weight-gradient stream): the reduces of that stream's launches run in groups of this many
     size_t f_base;           // byte offset of the fp32 region
     size_t f_part, f_bnws;   // float offsets: conv stat partials, bn backward scratch
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
@@ -230,9 +237,29 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     }
     for (int i = 0; i < n_units; ++i)
         if (p->units[i].no_bn && !p->units[i].has_dzr) { clhip_set_error("clhip_plan_create: unit %d has no BatchNorm and no consumer", i); delete p; return nullptr; }
+    {
+        const double net_flops = 1.0e9 * (clhip_cfg("WGRAD_NET_GFLOP") ? atof(clhip_cfg("WGRAD_NET_GFLOP")) : 4.0);
+        p->side_ok = false;
+        for (const Unit& u : p->units)
+            if (2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout >= net_flops) p->side_ok = true;
+    }
     p->dz_off = off; off = align_up(off + max_z);
     p->dz_off2 = off; off = align_up(off + max_z);
     p->wg_off = off; off = align_up(off + max_wg);
+    // networks whose weight gradients stay on the caller's stream (no layer big enough for the side stream: the CIFAR ResNet-32s): one
+    // scratch region PER UNIT, so that the partial-block reduces can wait for the end of the backward and run as one launch
+    // (33 launches of ~5 us per CifarResNet-32 step otherwise); WGRAD_DEFER=0 keeps the per-layer reduces
+    static const bool defer_off = clhip_cfg("WGRAD_DEFER") != nullptr && atoi(clhip_cfg("WGRAD_DEFER")) == 0;
+    p->defer_reduce = !p->side_ok && !defer_off;
+    static const int defer_side = clhip_cfg("WGRAD_DEFER_SIDE") ? atoi(clhip_cfg("WGRAD_DEFER_SIDE")) : 0;
+    p->defer_side = p->side_ok ? defer_side : 0;
+    for (Unit& u : p->units) {
+        u.wg_own = p->wg_off;
+        if (p->defer_reduce || p->defer_side > 0) {
+            u.wg_own = off;
+            off = align_up(off + clhip_conv_wgrad_ws_bytes(N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, dtype));
+        }
+    }
     p->wg_off2 = off; off = align_up(off + max_wg2);
     p->f_base = off;
     nfloat = (nfloat + 63) / 64 * 64;
@@ -251,12 +278,6 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
             return nullptr;
         }
         p->feat_dim = pool_win > 0 ? last.C * (last.H / pool_win) * (last.W / pool_win) : last.C;
-    }
-    {
-        const double net_flops = 1.0e9 * (clhip_cfg("WGRAD_NET_GFLOP") ? atof(clhip_cfg("WGRAD_NET_GFLOP")) : 4.0);
-        p->side_ok = false;
-        for (const Unit& u : p->units)
-            if (2.0 * (double)u.M * u.d.ksize * u.d.ksize * u.d.cin * u.d.cout >= net_flops) p->side_ok = true;
     }
     // gradient write/accumulate flags: simulate the reverse sweep
     std::vector<char> written(p->acts.size(), 0);
@@ -645,6 +666,10 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     }
     // whatever path leaves this function (an error return included), no armed one-shot event survives it
     struct StopEventGuard { ~StopEventGuard() { clhip_bn_set_stop_event(nullptr); } } stop_event_guard;
+    const bool defer_side = p->defer_side > 0 && two_streams;
+    struct DeferGuard { bool on; ~DeferGuard() { if (on) clhip_wgrad_defer_abort(); } } defer_guard{p->defer_reduce || defer_side};
+    if (p->defer_reduce || defer_side) clhip_wgrad_defer_begin();
+    int side_deferred = 0;
     static const int br_mode_b = clhip_cfg("BRANCH_STREAM") ? atoi(clhip_cfg("BRANCH_STREAM")) : 2;
     const bool br_on = two_streams && (br_mode_b == 1 || br_mode_b == 3) && branch_stream_on(p, main_s);
     bool br_used = false;
@@ -758,8 +783,10 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             (void)hipStreamWaitEvent(main_s, p->ev_end, 0);
             p->wg_pending[0] = p->wg_pending[1] = false;
         }
-        TRY(clhip_conv_wgrad(in, dz, grads + u.d.w_off, ws + p->wg_off, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
+        if (defer_side) clhip_wgrad_defer_pause(!on_side);             // only the side stream's launches are collected
+        TRY(clhip_conv_wgrad(in, dz, grads + u.d.w_off, ws + u.wg_own, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, wg_stream));
+        if (defer_side && on_side && ++side_deferred % p->defer_side == 0) TRY(clhip_wgrad_defer_flush(p->side, false));
         if (on_side) {
             (void)hipEventRecord(p->ev_wg[k], p->side);
             p->wg_pending[k] = true;
@@ -779,6 +806,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         }
     }
+    if (p->defer_reduce) { TRY(clhip_wgrad_defer_flush(main_s, true)); defer_guard.on = false; }      // all "dw += slab" of this range, one launch
+    if (defer_side) { clhip_wgrad_defer_pause(false); TRY(clhip_wgrad_defer_flush(p->side, true)); defer_guard.on = false; }
     if (br_used) {                                                     // ... and everything the branch stream wrote
         (void)hipEventRecord(p->ev_br_end, p->br);
         (void)hipStreamWaitEvent(main_s, p->ev_br_end, 0);
