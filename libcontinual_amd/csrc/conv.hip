@@ -606,9 +606,13 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     return CLHIP_EINVAL;
 }
 
+int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);      // conv3.hip
+
 extern "C" int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
     if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
-    return (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
+    if (use_v1() || !use_v3()) return 0;
+    return (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
 }
 
 extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod,
@@ -618,6 +622,9 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
     CLHIP_CHECK_ARG(dz && w_dg && dx && z_prod && mean && invstd && acc);
     CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
     CLHIP_CHECK_ARG(clhip_conv_dgrad_bn_reduce_supported(N, H, W, C, K, ksize, stride, pad, dtype));
+    if (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))      // 16 -> 16 / 32 -> 32 channels: the register-resident kernels' epilogue
+        return clhip_conv16_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
+                                      static_cast<hipStream_t>(stream));
     return clhip_conv4_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
                                  static_cast<hipStream_t>(stream));
 }

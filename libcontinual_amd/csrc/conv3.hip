@@ -31,7 +31,66 @@ struct Conv3Params {
     int patch_bytes;     // np*128 rounded up to 256
     int nbuf;            // patch buffers (2 when Cs > 64)
     int debug;           // CLHIP_ABLATION builds only (CLHIP_CONV3_DEBUG): 1 = skip weight streaming, 2 = skip MFMA, 4 = skip patch loads, 8 = skip stores
+    // conv16 / conv32 dgrad only: BatchNorm-backward sums of the layer that PRODUCED the tensor whose gradient this launch completes
+    // (sum g and sum g * xhat per channel, g = dy masked by the producer's ReLU), from the fp32 results in the epilogue -- see conv4.hip
+    const bf16_t* bn_z = nullptr;    // [N,H,W,Cd] pre-BatchNorm output of that layer, or nullptr: no reduction
+    const bf16_t* bn_y = nullptr;    // its post-activation output (ReLU mask y > 0), or nullptr: no ReLU
+    const float* bn_mean = nullptr;
+    const float* bn_invstd = nullptr;
+    double* bn_acc = nullptr;        // [bn_rep][2][Cd]
+    int bn_rep = 1;
 };
+
+// BatchNorm-backward sums in the epilogue of the register-resident dgrad kernels (conv16 / conv32): `v[i][e]` = the final fp32 gradient
+// of pixel m0 + wave*64 + i*16 + fr, channel c0 + e (c0 = this lane's first channel of the 4-channel group).  Per-channel sums over the
+// workgroup's 256 pixels: 16-lane DPP sums, the four waves through LDS, then one fp64 atomic per channel and sum into the producer's
+// accumulator replica; the centred form  sum g * xhat = invstd * (sum g z' - mean * sum g)  is taken once per channel.
+template <int C, int NJ>
+__device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const float (&v)[4][NJ][4], int m0, int wave, int fr, int fg, int tid, char* smem) {
+    float sv[NJ * 8];
+#pragma unroll
+    for (int q = 0; q < NJ * 8; ++q) sv[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = m0 + wave * 64 + i * 16 + fr;
+        if (pix < p.M) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const size_t at = (size_t)pix * C + j * 16 + fg * 4;
+                const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + at);
+                uint2 yy = make_uint2(0x3f803f80u, 0x3f803f80u);
+                if (p.bn_y != nullptr) yy = *reinterpret_cast<const uint2*>(p.bn_y + at);
+                const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
+                const float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = y4[e] > 0.f ? v[i][j][e] : 0.f;
+                    sv[j * 4 + e] += g;
+                    sv[NJ * 4 + j * 4 + e] = fmaf(g, z4[e], sv[NJ * 4 + j * 4 + e]);
+                }
+            }
+        }
+    }
+    row16_sum_n(sv);
+    __syncthreads();                                         // the patch is dead
+    float* red = reinterpret_cast<float*>(smem);             // [4 waves][2][C]
+    if (fr == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            *reinterpret_cast<float4*>(red + (wave * 2 + 0) * C + j * 16 + fg * 4) = make_float4(sv[j * 4], sv[j * 4 + 1], sv[j * 4 + 2], sv[j * 4 + 3]);
+            *reinterpret_cast<float4*>(red + (wave * 2 + 1) * C + j * 16 + fg * 4) = make_float4(sv[NJ * 4 + j * 4], sv[NJ * 4 + j * 4 + 1], sv[NJ * 4 + j * 4 + 2], sv[NJ * 4 + j * 4 + 3]);
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int which = tid / C, cc = tid - which * C;
+        float t = 0.f, sg = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) { t += red[(w2 * 2 + which) * C + cc]; sg += red[(w2 * 2 + 0) * C + cc]; }
+        if (which == 1) t = p.bn_invstd[cc] * (t - p.bn_mean[cc] * sg);
+        atomicAdd(p.bn_acc + ((size_t)(blockIdx.x & (p.bn_rep - 1)) * 2 + which) * C + cc, (double)t);
+    }
+}
 
 // the production build carries no ablation branches (ABL=1 csrc/build.sh builds libclhip_abl.so with them)
 #ifdef CLHIP_ABLATION
@@ -539,11 +598,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
         }
     }
     // D[row = channel fg*4 + e][col = pixel fr]
+    float fin[4][1][4];                                      // the stored gradient before its bf16 rounding (dgrad + BatchNorm-backward sums)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pix = m0 + wave * 64 + i * 16 + fr;
+        float v0 = acc[i][0], v1 = acc[i][1], v2 = acc[i][2], v3 = acc[i][3];
         if (pix < p.M) {
-            float v0 = acc[i][0], v1 = acc[i][1], v2 = acc[i][2], v3 = acc[i][3];
             bf16_t* o = p.dst + (size_t)pix * 16 + fg * 4;
             if (MODE == 1 && p.accumulate) {
                 const uint2 old = *reinterpret_cast<const uint2*>(o);
@@ -552,7 +612,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
             }
             *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
+        fin[i][0][0] = v0; fin[i][0][1] = v1; fin[i][0][2] = v2; fin[i][0][3] = v3;
     }
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<16, 1>(p, fin, m0, wave, fr, fg, tid, smem);
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float sv[8];
 #pragma unroll
@@ -629,13 +691,14 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[t][j]), __builtin_bit_cast(bf16x8_t, x), acc[i][j], 0, 0, 0);
         }
     }
+    float fin[4][2][4];                                      // the stored gradient before its bf16 rounding (dgrad + BatchNorm-backward sums)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pix = m0 + wave * 64 + i * 16 + fr;
-        if (pix < p.M) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+        for (int j = 0; j < 2; ++j) {
+            float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+            if (pix < p.M) {
                 bf16_t* o = p.dst + (size_t)pix * 32 + j * 16 + fg * 4;
                 if (MODE == 1 && p.accumulate) {
                     const uint2 old = *reinterpret_cast<const uint2*>(o);
@@ -644,8 +707,10 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
                 }
                 *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
             }
+            fin[i][j][0] = v0; fin[i][j][1] = v1; fin[i][j][2] = v2; fin[i][j][3] = v3;
         }
     }
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<32, 2>(p, fin, m0, wave, fr, fg, tid, smem);
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float sv[16];                                        // [j][e] sums, then [j][e] sums of squares
 #pragma unroll
@@ -736,9 +801,19 @@ bool clhip_conv16_supported(int H, int W, int Cs, int Cd, int ksize, int stride,
 
 int clhip_conv16_tiles_m(int M) { return (M + 255) / 256; }
 
+int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
+
 int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                         hipStream_t st) {
+    return clhip_conv16_launch_bn(src, wt, dst, stats, stat_acc, stat_rep, N, H, W, C, accumulate, mode, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+}
+
+int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st) {
     Conv3Params p;
+    p.bn_z = static_cast<const bf16_t*>(bn_z); p.bn_y = static_cast<const bf16_t*>(bn_y); p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
+    p.bn_acc = bn_acc; p.bn_rep = bn_rep > 0 ? bn_rep : 1;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = C; p.Cd = C; p.accumulate = accumulate; p.M = N * H * W;

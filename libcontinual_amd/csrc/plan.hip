@@ -298,7 +298,9 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     // never; =1: every qualifying layer (CLHIP_BN_FUSE_MAX_M bounds the pixels).  Read per plan: tests build both variants.
     const char* fe = clhip_cfg("BN_FUSE");
     const bool fuse_on = fe == nullptr || atoi(fe) != 0;
-    const long long fuse_max_m = clhip_cfg("BN_FUSE_MAX_M") ? atoll(clhip_cfg("BN_FUSE_MAX_M")) : (fe == nullptr ? 16384 : (1ll << 62));
+    // (plans without a weight-gradient stream -- the CIFAR ResNet-32s, every launch of which sits at its latency floor -- fuse wherever a
+    //  kernel supports it: one launch less per unit, measured in profiles/r03_step_notes.md)
+    const long long fuse_max_m = clhip_cfg("BN_FUSE_MAX_M") ? atoll(clhip_cfg("BN_FUSE_MAX_M")) : ((fe == nullptr && p->side_ok) ? 16384 : (1ll << 62));
     p->bwd_sums_ready.assign(p->units.size(), 0);
     for (int i = 0; i < n_units; ++i) {
         Unit& u = p->units[i];

@@ -768,7 +768,9 @@ def test_conv_fwd_stat_accumulator(mode, shape):
             assert (acc.abs().amax(dim=(1, 2)) > 0).all()          # every replica received some workgroups
 
 
-@pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64), (4, 8, 8, 128, 256), (6, 4, 4, 512, 512), (3, 12, 20, 64, 128), (32, 8, 8, 64, 64)])
+@pytest.mark.parametrize("shape", [(8, 16, 16, 64, 64), (4, 8, 8, 128, 256), (6, 4, 4, 512, 512), (3, 12, 20, 64, 128), (32, 8, 8, 64, 64),
+                                   # the register-resident 16 -> 16 / 32 -> 32 kernels (conv3.hip conv16 / conv32): several tiles, ragged tile, odd image
+                                   (9, 32, 32, 16, 16), (33, 16, 16, 32, 32), (3, 7, 5, 16, 16), (2, 5, 9, 32, 32)])
 @pytest.mark.parametrize("relu,accumulate", [(1, 0), (1, 1), (0, 0)])
 def test_dgrad_with_fused_batchnorm_backward_reduction(shape, relu, accumulate):
     """clhip_conv_dgrad_bn_reduce + clhip_bn_bwd_apply_acc (the dgrad epilogue accumulates sum g and sum g * xhat of the producing
