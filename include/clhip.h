@@ -309,6 +309,16 @@ int clhip_herding_select(const float* feats /*[n,D], L2-normalised*/, int n, int
  *   K % 64 == 0, N % 4 == 0.                                                                                    */
 int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                   int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
+/* The input gradient AND the weight gradient of one layer in ONE launch (both consume dz and nothing of each other): the layers whose two
+ * backward convolutions are launches at their latency floor -- 3x3/s1/p1 with 16 -> 16 channels on 32-wide or 32 -> 32 channels on 16-wide
+ * images, bf16 (CifarResNet-32 stages 1 and 2, core/model/backbone/resnet.py:289-316 under autograd).  Same arguments and results (bit for
+ * bit) as clhip_conv_dgrad [or clhip_conv_dgrad_bn_reduce when z_prod != NULL: then y_prod (nullable), mean, invstd, acc, replicas as there]
+ * followed by clhip_conv_wgrad with scratch `ws` (clhip_conv_wgrad_ws_bytes; required: the weight gradient is the deterministic form). */
+int clhip_conv_dgrad_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, void* ws,
+                           const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas,
+                           int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);
+
 /* ---- run-time configuration ------------------------------------------------------------------------------------------------
  * ONE entry point for every dispatch switch, tuning value and micro-benchmark hook of the library (there are no other steering
  * exports).  `key` is a name from the list below (a leading "CLHIP_" is accepted), `value` its new value as text; value == NULL
@@ -319,7 +329,7 @@ int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
  *   dispatch (0 / 1 unless noted):
  *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
- *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
+ *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
  *     activations), BN_FUSE_MAX_M, BN_MASK_BITS, BN_MASK_FROM_Y, BN_ONEPASS, PREP_NARROW,
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), BRANCH_STREAM (shortcut branches on a third stream: 0 never, 1 forward and backward, 2 forward only = default, 3 backward only), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD

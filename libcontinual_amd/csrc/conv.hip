@@ -629,6 +629,27 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
                                  static_cast<hipStream_t>(stream));
 }
 
+bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
+int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
+
+extern "C" int clhip_conv_dgrad_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
+    if (use_v1() || !use_v3()) return 0;
+    return clhip_bwd_fused_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype) ? 1 : 0;
+}
+
+extern "C" int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, void* ws,
+                                      const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas,
+                                      int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(x && dz && w_dg && dx && dw && ws);
+    CLHIP_CHECK_ARG(clhip_conv_dgrad_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype));
+    CLHIP_CHECK_ARG(z_prod == nullptr || (mean && invstd && acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
+    return clhip_bwd_fused_launch(x, dz, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, z_prod, y_prod, mean, invstd, acc, replicas,
+                                  static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!use_v1() && use_v3() && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_stem_wgrad_ws_bytes(N, H, W, Creal, K);
     if (!use_v1() && use_v3() && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad4_ws_bytes(N, H, W, C, K, ksize, stride);

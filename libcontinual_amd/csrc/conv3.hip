@@ -46,7 +46,7 @@ struct Conv3Params {
 // workgroup's 256 pixels: 16-lane DPP sums, the four waves through LDS, then one fp64 atomic per channel and sum into the producer's
 // accumulator replica; the centred form  sum g * xhat = invstd * (sum g z' - mean * sum g)  is taken once per channel.
 template <int C, int NJ>
-__device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const float (&v)[4][NJ][4], int m0, int wave, int fr, int fg, int tid, char* smem) {
+__device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const float (&v)[4][NJ][4], int m0, int wave, int fr, int fg, int tid, char* smem, int bx) {
     float sv[NJ * 8];
 #pragma unroll
     for (int q = 0; q < NJ * 8; ++q) sv[q] = 0.f;
@@ -88,7 +88,7 @@ __device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) { t += red[(w2 * 2 + which) * C + cc]; sg += red[(w2 * 2 + 0) * C + cc]; }
         if (which == 1) t = p.bn_invstd[cc] * (t - p.bn_mean[cc] * sg);
-        atomicAdd(p.bn_acc + ((size_t)(blockIdx.x & (p.bn_rep - 1)) * 2 + which) * C + cc, (double)t);
+        atomicAdd(p.bn_acc + ((size_t)(bx & (p.bn_rep - 1)) * 2 + which) * C + cc, (double)t);
     }
 }
 
@@ -551,12 +551,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
 // after the patch is staged.  Lane (fr, fg) ends with channels 4 fg .. 4 fg + 3 of pixel fr: one 8-byte store, 512 contiguous
 // bytes per wave instruction, no output staging.  MODE as in conv3_kernel (the dgrad weight copy has the same [Cd][9][Cs] layout).
 template <int MODE>
-__global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
+__device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, char* smem) {      // bx = tile index (a workgroup of a plain or a fused launch)
     constexpr int BM = 256, PP = 32;                         // pixels per workgroup, LDS bytes per pixel
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = bx * BM;
     const int W = p.W, halo = W + 1;
     const int half = fg & 1, tsel = fg >> 1;                // which 8 channels / which tap of the pair this lane feeds
 
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
         }
         fin[i][0][0] = v0; fin[i][0][1] = v1; fin[i][0][2] = v2; fin[i][0][3] = v3;
     }
-    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<16, 1>(p, fin, m0, wave, fr, fg, tid, smem);
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<16, 1>(p, fin, m0, wave, fr, fg, tid, smem, bx);
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float sv[8];
 #pragma unroll
@@ -639,22 +638,26 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
         if (tid < 32) {
             const int which = tid >> 4, cc = tid & 15;
             const float t = red[(0 * 2 + which) * 16 + cc] + red[(1 * 2 + which) * 16 + cc] + red[(2 * 2 + which) * 16 + cc] + red[(3 * 2 + which) * 16 + cc];
-            if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * 16 + cc, (double)t);
-            else p.stats[((size_t)blockIdx.x * 2 + which) * 16 + cc] = t;
+            if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(bx & (p.stat_rep - 1)) * 2 + which) * 16 + cc, (double)t);
+            else p.stats[((size_t)bx * 2 + which) * 16 + cc] = t;
         }
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv16_body<MODE>(p, blockIdx.x, smem);
 }
 
 // conv32: the same scheme for 32 -> 32 channels (ResNet-32 stage 2).  One tap fills a K = 32 step, the 32 output channels are two
 // MFMA row tiles, the weights are 18 operands (72 registers) per lane; the patch pitch is 96 bytes (64 of data), which puts the 16
 // lanes a ds_read_b128 services together on 16 distinct bank quartets.
 template <int MODE>
-__global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
+__device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, char* smem) {
     constexpr int BM = 256, PP = 96;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = bx * BM;
     const int W = p.W, halo = W + 1;
 
     uint4 wreg[9][2];
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
             fin[i][j][0] = v0; fin[i][j][1] = v1; fin[i][j][2] = v2; fin[i][j][3] = v3;
         }
     }
-    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<32, 2>(p, fin, m0, wave, fr, fg, tid, smem);
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<32, 2>(p, fin, m0, wave, fr, fg, tid, smem, bx);
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float sv[16];                                        // [j][e] sums, then [j][e] sums of squares
 #pragma unroll
@@ -742,10 +745,15 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
             float t = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) t += red[(w2 * 2 + which) * 32 + cc];
-            if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + which) * 32 + cc, (double)t);
-            else p.stats[((size_t)blockIdx.x * 2 + which) * 32 + cc] = t;
+            if (p.stat_acc != nullptr) atomicAdd(p.stat_acc + ((size_t)(bx & (p.stat_rep - 1)) * 2 + which) * 32 + cc, (double)t);
+            else p.stats[((size_t)bx * 2 + which) * 32 + cc] = t;
         }
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv32_body<MODE>(p, blockIdx.x, smem);
 }
 
 template <int WM, int WN, int MODE>
@@ -1066,15 +1074,14 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
 namespace {
 struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; };
 
-__global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
+__device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int bx, char* smem) {      // bx = image
     constexpr int W = 32, PW = 34, PX = 32;                  // image width, padded width, bytes per pixel (16 bf16)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H;
     char* xs = smem;                                         // (H + 2) x 34 pixels
     char* zs = smem + (H + 2) * PW * PX;                     // H x 32 pixels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const size_t img = (size_t)blockIdx.x * H * W;
+    const size_t img = (size_t)bx * H * W;
     // zero the padded image, then drop the real pixels in; the gradient image is copied as is
     const int xchunks = (H + 2) * PW * 2;
     for (int i = tid; i < xchunks; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
@@ -1110,8 +1117,12 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[wave * 2304 + ((fg * 4 + e) * 9 + t) * 16 + fr] = acc[t][e];
     __syncthreads();
-    float* out = p.slab + (size_t)blockIdx.x * 2304;
+    float* out = p.slab + (size_t)bx * 2304;
     for (int i = tid; i < 2304; i += 256) out[i] = red[i] + red[2304 + i] + red[4608 + i] + red[6912 + i];
+}
+__global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad16_body(p, blockIdx.x, smem);
 }
 }  // namespace
 
@@ -1127,15 +1138,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
 namespace {
 struct Wgrad32Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; };
 
-__global__ __launch_bounds__(256) void wgrad32_kernel(Wgrad32Params p) {
+__device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int ot, const int grp, char* smem) {
     constexpr int W = 16, PW = 18, PX = 64, PZ = 32;          // image width, padded width, bytes per input pixel (32 bf16), per gradient pixel (this tile's 16)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, HW = H * W;
     char* xs = smem;                                          // (H + 2) x 18 pixels
     char* zs = smem + (H + 2) * PW * PX;                      // H x 16 pixels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int ot = blockIdx.x, grp = blockIdx.y;
     const int it = wave & 1, th = wave >> 1;                  // in-channel tile, tap half
     const int n_beg = grp * p.img_per_group, n_end = min(p.N, n_beg + p.img_per_group);
     // zero the padded image once: only its interior is rewritten per image
@@ -1200,6 +1209,10 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(Wgrad32Params p) {
         if (q < nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[((ot * 16 + fg * 4 + e) * 9 + t0 + q) * 32 + it * 16 + fr] = acc[q][e];
+}
+__global__ __launch_bounds__(256) void wgrad32_kernel(Wgrad32Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad32_body(p, blockIdx.x, blockIdx.y, smem);
 }
 
 int wgrad32_groups(int N) { const int ipg = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1); return (N + ipg - 1) / ipg; }
@@ -1278,6 +1291,69 @@ int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int
     CLHIP_LAUNCH_CHECK();
     if (ws != nullptr) return clhip_wgrad_reduce_launch(ws, dw, (int64_t)K * 9 * C / 4, splits, st);
     return CLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Horizontal fusion of a layer's two backward convolutions (round 3).  The input gradient (conv16 / conv32 in dgrad mode) and the weight
+// gradient (wgrad16 / wgrad32) of a layer both read dz and depend on nothing else of each other; on CifarResNet-32 each is a launch at
+// its latency floor (8-15 us and 10-12 us) on ONE stream -- a second stream does not pay there (events cost what the overlap wins,
+// profiles/r03_step_notes.md).  One launch carries both: blocks [0, nw) run the weight-gradient body, blocks [nw, nw + nd) the
+// dgrad body (the longer-running weight-gradient workgroups are dispatched first); same device functions as the stand-alone kernels,
+// so the results are bit-identical to the two-launch path.
+namespace {
+__global__ __launch_bounds__(256) void bwd16_fused_kernel(Conv3Params pd, Wgrad16Params pw, int nw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nw) wgrad16_body(pw, blockIdx.x, smem);
+    else conv16_body<1>(pd, (int)blockIdx.x - nw, smem);
+}
+__global__ __launch_bounds__(256) void bwd32_fused_kernel(Conv3Params pd, Wgrad32Params pw, int nw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nw) wgrad32_body(pw, blockIdx.x & 1, blockIdx.x >> 1, smem);
+    else conv32_body<1>(pd, (int)blockIdx.x - nw, smem);
+}
+}  // namespace
+
+bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    static const bool off = clhip_cfg("BWD_FUSED") != nullptr && atoi(clhip_cfg("BWD_FUSED")) == 0;
+    if (off) return false;
+    return clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype) || clhip_wgrad32_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype);
+}
+
+int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st) {
+    Conv3Params pd;
+    pd.bn_z = static_cast<const bf16_t*>(bn_z); pd.bn_y = static_cast<const bf16_t*>(bn_y); pd.bn_mean = bn_mean; pd.bn_invstd = bn_invstd;
+    pd.bn_acc = bn_acc; pd.bn_rep = bn_rep > 0 ? bn_rep : 1;
+    pd.src = static_cast<const bf16_t*>(dz); pd.wt = static_cast<const bf16_t*>(w_dg); pd.dst = static_cast<bf16_t*>(dx);
+    pd.stats = nullptr; pd.stat_acc = nullptr; pd.stat_rep = 1;
+    pd.N = N; pd.H = H; pd.W = W; pd.wshift = ilog2_exact(W); pd.hshift = ilog2_exact(H); pd.Cs = C; pd.Cd = C; pd.accumulate = accumulate; pd.M = N * H * W;
+    pd.np = 256 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * (C == 16 ? 32 : 96); pd.nbuf = 1; pd.debug = 0;
+    const int nd = clhip_conv16_tiles_m(pd.M);
+    size_t lds = (size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024;
+    if (C == 16) {
+        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H};
+        size_t wl = (size_t)((H + 2) * 34 + H * 32) * 32;
+        if (wl < 4 * 2304 * sizeof(float)) wl = 4 * 2304 * sizeof(float);
+        if (wl > lds) lds = wl;
+        static size_t attr = 0;
+        if (lds > attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                clhip_set_error("bwd16_fused: cannot reserve %zu bytes of LDS", lds);
+                return CLHIP_EHIP;
+            }
+            attr = lds;
+        }
+        hipLaunchKernelGGL(bwd16_fused_kernel, dim3(N + nd), dim3(256), lds, st, pd, pw, N);
+        CLHIP_LAUNCH_CHECK();
+        return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N, st);
+    }
+    const int groups = wgrad32_groups(N);
+    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1)};
+    const size_t wl = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
+    if (wl > lds) lds = wl;
+    hipLaunchKernelGGL(bwd32_fused_kernel, dim3(2 * groups + nd), dim3(256), lds, st, pd, pw, 2 * groups);
+    CLHIP_LAUNCH_CHECK();
+    return clhip_wgrad_reduce_launch(ws, dw, 2304, groups, st);
 }
 
 // ---- deferred reduces.  Every partial-block weight-gradient kernel ends with "dw += sum of my slab".  On CifarResNet-32 those are 33

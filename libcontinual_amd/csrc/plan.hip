@@ -786,6 +786,20 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             p->wg_pending[0] = p->wg_pending[1] = false;
         }
         if (defer_side) clhip_wgrad_defer_pause(!on_side);             // only the side stream's launches are collected
+        // layers whose dgrad and weight gradient are both launches at their latency floor on this one stream: ONE launch for the two
+        // (clhip_conv_dgrad_wgrad, conv3.hip: CifarResNet-32 stages 1 and 2)
+        const bool both = !on_side && u.d.src != 0 && !u.raw_src && !(p->br_act >= 0 && u.d.src == p->br_act) &&
+                          clhip_conv_dgrad_wgrad_supported(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) &&
+                          clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0;
+        if (both) {
+            const Unit* prod = u.fuse_src_bn ? &p->units[u.d.src - 1] : nullptr;
+            TRY(clhip_conv_dgrad_wgrad(in, dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, grads + u.d.w_off, ws + u.wg_own,
+                                       prod ? ws + prod->z_off : nullptr, (prod && prod->relu) ? ws + src.y_off : nullptr, prod ? fr + prod->f_mean : nullptr,
+                                       prod ? fr + prod->f_invstd : nullptr, prod ? reinterpret_cast<double*>(ws + p->acc_off) + prod->a_bwd : nullptr,
+                                       prod ? prod->rep_bwd : 1, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            if (prod) p->bwd_sums_ready[u.d.src - 1] = 1;
+            continue;
+        }
         TRY(clhip_conv_wgrad(in, dz, grads + u.d.w_off, ws + u.wg_own, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, wg_stream));
         if (defer_side && on_side && ++side_deferred % p->defer_side == 0) TRY(clhip_wgrad_defer_flush(p->side, false));

@@ -232,6 +232,59 @@ def test_weight_stationary_conv5(shape):
         assert (a.float() - b.float()).abs().max() <= 2 ** -7 * float(r.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(9, 32, 32, 16), (140, 32, 32, 16), (33, 16, 16, 32), (140, 16, 16, 32), (3, 8, 16, 32)])
+@pytest.mark.parametrize("with_bn,accumulate", [(0, 0), (1, 1), (1, 0)])
+def test_dgrad_and_wgrad_in_one_launch(shape, with_bn, accumulate):
+    """clhip_conv_dgrad_wgrad (the input gradient and the weight gradient of a 16 -> 16 / 32 -> 32-channel layer as ONE launch: the two device
+    bodies of the stand-alone kernels behind one grid) against the two-launch path on the same operands: dx, the BatchNorm-backward sums
+    of its epilogue and dw are BIT-IDENTICAL (same code, same partial-block order), with and without accumulation into dx."""
+    N, H, W, C = shape
+    L = _lib.lib()
+    code, tdt = DT["bf16"]
+    if not L.clhip_conv_dgrad_wgrad_supported(N, H, W, C, C, C, 3, 1, 1, code):
+        pytest.skip("layer outside the fused launch's domain")
+    x = to_nhwc(quant(rnd((N, C, H, W), 61), tdt), tdt)
+    dz = to_nhwc(quant(rnd((N, C, H, W), 62, 0.5), tdt), tdt)
+    wd = quant(rnd((C, 9, C), 63, 0.1), tdt).to(tdt).to(DEV).contiguous()
+    zp, yp = to_nhwc(quant(rnd((N, C, H, W), 64, 1.5), tdt), tdt), to_nhwc(quant(torch.relu(rnd((N, C, H, W), 65)), tdt), tdt)
+    mean, invstd = (rnd((C,), 66) * 0.3).to(DEV), (rnd((C,), 67).abs() + 0.5).to(DEV)
+    old = to_nhwc(quant(rnd((N, C, H, W), 68, 0.3), tdt), tdt)
+    wsb = L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, C, 3, 1, 1, code)
+    assert wsb > 0
+    rep = 4
+
+    def run(fused):
+        dx = old.clone() if accumulate else torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+        dw = torch.full((C, 9, C), 0.25, device=DEV)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        acc = torch.zeros(rep, 2, C, dtype=torch.float64, device=DEV)
+        bn = (zp.data_ptr(), yp.data_ptr(), mean.data_ptr(), invstd.data_ptr(), acc.data_ptr(), rep) if with_bn else (None, None, None, None, None, 1)
+        if fused:
+            call("clhip_conv_dgrad_wgrad", x.data_ptr(), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), accumulate, dw.data_ptr(), ws.data_ptr(), *bn,
+                 N, H, W, C, C, C, 3, 1, 1, code, st())
+        else:
+            if with_bn:
+                call("clhip_conv_dgrad_bn_reduce", dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), accumulate, zp.data_ptr(), yp.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                     acc.data_ptr(), rep, N, H, W, C, C, 3, 1, 1, code, st())
+            else:
+                call("clhip_conv_dgrad", dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), accumulate, N, H, W, C, C, 3, 1, 1, code, st())
+            call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, H, W, C, C, C, 3, 1, 1, code, st())
+        torch.cuda.synchronize()
+        return dx, dw, acc.sum(0)
+
+    dx_f, dw_f, s_f = run(True)
+    dx_u, dw_u, s_u = run(False)
+    assert torch.equal(dx_f, dx_u) and torch.equal(dw_f, dw_u)
+    if with_bn:          # fp64 atomics into 4 replicas: the same addends, summed in arrival order
+        assert ((s_f - s_u).abs() <= 1e-12 * s_u.abs().clamp(min=1.0)).all()
+    # and against fp64 math for the weight gradient (the dgrad / sums are covered by their own tests)
+    xr = from_nhwc(x).double()
+    wr = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, None, 1, 1).backward(from_nhwc(dz).double())
+    got = dw_f.cpu().double().reshape(C, 3, 3, C).permute(0, 3, 1, 2) - 0.25
+    assert (got - wr.grad).abs().max() <= 2e-4 * float(wr.grad.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_wgrad(case, mode):
