@@ -494,18 +494,30 @@ __global__ __launch_bounds__(256) void gram_kernel(const T* __restrict__ x, floa
 // ------------------------------------------------------------------------------------------------- L2P
 // One block.  q [B, D] (cls features), key [pool, D].  Per-sample cosine top-k, batch-majority top-k (ties -> lowest id),
 // gathered prompt tokens, reduce_sim = sum_b sum_{k in ids} <kn_k, qn_b> / B and its gradient w.r.t. key.
-__global__ __launch_bounds__(256) void l2p_select_kernel(const float* __restrict__ q, const float* __restrict__ key, const float* __restrict__ prompt,
+__global__ __launch_bounds__(1024) void l2p_select_kernel(const float* __restrict__ q, const float* __restrict__ key, const float* __restrict__ prompt,
                                                           int B, int D, int pool, int top_k, int length, int* __restrict__ ids,
                                                           float* __restrict__ prompt_tokens, float* __restrict__ reduce_sim, float* __restrict__ dkey,
                                                           float* __restrict__ scratch /* [B + pool + D + B*pool] */) {
     __shared__ int counts[64];
     __shared__ int sel[64];
-    __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[16];
+    // 16 waves (round 3): the B x pool cosine products are one wave each -- with 4 waves the 160 products of the bench batch were 40
+    // dependent rounds of 12 loads per lane (120 us); every loop below strides by the block's own size
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = 16, NT = 1024;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 16; ++w2) t += red[w2];
+        return t;
+    };
     float* qinv = scratch;                 // [B]    1 / max(|q_b|, eps)
     float* kinv = scratch + B;             // [pool]
     float* sbar = scratch + B + pool;      // [D]    sum_b qn_b / B
-    for (int r = wave; r < B + pool; r += 4) {
+    for (int r = wave; r < B + pool; r += NW) {
         const float* v = r < B ? q + (size_t)r * D : key + (size_t)(r - B) * D;
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += v[c] * v[c];
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(256) void l2p_select_kernel(const float* __restrict
     // cosine similarities sim[b][j] (one wave per pair, lanes over D: coalesced), then per-sample top-k: one wave per sample,
     // lane = prompt id (pool <= 64)
     float* sim = scratch + B + pool + D;   // [B * pool]
-    for (int pr = wave; pr < B * pool; pr += 4) {
+    for (int pr = wave; pr < B * pool; pr += NW) {
         const int b = pr / pool, j = pr - b * pool;
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += q[(size_t)b * D + c] * key[(size_t)j * D + c];
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(256) void l2p_select_kernel(const float* __restrict
         if (lane == 0) sim[pr] = s * qinv[b] * kinv[j];
     }
     __syncthreads();
-    for (int b = wave; b < B; b += 4) {
+    for (int b = wave; b < B; b += NW) {
         float sv = lane < pool ? sim[b * pool + lane] : -INFINITY;
         for (int k = 0; k < top_k; ++k) {
             float best = wave_max(sv);
@@ -546,26 +558,26 @@ __global__ __launch_bounds__(256) void l2p_select_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int i = tid; i < top_k * length * D; i += 256) {
+    for (int i = tid; i < top_k * length * D; i += NT) {
         const int k = i / (length * D), rem = i - k * length * D;
         prompt_tokens[i] = prompt[(size_t)sel[k] * length * D + rem];
     }
-    for (int c = tid; c < D; c += 256) {
+    for (int c = tid; c < D; c += NT) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += q[(size_t)b * D + c] * qinv[b];
         sbar[c] = s / B;
     }
-    for (int i = tid; i < pool * D; i += 256) dkey[i] = 0.f;
+    for (int i = tid; i < pool * D; i += NT) dkey[i] = 0.f;
     __syncthreads();
     float total = 0.f;
     for (int k = 0; k < top_k; ++k) {
         const int j = sel[k];
         float dot = 0.f;
-        for (int c = tid; c < D; c += 256) dot += key[(size_t)j * D + c] * kinv[j] * sbar[c];
-        dot = block_sum_256(dot, red);
+        for (int c = tid; c < D; c += NT) dot += key[(size_t)j * D + c] * kinv[j] * sbar[c];
+        dot = block_sum(dot);
         total += dot;
         // d<kn, s>/dkey = (s - kn <kn, s>) / |key|
-        for (int c = tid; c < D; c += 256) dkey[(size_t)j * D + c] = (sbar[c] - key[(size_t)j * D + c] * kinv[j] * dot) * kinv[j];
+        for (int c = tid; c < D; c += NT) dkey[(size_t)j * D + c] = (sbar[c] - key[(size_t)j * D + c] * kinv[j] * dot) * kinv[j];
         __syncthreads();
     }
     if (tid == 0) *reduce_sim = total;
@@ -766,7 +778,7 @@ extern "C" int clhip_l2p_select(const float* cls_feat, const float* prompt_key, 
                                 float* prompt_tokens, float* reduce_sim, float* dkey, float* scratch, void* stream) {
     CLHIP_CHECK_ARG(cls_feat && prompt_key && prompt && ids && prompt_tokens && reduce_sim && dkey && scratch);
     CLHIP_CHECK_ARG(B > 0 && D > 0 && pool > 0 && pool <= 64 && top_k > 0 && top_k <= pool && length > 0);
-    hipLaunchKernelGGL(l2p_select_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cls_feat, prompt_key, prompt, B, D, pool, top_k, length, ids,
+    hipLaunchKernelGGL(l2p_select_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cls_feat, prompt_key, prompt, B, D, pool, top_k, length, ids,
                        prompt_tokens, reduce_sim, dkey, scratch);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
