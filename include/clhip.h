@@ -446,6 +446,15 @@ int clhip_augment_crop_flip(const uint8_t* store, const int64_t* index, const in
                             float* out, int B, int H, int W, int S, int pad, const float* mean3, const float* std3, void* stream);
 int clhip_augment_rrc_flip(const uint8_t* store, const int64_t* index, const int32_t* params, float* out, int B, int H, int W, int S,
                            const float* mean3, const float* std3, void* stream);
+/* rrc_aa = the same pipeline for stores whose images are LARGER than S (ImageNet-R, config/InfLoRA_opt-vit-imagenetr-b20-20-10.yaml
+ *   :28-35), where torchvision's resize on PIL images anti-aliases: Pillow's two fixed-point passes (triangle filter of support
+ *   max(scale, 1), 22-bit weights, uint8 intermediate image), reproduced bit for bit.  The store may be RAGGED: image i = uint8
+ *   [hw[2i], hw[2i+1], 3] at store + offsets[i] (offsets / hw NULL: a uniform [Nimg, H, W, 3] store).  max_box >= the largest
+ *   crop-box side of the batch (sizes the coefficient table: ws of clhip_augment_rrc_aa_ws_bytes(B, S, max_box) bytes). */
+size_t clhip_augment_rrc_aa_ws_bytes(int B, int S, int max_box);
+int clhip_augment_rrc_aa(const uint8_t* store, const int64_t* offsets /*nullable*/, const int32_t* hw /*nullable*/, const int64_t* index,
+                         const int32_t* params, float* out, void* ws, int B, int H, int W, int S, int max_box, const float* mean3,
+                         const float* std3, void* stream);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,8 @@ _PROTOS = {
     "clhip_herding_select": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "clhip_augment_crop_flip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_augment_rrc_flip": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
+    "clhip_augment_rrc_aa_ws_bytes": (_sz, [_i, _i, _i]),
+    "clhip_augment_rrc_aa": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_config": (_i, [C.c_char_p, C.c_char_p]),
     "clhip_gemm5_config": (None, [_i]),

@@ -37,9 +37,43 @@ class SingleDataset(Dataset):
         return {"image": self.trfms(img), "label": int(self.labels[idx])}
 
 
+class RaggedStore:
+    """uint8 images of DIFFERENT sizes in one flat buffer (ImageNet-R: the reference decodes a JPEG per sample per epoch,
+    core/data/dataset.py:248-266; here every image is decoded once): image i = flat[offsets[i]:offsets[i+1]] viewed as
+    [hw[i,0], hw[i,1], 3].  `store[i]` gives that view, so the CPU transforms work on it like on an [N,H,W,3] array."""
+
+    def __init__(self, frames):
+        self.hw = np.asarray([f.shape[:2] for f in frames], dtype=np.int32).reshape(-1, 2)
+        sizes = self.hw[:, 0].astype(np.int64) * self.hw[:, 1] * 3
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.flat = np.empty(int(self.offsets[-1]), np.uint8)
+        for i, f in enumerate(frames):
+            assert f.dtype == np.uint8 and f.ndim == 3 and f.shape[2] == 3
+            self.flat[self.offsets[i]:self.offsets[i + 1]] = f.reshape(-1)
+
+    def __len__(self):
+        return len(self.hw)
+
+    def __getitem__(self, i):
+        h, w = self.hw[int(i)]
+        return self.flat[self.offsets[int(i)]:self.offsets[int(i) + 1]].reshape(h, w, 3)
+
+
+class DeviceRaggedStore:
+    def __init__(self, store, device):
+        self.flat, self.offsets, self.hw = (torch.as_tensor(a).to(device) for a in (store.flat, store.offsets[:-1].copy(), store.hw))
+        self.hw_host = torch.as_tensor(store.hw)
+
+
+def store_hw(store):
+    """((H, W) or None, ragged) of an image store: the two facts `gpu_plan` needs"""
+    return (None, True) if isinstance(store, RaggedStore) else (tuple(store.shape[1:3]), False)
+
+
 class ArrayDataset(Dataset):
-    """`store` is a uint8 array [N,H,W,3]; `images` holds indices into it.  The store object is shared by every per-task view
-    (and by copies of a view); `device_store()` uploads it once and keeps it resident for the GPU input pipeline."""
+    """`store` is a uint8 array [N,H,W,3] (or a RaggedStore); `images` holds indices into it.  The store object is shared by
+    every per-task view (and by copies of a view); `device_store()` uploads it once and keeps it resident for the GPU input
+    pipeline."""
 
     def __init__(self, store, images, labels, trfms, mode="train", resident=None):
         self.store, self.trfms, self.mode, self.data_root = store, trfms, mode, None
@@ -54,7 +88,8 @@ class ArrayDataset(Dataset):
     def device_store(self, device):
         key = str(device)
         if key not in self._resident:
-            self._resident[key] = torch.as_tensor(np.ascontiguousarray(self.store)).to(device)
+            self._resident[key] = (DeviceRaggedStore(self.store, device) if isinstance(self.store, RaggedStore)
+                                   else torch.as_tensor(np.ascontiguousarray(self.store)).to(device))
         return self._resident[key]
 
     def __len__(self):
@@ -86,7 +121,7 @@ def make_loader(dataset, batch_size, shuffle, num_workers=0, device=None, drop_l
     transform pipeline the augment kernels implement and `device` is a HIP device; otherwise torch's DataLoader"""
     if device is not None and torch.device(device).type == "cuda" and hasattr(dataset, "device_store"):
         from .gpu_loader import GpuBatchLoader, gpu_plan
-        plan = gpu_plan(dataset.trfms, tuple(dataset.store.shape[1:3]) if hasattr(dataset, "store") else None)
+        plan = gpu_plan(dataset.trfms, *store_hw(dataset.store))
         if plan is not None:
             return GpuBatchLoader(dataset, batch_size, shuffle, device, plan, drop_last=drop_last)
     return DataLoader(dataset, shuffle=shuffle, batch_size=batch_size, drop_last=drop_last, num_workers=num_workers, pin_memory=False)
@@ -117,9 +152,11 @@ def get_dataloader(config, mode, cls_map=None, device=None):
 
 
 def preloaded_datasets(config, mode, trfms, bs, cls_map, device):
-    """`preload: true`: decode the whole class-folder tree ONCE into a uint8 store (all images must share one size, e.g. the
-    CIFAR-100 PNG export: 50 000 x 32 x 32 x 3 = 150 MB) so that the per-task datasets are index views and the GPU input pipeline
-    can serve every batch from HBM.  Same class order / task split as the on-disk path."""
+    """`preload: true`: decode the whole class-folder tree ONCE into a uint8 store so that the per-task datasets are index views
+    and the GPU input pipeline can serve every batch from HBM (CIFAR-100 PNG export: 50 000 x 32 x 32 x 3 = 150 MB; ImageNet-R:
+    about 13 GB of differently sized images in a RaggedStore).  The DETERMINISTIC head of the transform list (Resize / CenterCrop
+    of the test pipelines, config/InfLoRA_opt-vit-imagenetr-b20-20-10.yaml:37-43) is applied here, once, with the same PIL calls
+    the per-sample path makes, and removed from the per-batch transform.  Same class order / task split as the on-disk path."""
     from PIL import Image
     data_root = config["data_root"]
     if cls_map is None:
@@ -127,13 +164,17 @@ def preloaded_datasets(config, mode, trfms, bs, cls_map, device):
         perm = config["class_order"] if "class_order" in config else np.random.permutation(len(cls_list))
         cls_map = {label: cls_list[ori] for label, ori in enumerate(perm)}
     n_cls = config["init_cls_num"] + (config["task_num"] - 1) * config["inc_cls_num"]
+    head, trfms = T.split_deterministic_head(trfms)
     frames, labels = [], []
     for label in range(n_cls):
         d = os.path.join(data_root, mode, cls_map[label])
         for f in sorted(os.listdir(d)):
-            frames.append(np.asarray(Image.open(os.path.join(d, f)).convert("RGB")))
+            img = Image.open(os.path.join(d, f)).convert("RGB")
+            for t in head:
+                img = t(img)
+            frames.append(np.ascontiguousarray(np.asarray(img)))
             labels.append(label)
-    store = np.stack(frames)
+    store = np.stack(frames) if len({f.shape for f in frames}) == 1 else RaggedStore(frames)
     labels = np.asarray(labels)
     shared = {}
 

@@ -166,6 +166,18 @@ class RandomResizedCrop:
         return np.asarray(im.crop(box).resize((self.size[1], self.size[0]), self.interp))
 
 
+def split_deterministic_head(trfms):
+    """(leading Resize / CenterCrop transforms, Compose of the rest): the head does not depend on the random state, so a
+    preloading dataset applies it once per image instead of once per sample per epoch"""
+    if not isinstance(trfms, Compose):
+        return [], trfms
+    ts = list(trfms.transforms)
+    k = 0
+    while k < len(ts) and isinstance(ts[k], (Resize, CenterCrop)):
+        k += 1
+    return ts[:k], Compose(ts[k:])
+
+
 _BY_NAME = {}
 
 

@@ -233,3 +233,72 @@ def test_input_pipeline_tables_equal_the_reference_fixture(golden):
     te = T.cifar_resnet_transform("test", 32)
     for k in range(len(fx["cifar_test_expected"])):
         assert np.abs(te(fx["cifar_images"][k]).numpy() - fx["cifar_test_expected"][k]).max() <= 1e-6
+
+
+def test_resample_oracle_matches_pillow_and_the_fixture(golden):
+    """oracle/resample.py restates Pillow's anti-aliased bilinear resize (the arithmetic behind torchvision's RandomResizedCrop on the
+    PIL images of the reference's ImageNet-R pipeline).  Pinned: bit-exact against Pillow itself on random sizes (shrinking, enlarging,
+    mixed, one-pixel outputs) and against tests/golden/augment_aa.npz (boxes + expected outputs, oracle/gen_augment_aa_golden.py)."""
+    from PIL import Image
+    from oracle.resample import resize_bilinear, resized_crop
+    rs = np.random.RandomState(0)
+    for t in range(14):
+        H, W = (int(v) for v in rs.randint(2, 180, 2))
+        oh, ow = ((48, 48), (1, 7), (int(rs.randint(1, 90)), int(rs.randint(1, 90))))[t % 3]
+        img = (rs.rand(H, W, 3) * 255).astype(np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(resize_bilinear(img, oh, ow), want), (H, W, oh, ow)
+    fx = golden("augment_aa")
+    for j in (0, 1, 3, 7):                                          # the small outputs (the 224 x 224 case runs on the GPU test)
+        top, left, h, w, fl = (int(v) for v in fx["boxes"][j])
+        S = int(fx["out_sizes"][j])
+        got = resized_crop(fx[f"image_{int(fx['which'][j])}"], top, left, h, w, S, S)
+        assert np.array_equal(got[:, ::-1] if fl else got, fx[f"train_expected_u8_{j}"]), j
+
+
+def test_ragged_store_preload_and_deterministic_head(tmp_path, golden):
+    """`preload: true` on a class-folder tree of differently sized images (ImageNet-R): the train split becomes a RaggedStore whose
+    views are the decoded images; the test pipeline's Resize(256, BICUBIC) + CenterCrop(224) head is applied once at load (equal to
+    the fixture made with the reference's YAML parameters) and only ToTensor stays per batch; the box sampler stays inside every image."""
+    from PIL import Image
+    from libcontinual_amd.data import transforms as T
+    from libcontinual_amd.data.dataset import RaggedStore, get_dataloader, store_hw
+    from libcontinual_amd.data.gpu_loader import _rrc_boxes, gpu_plan
+    fx = golden("augment_aa")
+    n_img = len(fx["hw"])
+    for mode in ("train", "test"):
+        for k in range(n_img):
+            d = tmp_path / mode / f"c{k % 2}"
+            d.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(fx[f"image_{k}"]).save(d / f"{k}.png")
+    S = int(fx["size"][0])
+    cfg = dict(data_root=str(tmp_path), dataset="imagenet-r", preload=True, batch_size=4, num_workers=0, task_num=2, init_cls_num=1, inc_cls_num=1,
+               class_order=[0, 1],
+               train_trfms=[{"RandomResizedCrop": {"size": S, "scale": fx["scale"].tolist(), "ratio": fx["ratio"].tolist()}},
+                            {"RandomHorizontalFlip": {"p": float(fx["flip_p"][0])}}, {"ToTensor": {}}],
+               test_trfms=[{"Resize": {"size": 256, "interpolation": "BICUBIC"}}, {"CenterCrop": {"size": S}}, {"ToTensor": {}}])
+    train = get_dataloader(cfg, "train")
+    ds = train.get_loader(0).dataset
+    assert isinstance(ds.store, RaggedStore) and store_hw(ds.store) == (None, True) and len(ds.store) == n_img
+    order = [k for c in range(2) for k in range(n_img) if k % 2 == c]                   # class folders in label order, files sorted
+    for pos, k in enumerate(order):
+        assert np.array_equal(ds.store[pos], fx[f"image_{k}"])
+    assert gpu_plan(ds.trfms, *store_hw(ds.store))["kind"] == "rrc_aa" and gpu_plan(ds.trfms, (32, 32))["kind"] == "rrc_flip"
+    assert gpu_plan(ds.trfms, (500, 375))["kind"] == "rrc_aa" and gpu_plan(T.cifar_resnet_transform("train", 32), None, True) is None
+    torch.manual_seed(0)
+    assert ds[1]["image"].shape == (3, S, S)                                            # the per-sample CPU path works on the views
+    test = get_dataloader(cfg, "test", cls_map=train.cls_map)
+    tds = test.get_loader(1)[1].dataset
+    assert store_hw(tds.store) == ((S, S), False) and [type(t).__name__ for t in tds.trfms.transforms] == ["ToTensor"]
+    assert gpu_plan(tds.trfms, *store_hw(tds.store))["kind"] == "crop_flip"
+    pos = order.index(1)
+    assert np.array_equal(tds.store[pos], fx["test_expected_u8_1"])
+    # vectorised torchvision get_params: inside the image, aspect within `ratio` up to rounding, centre-crop fallback for extreme shapes
+    torch.manual_seed(1)
+    Hs, Ws = torch.randint(40, 700, (4000,)), torch.randint(40, 700, (4000,))
+    Hs[:8], Ws[:8] = 30, 900
+    y0, x0, h, w = _rrc_boxes(Hs, Ws, (0.05, 1.0), (0.75, 1.333)).long().unbind(1)
+    assert bool(((h > 0) & (w > 0) & (y0 >= 0) & (x0 >= 0) & (y0 + h <= Hs) & (x0 + w <= Ws)).all())
+    assert h[:8].tolist() == [30] * 8 and w[:8].tolist() == [40] * 8 and x0[:8].tolist() == [430] * 8
+    frac = (h * w).double() / (Hs * Ws).double()
+    assert 0.04 < float(frac[8:].min()) and float(frac[8:].max()) <= 1.0 and 0.25 < float(frac[8:].mean()) < 0.55      # first valid of 10 tries: large boxes are rejected more often on elongated images

@@ -163,3 +163,94 @@ def test_augment_kernels_against_the_committed_reference_fixture(golden):
         want = torch.as_tensor(fx[f"vit_train_expected_u8_{k}"]).permute(2, 0, 1).float() / 255.0
         diff = (o[0].cpu() - want).abs() * 255
         assert float(diff.max()) <= 1.01 and float(diff.mean()) < 0.35, (k, size, float(diff.max()), float(diff.mean()))
+
+
+def _aa(flat, offsets, hw, idx, params, S, uniform=None):
+    B = len(params)
+    max_box = int(np.asarray(params)[:, 2:4].max())
+    from libcontinual_amd import _lib
+    ws = torch.empty(_lib.lib().clhip_augment_rrc_aa_ws_bytes(B, S, max_box), dtype=torch.uint8, device=DEV)
+    out = torch.empty(B, 3, S, S, device=DEV)
+    mean, std = (C.c_float * 3)(0.0, 0.0, 0.0), (C.c_float * 3)(1.0, 1.0, 1.0)
+    keep = [torch.as_tensor(flat).to(DEV), torch.as_tensor(np.asarray(idx, np.int64)).to(DEV), torch.as_tensor(np.asarray(params, np.int32)).to(DEV)]
+    if uniform is None:
+        keep += [torch.as_tensor(offsets).to(DEV), torch.as_tensor(hw).to(DEV)]
+        call("clhip_augment_rrc_aa", keep[0].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), out.data_ptr(),
+             ws.data_ptr(), B, 0, 0, S, max_box, mean, std, st())
+    else:
+        call("clhip_augment_rrc_aa", keep[0].data_ptr(), None, None, keep[1].data_ptr(), keep[2].data_ptr(), out.data_ptr(), ws.data_ptr(), B,
+             uniform[0], uniform[1], S, max_box, mean, std, st())
+    torch.cuda.synchronize()
+    return (out.cpu() * 255).round().permute(0, 2, 3, 1).numpy().astype(np.uint8), out.cpu()
+
+
+def test_antialiased_rrc_is_bit_exact_on_the_reference_fixture_and_random_ragged_stores(golden):
+    """f2 for ImageNet-R: the anti-aliased RandomResizedCrop kernel on a ragged store equals Pillow's resize bit for
+    bit -- against tests/golden/augment_aa.npz (boxes and outputs of the reference's YAML pipeline, 224 x 224 case included), against
+    the oracle on random images / boxes (shrinking by up to 12x, enlarging, flips), and on a uniform store."""
+    from libcontinual_amd.data.dataset import RaggedStore
+    from oracle.resample import resized_crop
+    fx = golden("augment_aa")
+    store = RaggedStore([fx[f"image_{k}"] for k in range(len(fx["hw"]))])
+    assert np.array_equal(store.hw, fx["hw"])
+    for S in sorted(set(int(v) for v in fx["out_sizes"])):
+        sel = [j for j in range(len(fx["boxes"])) if int(fx["out_sizes"][j]) == S]
+        got, raw = _aa(store.flat, store.offsets[:-1].copy(), store.hw, fx["which"][sel], fx["boxes"][sel], S)
+        for n, j in enumerate(sel):
+            assert np.array_equal(got[n], fx[f"train_expected_u8_{j}"]), (S, j)
+            assert float((raw[n] - torch.as_tensor(fx[f"train_expected_u8_{j}"]).permute(2, 0, 1).float() / 255.0).abs().max()) <= 1e-7   # ToTensor
+    rs = np.random.RandomState(5)
+    frames = [(rs.rand(int(rs.randint(8, 400)), int(rs.randint(8, 400)), 3) * 255).astype(np.uint8) for _ in range(9)]
+    rag = RaggedStore(frames)
+    idx, params = [], []
+    for n in range(24):
+        k = int(rs.randint(0, 9))
+        H, W = frames[k].shape[:2]
+        h, w = int(rs.randint(1, H + 1)), int(rs.randint(1, W + 1))
+        idx.append(k)
+        params.append([int(rs.randint(0, H - h + 1)), int(rs.randint(0, W - w + 1)), h, w, int(rs.randint(0, 2))])
+    for S in (32, 7):
+        got, _ = _aa(rag.flat, rag.offsets[:-1].copy(), rag.hw, idx, params, S)
+        for n, (k, (y0, x0, h, w, fl)) in enumerate(zip(idx, params)):
+            want = resized_crop(frames[k], y0, x0, h, w, S, S)
+            assert np.array_equal(got[n], want[:, ::-1] if fl else want), (S, n, frames[k].shape, params[n])
+    uni = (rs.rand(4, 96, 80, 3) * 255).astype(np.uint8)
+    par = [[0, 0, 96, 80, 0], [10, 5, 70, 60, 1], [40, 40, 8, 8, 0], [1, 2, 90, 33, 1]]
+    got, _ = _aa(uni.reshape(-1), None, None, [0, 1, 2, 3], par, 24, uniform=(96, 80))
+    for n, (y0, x0, h, w, fl) in enumerate(par):
+        want = resized_crop(uni[n], y0, x0, h, w, 24, 24)
+        assert np.array_equal(got[n], want[:, ::-1] if fl else want), n
+
+
+def test_ragged_loader_epoch_matches_pillow_for_the_boxes_it_drew():
+    """GpuBatchLoader over a RaggedStore (ImageNet-R layout): one epoch covers every sample once, batches are [B,3,S,S] on the device,
+    and re-drawing the epoch's boxes with the same seed reproduces every image with Pillow on the host."""
+    from PIL import Image
+    from libcontinual_amd.data.dataset import RaggedStore
+    from libcontinual_amd.data.gpu_loader import _rrc_boxes
+    rs = np.random.RandomState(2)
+    frames = [(rs.rand(int(rs.randint(40, 260)), int(rs.randint(40, 260)), 3) * 255).astype(np.uint8) for _ in range(21)]
+    tr = T.create_transforms([{"RandomResizedCrop": {"size": 48, "scale": [0.05, 1.0], "ratio": [0.75, 1.333]}}, {"RandomHorizontalFlip": {"p": 0.5}},
+                              {"ToTensor": {}}])
+    ds = ArrayDataset(RaggedStore(frames), list(range(21)), list(range(21)), tr, "train")
+    loader = make_loader(ds, 8, True, 0, DEV)
+    assert isinstance(loader, GpuBatchLoader) and loader.plan["kind"] == "rrc_aa" and len(loader) == 3
+    torch.manual_seed(3)
+    batches = [(b["image"].cpu(), b["label"].tolist()) for b in loader]
+    assert sorted(l for _, ls in batches for l in ls) == list(range(21)) and batches[0][0].shape == (8, 3, 48, 48)
+    # the loader's draw order: permutation, flips, boxes
+    torch.manual_seed(3)
+    order = torch.randperm(21)
+    flip = (torch.rand(21) < 0.5).int()
+    hw = torch.as_tensor(ds.store.hw)[order].long()
+    boxes = _rrc_boxes(hw[:, 0], hw[:, 1], (0.05, 1.0), (0.75, 1.333))
+    pos = 0
+    for img, labels in batches:
+        for n, l in enumerate(labels):
+            assert l == int(order[pos])
+            y0, x0, h, w = (int(v) for v in boxes[pos])
+            want = np.asarray(Image.fromarray(frames[l]).crop((x0, y0, x0 + w, y0 + h)).resize((48, 48), Image.BILINEAR))
+            if int(flip[pos]):
+                want = want[:, ::-1]
+            assert np.array_equal((img[n] * 255).round().permute(1, 2, 0).numpy().astype(np.uint8), want), (pos, l)
+            pos += 1
