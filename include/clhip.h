@@ -319,6 +319,20 @@ int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void
                            const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas,
                            int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);
 
+/* The input gradient of a DOWN-SAMPLING block entry in one launch (core/model/backbone/resnet.py:226-234: `conv1` 3x3/s2/p1 and
+ * `downsample[0]` 1x1/s2/p0 both read the block input x [N,H,W,C]):  dx (+)= dgrad3x3s2(dz, W) + dgrad1x1s2(dz_sc, W_sc).
+ * dz, dz_sc [N,H/2,W/2,K]; dz_sc NULL: the 3x3 convolution alone.  The weights come as ONE packed buffer of
+ * clhip_conv_dgrad_pair_packed_bytes(C, K) bytes made by clhip_conv_dgrad_pair_pack from the dgrad copies w_dg [C][9][K] and
+ * w_sc_dg [C][1][K] (nullable) of clhip_conv_weight_prep -- per (64-channel tile, 16-wide K chunk) the LDS image of that chunk's ten
+ * taps (csrc/conv6.hip); a plan writes this layout in its own weight preparation.  Same result as clhip_conv_dgrad of the shortcut
+ * followed by clhip_conv_dgrad(accumulate) of the 3x3 layer up to the bf16 rounding of the intermediate (here the two are summed
+ * in fp32).  bf16, C % 64 == 0, K % 32 == 0, H/2 and W/2 powers of two, W/2 <= 16 (ResNet-18's three entries).  _supported: 1 / 0. */
+int clhip_conv_dgrad_pair_supported(int N, int H, int W, int C, int K, int dtype);
+size_t clhip_conv_dgrad_pair_packed_bytes(int C, int K);
+int clhip_conv_dgrad_pair_pack(const void* w_dg, const void* w_sc_dg /*nullable*/, void* packed, int C, int K, int dtype, void* stream);
+int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_sc /*nullable*/, void* dx, int accumulate, int N, int H,
+                          int W, int C, int K, int dtype, void* stream);
+
 /* ---- run-time configuration ------------------------------------------------------------------------------------------------
  * ONE entry point for every dispatch switch, tuning value and micro-benchmark hook of the library (there are no other steering
  * exports).  `key` is a name from the list below (a leading "CLHIP_" is accepted), `value` its new value as text; value == NULL
@@ -327,7 +341,7 @@ int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void
  * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
  * pin a code path, tools/ to sweep.
  *   dispatch (0 / 1 unless noted):
- *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV_V1,
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
  *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
@@ -337,7 +351,7 @@ int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void
  *     WGRAD_TARGET (workgroups of the weight-gradient kernels), WGRAD_NET_GFLOP, WGRAD4_MIN_STEPS, WGRAD4_MIN_TOTAL, CONV3_CFG "wm,wn",
  *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
  *     STEM_WGRAD_GRID, SHORTCUT_MIN_PIXELS, BN_ACC_CPT, BN_BWD_ITERS
- *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG,
+ *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG, CONV6_DEBUG (read once),
  *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE (device address of
  *     a stamp buffer as a number; ablation builds only) */
 int clhip_config(const char* key, const char* value);

@@ -28,13 +28,13 @@ const char* const kKeys[] = {
     // dispatch switches (A/B runs, tests that pin a code path)
     "ATTN_GENERIC", "BN_FUSE", "BN_FUSE_MAX_M", "BN_MASK_BITS", "BN_MASK_FROM_Y", "BN_PARTIALS", "CE_ROWS", "CONV3G", "CONV4", "CONV_V1",
     "GEMM5", "GEMM_NO_SPLIT", "GEMM_TAIL", "NO_CONV16", "NO_CONV3", "NO_PARITY_DGRAD", "NO_SHORTCUT", "NO_STEM", "PREP_NARROW", "WGRAD4",
-    "WGRAD_NO_TR", "WGRAD2_ATOMIC", "WGRAD_DEFER", "WGRAD_DEFER_SIDE", "BWD_FUSED", "WGRAD_STREAM", "BRANCH_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "BN_ONEPASS", "WGRAD5", "WGRAD32",
+    "WGRAD_NO_TR", "WGRAD2_ATOMIC", "WGRAD_DEFER", "WGRAD_DEFER_SIDE", "BWD_FUSED", "WGRAD_STREAM", "BRANCH_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "CONV6", "CONV6_PAIR", "CONV6_DEBUG", "BN_ONEPASS", "WGRAD5", "WGRAD32",
     // tuning values
     "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
     "CONV5_MIN_TILES", "CONV5_GRID",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
-    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE",
+    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE", "CONV6_TRACE",
 };
 std::mutex g_cfg_mu;
 // values are strdup'ed and never freed: look-up sites cache the pointer (a few bytes per clhip_config call, by design)
@@ -55,6 +55,8 @@ void clhip_gemm5_set_trace(unsigned long long* dev_buf);
 void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
 void clhip_conv5_enable(int on);
 void clhip_conv5_min_tiles(int n);
+void clhip_conv6_enable(int on);
+void clhip_conv6_set_trace(unsigned long long* buf, int wg);
 
 const char* clhip_cfg(const char* name) {
     {
@@ -83,8 +85,15 @@ extern "C" int clhip_config(const char* key, const char* value) {
     if (strcmp(key, "GEMM5_DEBUG") == 0) { clhip_gemm5_set_debug(atoi(v)); return CLHIP_OK; }
     if (strcmp(key, "CONV4_TRACE") == 0) { clhip_conv4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "GEMM5_TRACE") == 0) { clhip_gemm5_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
+    if (strcmp(key, "CONV6_TRACE") == 0) {                         // "pointer[,workgroup]"
+        char* end = nullptr;
+        unsigned long long ptr = strtoull(v, &end, 0);
+        clhip_conv6_set_trace(reinterpret_cast<unsigned long long*>(ptr), (end && *end == ',') ? atoi(end + 1) : 0);
+        return CLHIP_OK;
+    }
     if (strcmp(key, "WGRAD4_TRACE") == 0) { clhip_wgrad4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "CONV5") == 0) clhip_conv5_enable(value ? atoi(v) : -1);                   // immediate AND recorded below
+    if (strcmp(key, "CONV6") == 0) clhip_conv6_enable(value ? atoi(v) : -1);
     if (strcmp(key, "CONV5_MIN_TILES") == 0) clhip_conv5_min_tiles(value ? atoi(v) : -1);
     std::lock_guard<std::mutex> lk(g_cfg_mu);
     if (value == nullptr) {

@@ -650,6 +650,31 @@ extern "C" int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void*
                                   static_cast<hipStream_t>(stream));
 }
 
+bool clhip_dgrad6_supported(int N, int H, int W, int C, int K, int dtype);      // conv6.hip
+size_t clhip_dgrad6_packed_bytes(int C, int K);
+int clhip_dgrad6_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C, int K, hipStream_t st);
+int clhip_dgrad6_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st);
+
+extern "C" int clhip_conv_dgrad_pair_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
+    if (use_v1() || !use_v3()) return 0;
+    return clhip_dgrad6_supported(N, H, W, C, K, dtype) ? 1 : 0;
+}
+
+extern "C" size_t clhip_conv_dgrad_pair_packed_bytes(int C, int K) { return (C > 0 && K > 0 && C % 64 == 0 && K % 16 == 0) ? clhip_dgrad6_packed_bytes(C, K) : 0; }
+
+extern "C" int clhip_conv_dgrad_pair_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C, int K, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(w_dg && packed && dtype == CLHIP_BF16 && clhip_conv_dgrad_pair_packed_bytes(C, K) > 0);
+    return clhip_dgrad6_pack(w_dg, w_sc_dg, packed, C, K, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K,
+                                     int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dz && w_packed && dx);
+    CLHIP_CHECK_ARG(clhip_conv_dgrad_pair_supported(N, H, W, C, K, dtype));
+    return clhip_dgrad6_launch(dz, w_packed, dz_sc, dx, accumulate, N, H, W, C, K, static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!use_v1() && use_v3() && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_stem_wgrad_ws_bytes(N, H, W, Creal, K);
     if (!use_v1() && use_v3() && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad4_ws_bytes(N, H, W, C, K, ksize, stride);

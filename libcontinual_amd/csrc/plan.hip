@@ -45,6 +45,10 @@ struct Unit {
     int tiles;
     size_t z_off;
     size_t sh_fwd, sh_dg;          // byte offsets in the shadow buffer
+    size_t sh_pk;                  // packed dgrad weights of a paired down-sampling entry (3x3/s2 unit; see `pair`)
+    int pair;                      // >= 0: this 3x3/s2 unit and the 1x1/s2 shortcut unit `pair` read the same activation: ONE launch writes its
+                                   // gradient (clhip_conv_dgrad_pair); on the shortcut unit: the index of the 3x3 unit
+    bool pair_acc;                 // the accumulate flag of that one launch (= the shortcut dgrad's, the first writer of the two)
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
     size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([rep][2][cout] each)
     int rep_fwd, rep_bwd;                        // accumulator replicas (power of two): ~64 producer workgroups per replica
@@ -321,6 +325,28 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (!clhip_conv_dgrad_bn_reduce_supported(N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, dtype)) continue;
         u.fuse_src_bn = true;
     }
+    // down-sampling entries: a 3x3/s2/p1 unit a and a 1x1/s2/p0 unit b > a with the same source activation and channel counts, the only two
+    // consumers of that activation -> their two input gradients are one launch at unit a (conv6.hip); the packed weights of both live at a.sh_pk
+    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; }
+    static const bool pair_off = clhip_cfg("CONV6_PAIR") != nullptr && atoi(clhip_cfg("CONV6_PAIR")) == 0;
+    for (int b = 0; b < n_units && !pair_off; ++b) {
+        Unit& ub = p->units[b];
+        if (ub.d.ksize != 1 || ub.d.stride != 2 || ub.d.pad != 0 || ub.pre_res || ub.raw_src || ub.no_bn || ub.has_dzr || ub.d.src < 1) continue;
+        int a = -1, users = 0;
+        for (int k = 0; k < n_units; ++k) {
+            const Unit& o = p->units[k];
+            if (o.d.src == ub.d.src || o.d.res == ub.d.src) ++users;
+            if (k < b && o.d.src == ub.d.src && o.d.ksize == 3 && o.d.stride == 2 && o.d.pad == 1 && !o.raw_src && !o.pre_res && !o.no_bn && !o.has_dzr &&
+                o.d.cout == ub.d.cout && o.cin_pad == ub.cin_pad && !o.fuse_src_bn)
+                a = k;
+        }
+        if (a < 0 || users != 2 || p->units[a].pair >= 0) continue;
+        Unit& ua = p->units[a];
+        if (!clhip_conv_dgrad_pair_supported(N, ua.H, ua.W, ua.cin_pad, ua.d.cout, dtype)) continue;
+        ua.pair = b; ub.pair = a;
+        ua.pair_acc = ub.dx_acc;
+        ua.sh_pk = p->shadow_bytes; p->shadow_bytes = align_up(p->shadow_bytes + clhip_conv_dgrad_pair_packed_bytes(ua.cin_pad, ua.d.cout));
+    }
     return p;
 }
 
@@ -376,7 +402,12 @@ static bool branch_stream_on(clhip_plan* p, hipStream_t main_s) {
 // the per-conv descriptors travel by value in the kernel arguments, a block finds its conv by a short uniform scan.
 namespace {
 constexpr int kPrepMax = 48;
-struct PrepEntry { int64_t w_off; int64_t wf_off, wd_off; int K, taps, Creal, Cpad; unsigned first_block; };
+struct PrepEntry { int64_t w_off; int64_t wf_off, wd_off; int64_t wp_off; int wp_tap0; int K, taps, Creal, Cpad; unsigned first_block; };
+// third copy (wp_off >= 0): the packed dgrad layout of conv6.hip -- per (64-channel tile of C, 16-wide chunk of K) 64 rows x 21 sixteen-byte
+// slots, slot 2 * tap + (k % 16) / 8; the shortcut unit of a pair writes its single tap as tap 9 of its partner's buffer
+__device__ __forceinline__ size_t packed_index(int c, int tap, int k, int K) {
+    return ((((size_t)(c >> 6) * (K >> 4) + (k >> 4)) * 64 + (c & 63)) * 21 + tap * 2 + ((k >> 3) & 1)) * 8 + (k & 7);
+}
 struct PrepTable { int n; PrepEntry e[kPrepMax]; };
 
 // block = one (tap, 32 out-channels x 32 in-channels) tile: coalesced fp32 reads along C, coalesced writes of the forward copy
@@ -409,7 +440,10 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* __r
     T* wd = reinterpret_cast<T*>(shadow + d.wd_off);
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, k = k0 + tx;
-        if (c < d.Cpad && k < d.K) Elem<T>::st(wd + ((size_t)c * d.taps + tap) * d.K + k, tile[tx][i]);
+        if (c < d.Cpad && k < d.K) {
+            Elem<T>::st(wd + ((size_t)c * d.taps + tap) * d.K + k, tile[tx][i]);
+            if (d.wp_off >= 0) Elem<T>::st(reinterpret_cast<T*>(shadow + d.wp_off) + packed_index(c, d.wp_tap0 + tap, k, d.K), tile[tx][i]);
+        }
     }
 }
 
@@ -447,9 +481,11 @@ __global__ __launch_bounds__(256) void weight_prep_multi64_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int cc = ty + 16 * i, c = c0 + cc, k = k0 + tx;
-        if (c < d.Cpad && k < d.K)
-            *reinterpret_cast<uint2*>(wd + ((size_t)c * d.taps + tap) * d.K + k) =
-                make_uint2(pack_bf16x2(tile[tx][cc], tile[tx + 1][cc]), pack_bf16x2(tile[tx + 2][cc], tile[tx + 3][cc]));
+        if (c < d.Cpad && k < d.K) {
+            const uint2 v = make_uint2(pack_bf16x2(tile[tx][cc], tile[tx + 1][cc]), pack_bf16x2(tile[tx + 2][cc], tile[tx + 3][cc]));
+            *reinterpret_cast<uint2*>(wd + ((size_t)c * d.taps + tap) * d.K + k) = v;
+            if (d.wp_off >= 0) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(shadow + d.wp_off) + packed_index(c, d.wp_tap0 + tap, k, d.K)) = v;
+        }
     }
 }
 }  // namespace
@@ -471,6 +507,12 @@ extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void*
             const Unit& u = p->units[i];
             PrepEntry& e = t.e[t.n++];
             e.w_off = u.d.w_off; e.wf_off = (int64_t)u.sh_fwd; e.wd_off = u.d.src != 0 ? (int64_t)u.sh_dg : -1;
+            e.wp_off = -1; e.wp_tap0 = 0;
+            if (u.pair >= 0) {                        // the 3x3 unit owns the packed buffer, the shortcut unit adds its tap
+                const bool owner = u.d.ksize == 3;
+                e.wp_off = (int64_t)(owner ? u.sh_pk : p->units[u.pair].sh_pk);
+                e.wp_tap0 = owner ? 0 : 9;
+            }
             e.K = u.d.cout; e.taps = u.d.ksize * u.d.ksize; e.Creal = u.d.cin; e.Cpad = u.cin_pad;
             e.first_block = blocks;
             blocks += (unsigned)(e.taps * ((e.K + tb - 1) / tb) * ((e.Cpad + tb - 1) / tb));
@@ -680,13 +722,20 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         (void)hipStreamWaitEvent(main_s, p->ev_bjoin[p->br_slot], 0);
         p->br_act = -1;
     };
+    // down-sampling entries: the shortcut unit leaves its dz where it is and skips its own input gradient; the block's 3x3/s2 unit,
+    // two iterations of this loop at most later and on the other dz buffer, produces the gradient of their common input in ONE launch
+    // (clhip_conv_dgrad_pair).  Needs both units inside this call's range; on one stream (graph capture), where every unit uses the first
+    // dz buffer, the shortcut unit takes the twin -- the arithmetic of a step does not depend on the stream layout.
+    const bool pair_on = !br_on;
+    const void* pair_dz = nullptr;
     int k = 0;
     for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
         void* dres = (u.d.res >= 0 && !u.pre_res) ? ws + p->acts[u.d.res].dy_off : nullptr;
-        char* dz = ws + (two_streams && k ? p->dz_off2 : p->dz_off);
+        const bool pair_b = pair_on && u.pair >= 0 && u.d.ksize == 1 && u.pair == i - 1 && u.pair >= unit_lo;
+        char* dz = ws + ((two_streams ? k != 0 : pair_b) ? p->dz_off2 : p->dz_off);
         if (br_on && u.branch >= 0 && p->bfork_ev[u.branch] != nullptr) {
             // ---- shortcut branch (1x1 conv -> BN, its activation consumed as a residual only): BatchNorm backward, input gradient and weight
             //      gradient on the branch stream, beside the main path's next unit (which shares nothing with it but the gradient of their
@@ -817,6 +866,11 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                                            fr + prod.f_mean, fr + prod.f_invstd, reinterpret_cast<double*>(ws + p->acc_off) + prod.a_bwd, prod.rep_bwd,
                                            p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
             p->bwd_sums_ready[u.d.src - 1] = 1;
+        } else if (pair_b) {
+            pair_dz = dz;                                      // its partner is the next unit of this sweep
+        } else if (pair_on && u.pair >= 0 && u.d.ksize == 3 && pair_dz != nullptr) {
+            TRY(clhip_conv_dgrad_pair(dz, sh + u.sh_pk, pair_dz, ws + src.dy_off, u.pair_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout, p->dtype, stream));
+            pair_dz = nullptr;
         } else if (u.d.src != 0) {
             TRY(clhip_conv_dgrad(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));

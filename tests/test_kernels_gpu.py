@@ -888,3 +888,55 @@ def test_dgrad_with_fused_batchnorm_backward_reduction(shape, relu, accumulate):
     assert (dz_f - dz_u).abs().max() <= tol("bf16", dz_ref) * 2.5
     assert (dg_f - s_ref[1]).abs().max() <= 4e-3 * scale[1].max()
     assert (db_f - s_ref[0]).abs().max() <= 4e-3 * scale[0].max()
+
+
+PAIR_CASES = [(256, 32, 32, 64, 128), (20, 32, 32, 64, 128), (3, 32, 32, 64, 128), (70, 16, 16, 128, 256), (256, 8, 8, 256, 512), (9, 8, 8, 256, 512),
+              (33, 4, 4, 64, 64), (9, 16, 8, 64, 32)]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_stride2_dgrad_pair_one_launch(case):
+    """conv6.hip: the input gradient of a down-sampling block entry -- dgrad of the 3x3 / s2 / p1 convolution + dgrad of the 1x1 / s2
+    shortcut, both classes of accumulators in one launch -- against the fp64 transposed convolutions and against the two separate
+    launches it replaces; with and without the shortcut operand, with accumulation; ResNet-18's three entries at batch 256, ragged
+    last tiles, tiles spanning images, 256- and 128-pixel workgroups, non-square maps."""
+    N, H, W, C, K = case
+    code, tdt = DT["bf16"]
+    L = _lib.lib()
+    assert L.clhip_conv_dgrad_pair_supported(N, H, W, C, K, code) == 1
+    Ho, Wo = H // 2, W // 2
+    w3 = quant(rnd((K, C, 3, 3), 5, 1.0 / (K * 9) ** 0.5), tdt)
+    w1 = quant(rnd((K, C, 1, 1), 8, 1.0 / K ** 0.5), tdt)
+    dz = quant(rnd((N, K, Ho, Wo), 6), tdt)
+    dzs = quant(rnd((N, K, Ho, Wo), 9), tdt)
+    xr = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w3.double(), None, 2, 1).backward(dz.double())
+    ref3 = xr.grad.clone()
+    xr.grad = None
+    F.conv2d(xr, w1.double(), None, 2, 0).backward(dzs.double())
+    ref1 = xr.grad.clone()
+    w3d = w3.permute(1, 2, 3, 0).contiguous().to(tdt).to(DEV)
+    w1d = w1.permute(1, 2, 3, 0).contiguous().to(tdt).to(DEV)
+    dzd, dzsd = to_nhwc(dz, tdt), to_nhwc(dzs, tdt)
+    pk = torch.full((L.clhip_conv_dgrad_pair_packed_bytes(C, K),), 0x7f, dtype=torch.uint8, device=DEV)
+    pk3 = torch.full_like(pk, 0x7f)                                   # (0x7f7f = a large bf16: an unwritten slot that is read shows)
+    call("clhip_conv_dgrad_pair_pack", w3d.data_ptr(), w1d.data_ptr(), pk.data_ptr(), C, K, code, st())
+    call("clhip_conv_dgrad_pair_pack", w3d.data_ptr(), None, pk3.data_ptr(), C, K, code, st())
+    dx = torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+    call("clhip_conv_dgrad_pair", dzd.data_ptr(), pk.data_ptr(), dzsd.data_ptr(), dx.data_ptr(), 0, N, H, W, C, K, code, st())
+    ref = ref3 + ref1
+    assert (from_nhwc(dx).double() - ref).abs().max() <= tol("bf16", ref)
+    # the two launches it replaces (shortcut first, then the 3x3 layer accumulating): equal up to the bf16 rounding of the intermediate
+    two = torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+    call("clhip_conv_dgrad", dzsd.data_ptr(), w1d.data_ptr(), two.data_ptr(), 0, N, H, W, C, K, 1, 2, 0, code, st())
+    call("clhip_conv_dgrad", dzd.data_ptr(), w3d.data_ptr(), two.data_ptr(), 1, N, H, W, C, K, 3, 2, 1, code, st())
+    assert (dx.float() - two.float()).abs().max() <= 2 ** -6 * ref.abs().max()
+    # without the shortcut operand; with accumulation
+    dx3 = torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+    call("clhip_conv_dgrad_pair", dzd.data_ptr(), pk3.data_ptr(), None, dx3.data_ptr(), 0, N, H, W, C, K, code, st())
+    assert (from_nhwc(dx3).double() - ref3).abs().max() <= tol("bf16", ref3)
+    base = quant(rnd((N, C, H, W), 7), tdt)
+    dxa = to_nhwc(base, tdt)
+    call("clhip_conv_dgrad_pair", dzd.data_ptr(), pk.data_ptr(), dzsd.data_ptr(), dxa.data_ptr(), 1, N, H, W, C, K, code, st())
+    ref2 = ref + base.double()
+    assert (from_nhwc(dxa).double() - ref2).abs().max() <= tol("bf16", ref2) * 1.5
