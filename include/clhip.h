@@ -319,6 +319,30 @@ int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void
                            const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas,
                            int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);
 
+/* "Lazy" BatchNorm input (core/model/backbone/resnet.py:289-316: conv -> bn -> relu -> conv inside a basic block).  The consumer
+ * convolution reads its producer's PRE-BatchNorm output z' and applies relu(scale * z' + shift) while it stages the operand: the
+ * producer's BatchNorm-apply launch and its activation tensor do not exist (the values are bit for bit the ones clhip_bn_apply_train would
+ * have stored).  Every workgroup derives scale / shift from the producer's statistics accumulators as clhip_bn_apply_train does;
+ * the launch also leaves `mean`, `invstd` (for clhip_bn_bwd_*) and `coef` = [2][C] scale, shift, and updates the running statistics.
+ * Served by the kernels that stage their operand through registers: 3x3/s1/p1 with 16 -> 16 or 32 -> 32 channels, bf16 (CifarResNet-32
+ * stages 1 and 2).  The backward of that consumer takes the same tensor and `coef`: clhip_conv_dgrad_wgrad_bn_input = clhip_conv_dgrad_wgrad
+ * with x = relu(coef[0] * x_z + coef[1]) and, when acc != NULL, the producer's BatchNorm-backward sums reduced in the dgrad epilogue
+ * with its ReLU mask taken from x_z (z_prod == x_z). */
+typedef struct clhip_bn_input {
+    const double* stat_acc; int replicas;     /* the producer's [replicas][2][C] fp64 sums (clhip_conv_fwd_acc) */
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;  /* nullable pair */
+    float momentum, eps;
+    float* mean; float* invstd;               /* out [C] */
+    float* coef;                              /* out [2][C] */
+} clhip_bn_input;
+int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
+int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn /*host*/, const void* w_fwd, void* z, double* stat_acc, int replicas,
+                                int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream);
+int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw,
+                                    void* ws, const float* mean, const float* invstd, double* acc /*nullable*/, int replicas, int N, int H, int W,
+                                    int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);
+
 /* The input gradient of a DOWN-SAMPLING block entry in one launch (core/model/backbone/resnet.py:226-234: `conv1` 3x3/s2/p1 and
  * `downsample[0]` 1x1/s2/p0 both read the block input x [N,H,W,C]):  dx (+)= dgrad3x3s2(dz, W) + dgrad1x1s2(dz_sc, W_sc).
  * dz, dz_sc [N,H/2,W/2,K]; dz_sc NULL: the 3x3 convolution alone.  The weights come as ONE packed buffer of
@@ -341,7 +365,7 @@ int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_s
  * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
  * pin a code path, tools/ to sweep.
  *   dispatch (0 / 1 unless noted):
- *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV_V1,
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), BN_INPUT (0: no lazy BatchNorm inputs), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
  *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small

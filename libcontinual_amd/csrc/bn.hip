@@ -239,42 +239,6 @@ template <typename T> __device__ __forceinline__ bool stored_positive(float v);
 template <> __device__ __forceinline__ bool stored_positive<float>(float v) { return v > 0.f; }
 template <> __device__ __forceinline__ bool stored_positive<bf16_t>(float v) { return v > 0.f && (pack_bf16x2(v, 0.f) & 0xffffu) != 0u; }
 
-// Sums of the fp64 accumulator replicas [rep][2][C] for the consumers' prologues: -> s1 (sum) and s2 (second sum) of channel c for the
-// threads c < C (c + 256 k for wide layers).  Every load of a thread is independent and issued before the first add, and with 2 C < 256
-// the replicas are split over 256 / (2 C) thread groups and combined through LDS: the serial loop this replaces made `rep` (16-32)
-// dependent L2 round trips, ~10 us -- most of the 8 x 8 / 4 x 4 layers' BatchNorm launches (tools/bn_bench.py).
-__device__ inline void sum_strided2(const double* __restrict__ p1, const double* __restrict__ p2, int n, size_t stride, double& s1, double& s2) {
-    s1 = 0.0; s2 = 0.0;
-    for (int r0 = 0; r0 < n; r0 += 8) {
-        double v1[8], v2[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool in = r0 + i < n;
-            v1[i] = in ? p1[(size_t)(r0 + i) * stride] : 0.0;
-            v2[i] = in ? p2[(size_t)(r0 + i) * stride] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { s1 += v1[i]; s2 += v2[i]; }
-    }
-}
-
-// narrow layers (2 C <= 128): part sums of thread group t / (2 C) into sred[256]; afterwards channel c reads sred[part * 2 C + which * C + c]
-__device__ inline void replica_parts(const double* __restrict__ acc, int rep, int C, double* sred) {
-    const int n2 = 2 * C, parts = 256 / n2;
-    const int col = threadIdx.x % n2, part = threadIdx.x / n2;
-    const int n = (rep - part + parts - 1) / parts;                     // replicas part, part + parts, ...
-    double s = 0.0;
-    for (int r0 = 0; r0 < n; r0 += 8) {
-        double v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = r0 + i < n ? acc[(size_t)(part + (r0 + i) * parts) * n2 + col] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[i];
-    }
-    sred[threadIdx.x] = s;
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------------------- accumulator ("acc") variants
 // The per-layer finalize launches (bn_finalize, bn_bwd_finalize: 40 x ~6 us of a 3.3 ms ResNet-18 step) disappear when the
 // producer adds its per-channel sums into a [2][C] fp64 accumulator with hardware fp64 atomics (order-independent to ~1e-16)

@@ -439,7 +439,7 @@ int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats,
                        int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st);
 bool clhip_wgrad32_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
 size_t clhip_wgrad32_ws_bytes(int N);
-int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st);
+int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st);
 size_t clhip_wgrad2_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad);
 int clhip_wgrad2_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, int ksize, int stride,
                         int pad, int dtype, hipStream_t st);
@@ -461,7 +461,7 @@ int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats
 bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 size_t clhip_wgrad16_ws_bytes(int N);
-int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st);
+int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st);
 int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int Creal, int K, hipStream_t st);
 size_t clhip_wgrad3_ws_bytes(int N, int H, int W, int C, int K);
 bool clhip_stem_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
@@ -631,7 +631,43 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
 
 bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
 int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
-                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* x_coef,
+                           hipStream_t st);
+int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
+                           const clhip_bn_input* in, hipStream_t st);
+
+// ---- "lazy" BatchNorm input: the consumer applies relu(bn(z)) of its producer while it stages its operand (conv3.hip conv16 / conv32: the
+//      kernels that stage through registers); the producer's apply launch and activation tensor do not exist
+extern "C" int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
+    if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
+    if (use_v1() || !use_v3()) return 0;
+    const char* cfg = clhip_cfg("BN_INPUT");
+    const bool off = cfg != nullptr && atoi(cfg) == 0;
+    return (!off && clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype) && clhip_bwd_fused_supported(N, H, W, C, C, K, ksize, stride, pad, dtype)) ? 1 : 0;
+}
+
+extern "C" int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, const void* w_fwd, void* z, double* stat_acc, int replicas, int N,
+                                           int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(z_in && bn && w_fwd && z && stat_acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    CLHIP_CHECK_ARG(bn->stat_acc && bn->gamma && bn->beta && bn->mean && bn->invstd && bn->coef && bn->replicas >= 1 && bn->replicas <= 64);
+    CLHIP_CHECK_ARG((bn->running_mean == nullptr) == (bn->running_var == nullptr));
+    CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype));
+    return clhip_conv16_launch_ex(z_in, w_fwd, z, nullptr, stat_acc, replicas, N, H, W, C, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, bn,
+                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw,
+                                               void* ws, const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C,
+                                               int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(x_z && x_coef && dz && w_dg && dx && dw && ws);
+    CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype) && Creal == C);
+    CLHIP_CHECK_ARG(acc == nullptr || (mean && invstd && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
+    return clhip_bwd_fused_launch(x_z, dz, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, acc ? x_z : nullptr, nullptr, mean, invstd, acc, replicas,
+                                  x_coef, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int clhip_conv_dgrad_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
@@ -646,7 +682,7 @@ extern "C" int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void*
     CLHIP_CHECK_ARG(x && dz && w_dg && dx && dw && ws);
     CLHIP_CHECK_ARG(clhip_conv_dgrad_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype));
     CLHIP_CHECK_ARG(z_prod == nullptr || (mean && invstd && acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
-    return clhip_bwd_fused_launch(x, dz, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, z_prod, y_prod, mean, invstd, acc, replicas,
+    return clhip_bwd_fused_launch(x, dz, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, z_prod, y_prod, mean, invstd, acc, replicas, nullptr,
                                   static_cast<hipStream_t>(stream));
 }
 
@@ -715,9 +751,9 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* 
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_wgrad3_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, Creal, K, st);
     if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
-        return clhip_wgrad16_launch(x, dz, dw, static_cast<float*>(ws), N, H, st);
+        return clhip_wgrad16_launch(x, dz, dw, static_cast<float*>(ws), N, H, nullptr, st);
     if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad32_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
-        return clhip_wgrad32_launch(x, dz, dw, static_cast<float*>(ws), N, H, st);
+        return clhip_wgrad32_launch(x, dz, dw, static_cast<float*>(ws), N, H, nullptr, st);
     if (!use_v1()) return clhip_wgrad2_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, Creal, K, ksize, stride, pad, dtype, st);
     static const bool no_tr = clhip_cfg("WGRAD_NO_TR") != nullptr;
     if (dtype == CLHIP_BF16) {

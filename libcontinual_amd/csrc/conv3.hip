@@ -39,7 +39,53 @@ struct Conv3Params {
     const float* bn_invstd = nullptr;
     double* bn_acc = nullptr;        // [bn_rep][2][Cd]
     int bn_rep = 1;
+    const float* bn_coef = nullptr;  // [2][Cd] scale, shift of that layer: its ReLU mask from z when bn_y == nullptr (the activation was never written)
+    // conv16 / conv32 FORWARD only ("lazy" input): src is the PRE-BatchNorm output z' of the producing layer and the operand is
+    // relu(scale * z' + shift), applied while the patch is staged -- the producer's BatchNorm-apply launch and its activation tensor do
+    // not exist.  Every workgroup derives scale / shift from the producer's fp64 statistics accumulators exactly as bn_apply_train_kernel
+    // does; workgroup 0 also leaves mean / invstd / scale / shift for the backward and updates the running statistics.
+    const double* in_acc = nullptr;  // [in_rep][2][Cs], or nullptr: src is an ordinary activation
+    int in_rep = 1;
+    const float* in_gamma = nullptr; const float* in_beta = nullptr;
+    float* in_rm = nullptr; float* in_rv = nullptr;
+    float in_momentum = 0.f, in_eps = 0.f;
+    double in_invM = 0.0, in_unbias = 1.0;
+    float* in_mean_o = nullptr; float* in_invstd_o = nullptr; float* in_coef_o = nullptr;      // [Cs], [Cs], [2][Cs]
 };
+
+// scale / shift of a lazy input into coef[2][C] (LDS); the arithmetic of bn_apply_train_kernel's prologue (bn.hip), bf16 mode
+template <int C>
+__device__ __forceinline__ void lazy_input_coefs(const Conv3Params& p, int bx, float* coef) {
+    __shared__ double sred[256];
+    replica_parts(p.in_acc, p.in_rep, C, sred);
+    const int c = threadIdx.x;
+    if (c < C) {
+        const bool first = bx == 0;
+        const bool upd = first && p.in_rm != nullptr;
+        const float rm_old = upd ? p.in_rm[c] : 0.f, rv_old = upd ? p.in_rv[c] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; }
+        const double mean = s1 * p.in_invM;
+        double var = s2 * p.in_invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float istd = rsqrtf((float)var + p.in_eps);
+        const float sc = p.in_gamma[c] * istd;
+        const float sh = p.in_beta[c] - (float)mean * sc;
+        coef[c] = sc;
+        coef[C + c] = sh;
+        if (first) {
+            p.in_mean_o[c] = (float)mean;
+            p.in_invstd_o[c] = istd;
+            p.in_coef_o[c] = sc;
+            p.in_coef_o[C + c] = sh;
+            if (upd) {
+                p.in_rm[c] = (1.f - p.in_momentum) * rm_old + p.in_momentum * (float)mean;
+                p.in_rv[c] = (1.f - p.in_momentum) * rv_old + p.in_momentum * (float)(var * p.in_unbias);
+            }
+        }
+    }
+    __syncthreads();
+}
 
 // BatchNorm-backward sums in the epilogue of the register-resident dgrad kernels (conv16 / conv32): `v[i][e]` = the final fp32 gradient
 // of pixel m0 + wave*64 + i*16 + fr, channel c0 + e (c0 = this lane's first channel of the 4-channel group).  Per-channel sums over the
@@ -61,7 +107,11 @@ __device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const
                 uint2 yy = make_uint2(0x3f803f80u, 0x3f803f80u);
                 if (p.bn_y != nullptr) yy = *reinterpret_cast<const uint2*>(p.bn_y + at);
                 const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
-                const float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
+                float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
+                if (p.bn_y == nullptr && p.bn_coef != nullptr) {           // the producer's activation was never written: its sign from z (as bn.hip's z-mask kernels)
+                    const float4 sc = *reinterpret_cast<const float4*>(p.bn_coef + j * 16 + fg * 4), sh = *reinterpret_cast<const float4*>(p.bn_coef + C + j * 16 + fg * 4);
+                    y4[0] = fmaf(z4[0], sc.x, sh.x); y4[1] = fmaf(z4[1], sc.y, sh.y); y4[2] = fmaf(z4[2], sc.z, sh.z); y4[3] = fmaf(z4[3], sc.w, sh.w);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float g = y4[e] > 0.f ? v[i][j][e] : 0.f;
@@ -572,10 +622,22 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
     }
     // patch: pixels [m0 - halo, m0 + BM + halo) as 16-byte half rows, plus one zero row for the out-of-image taps
     const int nchunks = p.np * 2;
+    const bool lazy = MODE == 0 && p.in_acc != nullptr;
+    float isc[8], ish[8];
+    if (lazy) {                                              // this thread stages channels (tid & 1) * 8 .. + 8 of every pixel it touches
+        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
+        lazy_input_coefs<16>(p, bx, coef);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 1) * 8 + e]; ish[e] = coef[16 + (tid & 1) * 8 + e]; }
+    }
     for (int idx = tid; idx < nchunks; idx += 256) {
         const int q = idx >> 1, ch = idx & 1;
         const long long g = (long long)m0 - halo + q;
-        const uint4 v = (g >= 0 && g < p.M) ? *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8) : make_uint4(0, 0, 0, 0);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g < p.M) {
+            v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
+            if (lazy) v = bn_relu8_bf16(v, isc, ish);
+        }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
     }
     if (tid < 2) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
@@ -666,10 +728,22 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) wreg[t][j] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(j * 16 + fr) * 288 + t * 32 + fg * 8);
     const int nchunks = p.np * 4;
+    const bool lazy = MODE == 0 && p.in_acc != nullptr;
+    float isc[8], ish[8];
+    if (lazy) {                                              // this thread stages channels (tid & 3) * 8 .. + 8
+        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
+        lazy_input_coefs<32>(p, bx, coef);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 3) * 8 + e]; ish[e] = coef[32 + (tid & 3) * 8 + e]; }
+    }
     for (int idx = tid; idx < nchunks; idx += 256) {
         const int q = idx >> 2, ch = idx & 3;
         const long long g = (long long)m0 - halo + q;
-        const uint4 v = (g >= 0 && g < p.M) ? *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8) : make_uint4(0, 0, 0, 0);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g < p.M) {
+            v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
+            if (lazy) v = bn_relu8_bf16(v, isc, ish);
+        }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
     }
     if (tid < 4) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
@@ -811,6 +885,9 @@ int clhip_conv16_tiles_m(int M) { return (M + 255) / 256; }
 
 int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
+int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
+                           const clhip_bn_input* in, hipStream_t st);
 
 int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                         hipStream_t st) {
@@ -819,14 +896,28 @@ int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats
 
 int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st) {
+    return clhip_conv16_launch_ex(src, wt, dst, stats, stat_acc, stat_rep, N, H, W, C, accumulate, mode, bn_z, bn_y, bn_mean, bn_invstd, bn_acc, bn_rep, nullptr, nullptr, st);
+}
+
+// bn_coef: the dgrad epilogue's ReLU mask from z (bn_y == nullptr); in: forward with a lazy BatchNorm input (src = the producer's z)
+int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
+                           const clhip_bn_input* in, hipStream_t st) {
     Conv3Params p;
+    p.bn_coef = bn_coef;
+    if (in != nullptr) {
+        p.in_acc = in->stat_acc; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
+        p.in_momentum = in->momentum; p.in_eps = in->eps; p.in_mean_o = in->mean; p.in_invstd_o = in->invstd; p.in_coef_o = in->coef;
+        const double M = (double)N * H * W;
+        p.in_invM = 1.0 / M; p.in_unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
+    }
     p.bn_z = static_cast<const bf16_t*>(bn_z); p.bn_y = static_cast<const bf16_t*>(bn_y); p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
     p.bn_acc = bn_acc; p.bn_rep = bn_rep > 0 ? bn_rep : 1;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = C; p.Cd = C; p.accumulate = accumulate; p.M = N * H * W;
     p.np = 256 + 2 * W + 2; p.patch_bytes = (p.np + 1) * (C == 16 ? 32 : 96); p.nbuf = 1; p.debug = 0;
-    const size_t lds = (size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024;
+    const size_t lds = ((size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024) + 256;      // + the lazy input's [2][C] coefficients
     const dim3 grid(clhip_conv16_tiles_m(p.M));
     if (C == 16) {
         if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, grid, dim3(256), lds, st, p);
@@ -1072,7 +1163,7 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
 // are constant address offsets into the padded image.  Each of the 4 waves takes 8 rows into 9 accumulator tiles; the waves are
 // summed through LDS and the image's 2304 partial sums go to a slab that wgrad3_reduce_kernel adds up in a fixed order.
 namespace {
-struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; };
+struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; const float* x_coef = nullptr; };      // x_coef [2][16]: x is a pre-BatchNorm tensor, the operand relu(scale x + shift)
 
 __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int bx, char* smem) {      // bx = image
     constexpr int W = 32, PW = 34, PX = 32;                  // image width, padded width, bytes per pixel (16 bf16)
@@ -1087,9 +1178,16 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
     for (int i = tid; i < xchunks; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int chunks = H * W * 2;
+    float xsc[8], xsh[8];
+    if (p.x_coef != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = p.x_coef[(tid & 1) * 8 + e]; xsh[e] = p.x_coef[16 + (tid & 1) * 8 + e]; }
+    }
     for (int i = tid; i < chunks; i += 256) {
         const int pix = i >> 1, half = i & 1, r = pix >> 5, c = pix & 31;
-        *reinterpret_cast<uint4*>(xs + ((r + 1) * PW + c + 1) * PX + half * 16) = *reinterpret_cast<const uint4*>(p.x + (img + pix) * 16 + half * 8);
+        uint4 xv = *reinterpret_cast<const uint4*>(p.x + (img + pix) * 16 + half * 8);
+        if (p.x_coef != nullptr) xv = bn_relu8_bf16(xv, xsc, xsh);
+        *reinterpret_cast<uint4*>(xs + ((r + 1) * PW + c + 1) * PX + half * 16) = xv;
         *reinterpret_cast<uint4*>(zs + pix * PX + half * 16) = *reinterpret_cast<const uint4*>(p.dz + (img + pix) * 16 + half * 8);
     }
     __syncthreads();
@@ -1136,7 +1234,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
 // Wave w owns in-channel tile (w & 1) and taps {0..4} / {5..8} (w >> 1) over ALL K steps -- no cross-wave sum -- and the next image's
 // global loads are in flight while the current one is multiplied.  Partial blocks + wgrad3_reduce_kernel: bitwise reproducible.
 namespace {
-struct Wgrad32Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; };
+struct Wgrad32Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; const float* x_coef = nullptr; };      // x_coef [2][32] as in Wgrad16Params
 
 __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int ot, const int grp, char* smem) {
     constexpr int W = 16, PW = 18, PX = 64, PZ = 32;          // image width, padded width, bytes per input pixel (32 bf16), per gradient pixel (this tile's 16)
@@ -1151,6 +1249,11 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
     for (int i = tid; i < (H + 2) * PW * 4; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     const int nx = HW * 4, nz = HW * 2;                       // 16-byte chunks per image: input (4 per pixel), gradient slice (2 per pixel)
     uint4 rx[4], rz[2];
+    float xsc[8], xsh[8];                                     // chunk q = tid + 256 i covers channels (q & 3) * 8 = (tid & 3) * 8 of its pixel
+    if (p.x_coef != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = p.x_coef[(tid & 3) * 8 + e]; xsh[e] = p.x_coef[32 + (tid & 3) * 8 + e]; }
+    }
     auto gload = [&](int n) {
         const size_t base = (size_t)n * HW;
 #pragma unroll
@@ -1168,7 +1271,10 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + 256 * i;
-            if (q < nx) { const int px = q >> 2; *reinterpret_cast<uint4*>(xs + ((px / W + 1) * PW + (px % W) + 1) * PX + (q & 3) * 16) = rx[i]; }
+            if (q < nx) {
+                const int px = q >> 2;
+                *reinterpret_cast<uint4*>(xs + ((px / W + 1) * PW + (px % W) + 1) * PX + (q & 3) * 16) = p.x_coef != nullptr ? bn_relu8_bf16(rx[i], xsc, xsh) : rx[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1227,9 +1333,9 @@ size_t clhip_wgrad32_ws_bytes(int N) { return (size_t)wgrad32_groups(N) * 9216 *
 
 int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);
 
-int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st) {
+int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
     const int groups = wgrad32_groups(N);
-    Wgrad32Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, (N + groups - 1) / groups};
+    Wgrad32Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, (N + groups - 1) / groups, x_coef};
     // (groups was derived from the same images-per-group rule: recompute the per-group count exactly)
     p.img_per_group = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1);
     const size_t lds = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
@@ -1320,8 +1426,10 @@ bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int
 }
 
 int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
-                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st) {
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* x_coef,
+                           hipStream_t st) {
     Conv3Params pd;
+    pd.bn_coef = x_coef;                                     // a lazy x IS the producer's z: its ReLU mask comes from z as well (bn_y is NULL then)
     pd.bn_z = static_cast<const bf16_t*>(bn_z); pd.bn_y = static_cast<const bf16_t*>(bn_y); pd.bn_mean = bn_mean; pd.bn_invstd = bn_invstd;
     pd.bn_acc = bn_acc; pd.bn_rep = bn_rep > 0 ? bn_rep : 1;
     pd.src = static_cast<const bf16_t*>(dz); pd.wt = static_cast<const bf16_t*>(w_dg); pd.dst = static_cast<bf16_t*>(dx);
@@ -1329,9 +1437,9 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     pd.N = N; pd.H = H; pd.W = W; pd.wshift = ilog2_exact(W); pd.hshift = ilog2_exact(H); pd.Cs = C; pd.Cd = C; pd.accumulate = accumulate; pd.M = N * H * W;
     pd.np = 256 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * (C == 16 ? 32 : 96); pd.nbuf = 1; pd.debug = 0;
     const int nd = clhip_conv16_tiles_m(pd.M);
-    size_t lds = (size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024;
+    size_t lds = ((size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024) + 256;
     if (C == 16) {
-        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H};
+        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef};
         size_t wl = (size_t)((H + 2) * 34 + H * 32) * 32;
         if (wl < 4 * 2304 * sizeof(float)) wl = 4 * 2304 * sizeof(float);
         if (wl > lds) lds = wl;
@@ -1348,7 +1456,7 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
         return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N, st);
     }
     const int groups = wgrad32_groups(N);
-    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1)};
+    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef};
     const size_t wl = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
     if (wl > lds) lds = wl;
     hipLaunchKernelGGL(bwd32_fused_kernel, dim3(2 * groups + nd), dim3(256), lds, st, pd, pw, 2 * groups);
@@ -1429,8 +1537,8 @@ int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int spli
     return CLHIP_OK;
 }
 
-int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, hipStream_t st) {
-    Wgrad16Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H};
+int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
+    Wgrad16Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef};
     size_t lds = (size_t)((H + 2) * 34 + H * 32) * 32;
     if (lds < 4 * 2304 * sizeof(float)) lds = 4 * 2304 * sizeof(float);
     static size_t attr = 0;

@@ -48,6 +48,9 @@ struct Unit {
     size_t sh_pk;                  // packed dgrad weights of a paired down-sampling entry (3x3/s2 unit; see `pair`)
     int pair;                      // >= 0: this 3x3/s2 unit and the 1x1/s2 shortcut unit `pair` read the same activation: ONE launch writes its
                                    // gradient (clhip_conv_dgrad_pair); on the shortcut unit: the index of the 3x3 unit
+    int lazy_to;                   // >= 0: this unit's activation relu(bn(z)) is consumed by unit `lazy_to` alone, through a convolution kernel that applies it
+                                   // while it stages its operand (clhip_conv_fwd_acc_bn_input): the training forward skips the apply launch
+    int lazy_from;                 // >= 0: the producer of this unit's input is such a unit
     bool pair_acc;                 // the accumulate flag of that one launch (= the shortcut dgrad's, the first writer of the two)
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
     size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([rep][2][cout] each)
@@ -97,6 +100,7 @@ struct clhip_plan {
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
     size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
+    std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
     int feat_dim;
     bool side_ok;            // some unit's weight gradient is big enough for the side stream to pay (see clhip_plan_backward_range)
@@ -347,6 +351,26 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         ua.pair_acc = ub.dx_acc;
         ua.sh_pk = p->shadow_bytes; p->shadow_bytes = align_up(p->shadow_bytes + clhip_conv_dgrad_pair_packed_bytes(ua.cin_pad, ua.d.cout));
     }
+    // lazy activations: unit a = conv -> BN -> ReLU whose activation has exactly one consumer b, a convolution that can apply the BatchNorm + ReLU
+    // on its operand load (forward) and in its fused dgrad + weight-gradient launch (backward)
+    for (auto& u : p->units) { u.lazy_to = u.lazy_from = -1; }
+    p->lazy_live.assign(p->units.size(), 0);
+    static const bool mask_y = clhip_cfg("BN_MASK_FROM_Y") != nullptr;
+    for (int a = 0; a + 1 < n_units && want_acc && !mask_y; ++a) {
+        Unit& ua = p->units[a];
+        if (!ua.relu || ua.d.res >= 0 || ua.pre_res || ua.no_bn || ua.has_dzr || ua.rep_fwd <= 0 || ua.rep_bwd <= 0 || ua.mask_off != 0 || ua.branch >= 0 || ua.forks >= 0) continue;
+        int b = -1, users = 0;
+        for (int k = 0; k < n_units; ++k) {
+            const Unit& o = p->units[k];
+            if (o.d.src == a + 1) { ++users; b = k; if (o.raw_src) users += 2; }
+            if (o.d.res == a + 1) users += 2;
+        }
+        if (users != 1 || b <= a) continue;
+        Unit& ub = p->units[b];
+        if (ub.no_bn || ub.pre_res || ub.rep_fwd <= 0 || ub.cin_pad != ub.d.cin || ub.branch >= 0 || ub.pair >= 0) continue;
+        if (!clhip_conv_bn_input_supported(N, ub.H, ub.W, ub.cin_pad, ub.d.cout, ub.d.ksize, ub.d.stride, ub.d.pad, dtype)) continue;
+        ua.lazy_to = b; ub.lazy_from = a;
+    }
     return p;
 }
 
@@ -595,6 +619,10 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     static const int br_mode_f = clhip_cfg("BRANCH_STREAM") ? atoi(clhip_cfg("BRANCH_STREAM")) : 2;
     const bool br_on = use_acc && (br_mode_f == 1 || br_mode_f == 2) && branch_stream_on(p, (hipStream_t)stream);
     struct FwdStopGuard { ~FwdStopGuard() { clhip_bn_set_fwd_stop_event(nullptr); } } fwd_stop_guard;
+    const char* lazy_cfg = clhip_cfg("BN_INPUT");            // (looked up per call: the tests flip it between two models of one process)
+    const bool lazy_env = !(lazy_cfg != nullptr && atoi(lazy_cfg) == 0);
+    const bool lazy_on = lazy_env && training && use_acc;
+    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = 0;
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
@@ -623,8 +651,22 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 (void)hipStreamWaitEvent(p->br, p->ev_fork[u.branch], 0);
                 us = p->br;
             }
-            TRY(clhip_conv_fwd_acc(in, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
-                                   u.d.stride, u.d.pad, p->dtype, us));
+            if (u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) {
+                // the producer's BatchNorm + ReLU happen on this convolution's operand load: scale / shift, the saved statistics and the running
+                // statistics of the producer are this launch's by-products
+                const Unit& a = p->units[u.lazy_from];
+                clhip_bn_input bi;
+                bi.stat_acc = acc + a.a_fwd; bi.replicas = a.rep_fwd; bi.gamma = params + a.d.gamma_off; bi.beta = params + a.d.beta_off;
+                bi.running_mean = bn_stats + a.d.rm_off; bi.running_var = bn_stats + a.d.rv_off; bi.momentum = kBnMomentum; bi.eps = kBnEps;
+                bi.mean = fr + a.f_mean; bi.invstd = fr + a.f_invstd; bi.coef = fr + a.f_scale;
+                TRY(clhip_conv_fwd_acc_bn_input(ws + a.z_off, &bi, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout,
+                                                u.d.ksize, u.d.stride, u.d.pad, p->dtype, us));
+            } else {
+                TRY(clhip_conv_fwd_acc(in, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize,
+                                       u.d.stride, u.d.pad, p->dtype, us));
+            }
+            p->lazy_live[i] = 0;
+            if (lazy_on && u.lazy_to >= 0) { p->lazy_live[i] = 1; continue; }          // its one consumer applies the BatchNorm: no apply launch, no activation
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
             if (br_on && u.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)stream, p->ev_join[u.joins], 0);      // the residual comes from the branch stream
             if (br_on && u.forks >= 0) clhip_bn_set_fwd_stop_event(p->ev_fork[u.forks]);                           // this launch's completion starts the branch
@@ -728,6 +770,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     // dz buffer, the shortcut unit takes the twin -- the arithmetic of a step does not depend on the stream layout.
     const bool pair_on = !br_on;
     const void* pair_dz = nullptr;
+    // a lazy activation some launch of this sweep has to READ as a tensor after all: write it now (same values the forward would have stored)
+    auto materialise = [&](int a) -> int {
+        const Unit& ua = p->units[a];
+        if (!p->lazy_live[a]) return CLHIP_OK;
+        p->lazy_live[a] = 0;
+        return clhip_bn_apply(ws + ua.z_off, fr + ua.f_scale, fr + ua.f_shift, nullptr, ws + p->acts[a + 1].y_off, ua.M, ua.d.cout, 1, p->dtype, stream);
+    };
     int k = 0;
     for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
         const Unit& u = p->units[i];
@@ -840,6 +889,17 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const bool both = !on_side && u.d.src != 0 && !u.raw_src && !(p->br_act >= 0 && u.d.src == p->br_act) &&
                           clhip_conv_dgrad_wgrad_supported(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) &&
                           clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0;
+        if (both && u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) {
+            const Unit& a = p->units[u.lazy_from];                // x = relu(bn(z_a)) on the weight gradient's operand load, the producer's ReLU mask from z_a
+            const bool red = u.fuse_src_bn;
+            TRY(clhip_conv_dgrad_wgrad_bn_input(ws + a.z_off, fr + a.f_scale, dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, grads + u.d.w_off, ws + u.wg_own,
+                                                red ? fr + a.f_mean : nullptr, red ? fr + a.f_invstd : nullptr,
+                                                red ? reinterpret_cast<double*>(ws + p->acc_off) + a.a_bwd : nullptr, red ? a.rep_bwd : 1, p->N, u.H, u.W,
+                                                u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            if (red) p->bwd_sums_ready[u.lazy_from] = 1;
+            continue;
+        }
+        if (u.lazy_from >= 0) TRY(materialise(u.lazy_from));
         if (both) {
             const Unit* prod = u.fuse_src_bn ? &p->units[u.d.src - 1] : nullptr;
             TRY(clhip_conv_dgrad_wgrad(in, dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, grads + u.d.w_off, ws + u.wg_own,
@@ -897,6 +957,15 @@ extern "C" int clhip_plan_read_act(clhip_plan* p, const void* workspace, int idx
     CLHIP_CHECK_ARG(!(idx == 0 && which != 0));
     const char* ws = static_cast<const char*>(workspace);
     const Act& a = p->acts[idx];
+    if (which == 0 && idx >= 1 && p->lazy_live[idx - 1]) {
+        // a lazy activation (its consumer applied the BatchNorm on its operand load): write it on demand -- the buffer is there, the values
+        // are the ones the apply launch would have stored
+        const Unit& ua = p->units[idx - 1];
+        char* wsm = static_cast<char*>(const_cast<void*>(workspace));
+        float* fr = reinterpret_cast<float*>(wsm + p->f_base);
+        if (int e = clhip_bn_apply(wsm + ua.z_off, fr + ua.f_scale, fr + ua.f_shift, nullptr, wsm + a.y_off, ua.M, ua.d.cout, 1, p->dtype, stream)) return e;
+        p->lazy_live[idx - 1] = 0;
+    }
     const char* src = which == 0 ? ws + a.y_off : (which == 1 ? ws + p->units[idx - 1].z_off : ws + a.dy_off);
     return clhip_nhwc_to_nchw(src, out_nchw, p->N, a.C, a.H, a.W, p->dtype, stream);
 }

@@ -157,3 +157,28 @@ def test_resnet32_steps_are_reproducible(batch):
     dg = float((g0 - g1).abs().max()) / float(g0.abs().max())
     print(f"batch {batch}: eight steps twice: parameter deviation {d:.2e}, last gradient {dg:.2e}")
     assert d <= 1e-5 and dg <= 1e-4
+
+
+def test_lazy_batchnorm_inputs_do_not_change_a_resnet32_run():
+    """CifarResNet-32 trains with the first BatchNorm + ReLU of every stage-1 / stage-2 block applied on the second convolution's operand load
+    (clhip_conv_fwd_acc_bn_input: ten apply launches and ten activation tensors less per step).  The values are the ones the apply launch
+    would have stored, so a run with the switch off (BN_INPUT=0) ends where the default run ends, to the run-to-run tolerance of the
+    fp64-atomic sums."""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    out = []
+    try:
+        for lazy in (b"1", b"0"):
+            assert L.clhip_config(b"BN_INPUT", lazy) == 0
+            m = _make("ewc", 9)
+            o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+            T.train_steps(m, o, _batches(6, 64), None, "EWC", None, "cuda")
+            torch.cuda.synchronize()
+            out.append((m.network.backbone.flat_parameters()[0].clone(), m.network.backbone.flat_parameters()[1].clone()))
+    finally:
+        L.clhip_config(b"BN_INPUT", None)
+    (p0, g0), (p1, g1) = out
+    d = float((p0 - p1).abs().max()) / float(p0.abs().max())
+    dg = float((g0 - g1).abs().max()) / float(g0.abs().max())
+    print(f"lazy vs eager BatchNorm inputs, six steps: parameter deviation {d:.2e}, last gradient {dg:.2e}")
+    assert d <= 1e-5 and dg <= 1e-4

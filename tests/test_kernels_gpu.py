@@ -940,3 +940,74 @@ def test_stride2_dgrad_pair_one_launch(case):
     call("clhip_conv_dgrad_pair", dzd.data_ptr(), pk.data_ptr(), dzsd.data_ptr(), dxa.data_ptr(), 1, N, H, W, C, K, code, st())
     ref2 = ref + base.double()
     assert (from_nhwc(dxa).double() - ref2).abs().max() <= tol("bf16", ref2) * 1.5
+
+
+@pytest.mark.parametrize("shape", [(9, 32, 32, 16), (40, 16, 16, 32), (3, 7, 5, 16), (5, 8, 16, 32), (70, 16, 16, 32)])
+def test_lazy_batchnorm_input_forward_and_backward(shape):
+    """VERDICT r2 item 1b on the kernels that stage their operand through registers (conv16 / conv32): the consumer convolution applies its
+    producer's BatchNorm + ReLU while it loads the operand.  clhip_conv_fwd_acc_bn_input(z') must equal clhip_bn_apply_train(z') followed by
+    clhip_conv_fwd_acc BIT FOR BIT (output, saved statistics, coefficients, running statistics; its own fp64 sums to the atomics' order), and
+    clhip_conv_dgrad_wgrad_bn_input(z', coef) the fused backward on the materialised activation (dx, dw bit-identical; the producer's
+    BatchNorm-backward sums with the ReLU mask taken from z')."""
+    import ctypes as C
+
+    class BnInput(C.Structure):
+        _fields_ = [("stat_acc", C.c_void_p), ("replicas", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                    ("running_var", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("coef", C.c_void_p)]
+    N, H, W, Cc = shape
+    L = _lib.lib()
+    code, tdt = DT["bf16"]
+    if not L.clhip_conv_bn_input_supported(N, H, W, Cc, Cc, 3, 1, 1, code):
+        pytest.skip("layer outside the lazy-input kernels' domain")
+    M_ = N * H * W
+    zp = to_nhwc(quant(rnd((N, Cc, H, W), 71, 1.3), tdt), tdt)                    # the producer's pre-BatchNorm output
+    zf = zp.float().reshape(-1, Cc).double()
+    rep_in = 4
+    acc_in = torch.zeros(rep_in, 2, Cc, dtype=torch.float64, device=DEV)
+    acc_in[1, 0], acc_in[2, 1] = zf.sum(0), (zf * zf).sum(0)                        # the sums its convolution would have left, spread over replicas
+    gamma, beta = (rnd((Cc,), 72) * 0.2 + 1.0).to(DEV), (rnd((Cc,), 73) * 0.3).to(DEV)
+    w = quant(rnd((Cc, 9, Cc), 74, 0.1), tdt).to(tdt).to(DEV).contiguous()
+    mom, eps, rep = 0.1, 1e-5, 8
+
+    def fresh():
+        return dict(rm=torch.full((Cc,), 0.5, device=DEV), rv=torch.full((Cc,), 2.0, device=DEV), mean=torch.empty(Cc, device=DEV), invstd=torch.empty(Cc, device=DEV),
+                    coef=torch.full((2, Cc), float("nan"), device=DEV), z=torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV),
+                    acc=torch.zeros(rep, 2, Cc, dtype=torch.float64, device=DEV))
+    e, l = fresh(), fresh()
+    # eager: apply launch, then the convolution on the activation
+    y = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+    call("clhip_bn_apply_train", zp.data_ptr(), acc_in.data_ptr(), rep_in, M_, Cc, gamma.data_ptr(), beta.data_ptr(), e["rm"].data_ptr(), e["rv"].data_ptr(), mom, eps,
+         e["mean"].data_ptr(), e["invstd"].data_ptr(), None, y.data_ptr(), 1, code, st())
+    call("clhip_conv_fwd_acc", y.data_ptr(), w.data_ptr(), e["z"].data_ptr(), e["acc"].data_ptr(), rep, N, H, W, Cc, Cc, 3, 1, 1, code, st())
+    # lazy: one launch
+    bi = BnInput(acc_in.data_ptr(), rep_in, gamma.data_ptr(), beta.data_ptr(), l["rm"].data_ptr(), l["rv"].data_ptr(), mom, eps, l["mean"].data_ptr(),
+                 l["invstd"].data_ptr(), l["coef"].data_ptr())
+    call("clhip_conv_fwd_acc_bn_input", zp.data_ptr(), C.byref(bi), w.data_ptr(), l["z"].data_ptr(), l["acc"].data_ptr(), rep, N, H, W, Cc, Cc, 3, 1, 1, code, st())
+    torch.cuda.synchronize()
+    assert torch.equal(l["z"], e["z"])
+    for k in ("rm", "rv", "mean", "invstd"):
+        assert torch.equal(l[k], e[k]), k
+    sc = gamma * l["invstd"]
+    assert torch.equal(l["coef"][0], sc) and torch.allclose(l["coef"][1], beta - l["mean"] * sc, rtol=0, atol=1e-6)      # (the kernel's shift is one fma)
+    assert ((l["acc"].sum(0) - e["acc"].sum(0)).abs() <= 1e-12 * e["acc"].sum(0).abs().clamp(min=1.0)).all()
+    # ---- backward of the consumer: dgrad + weight gradient in one launch, the operand relu(bn(z')) recomputed on load
+    dz = to_nhwc(quant(rnd((N, Cc, H, W), 75, 0.5), tdt), tdt)
+    wd = quant(rnd((Cc, 9, Cc), 76, 0.1), tdt).to(tdt).to(DEV).contiguous()
+    wsb = L.clhip_conv_wgrad_ws_bytes(N, H, W, Cc, Cc, Cc, 3, 1, 1, code)
+    outs = []
+    for lazy in (False, True):
+        dx = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+        dw = torch.full((Cc, 9, Cc), 0.25, device=DEV)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        sums = torch.zeros(4, 2, Cc, dtype=torch.float64, device=DEV)
+        if lazy:
+            call("clhip_conv_dgrad_wgrad_bn_input", zp.data_ptr(), l["coef"].data_ptr(), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(),
+                 l["mean"].data_ptr(), l["invstd"].data_ptr(), sums.data_ptr(), 4, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
+        else:
+            call("clhip_conv_dgrad_wgrad", y.data_ptr(), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(), zp.data_ptr(), y.data_ptr(),
+                 e["mean"].data_ptr(), e["invstd"].data_ptr(), sums.data_ptr(), 4, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
+        torch.cuda.synchronize()
+        outs.append((dx, dw, sums.sum(0)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # mask from z' (fma > 0) against mask from the stored activation: they differ only where a positive value underflows to bf16 zero
+    assert ((outs[0][2] - outs[1][2]).abs() <= 1e-9 * outs[0][2].abs().clamp(min=1.0)).all()
