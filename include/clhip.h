@@ -336,6 +336,19 @@ typedef struct clhip_bn_input {
     float* mean; float* invstd;               /* out [C] */
     float* coef;                              /* out [2][C] */
 } clhip_bn_input;
+/* The same in the backward for the layer's OWN BatchNorm: clhip_conv_dgrad_wgrad_bn_grad = clhip_bn_bwd_apply_acc (ReLU mask from z, no residual)
+ * followed by clhip_conv_dgrad_wgrad, with the BatchNorm-backward result dz = scale * (g - mean(g) - xhat * mean(g xhat)) computed from dy and
+ * z on both bodies' operand loads instead of being written and re-read; `sums` are the [replicas][2][C] accumulators a consumer's dgrad
+ * epilogue filled (clhip_conv_dgrad_bn_reduce / clhip_conv_dgrad_wgrad*), one workgroup adds them to dgamma / dbeta.  Same domain. */
+typedef struct clhip_bn_grad {
+    const void* dy; const void* z;            /* [N,H,W,K] gradient of the layer's activation, its pre-BatchNorm output */
+    const double* sums; int replicas;
+    const float* mean; const float* invstd; const float* gamma; const float* beta;
+    float* dgamma; float* dbeta;              /* accumulated into */
+} clhip_bn_grad;
+int clhip_conv_dgrad_wgrad_bn_grad(const void* x, const clhip_bn_grad* bn /*host*/, const void* w_dg, void* dx, int accumulate, float* dw, void* ws,
+                                   const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas, int N,
+                                   int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);
 int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
 int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn /*host*/, const void* w_fwd, void* z, double* stat_acc, int replicas,
                                 int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream);
@@ -365,7 +378,7 @@ int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_s
  * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
  * pin a code path, tools/ to sweep.
  *   dispatch (0 / 1 unless noted):
- *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), BN_INPUT (0: no lazy BatchNorm inputs), CONV_V1,
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), BN_INPUT (0: no lazy BatchNorm inputs), BN_GRAD (0: no BatchNorm backward on the operand loads), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
  *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small

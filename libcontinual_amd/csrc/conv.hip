@@ -632,7 +632,7 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
 bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
 int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* x_coef,
-                           hipStream_t st);
+                           const clhip_bn_grad* lz, hipStream_t st);
 int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
                            const clhip_bn_input* in, hipStream_t st);
@@ -666,7 +666,19 @@ extern "C" int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_c
     CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype) && Creal == C);
     CLHIP_CHECK_ARG(acc == nullptr || (mean && invstd && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
     return clhip_bwd_fused_launch(x_z, dz, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, acc ? x_z : nullptr, nullptr, mean, invstd, acc, replicas,
-                                  x_coef, static_cast<hipStream_t>(stream));
+                                  x_coef, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int clhip_conv_dgrad_wgrad_bn_grad(const void* x, const clhip_bn_grad* bn, const void* w_dg, void* dx, int accumulate, float* dw, void* ws,
+                                              const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas,
+                                              int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(x && bn && w_dg && dx && dw && ws);
+    CLHIP_CHECK_ARG(bn->dy && bn->z && bn->sums && bn->mean && bn->invstd && bn->gamma && bn->beta && bn->dgamma && bn->dbeta && bn->replicas >= 1 && bn->replicas <= 64);
+    CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype) && Creal == C);
+    CLHIP_CHECK_ARG(z_prod == nullptr || (mean && invstd && acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
+    return clhip_bwd_fused_launch(x, nullptr, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, z_prod, y_prod, mean, invstd, acc, replicas, nullptr,
+                                  bn, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int clhip_conv_dgrad_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
@@ -683,7 +695,7 @@ extern "C" int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void*
     CLHIP_CHECK_ARG(clhip_conv_dgrad_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype));
     CLHIP_CHECK_ARG(z_prod == nullptr || (mean && invstd && acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
     return clhip_bwd_fused_launch(x, dz, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, z_prod, y_prod, mean, invstd, acc, replicas, nullptr,
-                                  static_cast<hipStream_t>(stream));
+                                  nullptr, static_cast<hipStream_t>(stream));
 }
 
 bool clhip_dgrad6_supported(int N, int H, int W, int C, int K, int dtype);      // conv6.hip

@@ -17,6 +17,64 @@
 
 namespace {
 
+// the BatchNorm backward of a layer folded into the operand loads of its own dgrad / weight-gradient launch (see Conv3Params::lz)
+struct LazyDz {
+    const bf16_t* dy = nullptr;      // [M][C] gradient of the layer's activation, or nullptr: the gradient operand is an ordinary tensor
+    const bf16_t* z = nullptr;       // [M][C] its pre-BatchNorm output
+    const double* sums = nullptr;    // [rep][2][C]: sum g, sum g * xhat
+    int rep = 1;
+    const float* mean = nullptr; const float* invstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    double invM = 0.0;
+    float* dgamma = nullptr; float* dbeta = nullptr;      // accumulated into by ONE workgroup of the launch
+};
+
+// coef[6][C] (LDS): mean(g), mean(g xhat), mean, invstd, scale, shift -- bn_bwd_apply_acc_kernel's prologue (bn.hip); `first` = the one
+// workgroup of the launch that also adds the sums to dgamma / dbeta
+template <int C>
+__device__ __forceinline__ void lazy_dz_coefs(const LazyDz& lz, bool first, float* coef) {
+    __shared__ double sred[256];
+    replica_parts(lz.sums, lz.rep, C, sred);
+    const int c = threadIdx.x;
+    if (c < C) {
+        const float db_old = first ? lz.dbeta[c] : 0.f, dg_old = first ? lz.dgamma[c] : 0.f;
+        const float m = lz.mean[c], is_c = lz.invstd[c], gi_c = lz.gamma[c] * is_c;
+        const float sh_c = lz.beta[c] - m * gi_c;
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; }
+        coef[c] = (float)(s1 * lz.invM);
+        coef[C + c] = (float)(s2 * lz.invM);
+        coef[2 * C + c] = m;
+        coef[3 * C + c] = is_c;
+        coef[4 * C + c] = gi_c;
+        coef[5 * C + c] = sh_c;
+        if (first) { lz.dbeta[c] = db_old + (float)s1; lz.dgamma[c] = dg_old + (float)s2; }
+    }
+    __syncthreads();
+}
+
+// this thread's eight channels c0 .. c0 + 7 of the table
+struct LazyDz8 { float k0[8], k1[8], mu[8], is[8], gi[8], sh[8]; };
+template <int C>
+__device__ __forceinline__ void lazy_dz_load(const float* coef, int c0, LazyDz8& t) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        t.k0[e] = coef[c0 + e]; t.k1[e] = coef[C + c0 + e]; t.mu[e] = coef[2 * C + c0 + e];
+        t.is[e] = coef[3 * C + c0 + e]; t.gi[e] = coef[4 * C + c0 + e]; t.sh[e] = coef[5 * C + c0 + e];
+    }
+}
+__device__ __forceinline__ uint4 lazy_dz8(uint4 dy, uint4 z, const LazyDz8& t) {
+    float g[8], zz[8], o[8];
+    unpack8(dy, g);
+    unpack8(z, zz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gg = fmaf(zz[e], t.gi[e], t.sh[e]) > 0.f ? g[e] : 0.f;
+        const float xh = (zz[e] - t.mu[e]) * t.is[e];
+        o[e] = t.gi[e] * (gg - t.k0[e] - xh * t.k1[e]);
+    }
+    return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+}
+
 struct Conv3Params {
     const bf16_t* src;   // [N,H,W,Cs]   (forward: x ; dgrad: dz)
     const bf16_t* wt;    // [Cd][9][Cs]
@@ -51,6 +109,11 @@ struct Conv3Params {
     float in_momentum = 0.f, in_eps = 0.f;
     double in_invM = 0.0, in_unbias = 1.0;
     float* in_mean_o = nullptr; float* in_invstd_o = nullptr; float* in_coef_o = nullptr;      // [Cs], [Cs], [2][Cs]
+    // conv16 / conv32 DGRAD only ("lazy" gradient): src is not read; the operand is the BatchNorm-backward result
+    //   dz = scale * (g - mean(g) - xhat * mean(g xhat)),  g = dy * (scale z + shift > 0),  xhat = (z - mean) * invstd
+    // of THIS layer's own BatchNorm, computed while the patch is staged from dy and z (bn_bwd_apply_acc_kernel's arithmetic, z-mask form);
+    // the two sums come from the fp64 accumulators a consumer's dgrad epilogue filled.  Workgroup 0 adds them to dgamma / dbeta.
+    LazyDz lz;
 };
 
 // scale / shift of a lazy input into coef[2][C] (LDS); the arithmetic of bn_apply_train_kernel's prologue (bn.hip), bf16 mode
@@ -600,7 +663,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
 // pitch (conflict-free for ds_read_b128), and a 16-pixel x 16-channel output tile costs 5 LDS reads + 5 MFMAs with no barrier
 // after the patch is staged.  Lane (fr, fg) ends with channels 4 fg .. 4 fg + 3 of pixel fr: one 8-byte store, 512 contiguous
 // bytes per wave instruction, no output staging.  MODE as in conv3_kernel (the dgrad weight copy has the same [Cd][9][Cs] layout).
-template <int MODE>
+template <int MODE, bool LZ = false>
 __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, char* smem) {      // bx = tile index (a workgroup of a plain or a fused launch)
     constexpr int BM = 256, PP = 32;                         // pixels per workgroup, LDS bytes per pixel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,13 +693,23 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 1) * 8 + e]; ish[e] = coef[16 + (tid & 1) * 8 + e]; }
     }
+    constexpr bool lzd = MODE == 1 && LZ;                    // (a template parameter: the table's 48 registers and the branch in the staging loop slowed EVERY dgrad launch when this was a run-time test)
+    LazyDz8 lt;
+    if constexpr (lzd) {                                     // the gradient operand = this layer's BatchNorm backward, from dy and z
+        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
+        lazy_dz_coefs<16>(p.lz, bx == 0, coef);
+        lazy_dz_load<16>(coef, (tid & 1) * 8, lt);
+    }
     for (int idx = tid; idx < nchunks; idx += 256) {
         const int q = idx >> 1, ch = idx & 1;
         const long long g = (long long)m0 - halo + q;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (g >= 0 && g < p.M) {
-            v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
-            if (lazy) v = bn_relu8_bf16(v, isc, ish);
+            if constexpr (lzd) v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 16 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 16 + ch * 8), lt);
+            else {
+                v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
+                if (lazy) v = bn_relu8_bf16(v, isc, ish);
+            }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
     }
@@ -714,7 +787,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
 // conv32: the same scheme for 32 -> 32 channels (ResNet-32 stage 2).  One tap fills a K = 32 step, the 32 output channels are two
 // MFMA row tiles, the weights are 18 operands (72 registers) per lane; the patch pitch is 96 bytes (64 of data), which puts the 16
 // lanes a ds_read_b128 services together on 16 distinct bank quartets.
-template <int MODE>
+template <int MODE, bool LZ = false>
 __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, char* smem) {
     constexpr int BM = 256, PP = 96;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -736,13 +809,23 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 3) * 8 + e]; ish[e] = coef[32 + (tid & 3) * 8 + e]; }
     }
+    constexpr bool lzd = MODE == 1 && LZ;
+    LazyDz8 lt;
+    if constexpr (lzd) {
+        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
+        lazy_dz_coefs<32>(p.lz, bx == 0, coef);
+        lazy_dz_load<32>(coef, (tid & 3) * 8, lt);
+    }
     for (int idx = tid; idx < nchunks; idx += 256) {
         const int q = idx >> 2, ch = idx & 3;
         const long long g = (long long)m0 - halo + q;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (g >= 0 && g < p.M) {
-            v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
-            if (lazy) v = bn_relu8_bf16(v, isc, ish);
+            if constexpr (lzd) v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 32 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 32 + ch * 8), lt);
+            else {
+                v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
+                if (lazy) v = bn_relu8_bf16(v, isc, ish);
+            }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
     }
@@ -917,7 +1000,7 @@ int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* st
     p.stats = stats; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = C; p.Cd = C; p.accumulate = accumulate; p.M = N * H * W;
     p.np = 256 + 2 * W + 2; p.patch_bytes = (p.np + 1) * (C == 16 ? 32 : 96); p.nbuf = 1; p.debug = 0;
-    const size_t lds = ((size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024) + 256;      // + the lazy input's [2][C] coefficients
+    const size_t lds = ((size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024) + 1024;      // + the lazy operands' coefficient tables ([2][C] / [6][C])
     const dim3 grid(clhip_conv16_tiles_m(p.M));
     if (C == 16) {
         if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, grid, dim3(256), lds, st, p);
@@ -1163,8 +1246,9 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
 // are constant address offsets into the padded image.  Each of the 4 waves takes 8 rows into 9 accumulator tiles; the waves are
 // summed through LDS and the image's 2304 partial sums go to a slab that wgrad3_reduce_kernel adds up in a fixed order.
 namespace {
-struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; const float* x_coef = nullptr; };      // x_coef [2][16]: x is a pre-BatchNorm tensor, the operand relu(scale x + shift)
+struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; const float* x_coef = nullptr; LazyDz lz; };      // x_coef [2][16]: x is a pre-BatchNorm tensor, the operand relu(scale x + shift)
 
+template <bool LZ = false>
 __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int bx, char* smem) {      // bx = image
     constexpr int W = 32, PW = 34, PX = 32;                  // image width, padded width, bytes per pixel (16 bf16)
     const int H = p.H;
@@ -1178,6 +1262,15 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
     for (int i = tid; i < xchunks; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int chunks = H * W * 2;
+    constexpr bool lzd = LZ;
+    LazyDz8 lt;
+    if constexpr (lzd) {                                     // (the staging area is still free: the coefficient table sits at its start until the fill)
+        float* coef = reinterpret_cast<float*>(zs);
+        __syncthreads();
+        lazy_dz_coefs<16>(p.lz, false, coef);
+        lazy_dz_load<16>(coef, (tid & 1) * 8, lt);
+        __syncthreads();
+    }
     float xsc[8], xsh[8];
     if (p.x_coef != nullptr) {
 #pragma unroll
@@ -1188,7 +1281,10 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
         uint4 xv = *reinterpret_cast<const uint4*>(p.x + (img + pix) * 16 + half * 8);
         if (p.x_coef != nullptr) xv = bn_relu8_bf16(xv, xsc, xsh);
         *reinterpret_cast<uint4*>(xs + ((r + 1) * PW + c + 1) * PX + half * 16) = xv;
-        *reinterpret_cast<uint4*>(zs + pix * PX + half * 16) = *reinterpret_cast<const uint4*>(p.dz + (img + pix) * 16 + half * 8);
+        uint4 zv;
+        if constexpr (lzd) zv = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (img + pix) * 16 + half * 8), *reinterpret_cast<const uint4*>(p.lz.z + (img + pix) * 16 + half * 8), lt);
+        else zv = *reinterpret_cast<const uint4*>(p.dz + (img + pix) * 16 + half * 8);
+        *reinterpret_cast<uint4*>(zs + pix * PX + half * 16) = zv;
     }
     __syncthreads();
 
@@ -1234,8 +1330,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(Wgrad16Params p) {
 // Wave w owns in-channel tile (w & 1) and taps {0..4} / {5..8} (w >> 1) over ALL K steps -- no cross-wave sum -- and the next image's
 // global loads are in flight while the current one is multiplied.  Partial blocks + wgrad3_reduce_kernel: bitwise reproducible.
 namespace {
-struct Wgrad32Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; const float* x_coef = nullptr; };      // x_coef [2][32] as in Wgrad16Params
+struct Wgrad32Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; const float* x_coef = nullptr; LazyDz lz; };      // x_coef [2][32] as in Wgrad16Params
 
+template <bool LZ = false>
 __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int ot, const int grp, char* smem) {
     constexpr int W = 16, PW = 18, PX = 64, PZ = 32;          // image width, padded width, bytes per input pixel (32 bf16), per gradient pixel (this tile's 16)
     const int H = p.H, HW = H * W;
@@ -1248,7 +1345,16 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
     // zero the padded image once: only its interior is rewritten per image
     for (int i = tid; i < (H + 2) * PW * 4; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     const int nx = HW * 4, nz = HW * 2;                       // 16-byte chunks per image: input (4 per pixel), gradient slice (2 per pixel)
-    uint4 rx[4], rz[2];
+    uint4 rx[4], rz[2], ry[2];
+    constexpr bool lzd = LZ;
+    LazyDz8 lt;
+    if constexpr (lzd) {                                      // gradient chunk q = tid + 256 i covers channels ot * 16 + (tid & 1) * 8
+        float* coef = reinterpret_cast<float*>(zs);
+        __syncthreads();
+        lazy_dz_coefs<32>(p.lz, false, coef);
+        lazy_dz_load<32>(coef, ot * 16 + (tid & 1) * 8, lt);
+        __syncthreads();
+    }
     float xsc[8], xsh[8];                                     // chunk q = tid + 256 i covers channels (q & 3) * 8 = (tid & 3) * 8 of its pixel
     if (p.x_coef != nullptr) {
 #pragma unroll
@@ -1264,9 +1370,15 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = tid + 256 * i;
-            rz[i] = q < nz ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+            if constexpr (lzd) {
+                rz[i] = q < nz ? *reinterpret_cast<const uint4*>(p.lz.dy + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+                ry[i] = q < nz ? *reinterpret_cast<const uint4*>(p.lz.z + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+            } else {
+                rz[i] = q < nz ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
+    auto lazy_or = [&](uint4 a, uint4 b) { if constexpr (lzd) return lazy_dz8(a, b, lt); else { (void)b; return a; } };
     auto sstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1279,7 +1391,7 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = tid + 256 * i;
-            if (q < nz) *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = rz[i];
+            if (q < nz) *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = lazy_or(rz[i], ry[i]);
         }
     };
     f32x4 acc[5];
@@ -1407,15 +1519,17 @@ int clhip_wgrad3_launch(const void* x, const void* dz, float* dw, float* ws, int
 // dgrad body (the longer-running weight-gradient workgroups are dispatched first); same device functions as the stand-alone kernels,
 // so the results are bit-identical to the two-launch path.
 namespace {
+template <bool LZ>
 __global__ __launch_bounds__(256) void bwd16_fused_kernel(Conv3Params pd, Wgrad16Params pw, int nw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nw) wgrad16_body(pw, blockIdx.x, smem);
-    else conv16_body<1>(pd, (int)blockIdx.x - nw, smem);
+    if ((int)blockIdx.x < nw) wgrad16_body<LZ>(pw, blockIdx.x, smem);
+    else conv16_body<1, LZ>(pd, (int)blockIdx.x - nw, smem);
 }
+template <bool LZ>
 __global__ __launch_bounds__(256) void bwd32_fused_kernel(Conv3Params pd, Wgrad32Params pw, int nw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nw) wgrad32_body(pw, blockIdx.x & 1, blockIdx.x >> 1, smem);
-    else conv32_body<1>(pd, (int)blockIdx.x - nw, smem);
+    if ((int)blockIdx.x < nw) wgrad32_body<LZ>(pw, blockIdx.x & 1, blockIdx.x >> 1, smem);
+    else conv32_body<1, LZ>(pd, (int)blockIdx.x - nw, smem);
 }
 }  // namespace
 
@@ -1427,8 +1541,15 @@ bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int
 
 int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* x_coef,
-                           hipStream_t st) {
+                           const clhip_bn_grad* lz, hipStream_t st) {
     Conv3Params pd;
+    LazyDz lzd;
+    if (lz != nullptr) {                                     // dz = the layer's own BatchNorm backward, computed on both bodies' operand loads
+        lzd.dy = static_cast<const bf16_t*>(lz->dy); lzd.z = static_cast<const bf16_t*>(lz->z); lzd.sums = lz->sums; lzd.rep = lz->replicas;
+        lzd.mean = lz->mean; lzd.invstd = lz->invstd; lzd.gamma = lz->gamma; lzd.beta = lz->beta; lzd.dgamma = lz->dgamma; lzd.dbeta = lz->dbeta;
+        lzd.invM = 1.0 / ((double)N * H * W);
+    }
+    pd.lz = lzd;
     pd.bn_coef = x_coef;                                     // a lazy x IS the producer's z: its ReLU mask comes from z as well (bn_y is NULL then)
     pd.bn_z = static_cast<const bf16_t*>(bn_z); pd.bn_y = static_cast<const bf16_t*>(bn_y); pd.bn_mean = bn_mean; pd.bn_invstd = bn_invstd;
     pd.bn_acc = bn_acc; pd.bn_rep = bn_rep > 0 ? bn_rep : 1;
@@ -1437,29 +1558,33 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     pd.N = N; pd.H = H; pd.W = W; pd.wshift = ilog2_exact(W); pd.hshift = ilog2_exact(H); pd.Cs = C; pd.Cd = C; pd.accumulate = accumulate; pd.M = N * H * W;
     pd.np = 256 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * (C == 16 ? 32 : 96); pd.nbuf = 1; pd.debug = 0;
     const int nd = clhip_conv16_tiles_m(pd.M);
-    size_t lds = ((size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024) + 256;
+    size_t lds = ((size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024) + 1024;
     if (C == 16) {
-        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef};
+        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef, lzd};
         size_t wl = (size_t)((H + 2) * 34 + H * 32) * 32;
         if (wl < 4 * 2304 * sizeof(float)) wl = 4 * 2304 * sizeof(float);
         if (wl > lds) lds = wl;
-        static size_t attr = 0;
-        if (lds > attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        static size_t attr[2] = {0, 0};
+        const int v = lz != nullptr;
+        if (lds > attr[v]) {
+            const void* kp = v ? reinterpret_cast<const void*>(bwd16_fused_kernel<true>) : reinterpret_cast<const void*>(bwd16_fused_kernel<false>);
+            if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 clhip_set_error("bwd16_fused: cannot reserve %zu bytes of LDS", lds);
                 return CLHIP_EHIP;
             }
-            attr = lds;
+            attr[v] = lds;
         }
-        hipLaunchKernelGGL(bwd16_fused_kernel, dim3(N + nd), dim3(256), lds, st, pd, pw, N);
+        if (v) hipLaunchKernelGGL(bwd16_fused_kernel<true>, dim3(N + nd), dim3(256), lds, st, pd, pw, N);
+        else hipLaunchKernelGGL(bwd16_fused_kernel<false>, dim3(N + nd), dim3(256), lds, st, pd, pw, N);
         CLHIP_LAUNCH_CHECK();
         return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N, st);
     }
     const int groups = wgrad32_groups(N);
-    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef};
+    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef, lzd};
     const size_t wl = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
     if (wl > lds) lds = wl;
-    hipLaunchKernelGGL(bwd32_fused_kernel, dim3(2 * groups + nd), dim3(256), lds, st, pd, pw, 2 * groups);
+    if (lz != nullptr) hipLaunchKernelGGL(bwd32_fused_kernel<true>, dim3(2 * groups + nd), dim3(256), lds, st, pd, pw, 2 * groups);
+    else hipLaunchKernelGGL(bwd32_fused_kernel<false>, dim3(2 * groups + nd), dim3(256), lds, st, pd, pw, 2 * groups);
     CLHIP_LAUNCH_CHECK();
     return clhip_wgrad_reduce_launch(ws, dw, 2304, groups, st);
 }

@@ -770,6 +770,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     // dz buffer, the shortcut unit takes the twin -- the arithmetic of a step does not depend on the stream layout.
     const bool pair_on = !br_on;
     const void* pair_dz = nullptr;
+    const char* lg_cfg = clhip_cfg("BN_GRAD");
+    const bool lazy_grad_on = !(lg_cfg != nullptr && atoi(lg_cfg) == 0);
     // a lazy activation some launch of this sweep has to READ as a tensor after all: write it now (same values the forward would have stored)
     auto materialise = [&](int a) -> int {
         const Unit& ua = p->units[a];
@@ -825,7 +827,17 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         static const bool ev_in_launch = clhip_cfg("EVENT_RECORD") == nullptr;
         const bool hook = on_side && ev_in_launch && !u.no_bn && u.rep_bwd > 0 && !u.has_dzr;
         if (hook) clhip_bn_set_stop_event(p->ev_dz[k]);
-        if (u.no_bn) {
+        // layers whose dgrad and weight gradient are both launches at their latency floor on this one stream: ONE launch for the two
+        // (clhip_conv_dgrad_wgrad, conv3.hip: CifarResNet-32 stages 1 and 2) ...
+        const bool both = !on_side && u.d.src != 0 && !u.raw_src && !(p->br_act >= 0 && u.d.src == p->br_act) &&
+                          clhip_conv_dgrad_wgrad_supported(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) &&
+                          clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0;
+        // ... and, where the unit's own BatchNorm backward is an apply pass with the ReLU mask from z (sums already reduced by the consumer's dgrad
+        // epilogue, no residual gradient to write), that pass happens on the operand loads of the same launch: dz is never written
+        const bool bn_grad = both && lazy_grad_on && !u.no_bn && !u.pre_res && !u.has_dzr && u.rep_bwd > 0 && p->bwd_sums_ready[i] && u.relu && dres == nullptr &&
+                             !mask_from_y && !(u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) && u.cin_pad == u.d.cin &&
+                             clhip_conv_bn_input_supported(p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype);
+        if (u.no_bn || bn_grad) {
         } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
             // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
             const bool zmask = u.relu && dres == nullptr && !mask_from_y;
@@ -886,9 +898,19 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         if (defer_side) clhip_wgrad_defer_pause(!on_side);             // only the side stream's launches are collected
         // layers whose dgrad and weight gradient are both launches at their latency floor on this one stream: ONE launch for the two
         // (clhip_conv_dgrad_wgrad, conv3.hip: CifarResNet-32 stages 1 and 2)
-        const bool both = !on_side && u.d.src != 0 && !u.raw_src && !(p->br_act >= 0 && u.d.src == p->br_act) &&
-                          clhip_conv_dgrad_wgrad_supported(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) &&
-                          clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0;
+        if (bn_grad) {
+            const Unit* prod = u.fuse_src_bn ? &p->units[u.d.src - 1] : nullptr;
+            clhip_bn_grad bg;
+            bg.dy = ws + dst.dy_off; bg.z = ws + u.z_off; bg.sums = reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd; bg.replicas = u.rep_bwd;
+            bg.mean = fr + u.f_mean; bg.invstd = fr + u.f_invstd; bg.gamma = params + u.d.gamma_off; bg.beta = params + u.d.beta_off;
+            bg.dgamma = grads + u.d.gamma_off; bg.dbeta = grads + u.d.beta_off;
+            TRY(clhip_conv_dgrad_wgrad_bn_grad(in, &bg, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, grads + u.d.w_off, ws + u.wg_own,
+                                               prod ? ws + prod->z_off : nullptr, (prod && prod->relu) ? ws + src.y_off : nullptr, prod ? fr + prod->f_mean : nullptr,
+                                               prod ? fr + prod->f_invstd : nullptr, prod ? reinterpret_cast<double*>(ws + p->acc_off) + prod->a_bwd : nullptr,
+                                               prod ? prod->rep_bwd : 1, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            if (prod) p->bwd_sums_ready[u.d.src - 1] = 1;
+            continue;
+        }
         if (both && u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) {
             const Unit& a = p->units[u.lazy_from];                // x = relu(bn(z_a)) on the weight gradient's operand load, the producer's ReLU mask from z_a
             const bool red = u.fuse_src_bn;

@@ -1011,3 +1011,37 @@ def test_lazy_batchnorm_input_forward_and_backward(shape):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # mask from z' (fma > 0) against mask from the stored activation: they differ only where a positive value underflows to bf16 zero
     assert ((outs[0][2] - outs[1][2]).abs() <= 1e-9 * outs[0][2].abs().clamp(min=1.0)).all()
+    # ---- the layer's OWN BatchNorm backward on the operand loads of its fused dgrad + weight-gradient launch (clhip_conv_dgrad_wgrad_bn_grad)
+    # against clhip_bn_bwd_apply_acc (z-mask form) followed by clhip_conv_dgrad_wgrad: dx, dw, dgamma, dbeta bit for bit
+
+    class BnGrad(C.Structure):
+        _fields_ = [("dy", C.c_void_p), ("z", C.c_void_p), ("sums", C.c_void_p), ("replicas", C.c_int), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                    ("gamma", C.c_void_p), ("beta", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+    xin = to_nhwc(quant(rnd((N, Cc, H, W), 77), tdt), tdt)                          # this layer's input
+    dy = to_nhwc(quant(rnd((N, Cc, H, W), 78, 0.5), tdt), tdt)                      # gradient of its activation
+    gsum = torch.zeros(4, 2, Cc, dtype=torch.float64, device=DEV)                   # sum g, sum g xhat as a consumer's epilogue leaves them
+    zfl = zp.float().reshape(-1, Cc)
+    gmask = (torch.addcmul(l["coef"][1], zfl, l["coef"][0]) > 0).float() * dy.float().reshape(-1, Cc)
+    xhat = (zfl - l["mean"]) * l["invstd"]
+    gsum[0, 0], gsum[3, 1] = gmask.double().sum(0), (gmask * xhat).double().sum(0)
+    res = []
+    for fused in (False, True):
+        dx = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+        dw = torch.full((Cc, 9, Cc), 0.25, device=DEV)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        dgam, dbet = torch.full((Cc,), 0.5, device=DEV), torch.full((Cc,), -0.25, device=DEV)
+        if fused:
+            bg = BnGrad(dy.data_ptr(), zp.data_ptr(), gsum.data_ptr(), 4, l["mean"].data_ptr(), l["invstd"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                        dgam.data_ptr(), dbet.data_ptr())
+            call("clhip_conv_dgrad_wgrad_bn_grad", xin.data_ptr(), C.byref(bg), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(), None, None, None, None,
+                 None, 1, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
+        else:
+            dzt = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+            call("clhip_bn_bwd_apply_acc", dy.data_ptr(), None, zp.data_ptr(), l["mean"].data_ptr(), l["invstd"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                 dgam.data_ptr(), dbet.data_ptr(), dzt.data_ptr(), None, 0, M_, Cc, 2, gsum.data_ptr(), 4, code, st())
+            call("clhip_conv_dgrad_wgrad", xin.data_ptr(), dzt.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(), None, None, None, None,
+                 None, 1, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
+        torch.cuda.synchronize()
+        res.append((dx, dw, dgam, dbet))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
