@@ -663,7 +663,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
 // pitch (conflict-free for ds_read_b128), and a 16-pixel x 16-channel output tile costs 5 LDS reads + 5 MFMAs with no barrier
 // after the patch is staged.  Lane (fr, fg) ends with channels 4 fg .. 4 fg + 3 of pixel fr: one 8-byte store, 512 contiguous
 // bytes per wave instruction, no output staging.  MODE as in conv3_kernel (the dgrad weight copy has the same [Cd][9][Cs] layout).
-template <int MODE, bool LZ = false>
+template <int MODE, bool LZ = false, bool LI = false>
 __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, char* smem) {      // bx = tile index (a workgroup of a plain or a fused launch)
     constexpr int BM = 256, PP = 32;                         // pixels per workgroup, LDS bytes per pixel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -685,9 +685,9 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
     }
     // patch: pixels [m0 - halo, m0 + BM + halo) as 16-byte half rows, plus one zero row for the out-of-image taps
     const int nchunks = p.np * 2;
-    const bool lazy = MODE == 0 && p.in_acc != nullptr;
+    constexpr bool lazy = MODE == 0 && LI;                    // lazy BatchNorm input (template parameter for the same reason as LZ)
     float isc[8], ish[8];
-    if (lazy) {                                              // this thread stages channels (tid & 1) * 8 .. + 8 of every pixel it touches
+    if constexpr (lazy) {                                    // this thread stages channels (tid & 1) * 8 .. + 8 of every pixel it touches
         float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
         lazy_input_coefs<16>(p, bx, coef);
 #pragma unroll
@@ -708,7 +708,7 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
             if constexpr (lzd) v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 16 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 16 + ch * 8), lt);
             else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
-                if (lazy) v = bn_relu8_bf16(v, isc, ish);
+                if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
@@ -778,16 +778,16 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
         }
     }
 }
-template <int MODE>
+template <int MODE, bool LI = false>
 __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv16_body<MODE>(p, blockIdx.x, smem);
+    conv16_body<MODE, false, LI>(p, blockIdx.x, smem);
 }
 
 // conv32: the same scheme for 32 -> 32 channels (ResNet-32 stage 2).  One tap fills a K = 32 step, the 32 output channels are two
 // MFMA row tiles, the weights are 18 operands (72 registers) per lane; the patch pitch is 96 bytes (64 of data), which puts the 16
 // lanes a ds_read_b128 services together on 16 distinct bank quartets.
-template <int MODE, bool LZ = false>
+template <int MODE, bool LZ = false, bool LI = false>
 __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, char* smem) {
     constexpr int BM = 256, PP = 96;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -801,9 +801,9 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) wreg[t][j] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(j * 16 + fr) * 288 + t * 32 + fg * 8);
     const int nchunks = p.np * 4;
-    const bool lazy = MODE == 0 && p.in_acc != nullptr;
+    constexpr bool lazy = MODE == 0 && LI;                    // lazy BatchNorm input (template parameter for the same reason as LZ)
     float isc[8], ish[8];
-    if (lazy) {                                              // this thread stages channels (tid & 3) * 8 .. + 8
+    if constexpr (lazy) {                                    // this thread stages channels (tid & 3) * 8 .. + 8
         float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
         lazy_input_coefs<32>(p, bx, coef);
 #pragma unroll
@@ -824,7 +824,7 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
             if constexpr (lzd) v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 32 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 32 + ch * 8), lt);
             else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
-                if (lazy) v = bn_relu8_bf16(v, isc, ish);
+                if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
@@ -907,10 +907,10 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
         }
     }
 }
-template <int MODE>
+template <int MODE, bool LI = false>
 __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv32_body<MODE>(p, blockIdx.x, smem);
+    conv32_body<MODE, false, LI>(p, blockIdx.x, smem);
 }
 
 template <int WM, int WN, int MODE>
@@ -1003,10 +1003,12 @@ int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* st
     const size_t lds = ((size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024) + 1024;      // + the lazy operands' coefficient tables ([2][C] / [6][C])
     const dim3 grid(clhip_conv16_tiles_m(p.M));
     if (C == 16) {
-        if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, grid, dim3(256), lds, st, p);
+        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv16_kernel<0, true>), grid, dim3(256), lds, st, p);
+        else if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(conv16_kernel<1>, grid, dim3(256), lds, st, p);
     } else {
-        if (mode == 0) hipLaunchKernelGGL(conv32_kernel<0>, grid, dim3(256), lds, st, p);
+        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv32_kernel<0, true>), grid, dim3(256), lds, st, p);
+        else if (mode == 0) hipLaunchKernelGGL(conv32_kernel<0>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(conv32_kernel<1>, grid, dim3(256), lds, st, p);
     }
     CLHIP_LAUNCH_CHECK();
