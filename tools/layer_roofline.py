@@ -73,6 +73,21 @@ def conv_rows(tag, N, H, W, C, K, ks, stride, count):
     row(shape + " wgrad", us, fl, act_in + act_out + dw.numel() * 4)
 
 
+def pair_row(tag, N, H, W, C, K):
+    """the step's launch for a down-sampling block entry: dgrad of the 3x3/s2 conv + dgrad of the 1x1/s2 shortcut, one launch (conv6.hip)"""
+    Ho, Wo = H // 2, W // 2
+    dz = torch.randn(N, Ho, Wo, K, device=dev).to(tdt)
+    dzs = torch.randn(N, Ho, Wo, K, device=dev).to(tdt)
+    w3 = (torch.randn(C, 9, K, device=dev) * 0.05).to(tdt)
+    w1 = (torch.randn(C, 1, K, device=dev) * 0.05).to(tdt)
+    dx = torch.empty(N, H, W, C, device=dev, dtype=tdt)
+    pk = torch.empty(_lib.lib().clhip_conv_dgrad_pair_packed_bytes(C, K), dtype=torch.uint8, device=dev)
+    _lib.call("clhip_conv_dgrad_pair_pack", w3.data_ptr(), w1.data_ptr(), pk.data_ptr(), C, K, code, st)
+    us = timed(lambda: _lib.call("clhip_conv_dgrad_pair", dz.data_ptr(), pk.data_ptr(), dzs.data_ptr(), dx.data_ptr(), 0, N, H, W, C, K, code, st))
+    row(f"{tag} {C}->{K} {H}x{W}: dgrad of k3 s2 + shortcut k1 s2, ONE launch (the step's form)", us, 2.0 * N * Ho * Wo * K * C * 10,
+        (dz.numel() + dzs.numel() + dx.numel()) * 2 + pk.numel())
+
+
 def gemm_row(tag, M, N, K, epi):
     A = torch.randn(M, K, device=dev).to(tdt)
     B = (torch.randn(N, K, device=dev) * 0.03).to(tdt)
@@ -92,12 +107,15 @@ conv_rows("stem", 256, 32, 32, 3, 64, 3, 1, 1)
 conv_rows("layer1", 256, 32, 32, 64, 64, 3, 1, 4)
 conv_rows("layer2.0", 256, 32, 32, 64, 128, 3, 2, 1)
 conv_rows("layer2.0 shortcut", 256, 32, 32, 64, 128, 1, 2, 1)
+pair_row("layer2.0", 256, 32, 32, 64, 128)
 conv_rows("layer2", 256, 16, 16, 128, 128, 3, 1, 3)
 conv_rows("layer3.0", 256, 16, 16, 128, 256, 3, 2, 1)
 conv_rows("layer3.0 shortcut", 256, 16, 16, 128, 256, 1, 2, 1)
+pair_row("layer3.0", 256, 16, 16, 128, 256)
 conv_rows("layer3", 256, 8, 8, 256, 256, 3, 1, 3)
 conv_rows("layer4.0", 256, 8, 8, 256, 512, 3, 2, 1)
 conv_rows("layer4.0 shortcut", 256, 8, 8, 256, 512, 1, 2, 1)
+pair_row("layer4.0", 256, 8, 8, 256, 512)
 conv_rows("layer4", 256, 4, 4, 512, 512, 3, 1, 3)
 print("\n## CifarResNet-32, batch 256, bf16\n\n" + HEAD)
 conv_rows("stem", 256, 32, 32, 3, 16, 3, 1, 1)
