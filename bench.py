@@ -352,6 +352,18 @@ def conv_rooflines(dev, dtype, B, workload):
               lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 2, 1, code, st),
               2.0 * M2 * 9 * C * K, (N * H * W * C + M2 * K) * es + K * 9 * C * 4, f"wgrad_s2/{N}x{H}x{W}x{C}x{K}",
               full_chip_run=lambda: wgrad_full(x, dz, dw, N, H, W, C, K, 2))
+        # the input gradient of that block entry: dgrad of the 3x3 / s2 convolution + dgrad of the 1x1 / s2 shortcut in one launch (conv6.hip)
+        if dtype == "bf16" and L.clhip_conv_dgrad_pair_supported(N, H, W, C, K, code):
+            dzs = torch.randn(N, H // 2, W // 2, K, device=dev).to(tdt)
+            w3 = (torch.randn(C, 9, K, device=dev) * 0.05).to(tdt)
+            w1 = (torch.randn(C, 1, K, device=dev) * 0.05).to(tdt)
+            dx = torch.empty(N, H, W, C, device=dev, dtype=tdt)
+            pk = torch.empty(L.clhip_conv_dgrad_pair_packed_bytes(C, K), dtype=torch.uint8, device=dev)
+            _lib.call("clhip_conv_dgrad_pair_pack", w3.data_ptr(), w1.data_ptr(), pk.data_ptr(), C, K, code, st)
+            entry("dgrad", "dgrad6_kernel<2, true>", f"dgrad6_kernel<2,true> dX of 3x3/s2 + 1x1/s2 shortcut in one launch @ [{N},{H // 2},{W // 2},{K}] x2 -> [{N},{H},{W},{C}]",
+                  N, H, W, C, K,
+                  lambda: _lib.call("clhip_conv_dgrad_pair", dz.data_ptr(), pk.data_ptr(), dzs.data_ptr(), dx.data_ptr(), 0, N, H, W, C, K, code, st),
+                  2.0 * M2 * 10 * C * K, (2 * M2 * K + N * H * W * C) * es + pk.numel(), f"dgrad_pair/{N}x{H}x{W}x{C}x{K}")
     # largest share of the step's kernel time first (committed in-step trace); without a trace, the order above
     out.sort(key=lambda e: -e.get("in_step_share_of_kernel_time", 0.0))
     return out
