@@ -332,7 +332,8 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     // down-sampling entries: a 3x3/s2/p1 unit a and a 1x1/s2/p0 unit b > a with the same source activation and channel counts, the only two
     // consumers of that activation -> their two input gradients are one launch at unit a (conv6.hip); the packed weights of both live at a.sh_pk
     for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; }
-    static const bool pair_off = clhip_cfg("CONV6_PAIR") != nullptr && atoi(clhip_cfg("CONV6_PAIR")) == 0;
+    const char* pair_cfg = clhip_cfg("CONV6_PAIR");             // (per plan: the tests build one with and one without)
+    const bool pair_off = pair_cfg != nullptr && atoi(pair_cfg) == 0;
     for (int b = 0; b < n_units && !pair_off; ++b) {
         Unit& ub = p->units[b];
         if (ub.d.ksize != 1 || ub.d.stride != 2 || ub.d.pad != 0 || ub.pre_res || ub.raw_src || ub.no_bn || ub.has_dzr || ub.d.src < 1) continue;

@@ -548,6 +548,38 @@ def test_fused_batchnorm_backward_reduction_at_network_level(arch, batch, monkey
     assert relnorm(flat1, flat0) < 2e-2          # 0.8-1.2 % observed: the two arrangements round different intermediate values to bf16
 
 
+def test_fused_stride2_input_gradient_inside_the_plan():
+    """ResNet-18 plans run the input gradient of every down-sampling block entry as ONE launch (conv6.hip: the 3x3/s2 dgrad and the shortcut's
+    1x1/s2 dgrad summed in fp32 accumulators, packed weights written by the plan's weight preparation).  Against the same plan with the two
+    separate launches (CONV6_PAIR=0: the shortcut's gradient is rounded to bf16 before the 3x3 layer's is added): the forward is untouched
+    (bit-identical features), the parameter gradients agree to the rounding of that one intermediate per block entry -- far inside the
+    operand-rounding yardstick of test_bf16_gradients_against_f32_mode_at_batch_256 -- and both agree with the f32 parity mode equally well."""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(64, 3, 32, 32, generator=g).to(DEV)
+    cw = (torch.randn(64, 512, generator=g) / 16).to(DEV)
+    out = {}
+    try:
+        for tag, dt, pair in (("pair", "bf16", b"1"), ("two", "bf16", b"0"), ("f32", "f32", b"1")):
+            assert L.clhip_config(b"CONV6_PAIR", pair) == 0
+            torch.manual_seed(7)
+            bb = M.resnet18(args={"dataset": "cifar100"}, dtype=dt).to(DEV)
+            bb.train()
+            f = bb(x)["features"]
+            (f * cw).sum().backward()
+            torch.cuda.synchronize()
+            out[tag] = (f.detach().float().cpu(), torch.cat([p.grad.detach().float().cpu().reshape(-1) for _, p in bb.named_parameters() if p.grad is not None]))
+    finally:
+        L.clhip_config(b"CONV6_PAIR", None)
+    (fp, gp), (ft, gt), (f3, g3) = out["pair"], out["two"], out["f32"]
+    assert torch.equal(fp, ft)
+    d = relnorm(gp, gt)
+    print("fused vs two-launch stride-2 input gradients: all parameter gradients differ by %.3e; against the f32 mode %.3f / %.3f" % (d, relnorm(gp, g3), relnorm(gt, g3)))
+    assert 0.0 < d < 2e-2                                   # (0: the switch did nothing)
+    assert relnorm(gp, g3) < 1.1 * relnorm(gt, g3) + 1e-3
+
+
 def test_bf16_gradients_against_f32_mode_at_batch_256():
     """BASELINE size, the two arithmetic modes of the SAME plan on the same weights and batch (ResNet-18, batch 256, random init):
     relative L2 norm of the difference PER LAYER (not a cosine: a cosine of 0.95 hides a 30 % error vector).
