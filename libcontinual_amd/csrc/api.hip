@@ -17,7 +17,7 @@ void clhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* clhip_last_error(void) { return g_err; }
-extern "C" int clhip_version(void) { return 101; }
+extern "C" int clhip_version(void) { return 102; }
 
 // ---- configuration: ONE documented entry point (clhip_config) instead of ad-hoc exports and scattered getenv calls.  Every switch
 //      has a name (the table below = the list in include/clhip.h); its value is what clhip_config() last set or, if never set, the
