@@ -417,6 +417,13 @@ int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats,
 // double-buffered LDS, split over the pixel axis (grid.z) with fp32 atomics into the gradient buffer.
 namespace {
 
+// ablation switches exist in ABL=1 builds only (a run-time test around every MFMA splits the K loop into basic blocks: conv6.hip's lesson)
+#ifdef CLHIP_ABLATION
+#define DBGW2(p) ((p).debug)
+#else
+#define DBGW2(p) 0
+#endif
+
 struct WgradParams2 {
     const void* x; const void* dz; float* dw;
     int N, H, W, C, log2C, Creal, Ho, Wo, lgHo, lgWo, K, ksize, stride, pad;
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradParams2 p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) if (!(p.debug & 2)) acc[i][j] = mma2<T>(zf[i], xf[j], acc[i][j]);
+                    for (int j = 0; j < NT; ++j) if (!(DBGW2(p) & 2)) acc[i][j] = mma2<T>(zf[i], xf[j], acc[i][j]);
             }
             if (more) sstore(st ^ 1);
             __syncthreads();
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradParams2 p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int o = o0 + (wo_ * MT + i) * 16 + fg * 4 + e;
-                if (o < p.K && !(p.debug & 8)) {
+                if (o < p.K && !(DBGW2(p) & 8)) {
                     const size_t at = ((size_t)o * taps + tp) * p.Creal + c;
                     // every (o, tap, c) belongs to exactly one (blockIdx.x, blockIdx.y) tile, and every split's tiles run (empty ones
                     // store zeros): the slab is fully written, no zeroing launch
