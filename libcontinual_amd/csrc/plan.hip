@@ -773,6 +773,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     const void* pair_dz = nullptr;
     const char* lg_cfg = clhip_cfg("BN_GRAD");
     const bool lazy_grad_on = !(lg_cfg != nullptr && atoi(lg_cfg) == 0);
+    const char* lgc_cfg = clhip_cfg("BN_GRAD_MINC");
+    const int lazy_grad_minc = lgc_cfg != nullptr ? atoi(lgc_cfg) : 0;
     // a lazy activation some launch of this sweep has to READ as a tensor after all: write it now (same values the forward would have stored)
     auto materialise = [&](int a) -> int {
         const Unit& ua = p->units[a];
@@ -835,7 +837,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                           clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0;
         // ... and, where the unit's own BatchNorm backward is an apply pass with the ReLU mask from z (sums already reduced by the consumer's dgrad
         // epilogue, no residual gradient to write), that pass happens on the operand loads of the same launch: dz is never written
-        const bool bn_grad = both && lazy_grad_on && !u.no_bn && !u.pre_res && !u.has_dzr && u.rep_bwd > 0 && p->bwd_sums_ready[i] && u.relu && dres == nullptr &&
+        const bool bn_grad = both && lazy_grad_on && u.d.cout >= lazy_grad_minc && !u.no_bn && !u.pre_res && !u.has_dzr && u.rep_bwd > 0 && p->bwd_sums_ready[i] && u.relu && dres == nullptr &&
                              !mask_from_y && !(u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) && u.cin_pad == u.d.cin &&
                              clhip_conv_bn_input_supported(p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype);
         if (u.no_bn || bn_grad) {
