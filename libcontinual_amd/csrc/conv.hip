@@ -669,7 +669,7 @@ extern "C" int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_c
                                   x_coef, nullptr, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int clhip_conv_dgrad_wgrad_bn_grad(const void* x, const clhip_bn_grad* bn, const void* w_dg, void* dx, int accumulate, float* dw, void* ws,
+extern "C" int clhip_conv_dgrad_wgrad_bn_grad(const void* x, const float* x_coef, const clhip_bn_grad* bn, const void* w_dg, void* dx, int accumulate, float* dw, void* ws,
                                               const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc, int replicas,
                                               int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream) {
     if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
@@ -677,8 +677,9 @@ extern "C" int clhip_conv_dgrad_wgrad_bn_grad(const void* x, const clhip_bn_grad
     CLHIP_CHECK_ARG(bn->dy && bn->z && bn->sums && bn->mean && bn->invstd && bn->gamma && bn->beta && bn->dgamma && bn->dbeta && bn->replicas >= 1 && bn->replicas <= 64);
     CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype) && Creal == C);
     CLHIP_CHECK_ARG(z_prod == nullptr || (mean && invstd && acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0));
-    return clhip_bwd_fused_launch(x, nullptr, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, z_prod, y_prod, mean, invstd, acc, replicas, nullptr,
-                                  bn, static_cast<hipStream_t>(stream));
+    CLHIP_CHECK_ARG(bn->relu_mask != nullptr || bn->dres == nullptr);          // a residual gradient only exists behind a masked (+res) layer
+    return clhip_bwd_fused_launch(x, nullptr, w_dg, dx, accumulate, dw, static_cast<float*>(ws), N, H, W, C, x_coef != nullptr ? (z_prod ? x : nullptr) : z_prod,
+                                  x_coef != nullptr ? nullptr : y_prod, mean, invstd, acc, replicas, x_coef, bn, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int clhip_conv_dgrad_wgrad_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {

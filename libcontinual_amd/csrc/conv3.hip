@@ -26,6 +26,9 @@ struct LazyDz {
     const float* mean = nullptr; const float* invstd = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
     double invM = 0.0;
     float* dgamma = nullptr; float* dbeta = nullptr;      // accumulated into by ONE workgroup of the launch
+    const unsigned char* mask = nullptr;                  // packed ReLU mask of a conv -> BN -> +res -> ReLU layer (one byte per 8 elements), or nullptr: the mask from z
+    bf16_t* dres = nullptr;                               // that layer's residual gradient g = dy * mask, written (dres_acc 0) or accumulated (1) by the dgrad body
+    int dres_acc = 0;
 };
 
 // coef[6][C] (LDS): mean(g), mean(g xhat), mean, invstd, scale, shift -- bn_bwd_apply_acc_kernel's prologue (bn.hip); `first` = the one
@@ -62,17 +65,36 @@ __device__ __forceinline__ void lazy_dz_load(const float* coef, int c0, LazyDz8&
         t.is[e] = coef[3 * C + c0 + e]; t.gi[e] = coef[4 * C + c0 + e]; t.sh[e] = coef[5 * C + c0 + e];
     }
 }
-__device__ __forceinline__ uint4 lazy_dz8(uint4 dy, uint4 z, const LazyDz8& t) {
+// bits == true: the ReLU mask comes from the packed byte `mb` (bit e = element e), else from the sign of scale z + shift; gg = the masked gradient
+__device__ __forceinline__ uint4 lazy_dz8(uint4 dy, uint4 z, const LazyDz8& t, bool bits, unsigned mb, float (&gg)[8]) {
     float g[8], zz[8], o[8];
     unpack8(dy, g);
     unpack8(z, zz);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float gg = fmaf(zz[e], t.gi[e], t.sh[e]) > 0.f ? g[e] : 0.f;
+        const bool on = bits ? ((mb >> e) & 1u) != 0u : fmaf(zz[e], t.gi[e], t.sh[e]) > 0.f;
+        gg[e] = on ? g[e] : 0.f;
         const float xh = (zz[e] - t.mu[e]) * t.is[e];
-        o[e] = t.gi[e] * (gg - t.k0[e] - xh * t.k1[e]);
+        o[e] = t.gi[e] * (gg[e] - t.k0[e] - xh * t.k1[e]);
     }
     return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+}
+__device__ __forceinline__ uint4 lazy_dz8(uint4 dy, uint4 z, const LazyDz8& t, bool bits, unsigned mb) {
+    float gg[8];
+    return lazy_dz8(dy, z, t, bits, mb, gg);
+}
+// the dgrad body owns the residual gradient of its tile's pixels: dres (+)= gg, as bn_bwd_apply_acc_kernel stores it
+__device__ __forceinline__ void lazy_dres_store(bf16_t* q, const float (&gg)[8], int accumulate) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gg[e];
+    if (accumulate) {
+        float old[8];
+        unpack8(*reinterpret_cast<const uint4*>(q), old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = old[e] + gg[e];
+    }
+    *reinterpret_cast<uint4*>(q) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
 struct Conv3Params {
@@ -705,8 +727,13 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
         const long long g = (long long)m0 - halo + q;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (g >= 0 && g < p.M) {
-            if constexpr (lzd) v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 16 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 16 + ch * 8), lt);
-            else {
+            if constexpr (lzd) {
+                const bool bits = p.lz.mask != nullptr;
+                const unsigned mb = bits ? p.lz.mask[(size_t)g * 2 + ch] : 0u;
+                float gg[8];
+                v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 16 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 16 + ch * 8), lt, bits, mb, gg);
+                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * 16 + ch * 8, gg, p.lz.dres_acc);
+            } else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
                 if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
@@ -821,8 +848,13 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
         const long long g = (long long)m0 - halo + q;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (g >= 0 && g < p.M) {
-            if constexpr (lzd) v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 32 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 32 + ch * 8), lt);
-            else {
+            if constexpr (lzd) {
+                const bool bits = p.lz.mask != nullptr;
+                const unsigned mb = bits ? p.lz.mask[(size_t)g * 4 + ch] : 0u;
+                float gg[8];
+                v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 32 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 32 + ch * 8), lt, bits, mb, gg);
+                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * 32 + ch * 8, gg, p.lz.dres_acc);
+            } else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
                 if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
@@ -1284,7 +1316,8 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
         if (p.x_coef != nullptr) xv = bn_relu8_bf16(xv, xsc, xsh);
         *reinterpret_cast<uint4*>(xs + ((r + 1) * PW + c + 1) * PX + half * 16) = xv;
         uint4 zv;
-        if constexpr (lzd) zv = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (img + pix) * 16 + half * 8), *reinterpret_cast<const uint4*>(p.lz.z + (img + pix) * 16 + half * 8), lt);
+        if constexpr (lzd) zv = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (img + pix) * 16 + half * 8), *reinterpret_cast<const uint4*>(p.lz.z + (img + pix) * 16 + half * 8), lt,
+                                         p.lz.mask != nullptr, p.lz.mask != nullptr ? p.lz.mask[(img + pix) * 2 + half] : 0u);
         else zv = *reinterpret_cast<const uint4*>(p.dz + (img + pix) * 16 + half * 8);
         *reinterpret_cast<uint4*>(zs + pix * PX + half * 16) = zv;
     }
@@ -1348,6 +1381,7 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
     for (int i = tid; i < (H + 2) * PW * 4; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     const int nx = HW * 4, nz = HW * 2;                       // 16-byte chunks per image: input (4 per pixel), gradient slice (2 per pixel)
     uint4 rx[4], rz[2], ry[2];
+    unsigned rm[2] = {0u, 0u};
     constexpr bool lzd = LZ;
     LazyDz8 lt;
     if constexpr (lzd) {                                      // gradient chunk q = tid + 256 i covers channels ot * 16 + (tid & 1) * 8
@@ -1375,12 +1409,13 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
             if constexpr (lzd) {
                 rz[i] = q < nz ? *reinterpret_cast<const uint4*>(p.lz.dy + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
                 ry[i] = q < nz ? *reinterpret_cast<const uint4*>(p.lz.z + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+                rm[i] = (q < nz && p.lz.mask != nullptr) ? p.lz.mask[(base + (q >> 1)) * 4 + ot * 2 + (q & 1)] : 0u;
             } else {
                 rz[i] = q < nz ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * 32 + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
             }
         }
     };
-    auto lazy_or = [&](uint4 a, uint4 b) { if constexpr (lzd) return lazy_dz8(a, b, lt); else { (void)b; return a; } };
+    auto lazy_or = [&](uint4 a, uint4 b, unsigned mb) { if constexpr (lzd) return lazy_dz8(a, b, lt, p.lz.mask != nullptr, mb); else { (void)b; (void)mb; return a; } };
     auto sstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1393,7 +1428,7 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = tid + 256 * i;
-            if (q < nz) *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = lazy_or(rz[i], ry[i]);
+            if (q < nz) *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = lazy_or(rz[i], ry[i], rm[i]);
         }
     };
     f32x4 acc[5];
@@ -1549,6 +1584,7 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     if (lz != nullptr) {                                     // dz = the layer's own BatchNorm backward, computed on both bodies' operand loads
         lzd.dy = static_cast<const bf16_t*>(lz->dy); lzd.z = static_cast<const bf16_t*>(lz->z); lzd.sums = lz->sums; lzd.rep = lz->replicas;
         lzd.mean = lz->mean; lzd.invstd = lz->invstd; lzd.gamma = lz->gamma; lzd.beta = lz->beta; lzd.dgamma = lz->dgamma; lzd.dbeta = lz->dbeta;
+        lzd.mask = static_cast<const unsigned char*>(lz->relu_mask); lzd.dres = static_cast<bf16_t*>(lz->dres); lzd.dres_acc = lz->dres_accumulate;
         lzd.invM = 1.0 / ((double)N * H * W);
     }
     pd.lz = lzd;

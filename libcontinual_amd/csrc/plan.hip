@@ -775,6 +775,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     const bool lazy_grad_on = !(lg_cfg != nullptr && atoi(lg_cfg) == 0);
     const char* lgc_cfg = clhip_cfg("BN_GRAD_MINC");
     const int lazy_grad_minc = lgc_cfg != nullptr ? atoi(lgc_cfg) : 0;
+    const char* lgr_cfg = clhip_cfg("BN_GRAD_RES");
+    const bool lazy_res_on = !(lgr_cfg != nullptr && atoi(lgr_cfg) == 0);
     // a lazy activation some launch of this sweep has to READ as a tensor after all: write it now (same values the forward would have stored)
     auto materialise = [&](int a) -> int {
         const Unit& ua = p->units[a];
@@ -837,9 +839,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                           clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0;
         // ... and, where the unit's own BatchNorm backward is an apply pass with the ReLU mask from z (sums already reduced by the consumer's dgrad
         // epilogue, no residual gradient to write), that pass happens on the operand loads of the same launch: dz is never written
-        const bool bn_grad = both && lazy_grad_on && u.d.cout >= lazy_grad_minc && !u.no_bn && !u.pre_res && !u.has_dzr && u.rep_bwd > 0 && p->bwd_sums_ready[i] && u.relu && dres == nullptr &&
-                             !mask_from_y && !(u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) && u.cin_pad == u.d.cin &&
-                             clhip_conv_bn_input_supported(p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype);
+        // (two forms: ReLU straight after the BatchNorm, mask from z; or conv -> BN -> +res -> ReLU with the packed mask of the forward, the residual
+        //  gradient written by the same launch)
+        const bool lazy_in = u.lazy_from >= 0 && p->lazy_live[u.lazy_from];
+        const bool bn_grad_ok = both && lazy_grad_on && u.d.cout >= lazy_grad_minc && !u.no_bn && !u.pre_res && !u.has_dzr && u.rep_bwd > 0 && p->bwd_sums_ready[i] &&
+                                u.relu && !mask_from_y && u.cin_pad == u.d.cin &&                                 clhip_conv_bn_input_supported(p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype);
+        const bool bn_grad = bn_grad_ok && (dres == nullptr ? true : (u.mask_off != 0 && lazy_res_on));
         if (u.no_bn || bn_grad) {
         } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
             // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
@@ -907,10 +912,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             bg.dy = ws + dst.dy_off; bg.z = ws + u.z_off; bg.sums = reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd; bg.replicas = u.rep_bwd;
             bg.mean = fr + u.f_mean; bg.invstd = fr + u.f_invstd; bg.gamma = params + u.d.gamma_off; bg.beta = params + u.d.beta_off;
             bg.dgamma = grads + u.d.gamma_off; bg.dbeta = grads + u.d.beta_off;
-            TRY(clhip_conv_dgrad_wgrad_bn_grad(in, &bg, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, grads + u.d.w_off, ws + u.wg_own,
-                                               prod ? ws + prod->z_off : nullptr, (prod && prod->relu) ? ws + src.y_off : nullptr, prod ? fr + prod->f_mean : nullptr,
-                                               prod ? fr + prod->f_invstd : nullptr, prod ? reinterpret_cast<double*>(ws + p->acc_off) + prod->a_bwd : nullptr,
-                                               prod ? prod->rep_bwd : 1, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            bg.relu_mask = dres != nullptr ? ws + u.mask_off : nullptr; bg.dres = dres; bg.dres_accumulate = u.dres_acc;
+            const Unit* la = lazy_in ? &p->units[u.lazy_from] : nullptr;       // its input is a lazy activation as well: x = z of that unit + its coefficients
+            TRY(clhip_conv_dgrad_wgrad_bn_grad(la ? ws + la->z_off : in, la ? fr + la->f_scale : nullptr, &bg, sh + u.sh_dg, ws + src.dy_off, u.dx_acc,
+                                               grads + u.d.w_off, ws + u.wg_own, prod ? ws + prod->z_off : nullptr, (prod && prod->relu) ? ws + src.y_off : nullptr,
+                                               prod ? fr + prod->f_mean : nullptr, prod ? fr + prod->f_invstd : nullptr,
+                                               prod ? reinterpret_cast<double*>(ws + p->acc_off) + prod->a_bwd : nullptr, prod ? prod->rep_bwd : 1, p->N, u.H, u.W,
+                                               u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
             if (prod) p->bwd_sums_ready[u.d.src - 1] = 1;
             continue;
         }

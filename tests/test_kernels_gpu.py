@@ -1016,7 +1016,8 @@ def test_lazy_batchnorm_input_forward_and_backward(shape):
 
     class BnGrad(C.Structure):
         _fields_ = [("dy", C.c_void_p), ("z", C.c_void_p), ("sums", C.c_void_p), ("replicas", C.c_int), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                    ("gamma", C.c_void_p), ("beta", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+                    ("gamma", C.c_void_p), ("beta", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("relu_mask", C.c_void_p), ("dres", C.c_void_p),
+                    ("dres_accumulate", C.c_int)]
     xin = to_nhwc(quant(rnd((N, Cc, H, W), 77), tdt), tdt)                          # this layer's input
     dy = to_nhwc(quant(rnd((N, Cc, H, W), 78, 0.5), tdt), tdt)                      # gradient of its activation
     gsum = torch.zeros(4, 2, Cc, dtype=torch.float64, device=DEV)                   # sum g, sum g xhat as a consumer's epilogue leaves them
@@ -1032,8 +1033,8 @@ def test_lazy_batchnorm_input_forward_and_backward(shape):
         dgam, dbet = torch.full((Cc,), 0.5, device=DEV), torch.full((Cc,), -0.25, device=DEV)
         if fused:
             bg = BnGrad(dy.data_ptr(), zp.data_ptr(), gsum.data_ptr(), 4, l["mean"].data_ptr(), l["invstd"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                        dgam.data_ptr(), dbet.data_ptr())
-            call("clhip_conv_dgrad_wgrad_bn_grad", xin.data_ptr(), C.byref(bg), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(), None, None, None, None,
+                        dgam.data_ptr(), dbet.data_ptr(), None, None, 0)
+            call("clhip_conv_dgrad_wgrad_bn_grad", xin.data_ptr(), None, C.byref(bg), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(), None, None, None, None,
                  None, 1, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
         else:
             dzt = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
@@ -1045,3 +1046,38 @@ def test_lazy_batchnorm_input_forward_and_backward(shape):
         res.append((dx, dw, dgam, dbet))
     for a_, b_ in zip(res[0], res[1]):
         assert torch.equal(a_, b_)
+    # ---- the +res form: conv -> BN -> +res -> ReLU with the forward's packed mask; the launch also writes / accumulates the residual gradient;
+    # its input here is itself a lazy activation (x = relu(bn(zin)) from coefficients): everything a ResNet-32 block's second unit needs at once
+    zin = to_nhwc(quant(rnd((N, Cc, H, W), 79, 1.2), tdt), tdt)
+    xmat = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+    call("clhip_bn_apply", zin.data_ptr(), l["coef"][0].contiguous().data_ptr(), l["coef"][1].contiguous().data_ptr(), None, xmat.data_ptr(), M_, Cc, 1, code, st())
+    mask = torch.randint(0, 256, (M_ * Cc // 8,), dtype=torch.uint8, device=DEV)
+    mbits = ((mask.long()[:, None] >> torch.arange(8, device=DEV)) & 1).reshape(-1, Cc).float()
+    gm = mbits * dy.float().reshape(-1, Cc)
+    gsum2 = torch.zeros(4, 2, Cc, dtype=torch.float64, device=DEV)
+    gsum2[1, 0], gsum2[2, 1] = gm.double().sum(0), (gm * xhat).double().sum(0)
+    for accumulate in (0, 1):
+        res = []
+        for fused in (False, True):
+            dx = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+            dw = torch.full((Cc, 9, Cc), 0.25, device=DEV)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+            dgam, dbet = torch.full((Cc,), 0.5, device=DEV), torch.full((Cc,), -0.25, device=DEV)
+            dres = to_nhwc(quant(rnd((N, Cc, H, W), 80, 0.4), tdt), tdt)
+            psum = torch.zeros(4, 2, Cc, dtype=torch.float64, device=DEV)                  # the producer's sums out of the dgrad epilogue
+            if fused:
+                bg = BnGrad(dy.data_ptr(), zp.data_ptr(), gsum2.data_ptr(), 4, l["mean"].data_ptr(), l["invstd"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                            dgam.data_ptr(), dbet.data_ptr(), mask.data_ptr(), dres.data_ptr(), accumulate)
+                call("clhip_conv_dgrad_wgrad_bn_grad", zin.data_ptr(), l["coef"].data_ptr(), C.byref(bg), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(),
+                     zin.data_ptr(), None, l["mean"].data_ptr(), l["invstd"].data_ptr(), psum.data_ptr(), 4, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
+            else:
+                dzt = torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV)
+                call("clhip_bn_bwd_apply_acc", dy.data_ptr(), mask.data_ptr(), zp.data_ptr(), l["mean"].data_ptr(), l["invstd"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                     dgam.data_ptr(), dbet.data_ptr(), dzt.data_ptr(), dres.data_ptr(), accumulate, M_, Cc, 3, gsum2.data_ptr(), 4, code, st())
+                call("clhip_conv_dgrad_wgrad_bn_input", zin.data_ptr(), l["coef"].data_ptr(), dzt.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws.data_ptr(),
+                     l["mean"].data_ptr(), l["invstd"].data_ptr(), psum.data_ptr(), 4, N, H, W, Cc, Cc, Cc, 3, 1, 1, code, st())
+            torch.cuda.synchronize()
+            res.append((dx, dw, dgam, dbet, dres, psum.sum(0)))
+        for k_, (a_, b_) in enumerate(zip(res[0][:5], res[1][:5])):
+            assert torch.equal(a_, b_), (accumulate, k_)
+        assert ((res[0][5] - res[1][5]).abs() <= 1e-12 * res[0][5].abs().clamp(min=1.0)).all()
