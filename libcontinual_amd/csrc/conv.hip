@@ -437,6 +437,14 @@ int check_conv(int N, int H, int W, int C, int K, int ksize, int stride, int pad
 int clhip_conv2_tiles_m(int M, int Cd);
 int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
                        int Cd, int ksize, int stride, int pad, int accumulate, int mode, int dtype, hipStream_t st);
+bool clhip_conv64_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv3.hip
+int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
+                           const clhip_bn_input* in, hipStream_t st);
+
+bool clhip_wgrad64_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
+size_t clhip_wgrad64_ws_bytes(int N);
+int clhip_wgrad64_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st);
 bool clhip_wgrad32_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
 size_t clhip_wgrad32_ws_bytes(int N);
 int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st);
@@ -536,6 +544,9 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
     // the stems (<= 8 padded input channels): no LDS, weights in registers; serves the accumulator and the no-statistics forms
     if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_stem_supported(N, H, W, C, K, ksize, stride, pad, dtype))
         return clhip_stem_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, K, st);
+    // 64 -> 64 channels on small maps: register-resident filters, out channels split over the waves (statistics through the accumulators only)
+    if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_conv64_launch_ex(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, st);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype)) {
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
         int tiles_used = clhip_conv16_tiles_m(p.M);
@@ -593,6 +604,8 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
         return clhip_shortcut_dgrad(dz, w_dg, dx, accumulate, N, H, W, C, K, st);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, st);
+    if (!use_v1() && use_v3() && clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv64_launch_ex(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, st);
     if (!use_v1() && use_v3() && clhip_conv5_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv5_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype))
@@ -612,7 +625,8 @@ int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* st
 extern "C" int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
     if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
     if (use_v1() || !use_v3()) return 0;
-    return (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
+    return (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype) ||
+            clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
 }
 
 extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod,
@@ -622,6 +636,9 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
     CLHIP_CHECK_ARG(dz && w_dg && dx && z_prod && mean && invstd && acc);
     CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
     CLHIP_CHECK_ARG(clhip_conv_dgrad_bn_reduce_supported(N, H, W, C, K, ksize, stride, pad, dtype));
+    if (clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv64_launch_ex(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas, nullptr, nullptr,
+                                      static_cast<hipStream_t>(stream));
     if (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))      // 16 -> 16 / 32 -> 32 channels: the register-resident kernels' epilogue
         return clhip_conv16_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
                                       static_cast<hipStream_t>(stream));
@@ -644,7 +661,8 @@ extern "C" int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, 
     if (use_v1() || !use_v3()) return 0;
     const char* cfg = clhip_cfg("BN_INPUT");
     const bool off = cfg != nullptr && atoi(cfg) == 0;
-    return (!off && clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype) && clhip_bwd_fused_supported(N, H, W, C, C, K, ksize, stride, pad, dtype)) ? 1 : 0;
+    return (!off && (clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype)) &&
+            clhip_bwd_fused_supported(N, H, W, C, C, K, ksize, stride, pad, dtype)) ? 1 : 0;
 }
 
 extern "C" int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, const void* w_fwd, void* z, double* stat_acc, int replicas, int N,
@@ -654,6 +672,9 @@ extern "C" int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_inpu
     CLHIP_CHECK_ARG(bn->stat_acc && bn->gamma && bn->beta && bn->mean && bn->invstd && bn->coef && bn->replicas >= 1 && bn->replicas <= 64);
     CLHIP_CHECK_ARG((bn->running_mean == nullptr) == (bn->running_var == nullptr));
     CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype));
+    if (C == 64)
+        return clhip_conv64_launch_ex(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, bn,
+                                      static_cast<hipStream_t>(stream));
     return clhip_conv16_launch_ex(z_in, w_fwd, z, nullptr, stat_acc, replicas, N, H, W, C, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, bn,
                                   static_cast<hipStream_t>(stream));
 }
@@ -726,6 +747,7 @@ extern "C" int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const
 
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!use_v1() && use_v3() && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_stem_wgrad_ws_bytes(N, H, W, Creal, K);
+    if (!use_v1() && use_v3() && clhip_wgrad64_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad64_ws_bytes(N);
     if (!use_v1() && use_v3() && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad4_ws_bytes(N, H, W, C, K, ksize, stride);
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad3_ws_bytes(N, H, W, C, K);
     if (!use_v1() && use_v3() && clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad16_ws_bytes(N);
@@ -759,6 +781,8 @@ extern "C" int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* 
     CLHIP_CHECK_ARG(dtype == CLHIP_BF16 || dtype == CLHIP_F32);
     if (!use_v1() && use_v3() && ws != nullptr && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_stem_wgrad_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, Creal, K, st);
+    if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad64_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
+        return clhip_wgrad64_launch(x, dz, dw, static_cast<float*>(ws), N, H, nullptr, st);
     if (!use_v1() && use_v3() && ws != nullptr && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))
         return clhip_wgrad4_launch(x, dz, dw, static_cast<float*>(ws), N, H, W, C, K, ksize, stride, st);
     if (!use_v1() && use_v3() && clhip_wgrad3_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype))

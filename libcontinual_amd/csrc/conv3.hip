@@ -945,6 +945,149 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
     conv32_body<MODE, false, LI>(p, blockIdx.x, smem);
 }
 
+// conv64: 3x3 / s1 / p1 with 64 -> 64 channels on SMALL maps (CifarResNet-32 stage 3: 8x8 images, 16 384 pixels at batch 256 -- launches at their
+// latency floor, where conv4.hip's ring of slabs has nothing to amortise).  Same scheme as conv16 / conv32 with the output channels split over the
+// waves: wave w owns output channels 16 w .. 16 w + 15 and keeps THEIR filters in 72 registers (9 taps x two 32-wide K steps), a workgroup is 64
+// pixels, the patch sits in LDS at a 144-byte pitch (conflict-free for ds_read_b128), every wave multiplies all four 16-pixel tiles.  No cross-wave
+// reduction anywhere: a wave owns its channels' BatchNorm sums (forward statistics, backward sums) and adds them to the fp64 accumulators directly.
+// The patch is staged through registers, so the lazy BatchNorm operands of conv16 / conv32 apply (LI: input, LZ: gradient).
+template <int MODE, bool LZ = false, bool LI = false>
+__device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, char* smem) {
+    constexpr int BM = 64, PP = 144, C = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = bx * BM;
+    const int W = p.W, halo = W + 1;
+
+    uint4 wreg[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wreg[t][ks] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(wave * 16 + fr) * 576 + t * 64 + ks * 32 + fg * 8);
+    const int nchunks = p.np * 8;
+    constexpr bool lazy = MODE == 0 && LI;
+    constexpr bool lzd = MODE == 1 && LZ;
+    float isc[8], ish[8];
+    LazyDz8 lt;
+    float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
+    if constexpr (lazy) {                                    // this thread stages channels (tid & 7) * 8 .. + 8
+        lazy_input_coefs<C>(p, bx, coef);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 7) * 8 + e]; ish[e] = coef[C + (tid & 7) * 8 + e]; }
+    }
+    if constexpr (lzd) {
+        lazy_dz_coefs<C>(p.lz, bx == 0, coef);
+        lazy_dz_load<C>(coef, (tid & 7) * 8, lt);
+    }
+    for (int idx = tid; idx < nchunks; idx += 256) {
+        const int q = idx >> 3, ch = idx & 7;
+        const long long g = (long long)m0 - halo + q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g < p.M) {
+            if constexpr (lzd) {
+                const bool bits = p.lz.mask != nullptr;
+                const unsigned mb = bits ? p.lz.mask[(size_t)g * 8 + ch] : 0u;
+                float gg[8];
+                v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * C + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * C + ch * 8), lt, bits, mb, gg);
+                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * C + ch * 8, gg, p.lz.dres_acc);
+            } else {
+                v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * C + ch * 8);
+                if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
+            }
+        }
+        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
+    }
+    if (tid < 8) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    const int zaddr = p.np * PP + fg * 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = i * 16 + fr;
+        const int g = m0 + pl;
+        const unsigned mask = g < p.M ? tap_mask<MODE>(g, p) : 0u;
+        const int base = (pl + halo) * PP + fg * 16;
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, s_ = t - 3 * r;
+            const int shift = (MODE == 0 ? (r - 1) * W + (s_ - 1) : (1 - r) * W + (1 - s_)) * PP;
+            const int a = (mask & (1u << t)) ? base + shift : zaddr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 x = ldsq(smem + a + ks * 64);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[t][ks]), __builtin_bit_cast(bf16x8_t, x), acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = channel wave*16 + fg*4 + e][col = pixel fr]
+    const int c4 = wave * 16 + fg * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};      // forward: sum z, sum z^2; dgrad + bn_z: sum g, sum g z'
+    float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
+    const bool zmask = MODE == 1 && p.bn_z != nullptr && p.bn_y == nullptr && p.bn_coef != nullptr;
+    if (zmask) { msc = *reinterpret_cast<const float4*>(p.bn_coef + c4); msh = *reinterpret_cast<const float4*>(p.bn_coef + C + c4); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = m0 + i * 16 + fr;
+        float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+        if (pix < p.M) {
+            bf16_t* o = p.dst + (size_t)pix * C + c4;
+            if (MODE == 1 && p.accumulate) {
+                const uint2 old = *reinterpret_cast<const uint2*>(o);
+                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+            }
+            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] += acc[i][e]; s2[e] = fmaf(acc[i][e], acc[i][e], s2[e]); }
+            } else if (p.bn_z != nullptr) {
+                const size_t at = (size_t)pix * C + c4;
+                const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + at);
+                const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
+                float y4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.bn_y != nullptr) {
+                    const uint2 yy = *reinterpret_cast<const uint2*>(p.bn_y + at);
+                    y4[0] = __uint_as_float(yy.x << 16); y4[1] = __uint_as_float(yy.x & 0xffff0000u); y4[2] = __uint_as_float(yy.y << 16); y4[3] = __uint_as_float(yy.y & 0xffff0000u);
+                } else if (zmask) {
+                    y4[0] = fmaf(z4[0], msc.x, msh.x); y4[1] = fmaf(z4[1], msc.y, msh.y); y4[2] = fmaf(z4[2], msc.z, msh.z); y4[3] = fmaf(z4[3], msc.w, msh.w);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = y4[e] > 0.f ? v[e] : 0.f;
+                    s1[e] += g; s2[e] = fmaf(g, z4[e], s2[e]);
+                }
+            }
+        }
+    }
+    const bool fwd_stats = MODE == 0 && p.stat_acc != nullptr;
+    const bool bwd_sums = MODE == 1 && p.bn_z != nullptr;
+    if (fwd_stats || bwd_sums) {
+        float sv[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+        row16_sum_n(sv);                                     // over the 16 pixels of a lane group: this wave saw all 64 pixels of its channels
+        if (fr == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (fwd_stats) {
+                    double* a = p.stat_acc + (size_t)(bx & (p.stat_rep - 1)) * 2 * C;
+                    atomicAdd(a + c4 + e, (double)sv[e]);
+                    atomicAdd(a + C + c4 + e, (double)sv[4 + e]);
+                } else {
+                    double* a = p.bn_acc + (size_t)(bx & (p.bn_rep - 1)) * 2 * C;
+                    atomicAdd(a + c4 + e, (double)sv[e]);
+                    atomicAdd(a + C + c4 + e, (double)(p.bn_invstd[c4 + e] * (sv[4 + e] - p.bn_mean[c4 + e] * sv[e])));
+                }
+            }
+        }
+    }
+}
+template <int MODE, bool LI = false>
+__global__ __launch_bounds__(256) void conv64_kernel(Conv3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv64_body<MODE, false, LI>(p, blockIdx.x, smem);
+}
+
 template <int WM, int WN, int MODE>
 int launch3(Conv3Params& p, hipStream_t st) {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -1043,6 +1186,38 @@ int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* st
         else if (mode == 0) hipLaunchKernelGGL(conv32_kernel<0>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(conv32_kernel<1>, grid, dim3(256), lds, st, p);
     }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+bool clhip_conv64_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
+    static const bool off = clhip_cfg("CONV64") != nullptr && atoi(clhip_cfg("CONV64")) == 0;
+    // small maps only: from ~64 k pixels up conv4 / conv5 (LDS-DMA rings, persistent tiles) win; below, the launch is at its latency floor
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == 64 && Cd == 64 && W <= 16 && W >= 2 && H >= 1 && (int64_t)N * H * W <= 32768;
+}
+
+int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
+                           const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
+                           const clhip_bn_input* in, hipStream_t st) {
+    Conv3Params p;
+    p.bn_coef = bn_coef;
+    if (in != nullptr) {
+        p.in_acc = in->stat_acc; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
+        p.in_momentum = in->momentum; p.in_eps = in->eps; p.in_mean_o = in->mean; p.in_invstd_o = in->invstd; p.in_coef_o = in->coef;
+        const double M = (double)N * H * W;
+        p.in_invM = 1.0 / M; p.in_unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
+    }
+    p.bn_z = static_cast<const bf16_t*>(bn_z); p.bn_y = static_cast<const bf16_t*>(bn_y); p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
+    p.bn_acc = bn_acc; p.bn_rep = bn_rep > 0 ? bn_rep : 1;
+    p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
+    p.stats = nullptr; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
+    p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = 64; p.Cd = 64; p.accumulate = accumulate; p.M = N * H * W;
+    p.np = 64 + 2 * W + 2; p.patch_bytes = (p.np + 1) * 144; p.nbuf = 1; p.debug = 0;
+    const size_t lds = (size_t)p.patch_bytes + 2048;
+    const dim3 grid((p.M + 63) / 64);
+    if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, true>), grid, dim3(256), lds, st, p);
+    else if (mode == 0) hipLaunchKernelGGL(conv64_kernel<0>, grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(conv64_kernel<1>, grid, dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -1470,6 +1645,108 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(Wgrad32Params p) {
     wgrad32_body(p, blockIdx.x, blockIdx.y, smem);
 }
 
+// wgrad64: dw[o][tap][c] for 64 -> 64 channels on 8-pixel-wide images (ResNet-32 stage 3).  Workgroup (out-channel tile ot of 16, image group):
+// wave w owns in-channel tile w and all nine taps (9 accumulator tiles), an MFMA K step = 32 pixels = four image rows; the padded image
+// (H + 2) x 10 pixels x 64 channels and the tile's 16 gradient channels sit in LDS, the next image's loads are in flight while this one is
+// multiplied.  Partial blocks per group + the fixed-order reduce: bitwise reproducible.
+struct Wgrad64Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; const float* x_coef = nullptr; LazyDz lz; };
+
+template <bool LZ = false>
+__device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int ot, const int grp, char* smem) {
+    constexpr int W = 8, PW = 10, PX = 144, PZ = 32, C = 64;  // image width, padded width, bytes per staged input pixel (128 + pad), per gradient pixel (this tile's 16 channels)
+    const int H = p.H, HW = H * W;
+    char* xs = smem;                                          // (H + 2) x 10 pixels
+    char* zs = smem + (H + 2) * PW * PX;                      // H x 8 pixels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int it = wave;                                      // in-channel tile
+    const int n_beg = grp * p.img_per_group, n_end = min(p.N, n_beg + p.img_per_group);
+    for (int i = tid; i < (H + 2) * PW * 9; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
+    const int nx = HW * 8, nz = HW * 2;                       // 16-byte chunks per image: input (8 per pixel), gradient slice (2 per pixel)
+    constexpr int NXI = 4;                                    // input chunks per thread (H <= 16)
+    uint4 rx[NXI], rz, ry;
+    unsigned rm = 0u;
+    constexpr bool lzd = LZ;
+    LazyDz8 lt;
+    if constexpr (lzd) {                                      // gradient chunk q = tid covers channels ot * 16 + (tid & 1) * 8
+        float* coef = reinterpret_cast<float*>(zs);
+        __syncthreads();
+        lazy_dz_coefs<C>(p.lz, false, coef);
+        lazy_dz_load<C>(coef, ot * 16 + (tid & 1) * 8, lt);
+        __syncthreads();
+    }
+    float xsc[8], xsh[8];                                     // input chunk q = tid + 256 i covers channels (q & 7) * 8 = (tid & 7) * 8
+    if (p.x_coef != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = p.x_coef[(tid & 7) * 8 + e]; xsh[e] = p.x_coef[C + (tid & 7) * 8 + e]; }
+    }
+    auto gload = [&](int n) {
+        const size_t base = (size_t)n * HW;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int q = tid + 256 * i;
+            rx[i] = q < nx ? *reinterpret_cast<const uint4*>(p.x + (base + (q >> 3)) * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
+        }
+        const int q = tid;
+        if constexpr (lzd) {
+            rz = q < nz ? *reinterpret_cast<const uint4*>(p.lz.dy + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+            ry = q < nz ? *reinterpret_cast<const uint4*>(p.lz.z + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+            rm = (q < nz && p.lz.mask != nullptr) ? p.lz.mask[(base + (q >> 1)) * 8 + ot * 2 + (q & 1)] : 0u;
+        } else {
+            rz = q < nz ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int q = tid + 256 * i;
+            if (q < nx) {
+                const int px = q >> 3;
+                *reinterpret_cast<uint4*>(xs + ((px / W + 1) * PW + (px % W) + 1) * PX + (q & 7) * 16) = p.x_coef != nullptr ? bn_relu8_bf16(rx[i], xsc, xsh) : rx[i];
+            }
+        }
+        const int q = tid;
+        if (q < nz) {
+            uint4 v = rz;
+            if constexpr (lzd) v = lazy_dz8(rz, ry, lt, p.lz.mask != nullptr, rm);
+            *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = v;
+        }
+    };
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane (fr, fg) of a transposing read: reduction element 8 fg + (fr >> 2) (+4 for the second read) = pixel (row h0 + fg, column (fr >> 2) [+ 4]),
+    // 8-byte segment fr & 3 of the 16-channel tile
+    const int prow = fg, pcol = fr >> 2, seg = (fr & 3) * 8;
+    if (n_beg < n_end) gload(n_beg);
+    for (int n = n_beg; n < n_end; ++n) {
+        __syncthreads();
+        sstore();
+        __syncthreads();
+        if (n + 1 < n_end) gload(n + 1);
+        for (int h0 = 0; h0 < H; h0 += 4) {
+            const uint4 zf = tr8(zs, ((h0 + prow) * W + pcol) * PZ + seg, 4 * PZ);
+            const int xb = ((h0 + prow) * PW + pcol) * PX + it * 32 + seg;       // padded coordinates: tap (r, s) adds r rows, s columns
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, sx = t - 3 * r;
+                const uint4 xf = tr8(xs, xb + (r * PW + sx) * PX, 4 * PX);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = out channel fg*4 + e][col = in channel fr]  ->  slab[grp][o][tap][c]
+    float* out = p.slab + (size_t)grp * (C * 9 * C);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[((ot * 16 + fg * 4 + e) * 9 + t) * C + it * 16 + fr] = acc[t][e];
+}
+__global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad64_body(p, blockIdx.x, blockIdx.y, smem);
+}
+
 int wgrad32_groups(int N) { const int ipg = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1); return (N + ipg - 1) / ipg; }
 }  // namespace
 
@@ -1491,6 +1768,22 @@ int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, in
     hipLaunchKernelGGL(wgrad32_kernel, dim3(2, groups), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
     return clhip_wgrad_reduce_launch(ws, dw, 2304, groups, st);
+}
+
+bool clhip_wgrad64_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    static const bool off = clhip_cfg("CONV64") != nullptr && atoi(clhip_cfg("CONV64")) == 0;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 64 && Creal == 64 && K == 64 && W == 8 && H >= 4 && H <= 16 && (H & 3) == 0 && N >= 1;
+}
+
+size_t clhip_wgrad64_ws_bytes(int N) { return (size_t)wgrad32_groups(N) * 36864 * sizeof(float); }
+
+int clhip_wgrad64_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
+    const int groups = wgrad32_groups(N);
+    Wgrad64Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef};
+    const size_t lds = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
+    hipLaunchKernelGGL(wgrad64_kernel, dim3(4, groups), dim3(256), lds, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return clhip_wgrad_reduce_launch(ws, dw, 9216, groups, st);
 }
 
 bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
@@ -1570,10 +1863,18 @@ __global__ __launch_bounds__(256) void bwd32_fused_kernel(Conv3Params pd, Wgrad3
 }
 }  // namespace
 
+template <bool LZ>
+__global__ __launch_bounds__(256) void bwd64_fused_kernel(Conv3Params pd, Wgrad64Params pw, int nw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nw) wgrad64_body<LZ>(pw, blockIdx.x & 3, blockIdx.x >> 2, smem);
+    else conv64_body<1, LZ>(pd, (int)blockIdx.x - nw, smem);
+}
+
 bool clhip_bwd_fused_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     static const bool off = clhip_cfg("BWD_FUSED") != nullptr && atoi(clhip_cfg("BWD_FUSED")) == 0;
     if (off) return false;
-    return clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype) || clhip_wgrad32_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype);
+    return clhip_wgrad16_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype) || clhip_wgrad32_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype) ||
+           clhip_wgrad64_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype);
 }
 
 int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw, float* ws, int N, int H, int W, int C,
@@ -1595,6 +1896,18 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     pd.stats = nullptr; pd.stat_acc = nullptr; pd.stat_rep = 1;
     pd.N = N; pd.H = H; pd.W = W; pd.wshift = ilog2_exact(W); pd.hshift = ilog2_exact(H); pd.Cs = C; pd.Cd = C; pd.accumulate = accumulate; pd.M = N * H * W;
     pd.np = 256 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * (C == 16 ? 32 : 96); pd.nbuf = 1; pd.debug = 0;
+    if (C == 64) {
+        pd.np = 64 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * 144;
+        const int nd64 = (pd.M + 63) / 64, groups = wgrad32_groups(N);
+        Wgrad64Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef, lzd};
+        size_t lds64 = (size_t)pd.patch_bytes + 2048;
+        const size_t wl = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
+        if (wl > lds64) lds64 = wl;
+        if (lz != nullptr) hipLaunchKernelGGL(bwd64_fused_kernel<true>, dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
+        else hipLaunchKernelGGL(bwd64_fused_kernel<false>, dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
+        CLHIP_LAUNCH_CHECK();
+        return clhip_wgrad_reduce_launch(ws, dw, 9216, groups, st);
+    }
     const int nd = clhip_conv16_tiles_m(pd.M);
     size_t lds = ((size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024) + 1024;
     if (C == 16) {
