@@ -514,6 +514,8 @@ extern "C" int clhip_conv_fwd_tiles(int N, int H, int W, int C, int K, int ksize
     return (M + bm - 1) / bm;
 }
 
+static bool conv64_fwd_on() { const char* c = clhip_cfg("CONV64_FWD"); return !(c != nullptr && atoi(c) == 0); }
+
 static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_partials, double* stat_acc, int stat_rep, int N, int H, int W, int C,
                          int K, int ksize, int stride, int pad, int dtype, void* stream);
 
@@ -545,7 +547,7 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
     if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_stem_supported(N, H, W, C, K, ksize, stride, pad, dtype))
         return clhip_stem_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, K, st);
     // 64 -> 64 channels on small maps: register-resident filters, out channels split over the waves (statistics through the accumulators only)
-    if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+    if (!use_v1() && use_v3() && stat_partials == nullptr && conv64_fwd_on() && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype))
         return clhip_conv64_launch_ex(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, st);
     if (!use_v1() && use_v3() && clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype)) {
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
@@ -661,7 +663,7 @@ extern "C" int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, 
     if (use_v1() || !use_v3()) return 0;
     const char* cfg = clhip_cfg("BN_INPUT");
     const bool off = cfg != nullptr && atoi(cfg) == 0;
-    return (!off && (clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype)) &&
+    return (!off && (clhip_conv16_supported(H, W, C, K, ksize, stride, pad, dtype) || (conv64_fwd_on() && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype))) &&
             clhip_bwd_fused_supported(N, H, W, C, C, K, ksize, stride, pad, dtype)) ? 1 : 0;
 }
 

@@ -951,9 +951,9 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
 // pixels, the patch sits in LDS at a 144-byte pitch (conflict-free for ds_read_b128), every wave multiplies all four 16-pixel tiles.  No cross-wave
 // reduction anywhere: a wave owns its channels' BatchNorm sums (forward statistics, backward sums) and adds them to the fp64 accumulators directly.
 // The patch is staged through registers, so the lazy BatchNorm operands of conv16 / conv32 apply (LI: input, LZ: gradient).
-template <int MODE, bool LZ = false, bool LI = false>
+template <int MODE, bool LZ = false, bool LI = false, int BM = 64>
 __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, char* smem) {
-    constexpr int BM = 64, PP = 144, C = 64;
+    constexpr int PP = 144, C = 64, NT = BM / 16;                // BM pixels per workgroup (64: the fused backward launch; 128: the forward, half the statistics atomics)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int m0 = bx * BM;
@@ -1001,9 +1001,9 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
     __syncthreads();
 
     const int zaddr = p.np * PP + fg * 16;
-    f32x4 acc[4];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NT; ++i) {
         const int pl = i * 16 + fr;
         const int g = m0 + pl;
         const unsigned mask = g < p.M ? tap_mask<MODE>(g, p) : 0u;
@@ -1028,7 +1028,7 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
     const bool zmask = MODE == 1 && p.bn_z != nullptr && p.bn_y == nullptr && p.bn_coef != nullptr;
     if (zmask) { msc = *reinterpret_cast<const float4*>(p.bn_coef + c4); msh = *reinterpret_cast<const float4*>(p.bn_coef + C + c4); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NT; ++i) {
         const int pix = m0 + i * 16 + fr;
         float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
         if (pix < p.M) {
@@ -1082,10 +1082,10 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
         }
     }
 }
-template <int MODE, bool LI = false>
+template <int MODE, bool LI = false, int BM = 64>
 __global__ __launch_bounds__(256) void conv64_kernel(Conv3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv64_body<MODE, false, LI>(p, blockIdx.x, smem);
+    conv64_body<MODE, false, LI, BM>(p, blockIdx.x, smem);
 }
 
 template <int WM, int WN, int MODE>
@@ -1212,12 +1212,20 @@ int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* s
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stats = nullptr; p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.N = N; p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H); p.Cs = 64; p.Cd = 64; p.accumulate = accumulate; p.M = N * H * W;
-    p.np = 64 + 2 * W + 2; p.patch_bytes = (p.np + 1) * 144; p.nbuf = 1; p.debug = 0;
+    static const int bm_cfg = clhip_cfg("CONV64_BM") ? atoi(clhip_cfg("CONV64_BM")) : 64;       // (128-pixel tiles measured equal on ResNet-32 stage 3)
+    const int bm = (bm_cfg == 128 && p.M >= 128 * 128) ? 128 : 64;       // 128-pixel tiles while they still give every second CU a workgroup
+    p.np = bm + 2 * W + 2; p.patch_bytes = (p.np + 1) * 144; p.nbuf = 1; p.debug = 0;
     const size_t lds = (size_t)p.patch_bytes + 2048;
-    const dim3 grid((p.M + 63) / 64);
-    if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, true>), grid, dim3(256), lds, st, p);
-    else if (mode == 0) hipLaunchKernelGGL(conv64_kernel<0>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(conv64_kernel<1>, grid, dim3(256), lds, st, p);
+    const dim3 grid((p.M + bm - 1) / bm);
+    if (bm == 128) {
+        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, true, 128>), grid, dim3(256), lds, st, p);
+        else if (mode == 0) hipLaunchKernelGGL((conv64_kernel<0, false, 128>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv64_kernel<1, false, 128>), grid, dim3(256), lds, st, p);
+    } else {
+        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, true>), grid, dim3(256), lds, st, p);
+        else if (mode == 0) hipLaunchKernelGGL(conv64_kernel<0>, grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(conv64_kernel<1>, grid, dim3(256), lds, st, p);
+    }
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
