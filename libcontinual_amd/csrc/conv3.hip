@@ -1463,22 +1463,22 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
 // are constant address offsets into the padded image.  Each of the 4 waves takes 8 rows into 9 accumulator tiles; the waves are
 // summed through LDS and the image's 2304 partial sums go to a slab that wgrad3_reduce_kernel adds up in a fixed order.
 namespace {
-struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; const float* x_coef = nullptr; LazyDz lz; };      // x_coef [2][16]: x is a pre-BatchNorm tensor, the operand relu(scale x + shift)
+struct Wgrad16Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H; const float* x_coef = nullptr; LazyDz lz; int parts = 1; };      // parts: workgroups per image (row bands)      // x_coef [2][16]: x is a pre-BatchNorm tensor, the operand relu(scale x + shift)
 
 template <bool LZ = false>
-__device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int bx, char* smem) {      // bx = image
+__device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int bx, char* smem) {      // bx = image * parts + row band
     constexpr int W = 32, PW = 34, PX = 32;                  // image width, padded width, bytes per pixel (16 bf16)
-    const int H = p.H;
-    char* xs = smem;                                         // (H + 2) x 34 pixels
-    char* zs = smem + (H + 2) * PW * PX;                     // H x 32 pixels
+    const int H = p.H, RH = H / p.parts;                     // a workgroup owns RH rows of one image (two bands per 32-row image: twice the workgroups,
+    const int im = bx / p.parts, r0 = (bx - im * p.parts) * RH;      // half the serial staging -> multiply -> reduce chain each; the halo rows come from the neighbour band)
+    char* xs = smem;                                         // (RH + 2) x 34 pixels
+    char* zs = smem + (RH + 2) * PW * PX;                    // RH x 32 pixels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const size_t img = (size_t)bx * H * W;
-    // zero the padded image, then drop the real pixels in; the gradient image is copied as is
-    const int xchunks = (H + 2) * PW * 2;
+    const size_t img = (size_t)im * H * W;
+    // zero the padded band, then drop the real pixels in (rows r0 - 1 .. r0 + RH of the image where they exist); the gradient band is copied as is
+    const int xchunks = (RH + 2) * PW * 2;
     for (int i = tid; i < xchunks; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const int chunks = H * W * 2;
     constexpr bool lzd = LZ;
     LazyDz8 lt;
     if constexpr (lzd) {                                     // (the staging area is still free: the coefficient table sits at its start until the fill)
@@ -1493,16 +1493,22 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xsc[e] = p.x_coef[(tid & 1) * 8 + e]; xsh[e] = p.x_coef[16 + (tid & 1) * 8 + e]; }
     }
-    for (int i = tid; i < chunks; i += 256) {
-        const int pix = i >> 1, half = i & 1, r = pix >> 5, c = pix & 31;
-        uint4 xv = *reinterpret_cast<const uint4*>(p.x + (img + pix) * 16 + half * 8);
+    for (int i = tid; i < (RH + 2) * W * 2; i += 256) {
+        const int lp = i >> 1, half = i & 1, lr = lp >> 5, c = lp & 31;      // local padded row lr = image row r0 - 1 + lr
+        const int row = r0 - 1 + lr;
+        if (row < 0 || row >= H) continue;
+        uint4 xv = *reinterpret_cast<const uint4*>(p.x + (img + (size_t)row * W + c) * 16 + half * 8);
         if (p.x_coef != nullptr) xv = bn_relu8_bf16(xv, xsc, xsh);
-        *reinterpret_cast<uint4*>(xs + ((r + 1) * PW + c + 1) * PX + half * 16) = xv;
+        *reinterpret_cast<uint4*>(xs + (lr * PW + c + 1) * PX + half * 16) = xv;
+    }
+    for (int i = tid; i < RH * W * 2; i += 256) {
+        const int lp = i >> 1, half = i & 1;
+        const size_t pix = img + (size_t)r0 * W + lp;
         uint4 zv;
-        if constexpr (lzd) zv = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (img + pix) * 16 + half * 8), *reinterpret_cast<const uint4*>(p.lz.z + (img + pix) * 16 + half * 8), lt,
-                                         p.lz.mask != nullptr, p.lz.mask != nullptr ? p.lz.mask[(img + pix) * 2 + half] : 0u);
-        else zv = *reinterpret_cast<const uint4*>(p.dz + (img + pix) * 16 + half * 8);
-        *reinterpret_cast<uint4*>(zs + pix * PX + half * 16) = zv;
+        if constexpr (lzd) zv = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + pix * 16 + half * 8), *reinterpret_cast<const uint4*>(p.lz.z + pix * 16 + half * 8), lt,
+                                         p.lz.mask != nullptr, p.lz.mask != nullptr ? p.lz.mask[pix * 2 + half] : 0u);
+        else zv = *reinterpret_cast<const uint4*>(p.dz + pix * 16 + half * 8);
+        *reinterpret_cast<uint4*>(zs + lp * PX + half * 16) = zv;
     }
     __syncthreads();
 
@@ -1511,7 +1517,7 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // lane (fr, fg) of a transposing read addresses pixel column 8 fg + (fr >> 2) (+4 for the second read), segment fr & 3
     const int col = fg * 8 + (fr >> 2), seg = (fr & 3) * 8;
-    for (int h = wave; h < H; h += 4) {
+    for (int h = wave; h < RH; h += 4) {
         const uint4 zf = tr8(zs, (h * W + col) * PX + seg, 4 * PX);
         const int xb = ((h + 1) * PW + col + 1) * PX + seg;
 #pragma unroll
@@ -1755,7 +1761,12 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Params p) {
     wgrad64_body(p, blockIdx.x, blockIdx.y, smem);
 }
 
-int wgrad32_groups(int N) { const int ipg = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1); return (N + ipg - 1) / ipg; }
+int wgrad32_ipg(int N) {
+    static const int forced = clhip_cfg("WGRAD32_IPG") ? atoi(clhip_cfg("WGRAD32_IPG")) : 0;
+    if (forced > 0) return forced < N ? forced : N;
+    return N >= 128 ? N / 64 : (N >= 32 ? 2 : 1);
+}
+int wgrad32_groups(int N) { const int ipg = wgrad32_ipg(N); return (N + ipg - 1) / ipg; }
 }  // namespace
 
 bool clhip_wgrad32_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
@@ -1771,7 +1782,7 @@ int clhip_wgrad32_launch(const void* x, const void* dz, float* dw, float* ws, in
     const int groups = wgrad32_groups(N);
     Wgrad32Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, (N + groups - 1) / groups, x_coef};
     // (groups was derived from the same images-per-group rule: recompute the per-group count exactly)
-    p.img_per_group = N >= 128 ? N / 64 : (N >= 32 ? 2 : 1);
+    p.img_per_group = wgrad32_ipg(N);
     const size_t lds = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
     hipLaunchKernelGGL(wgrad32_kernel, dim3(2, groups), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
@@ -1787,7 +1798,7 @@ size_t clhip_wgrad64_ws_bytes(int N) { return (size_t)wgrad32_groups(N) * 36864 
 
 int clhip_wgrad64_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
     const int groups = wgrad32_groups(N);
-    Wgrad64Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef};
+    Wgrad64Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad32_ipg(N), x_coef};
     const size_t lds = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
     hipLaunchKernelGGL(wgrad64_kernel, dim3(4, groups), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
@@ -1799,7 +1810,16 @@ bool clhip_wgrad16_supported(int N, int H, int W, int C, int Creal, int K, int k
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 16 && Creal == 16 && K == 16 && W == 32 && H >= 1 && H <= 64 && N >= 1;
 }
 
-size_t clhip_wgrad16_ws_bytes(int N) { return (size_t)N * 2304 * sizeof(float); }
+// row bands per image (env WGRAD16_PARTS overrides): enough workgroups at small batches, not more partial blocks than pay at large ones
+static int wgrad16_parts(int N, int H) {
+    static const int forced = clhip_cfg("WGRAD16_PARTS") ? atoi(clhip_cfg("WGRAD16_PARTS")) : 0;
+    // measured on the ResNet-32 EWC step (ms): batch 256: 1 band 1.501, 2 bands 1.447, 4 bands 1.510; batch 32: 0.96-1.09 / 1.00-1.04 / 0.86-0.91
+    const int want = forced > 0 ? forced : (H == 32 ? (N < 96 ? 4 : 2) : 1);
+    if (want >= 4 && (H % 16) == 0) return 4;
+    return (want >= 2 && (H % 8) == 0) ? 2 : 1;
+}
+
+size_t clhip_wgrad16_ws_bytes(int N) { return (size_t)N * 4 * 2304 * sizeof(float); }      // (room for four bands per image)
 
 bool clhip_wgrad3_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!(dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C % 64 == 0 && K % 64 == 0 && Creal == C)) return false;
@@ -1907,7 +1927,7 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     if (C == 64) {
         pd.np = 64 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * 144;
         const int nd64 = (pd.M + 63) / 64, groups = wgrad32_groups(N);
-        Wgrad64Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef, lzd};
+        Wgrad64Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad32_ipg(N), x_coef, lzd};
         size_t lds64 = (size_t)pd.patch_bytes + 2048;
         const size_t wl = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
         if (wl > lds64) lds64 = wl;
@@ -1919,8 +1939,10 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     const int nd = clhip_conv16_tiles_m(pd.M);
     size_t lds = ((size_t)pd.patch_bytes > 1024 ? (size_t)pd.patch_bytes : 1024) + 1024;
     if (C == 16) {
-        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef, lzd};
-        size_t wl = (size_t)((H + 2) * 34 + H * 32) * 32;
+        const int parts = wgrad16_parts(N, H), nwg = N * parts;
+        Wgrad16Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef, lzd, parts};
+        const int RH = H / parts;
+        size_t wl = (size_t)((RH + 2) * 34 + RH * 32) * 32;
         if (wl < 4 * 2304 * sizeof(float)) wl = 4 * 2304 * sizeof(float);
         if (wl > lds) lds = wl;
         static size_t attr[2] = {0, 0};
@@ -1933,13 +1955,13 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
             }
             attr[v] = lds;
         }
-        if (v) hipLaunchKernelGGL(bwd16_fused_kernel<true>, dim3(N + nd), dim3(256), lds, st, pd, pw, N);
-        else hipLaunchKernelGGL(bwd16_fused_kernel<false>, dim3(N + nd), dim3(256), lds, st, pd, pw, N);
+        if (v) hipLaunchKernelGGL(bwd16_fused_kernel<true>, dim3(nwg + nd), dim3(256), lds, st, pd, pw, nwg);
+        else hipLaunchKernelGGL(bwd16_fused_kernel<false>, dim3(nwg + nd), dim3(256), lds, st, pd, pw, nwg);
         CLHIP_LAUNCH_CHECK();
-        return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N, st);
+        return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, nwg, st);
     }
     const int groups = wgrad32_groups(N);
-    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, N >= 128 ? N / 64 : (N >= 32 ? 2 : 1), x_coef, lzd};
+    Wgrad32Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad32_ipg(N), x_coef, lzd};
     const size_t wl = (size_t)(H + 2) * 18 * 64 + (size_t)H * 16 * 32;
     if (wl > lds) lds = wl;
     if (lz != nullptr) hipLaunchKernelGGL(bwd32_fused_kernel<true>, dim3(2 * groups + nd), dim3(256), lds, st, pd, pw, 2 * groups);
@@ -2022,8 +2044,10 @@ int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int spli
 }
 
 int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
-    Wgrad16Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef};
-    size_t lds = (size_t)((H + 2) * 34 + H * 32) * 32;
+    const int parts = wgrad16_parts(N, H);
+    Wgrad16Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, x_coef, LazyDz{}, parts};
+    const int RH = H / parts;
+    size_t lds = (size_t)((RH + 2) * 34 + RH * 32) * 32;
     if (lds < 4 * 2304 * sizeof(float)) lds = 4 * 2304 * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
@@ -2033,7 +2057,7 @@ int clhip_wgrad16_launch(const void* x, const void* dz, float* dw, float* ws, in
         }
         attr = lds;
     }
-    hipLaunchKernelGGL(wgrad16_kernel, dim3(N), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(N * parts), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
-    return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N, st);
+    return clhip_wgrad_reduce_launch(ws, dw, (int64_t)576, N * parts, st);
 }
