@@ -1794,11 +1794,20 @@ bool clhip_wgrad64_supported(int N, int H, int W, int C, int Creal, int K, int k
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 64 && Creal == 64 && K == 64 && W == 8 && H >= 4 && H <= 16 && (H & 3) == 0 && N >= 1;
 }
 
-size_t clhip_wgrad64_ws_bytes(int N) { return (size_t)wgrad32_groups(N) * 36864 * sizeof(float); }
+static int wgrad64_ipg(int N) {
+    static const int forced = clhip_cfg("WGRAD64_IPG") ? atoi(clhip_cfg("WGRAD64_IPG")) : 0;
+    if (forced > 0) return forced < N ? forced : N;
+    // a group's partial block is the whole 64 x 9 x 64 fp32 gradient (147 KB): 64 groups = 9.4 MB per layer written and read back by the reduce, nine
+    // layers per ResNet-32 step.  Measured on the EWC step at batch 256 (ms): 2 / 4 / 8 / 16 images per group: 1.52 / 1.445 / 1.426 / 1.506
+    return N >= 128 ? N / 32 : (N >= 32 ? 2 : 1);
+}
+static int wgrad64_groups(int N) { const int ipg = wgrad64_ipg(N); return (N + ipg - 1) / ipg; }
+
+size_t clhip_wgrad64_ws_bytes(int N) { return (size_t)wgrad64_groups(N) * 36864 * sizeof(float); }
 
 int clhip_wgrad64_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
-    const int groups = wgrad32_groups(N);
-    Wgrad64Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad32_ipg(N), x_coef};
+    const int groups = wgrad64_groups(N);
+    Wgrad64Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad64_ipg(N), x_coef};
     const size_t lds = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
     hipLaunchKernelGGL(wgrad64_kernel, dim3(4, groups), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
@@ -1926,8 +1935,8 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
     pd.np = 256 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * (C == 16 ? 32 : 96); pd.nbuf = 1; pd.debug = 0;
     if (C == 64) {
         pd.np = 64 + 2 * W + 2; pd.patch_bytes = (pd.np + 1) * 144;
-        const int nd64 = (pd.M + 63) / 64, groups = wgrad32_groups(N);
-        Wgrad64Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad32_ipg(N), x_coef, lzd};
+        const int nd64 = (pd.M + 63) / 64, groups = wgrad64_groups(N);
+        Wgrad64Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad64_ipg(N), x_coef, lzd};
         size_t lds64 = (size_t)pd.patch_bytes + 2048;
         const size_t wl = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
         if (wl > lds64) lds64 = wl;
