@@ -272,6 +272,12 @@ int clhip_ewc_penalty(const float* p, const float* ref, const float* fisher, int
 /* dev_scale (nullable): device scalar multiplied into `weight` (the upstream autograd gradient, no host sync) */
 int clhip_ewc_grad(const float* p, const float* ref, const float* fisher, float* g, int64_t n, float weight,
                    const float* dev_scale, void* stream);
+/* the same over up to 4 (p, ref, fisher[, g]) segments in ONE launch (host arrays of device pointers / lengths): EWC's parameters are the backbone's
+ * flat buffer plus the head's weight and bias prefixes (ewc.py:207-225 loops over named_parameters) */
+int clhip_ewc_penalty_multi(int count, const float* const* p, const float* const* ref, const float* const* fisher, const int64_t* n, float weight,
+                            float* loss_out, int loss_accumulate, void* stream);
+int clhip_ewc_grad_multi(int count, const float* const* p, const float* const* ref, const float* const* fisher, float* const* g, const int64_t* n,
+                         float weight, const float* dev_scale, void* stream);
 int clhip_fisher_accum(float* fisher, const float* g, int64_t n, float scale, void* stream);
 int clhip_fisher_merge(float* new_f, const float* old_f, int64_t n, float alpha, void* stream);
 int clhip_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, float weight_decay,

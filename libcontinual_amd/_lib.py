@@ -118,6 +118,8 @@ _PROTOS = {
     "clhip_margin_rank_loss": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _p, _i, _p, _i, _p, _p]),
     "clhip_ewc_penalty": (_i, [_p, _p, _p, _l, _f, _p, _i, _p]),
     "clhip_ewc_grad": (_i, [_p, _p, _p, _p, _l, _f, _p, _p]),
+    "clhip_ewc_penalty_multi": (_i, [_i, _p, _p, _p, _p, _f, _p, _i, _p]),
+    "clhip_ewc_grad_multi": (_i, [_i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "clhip_fisher_accum": (_i, [_p, _p, _l, _f, _p]),
     "clhip_fisher_merge": (_i, [_p, _p, _l, _f, _p]),
     "clhip_sgd_step": (_i, [_p, _p, _p, _l, _f, _f, _f, _f, _p, _p, _f, _p]),

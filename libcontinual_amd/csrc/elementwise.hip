@@ -42,6 +42,42 @@ __global__ __launch_bounds__(256) void ewc_grad_kernel(const float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] += weight * f[i] * (p[i] - ref[i]);
 }
 
+// several (p, ref, F[, g]) segments in one launch: EWC's parameters are the backbone's flat buffer plus two head tensors, and three launches of a
+// few microseconds each per pass were three places in a launch-bound step's queue
+constexpr int kEwcSegs = 4;
+struct EwcSeg { const float* p; const float* ref; const float* f; float* g; long long n, n4; unsigned first_block, blocks; };
+struct EwcTable { int n; EwcSeg s[kEwcSegs]; };
+
+__global__ __launch_bounds__(256) void ewc_penalty_multi_kernel(EwcTable t, float weight, float* out) {
+    __shared__ float red[4];
+    int u = 0;
+    while (u + 1 < t.n && blockIdx.x >= t.s[u + 1].first_block) ++u;
+    const EwcSeg& e = t.s[u];
+    const long long stride = (long long)e.blocks * 256;
+    const long long i0 = (long long)(blockIdx.x - e.first_block) * 256 + threadIdx.x;
+    float acc = 0.f;
+    for (long long i = i0; i < e.n4; i += stride) {
+        float4 a = reinterpret_cast<const float4*>(e.p)[i], b = reinterpret_cast<const float4*>(e.ref)[i], c = reinterpret_cast<const float4*>(e.f)[i];
+        float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        acc += c.x * d0 * d0 + c.y * d1 * d1 + c.z * d2 * d2 + c.w * d3 * d3;
+    }
+    for (long long i = (e.n4 << 2) + i0; i < e.n; i += stride) {
+        float d = e.p[i] - e.ref[i];
+        acc += e.f[i] * d * d;
+    }
+    float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, 0.5f * weight * s);
+}
+
+__global__ __launch_bounds__(256) void ewc_grad_multi_kernel(EwcTable t, float weight, const float* __restrict__ dev_scale) {
+    if (dev_scale != nullptr) weight *= *dev_scale;
+    int u = 0;
+    while (u + 1 < t.n && blockIdx.x >= t.s[u + 1].first_block) ++u;
+    const EwcSeg& e = t.s[u];
+    const long long stride = (long long)e.blocks * 256;
+    for (long long i = (long long)(blockIdx.x - e.first_block) * 256 + threadIdx.x; i < e.n; i += stride) e.g[i] += weight * e.f[i] * (e.p[i] - e.ref[i]);
+}
+
 __global__ __launch_bounds__(256) void fisher_accum_kernel(float* __restrict__ fi, const float* __restrict__ g, int64_t n, float scale) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -148,6 +184,50 @@ extern "C" int clhip_ewc_penalty(const float* p, const float* ref, const float* 
     int64_t n4 = aligned ? (n >> 2) : 0;
     hipLaunchKernelGGL(ewc_penalty_kernel, dim3(ew_blocks4(aligned ? (n >> 2) + 1 : n)), dim3(256), 0, st, p, ref, fisher, n, n4,
                        weight, loss_out);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+static int ewc_table(int count, const float* const* p, const float* const* ref, const float* const* fisher, float* const* g, const int64_t* n, bool vec4,
+                     EwcTable& t, unsigned& blocks) {
+    t.n = 0; blocks = 0;
+    for (int k = 0; k < count; ++k) {
+        if (n[k] == 0) continue;
+        EwcSeg& e = t.s[t.n++];
+        e.p = p[k]; e.ref = ref[k]; e.f = fisher[k]; e.g = g ? g[k] : nullptr; e.n = n[k];
+        const bool aligned = vec4 && (((uintptr_t)p[k] | (uintptr_t)ref[k] | (uintptr_t)fisher[k]) & 15) == 0;
+        e.n4 = aligned ? (n[k] >> 2) : 0;
+        e.first_block = blocks;
+        e.blocks = (unsigned)ew_blocks4(aligned ? (n[k] >> 2) + 1 : n[k]);
+        blocks += e.blocks;
+    }
+    return t.n;
+}
+
+extern "C" int clhip_ewc_penalty_multi(int count, const float* const* p, const float* const* ref, const float* const* fisher, const int64_t* n, float weight,
+                                       float* loss_out, int loss_accumulate, void* stream) {
+    CLHIP_CHECK_ARG(count >= 1 && count <= kEwcSegs && p && ref && fisher && n && loss_out);
+    for (int k = 0; k < count; ++k) CLHIP_CHECK_ARG(n[k] >= 0 && (n[k] == 0 || (p[k] && ref[k] && fisher[k])));
+    hipStream_t st = (hipStream_t)stream;
+    if (!loss_accumulate) {
+        if (hipMemsetAsync(loss_out, 0, sizeof(float), st) != hipSuccess) { clhip_set_error("memset failed"); return CLHIP_EHIP; }
+    }
+    EwcTable t;
+    unsigned blocks;
+    if (ewc_table(count, p, ref, fisher, nullptr, n, true, t, blocks) == 0) return CLHIP_OK;
+    hipLaunchKernelGGL(ewc_penalty_multi_kernel, dim3(blocks), dim3(256), 0, st, t, weight, loss_out);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_ewc_grad_multi(int count, const float* const* p, const float* const* ref, const float* const* fisher, float* const* g, const int64_t* n,
+                                    float weight, const float* dev_scale, void* stream) {
+    CLHIP_CHECK_ARG(count >= 1 && count <= kEwcSegs && p && ref && fisher && g && n);
+    for (int k = 0; k < count; ++k) CLHIP_CHECK_ARG(n[k] >= 0 && (n[k] == 0 || (p[k] && ref[k] && fisher[k] && g[k])));
+    EwcTable t;
+    unsigned blocks;
+    if (ewc_table(count, p, ref, fisher, g, n, false, t, blocks) == 0) return CLHIP_OK;
+    hipLaunchKernelGGL(ewc_grad_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, weight, dev_scale);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

@@ -55,10 +55,10 @@ class _EwcLossFn(torch.autograd.Function):
              pred.data_ptr(), correct.data_ptr(), st)
         flat, _ = owner.network.backbone.flat_parameters()
         lam = float(owner.lamda)
-        ops.ewc_penalty(flat, owner._ref_flat, owner._fisher_flat, lam, loss, True)
         nw, nb = owner._ref_head_w.numel(), owner._ref_head_b.numel()
-        ops.ewc_penalty(head_w.detach().reshape(-1)[:nw], owner._ref_head_w.reshape(-1), owner._fisher_head_w.reshape(-1), lam, loss, True)
-        ops.ewc_penalty(head_b.detach()[:nb], owner._ref_head_b, owner._fisher_head_b, lam, loss, True)
+        ops.ewc_penalty_multi([(flat, owner._ref_flat, owner._fisher_flat),
+                               (head_w.detach().reshape(-1)[:nw], owner._ref_head_w.reshape(-1), owner._fisher_head_w.reshape(-1)),
+                               (head_b.detach()[:nb], owner._ref_head_b, owner._fisher_head_b)], lam, loss, True)
         aux.pred, aux.correct, aux.batch = pred, correct, B
         ctx.owner = owner
         ctx.save_for_backward(dlog, head_w, head_b)
@@ -76,14 +76,13 @@ class _EwcLossFn(torch.autograd.Function):
         gflat = bb.begin_grad_write()              # zeroes the buffer if this is the first write after zero_grad()
         flat, _ = bb.flat_parameters()
         lam = float(owner.lamda)
-        ops.ewc_grad(flat, owner._ref_flat, owner._fisher_flat, gflat, lam, gout)
-        bb.attach_grads()
         gw = torch.zeros_like(head_w)
         gb = torch.zeros_like(head_b)
         nw, nb = owner._ref_head_w.numel(), owner._ref_head_b.numel()
-        ops.ewc_grad(head_w.detach().reshape(-1)[:nw], owner._ref_head_w.reshape(-1), owner._fisher_head_w.reshape(-1),
-                     gw.view(-1)[:nw], lam, gout)
-        ops.ewc_grad(head_b.detach()[:nb], owner._ref_head_b, owner._fisher_head_b, gb[:nb], lam, gout)
+        ops.ewc_grad_multi([(flat, owner._ref_flat, owner._fisher_flat, gflat),
+                            (head_w.detach().reshape(-1)[:nw], owner._ref_head_w.reshape(-1), owner._fisher_head_w.reshape(-1), gw.view(-1)[:nw]),
+                            (head_b.detach()[:nb], owner._ref_head_b, owner._fisher_head_b, gb[:nb])], lam, gout)
+        bb.attach_grads()
         return dl, None, None, None, None, gw, gb, None
 
 

@@ -301,6 +301,32 @@ def ewc_grad(p, ref, fisher, g, weight, dev_scale=None):
     call("clhip_ewc_grad", _ptr(p), _ptr(ref), _ptr(fisher), _ptr(g), p.numel(), float(weight), _ptr(dev_scale), _st())
 
 
+def _ptr_array(ts):
+    import ctypes as C
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def ewc_penalty_multi(segs, weight, loss_out, accumulate):
+    """segs: [(p, ref, fisher), ...] (<= 4) -- one launch for all of them"""
+    import ctypes as C
+    for p, r, f in segs:
+        _dev(p, r, f)
+    _dev(loss_out)
+    n = (C.c_int64 * len(segs))(*[p.numel() for p, _, _ in segs])
+    call("clhip_ewc_penalty_multi", len(segs), _ptr_array([s[0] for s in segs]), _ptr_array([s[1] for s in segs]), _ptr_array([s[2] for s in segs]), n,
+         float(weight), _ptr(loss_out), int(accumulate), _st())
+
+
+def ewc_grad_multi(segs, weight, dev_scale=None):
+    """segs: [(p, ref, fisher, g), ...] (<= 4): g += weight * F * (p - ref), one launch"""
+    import ctypes as C
+    for p, r, f, g in segs:
+        _dev(p, r, f, g)
+    n = (C.c_int64 * len(segs))(*[s[0].numel() for s in segs])
+    call("clhip_ewc_grad_multi", len(segs), _ptr_array([s[0] for s in segs]), _ptr_array([s[1] for s in segs]), _ptr_array([s[2] for s in segs]),
+         _ptr_array([s[3] for s in segs]), n, float(weight), _ptr(dev_scale), _st())
+
+
 def fisher_accum(fisher, g, scale):
     _dev(fisher, g)
     call("clhip_fisher_accum", _ptr(fisher), _ptr(g), fisher.numel(), float(scale), _st())

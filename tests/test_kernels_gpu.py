@@ -664,6 +664,20 @@ def test_flat_elementwise_family():
     sc = torch.tensor([0.5], device=DEV)
     ops.ewc_grad(p, ref, f, g, 1000.0, sc)
     assert torch.allclose(g, g0 + 500.0 * f * (p - ref), rtol=1e-5, atol=1e-5)
+    # the multi-segment forms (EWC's backbone buffer + head weight + head bias in one launch): same values as the per-segment launches,
+    # with an unaligned and an empty segment among them
+    cuts = [(0, 70000), (70001, 99990), (99990, 99990), (99991, n)]
+    segs = [(p[a:b], ref[a:b], f[a:b]) for a, b in cuts]
+    outm = torch.empty(1, device=DEV)
+    ops.ewc_penalty_multi(segs, 10.0, outm, False)
+    wantm = sum(10.0 * (s[2].double() * (s[0].double() - s[1].double()) ** 2).sum() / 2 for s in segs)
+    assert abs(outm.item() - wantm.item()) < 1e-4 * wantm.item()
+    gm, gs = g0.clone(), g0.clone()
+    ops.ewc_grad_multi([(p[a:b], ref[a:b], f[a:b], gm[a:b]) for a, b in cuts], 1000.0, sc)
+    for a, b in cuts:
+        if b > a:
+            ops.ewc_grad(p[a:b], ref[a:b], f[a:b], gs[a:b], 1000.0, sc)
+    assert torch.equal(gm, gs)
     fi = torch.zeros(n, device=DEV)
     ops.fisher_accum(fi, g0, 32.0 / 96.0)
     assert torch.allclose(fi, g0 * g0 * (32.0 / 96.0), rtol=1e-6)
