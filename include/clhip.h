@@ -362,6 +362,18 @@ int clhip_conv_dgrad_wgrad_bn_grad(const void* x, const float* x_coef /*nullable
 int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
 int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn /*host*/, const void* w_fwd, void* z, double* stat_acc, int replicas,
                                 int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream);
+/* The same when the producer is a conv -> BN -> +res -> ReLU layer (the last unit of a basic block, resnet.py:312-316): the operand is
+ * relu(scale * z_in + shift + res), and because that activation has later readers (the next block's residual add, the backward) the
+ * launch also WRITES it and its packed ReLU mask -- each pixel by the workgroup that owns it -- exactly as clhip_bn_apply_train_mask would
+ * have: the apply launch disappears, the convolution's read of the activation becomes the read of z_in and res.  Same domain. */
+typedef struct clhip_bn_res_input {
+    const void* res;                          /* [N,H,W,C] the residual */
+    void* y;                                  /* out [N,H,W,C] relu(bn(z_in) + res) */
+    void* relu_mask;                          /* out [N*H*W*C/8] bytes, bit e = (stored element e > 0) */
+} clhip_bn_res_input;
+int clhip_conv_fwd_acc_bn_res_input(const void* z_in, const clhip_bn_input* bn /*host*/, const clhip_bn_res_input* rs /*host*/, const void* w_fwd, void* z,
+                                    double* stat_acc, int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype,
+                                    void* stream);
 int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw,
                                     void* ws, const float* mean, const float* invstd, double* acc /*nullable*/, int replicas, int N, int H, int W,
                                     int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);

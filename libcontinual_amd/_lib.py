@@ -73,6 +73,7 @@ _PROTOS = {
     "clhip_conv_dgrad_wgrad_supported": (_i, [_i] * 10),
     "clhip_conv_bn_input_supported": (_i, [_i] * 9),
     "clhip_conv_fwd_acc_bn_input": (_i, [_p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
+    "clhip_conv_fwd_acc_bn_res_input": (_i, [_p, _p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
     "clhip_conv_dgrad_wgrad_bn_input": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i] + [_i] * 10 + [_p]),
     "clhip_conv_dgrad_wgrad_bn_grad": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i] + [_i] * 10 + [_p]),
     "clhip_conv_dgrad_pair_supported": (_i, [_i] * 6),

@@ -188,6 +188,22 @@ __device__ inline void replica_parts(const double* __restrict__ acc, int rep, in
 
 // relu(scale * z + shift) of eight bf16 values, rounded back to bf16: exactly what bn_apply_train_kernel stores (fp32 fma, max, RNE), so
 // a consumer that applies it while staging its operand sees the tensor the apply pass would have written
+// relu(scale * z + shift + r), rounded to bf16, and the packed mask of the STORED values (bit e = element e > 0): what
+// bn_apply_train_kernel<T, true, true> stores for a conv -> BN -> +res -> ReLU layer (fma, add, max, RNE -- in that order)
+__device__ __forceinline__ uint4 bn_res_relu8_bf16(uint4 v, uint4 r, const float* sc, const float* sh, unsigned& mask) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
+    unsigned o[4];
+    mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lo = fmaxf(fmaf(__uint_as_float(w[k] << 16), sc[2 * k], sh[2 * k]) + __uint_as_float(rr[k] << 16), 0.f);
+        const float hi = fmaxf(fmaf(__uint_as_float(w[k] & 0xffff0000u), sc[2 * k + 1], sh[2 * k + 1]) + __uint_as_float(rr[k] & 0xffff0000u), 0.f);
+        o[k] = pack_bf16x2(lo, hi);
+        mask |= ((o[k] & 0x7fffu) != 0u && (o[k] & 0x8000u) == 0u ? 1u : 0u) << (2 * k);
+        mask |= ((o[k] & 0x7fff0000u) != 0u && (o[k] & 0x80000000u) == 0u ? 1u : 0u) << (2 * k + 1);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 __device__ __forceinline__ uint4 bn_relu8_bf16(uint4 v, const float* sc, const float* sh) {
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
     unsigned o[4];

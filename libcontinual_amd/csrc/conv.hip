@@ -440,7 +440,7 @@ int clhip_conv2_launch(const void* src, const void* wt, void* dst, float* stats,
 bool clhip_conv64_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv3.hip
 int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
-                           const clhip_bn_input* in, hipStream_t st);
+                           const clhip_bn_input* in, hipStream_t st, const clhip_bn_res_input* rs = nullptr);
 
 bool clhip_wgrad64_supported(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);      // conv3.hip
 size_t clhip_wgrad64_ws_bytes(int N);
@@ -654,7 +654,7 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
                            const clhip_bn_grad* lz, hipStream_t st);
 int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
-                           const clhip_bn_input* in, hipStream_t st);
+                           const clhip_bn_input* in, hipStream_t st, const clhip_bn_res_input* rs = nullptr);
 
 // ---- "lazy" BatchNorm input: the consumer applies relu(bn(z)) of its producer while it stages its operand (conv3.hip conv16 / conv32: the
 //      kernels that stage through registers); the producer's apply launch and activation tensor do not exist
@@ -667,8 +667,21 @@ extern "C" int clhip_conv_bn_input_supported(int N, int H, int W, int C, int K, 
             clhip_bwd_fused_supported(N, H, W, C, C, K, ksize, stride, pad, dtype)) ? 1 : 0;
 }
 
+static int conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, const clhip_bn_res_input* rs, const void* w_fwd, void* z, double* stat_acc,
+                                 int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream);
 extern "C" int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, const void* w_fwd, void* z, double* stat_acc, int replicas, int N,
                                            int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    return conv_fwd_acc_bn_input(z_in, bn, nullptr, w_fwd, z, stat_acc, replicas, N, H, W, C, K, ksize, stride, pad, dtype, stream);
+}
+// ... whose producer is a conv -> BN -> +res -> ReLU layer: the launch also writes the producer's activation and packed ReLU mask
+extern "C" int clhip_conv_fwd_acc_bn_res_input(const void* z_in, const clhip_bn_input* bn, const clhip_bn_res_input* rs, const void* w_fwd, void* z,
+                                               double* stat_acc, int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype,
+                                               void* stream) {
+    CLHIP_CHECK_ARG(rs && rs->res && rs->y && rs->relu_mask);
+    return conv_fwd_acc_bn_input(z_in, bn, rs, w_fwd, z, stat_acc, replicas, N, H, W, C, K, ksize, stride, pad, dtype, stream);
+}
+static int conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, const clhip_bn_res_input* rs, const void* w_fwd, void* z, double* stat_acc,
+                                 int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream) {
     if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
     CLHIP_CHECK_ARG(z_in && bn && w_fwd && z && stat_acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
     CLHIP_CHECK_ARG(bn->stat_acc && bn->gamma && bn->beta && bn->mean && bn->invstd && bn->coef && bn->replicas >= 1 && bn->replicas <= 64);
@@ -676,9 +689,9 @@ extern "C" int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_inpu
     CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype));
     if (C == 64)
         return clhip_conv64_launch_ex(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, bn,
-                                      static_cast<hipStream_t>(stream));
+                                      static_cast<hipStream_t>(stream), rs);
     return clhip_conv16_launch_ex(z_in, w_fwd, z, nullptr, stat_acc, replicas, N, H, W, C, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, bn,
-                                  static_cast<hipStream_t>(stream));
+                                  static_cast<hipStream_t>(stream), rs);
 }
 
 extern "C" int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw,

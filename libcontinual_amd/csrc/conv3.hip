@@ -131,6 +131,12 @@ struct Conv3Params {
     float in_momentum = 0.f, in_eps = 0.f;
     double in_invM = 0.0, in_unbias = 1.0;
     float* in_mean_o = nullptr; float* in_invstd_o = nullptr; float* in_coef_o = nullptr;      // [Cs], [Cs], [2][Cs]
+    // ... of a conv -> BN -> +res -> ReLU producer (LI == 2): the operand is relu(scale * z' + shift + r); the workgroup that owns a pixel also
+    // WRITES that activation and its packed ReLU mask (the block output has later readers: the next residual add, the backward) -- everything
+    // bn_apply_train_kernel<true, true> would have stored, from the consumer's staging loop
+    const bf16_t* in_res = nullptr;  // r [N,H,W,Cs]
+    bf16_t* in_y = nullptr;          // out [N,H,W,Cs]
+    unsigned char* in_mask = nullptr;      // out [N*H*W*Cs/8], bit e = stored value > 0
     // conv16 / conv32 DGRAD only ("lazy" gradient): src is not read; the operand is the BatchNorm-backward result
     //   dz = scale * (g - mean(g) - xhat * mean(g xhat)),  g = dy * (scale z + shift > 0),  xhat = (z - mean) * invstd
     // of THIS layer's own BatchNorm, computed while the patch is staged from dy and z (bn_bwd_apply_acc_kernel's arithmetic, z-mask form);
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
 // pitch (conflict-free for ds_read_b128), and a 16-pixel x 16-channel output tile costs 5 LDS reads + 5 MFMAs with no barrier
 // after the patch is staged.  Lane (fr, fg) ends with channels 4 fg .. 4 fg + 3 of pixel fr: one 8-byte store, 512 contiguous
 // bytes per wave instruction, no output staging.  MODE as in conv3_kernel (the dgrad weight copy has the same [Cd][9][Cs] layout).
-template <int MODE, bool LZ = false, bool LI = false>
+template <int MODE, bool LZ = false, int LI = 0>
 __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, char* smem) {      // bx = tile index (a workgroup of a plain or a fused launch)
     constexpr int BM = 256, PP = 32;                         // pixels per workgroup, LDS bytes per pixel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -707,7 +713,8 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
     }
     // patch: pixels [m0 - halo, m0 + BM + halo) as 16-byte half rows, plus one zero row for the out-of-image taps
     const int nchunks = p.np * 2;
-    constexpr bool lazy = MODE == 0 && LI;                    // lazy BatchNorm input (template parameter for the same reason as LZ)
+    constexpr bool lazy = MODE == 0 && LI != 0;
+    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out                    // lazy BatchNorm input (template parameter for the same reason as LZ)
     float isc[8], ish[8];
     if constexpr (lazy) {                                    // this thread stages channels (tid & 1) * 8 .. + 8 of every pixel it touches
         float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
@@ -735,7 +742,11 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
                 if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * 16 + ch * 8, gg, p.lz.dres_acc);
             } else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
-                if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
+                if constexpr (lres) {
+                    unsigned mb;
+                    v = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(p.in_res + (size_t)g * 16 + ch * 8), isc, ish, mb);
+                    if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + (size_t)g * 16 + ch * 8) = v; p.in_mask[(size_t)g * 2 + ch] = (unsigned char)mb; }
+                } else if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
@@ -805,7 +816,7 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
         }
     }
 }
-template <int MODE, bool LI = false>
+template <int MODE, int LI = 0>
 __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv16_body<MODE, false, LI>(p, blockIdx.x, smem);
@@ -814,7 +825,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(Conv3Params p) {
 // conv32: the same scheme for 32 -> 32 channels (ResNet-32 stage 2).  One tap fills a K = 32 step, the 32 output channels are two
 // MFMA row tiles, the weights are 18 operands (72 registers) per lane; the patch pitch is 96 bytes (64 of data), which puts the 16
 // lanes a ds_read_b128 services together on 16 distinct bank quartets.
-template <int MODE, bool LZ = false, bool LI = false>
+template <int MODE, bool LZ = false, int LI = 0>
 __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, char* smem) {
     constexpr int BM = 256, PP = 96;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -828,7 +839,8 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) wreg[t][j] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(j * 16 + fr) * 288 + t * 32 + fg * 8);
     const int nchunks = p.np * 4;
-    constexpr bool lazy = MODE == 0 && LI;                    // lazy BatchNorm input (template parameter for the same reason as LZ)
+    constexpr bool lazy = MODE == 0 && LI != 0;
+    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out                    // lazy BatchNorm input (template parameter for the same reason as LZ)
     float isc[8], ish[8];
     if constexpr (lazy) {                                    // this thread stages channels (tid & 3) * 8 .. + 8
         float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
@@ -856,7 +868,11 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
                 if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * 32 + ch * 8, gg, p.lz.dres_acc);
             } else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
-                if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
+                if constexpr (lres) {
+                    unsigned mb;
+                    v = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(p.in_res + (size_t)g * 32 + ch * 8), isc, ish, mb);
+                    if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + (size_t)g * 32 + ch * 8) = v; p.in_mask[(size_t)g * 4 + ch] = (unsigned char)mb; }
+                } else if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
@@ -939,7 +955,7 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
         }
     }
 }
-template <int MODE, bool LI = false>
+template <int MODE, int LI = 0>
 __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv32_body<MODE, false, LI>(p, blockIdx.x, smem);
@@ -951,7 +967,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(Conv3Params p) {
 // pixels, the patch sits in LDS at a 144-byte pitch (conflict-free for ds_read_b128), every wave multiplies all four 16-pixel tiles.  No cross-wave
 // reduction anywhere: a wave owns its channels' BatchNorm sums (forward statistics, backward sums) and adds them to the fp64 accumulators directly.
 // The patch is staged through registers, so the lazy BatchNorm operands of conv16 / conv32 apply (LI: input, LZ: gradient).
-template <int MODE, bool LZ = false, bool LI = false, int BM = 64>
+template <int MODE, bool LZ = false, int LI = 0, int BM = 64>
 __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, char* smem) {
     constexpr int PP = 144, C = 64, NT = BM / 16;                // BM pixels per workgroup (64: the fused backward launch; 128: the forward, half the statistics atomics)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -965,7 +981,8 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wreg[t][ks] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(wave * 16 + fr) * 576 + t * 64 + ks * 32 + fg * 8);
     const int nchunks = p.np * 8;
-    constexpr bool lazy = MODE == 0 && LI;
+    constexpr bool lazy = MODE == 0 && LI != 0;
+    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out
     constexpr bool lzd = MODE == 1 && LZ;
     float isc[8], ish[8];
     LazyDz8 lt;
@@ -992,7 +1009,11 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
                 if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * C + ch * 8, gg, p.lz.dres_acc);
             } else {
                 v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * C + ch * 8);
-                if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
+                if constexpr (lres) {
+                    unsigned mb;
+                    v = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(p.in_res + (size_t)g * C + ch * 8), isc, ish, mb);
+                    if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + (size_t)g * C + ch * 8) = v; p.in_mask[(size_t)g * 8 + ch] = (unsigned char)mb; }
+                } else if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
             }
         }
         *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
@@ -1082,7 +1103,7 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
         }
     }
 }
-template <int MODE, bool LI = false, int BM = 64>
+template <int MODE, int LI = 0, int BM = 64>
 __global__ __launch_bounds__(256) void conv64_kernel(Conv3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv64_body<MODE, false, LI, BM>(p, blockIdx.x, smem);
@@ -1145,7 +1166,7 @@ int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* st
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
 int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
-                           const clhip_bn_input* in, hipStream_t st);
+                           const clhip_bn_input* in, hipStream_t st, const clhip_bn_res_input* rs = nullptr);
 
 int clhip_conv16_launch(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                         hipStream_t st) {
@@ -1160,9 +1181,10 @@ int clhip_conv16_launch_bn(const void* src, const void* wt, void* dst, float* st
 // bn_coef: the dgrad epilogue's ReLU mask from z (bn_y == nullptr); in: forward with a lazy BatchNorm input (src = the producer's z)
 int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* stats, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
-                           const clhip_bn_input* in, hipStream_t st) {
+                           const clhip_bn_input* in, hipStream_t st, const clhip_bn_res_input* rs) {
     Conv3Params p;
     p.bn_coef = bn_coef;
+    if (rs != nullptr) { p.in_res = static_cast<const bf16_t*>(rs->res); p.in_y = static_cast<bf16_t*>(rs->y); p.in_mask = static_cast<unsigned char*>(rs->relu_mask); }
     if (in != nullptr) {
         p.in_acc = in->stat_acc; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
         p.in_momentum = in->momentum; p.in_eps = in->eps; p.in_mean_o = in->mean; p.in_invstd_o = in->invstd; p.in_coef_o = in->coef;
@@ -1178,11 +1200,13 @@ int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* st
     const size_t lds = ((size_t)p.patch_bytes > 1024 ? (size_t)p.patch_bytes : 1024) + 1024;      // + the lazy operands' coefficient tables ([2][C] / [6][C])
     const dim3 grid(clhip_conv16_tiles_m(p.M));
     if (C == 16) {
-        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv16_kernel<0, true>), grid, dim3(256), lds, st, p);
+        if (mode == 0 && in != nullptr && rs != nullptr) hipLaunchKernelGGL((conv16_kernel<0, 2>), grid, dim3(256), lds, st, p);
+        else if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv16_kernel<0, 1>), grid, dim3(256), lds, st, p);
         else if (mode == 0) hipLaunchKernelGGL(conv16_kernel<0>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(conv16_kernel<1>, grid, dim3(256), lds, st, p);
     } else {
-        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv32_kernel<0, true>), grid, dim3(256), lds, st, p);
+        if (mode == 0 && in != nullptr && rs != nullptr) hipLaunchKernelGGL((conv32_kernel<0, 2>), grid, dim3(256), lds, st, p);
+        else if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv32_kernel<0, 1>), grid, dim3(256), lds, st, p);
         else if (mode == 0) hipLaunchKernelGGL(conv32_kernel<0>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(conv32_kernel<1>, grid, dim3(256), lds, st, p);
     }
@@ -1198,9 +1222,10 @@ bool clhip_conv64_supported(int N, int H, int W, int Cs, int Cd, int ksize, int 
 
 int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,
                            const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, const float* bn_coef,
-                           const clhip_bn_input* in, hipStream_t st) {
+                           const clhip_bn_input* in, hipStream_t st, const clhip_bn_res_input* rs) {
     Conv3Params p;
     p.bn_coef = bn_coef;
+    if (rs != nullptr) { p.in_res = static_cast<const bf16_t*>(rs->res); p.in_y = static_cast<bf16_t*>(rs->y); p.in_mask = static_cast<unsigned char*>(rs->relu_mask); }
     if (in != nullptr) {
         p.in_acc = in->stat_acc; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
         p.in_momentum = in->momentum; p.in_eps = in->eps; p.in_mean_o = in->mean; p.in_invstd_o = in->invstd; p.in_coef_o = in->coef;
@@ -1218,11 +1243,13 @@ int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* s
     const size_t lds = (size_t)p.patch_bytes + 2048;
     const dim3 grid((p.M + bm - 1) / bm);
     if (bm == 128) {
-        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, true, 128>), grid, dim3(256), lds, st, p);
-        else if (mode == 0) hipLaunchKernelGGL((conv64_kernel<0, false, 128>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((conv64_kernel<1, false, 128>), grid, dim3(256), lds, st, p);
+        if (mode == 0 && in != nullptr && rs != nullptr) hipLaunchKernelGGL((conv64_kernel<0, 2, 128>), grid, dim3(256), lds, st, p);
+        else if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, 1, 128>), grid, dim3(256), lds, st, p);
+        else if (mode == 0) hipLaunchKernelGGL((conv64_kernel<0, 0, 128>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv64_kernel<1, 0, 128>), grid, dim3(256), lds, st, p);
     } else {
-        if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, true>), grid, dim3(256), lds, st, p);
+        if (mode == 0 && in != nullptr && rs != nullptr) hipLaunchKernelGGL((conv64_kernel<0, 2>), grid, dim3(256), lds, st, p);
+        else if (mode == 0 && in != nullptr) hipLaunchKernelGGL((conv64_kernel<0, 1>), grid, dim3(256), lds, st, p);
         else if (mode == 0) hipLaunchKernelGGL(conv64_kernel<0>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(conv64_kernel<1>, grid, dim3(256), lds, st, p);
     }

@@ -51,6 +51,10 @@ struct Unit {
     int lazy_to;                   // >= 0: this unit's activation relu(bn(z)) is consumed by unit `lazy_to` alone, through a convolution kernel that applies it
                                    // while it stages its operand (clhip_conv_fwd_acc_bn_input): the training forward skips the apply launch
     int lazy_from;                 // >= 0: the producer of this unit's input is such a unit
+    int res_lazy_to;               // >= 0: a conv -> BN -> +res -> ReLU unit whose first consumer, convolution `res_lazy_to`, applies the BatchNorm, the
+                                   // residual add and the ReLU on its operand load AND writes the activation + packed mask for the later readers
+                                   // (clhip_conv_fwd_acc_bn_res_input): the training forward skips the apply launch
+    int res_lazy_from;             // >= 0: this unit's input comes from such a unit
     bool pair_acc;                 // the accumulate flag of that one launch (= the shortcut dgrad's, the first writer of the two)
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
     size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([rep][2][cout] each)
@@ -100,6 +104,7 @@ struct clhip_plan {
     size_t wg_off;           // byte offset of the weight-gradient partial-block scratch (0 bytes if unused)
     size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
+    std::vector<char> res_pending;      // per unit: its forward skipped the (+res) apply launch and its consumer has not run yet
     std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
     int feat_dim;
@@ -372,6 +377,30 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (!clhip_conv_bn_input_supported(N, ub.H, ub.W, ub.cin_pad, ub.d.cout, ub.d.ksize, ub.d.stride, ub.d.pad, dtype)) continue;
         ua.lazy_to = b; ub.lazy_from = a;
     }
+    // the same for the LAST unit of a basic block (conv -> BN -> +res -> ReLU with a packed mask): its first consumer in unit order -- the next
+    // block's first convolution, ahead of that block's residual add -- applies it while staging and writes what the apply launch would have
+    for (auto& u : p->units) { u.res_lazy_to = u.res_lazy_from = -1; }
+    p->res_pending.assign(p->units.size(), 0);
+    for (int a = 0; a + 1 < n_units && want_acc && !mask_y; ++a) {
+        Unit& ua = p->units[a];
+        if (!ua.relu || ua.d.res < 0 || ua.pre_res || ua.no_bn || ua.has_dzr || ua.raw_src || ua.rep_fwd <= 0 || ua.mask_off == 0 || ua.branch >= 0 || ua.forks >= 0 ||
+            ua.lazy_to >= 0) continue;
+        int b = -1;
+        bool ok = true;
+        for (int k = 0; k < n_units; ++k) {
+            const Unit& o = p->units[k];
+            const bool reads = o.d.src == a + 1 || o.d.res == a + 1;
+            if (!reads) continue;
+            if (k <= a) { ok = false; break; }
+            if (b < 0) { if (o.d.src != a + 1 || o.raw_src) { ok = false; break; } b = k; }      // the first reader must be a convolution of the activation
+            else if (o.d.src == a + 1 && o.raw_src) { ok = false; break; }
+        }
+        if (!ok || b < 0) continue;
+        Unit& ub = p->units[b];
+        if (ub.no_bn || ub.pre_res || ub.rep_fwd <= 0 || ub.cin_pad != ub.d.cin || ub.branch >= 0 || ub.pair >= 0 || ub.lazy_from >= 0) continue;
+        if (!clhip_conv_bn_input_supported(N, ub.H, ub.W, ub.cin_pad, ub.d.cout, ub.d.ksize, ub.d.stride, ub.d.pad, dtype)) continue;
+        ua.res_lazy_to = b; ub.res_lazy_from = a;
+    }
     return p;
 }
 
@@ -623,7 +652,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const char* lazy_cfg = clhip_cfg("BN_INPUT");            // (looked up per call: the tests flip it between two models of one process)
     const bool lazy_env = !(lazy_cfg != nullptr && atoi(lazy_cfg) == 0);
     const bool lazy_on = lazy_env && training && use_acc;
-    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = 0;
+    const char* rlazy_cfg = clhip_cfg("BN_RES_INPUT");
+    const bool rlazy_on = lazy_on && !(rlazy_cfg != nullptr && atoi(rlazy_cfg) == 0);
+    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = 0;
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
@@ -652,7 +683,21 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 (void)hipStreamWaitEvent(p->br, p->ev_fork[u.branch], 0);
                 us = p->br;
             }
-            if (u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) {
+            if (u.res_lazy_from >= 0 && p->res_pending[u.res_lazy_from]) {
+                // the producer is a block's last unit: its BatchNorm + residual add + ReLU happen on this convolution's operand load, and this launch
+                // writes the activation and the packed mask for the readers that follow
+                const Unit& a = p->units[u.res_lazy_from];
+                clhip_bn_input bi;
+                bi.stat_acc = acc + a.a_fwd; bi.replicas = a.rep_fwd; bi.gamma = params + a.d.gamma_off; bi.beta = params + a.d.beta_off;
+                bi.running_mean = bn_stats + a.d.rm_off; bi.running_var = bn_stats + a.d.rv_off; bi.momentum = kBnMomentum; bi.eps = kBnEps;
+                bi.mean = fr + a.f_mean; bi.invstd = fr + a.f_invstd; bi.coef = fr + a.f_scale;
+                clhip_bn_res_input rs;
+                rs.res = ws + p->acts[a.d.res].y_off; rs.y = ws + src.y_off; rs.relu_mask = ws + a.mask_off;
+                if (br_on && a.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)us, p->ev_join[a.joins], 0);      // the residual comes from the branch stream
+                TRY(clhip_conv_fwd_acc_bn_res_input(ws + a.z_off, &bi, &rs, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad,
+                                                    u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, us));
+                p->res_pending[u.res_lazy_from] = 0;
+            } else if (u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) {
                 // the producer's BatchNorm + ReLU happen on this convolution's operand load: scale / shift, the saved statistics and the running
                 // statistics of the producer are this launch's by-products
                 const Unit& a = p->units[u.lazy_from];
@@ -668,6 +713,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
             }
             p->lazy_live[i] = 0;
             if (lazy_on && u.lazy_to >= 0) { p->lazy_live[i] = 1; continue; }          // its one consumer applies the BatchNorm: no apply launch, no activation
+            if (rlazy_on && u.res_lazy_to >= 0) { p->res_pending[i] = 1; continue; }   // its first consumer applies it and writes the activation + mask
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
             if (br_on && u.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)stream, p->ev_join[u.joins], 0);      // the residual comes from the branch stream
             if (br_on && u.forks >= 0) clhip_bn_set_fwd_stop_event(p->ev_fork[u.forks]);                           // this launch's completion starts the branch

@@ -182,3 +182,30 @@ def test_lazy_batchnorm_inputs_do_not_change_a_resnet32_run():
     dg = float((g0 - g1).abs().max()) / float(g0.abs().max())
     print(f"lazy vs eager BatchNorm inputs, six steps: parameter deviation {d:.2e}, last gradient {dg:.2e}")
     assert d <= 1e-5 and dg <= 1e-4
+
+
+def test_lazy_residual_batchnorm_inputs_do_not_change_a_resnet32_run():
+    """... and with the LAST BatchNorm + residual add + ReLU of a basic block applied by the next block's first convolution
+    (clhip_conv_fwd_acc_bn_res_input, which also writes the block output and its packed mask): a run with BN_RES_INPUT=0 ends where the
+    default run ends."""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    out = []
+    try:
+        for lazy in (b"1", b"0"):
+            assert L.clhip_config(b"BN_RES_INPUT", lazy) == 0
+            m = _make("ewc", 9)
+            o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+            T.train_steps(m, o, _batches(6, 64), None, "EWC", None, "cuda")
+            torch.cuda.synchronize()
+            out.append((m.network.backbone.flat_parameters()[0].clone(), m.network.backbone.flat_parameters()[1].clone(),
+                        m.network.backbone.flat_buffers().clone() if hasattr(m.network.backbone, "flat_buffers") else None))
+    finally:
+        L.clhip_config(b"BN_RES_INPUT", None)
+    (p0, g0, b0), (p1, g1, b1) = out
+    d = float((p0 - p1).abs().max()) / float(p0.abs().max())
+    dg = float((g0 - g1).abs().max()) / float(g0.abs().max())
+    print(f"lazy vs eager block-output BatchNorm, six steps: parameter deviation {d:.2e}, last gradient {dg:.2e}")
+    assert d <= 1e-5 and dg <= 1e-4
+    if b0 is not None:
+        assert float((b0 - b1).abs().max()) <= 1e-5 * float(b0.abs().max())

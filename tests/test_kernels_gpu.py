@@ -1100,3 +1100,57 @@ def test_lazy_batchnorm_input_forward_and_backward(shape):
         for k_, (a_, b_) in enumerate(zip(res[0][:5], res[1][:5])):
             assert torch.equal(a_, b_), (accumulate, k_)
         assert ((res[0][5] - res[1][5]).abs() <= 1e-12 * res[0][5].abs().clamp(min=1.0)).all()
+
+
+@pytest.mark.parametrize("shape", [(9, 32, 32, 16), (40, 16, 16, 32), (3, 7, 5, 16), (5, 8, 16, 32), (70, 8, 8, 64), (3, 16, 8, 64), (256, 8, 8, 64)])
+def test_lazy_batchnorm_residual_input(shape):
+    """The last unit of a basic block (conv -> BN -> +res -> ReLU, resnet.py:312-316) applied by its first consumer: clhip_conv_fwd_acc_bn_res_input(z',
+    res) must equal clhip_bn_apply_train_mask(z', res) followed by clhip_conv_fwd_acc BIT FOR BIT -- the convolution's output, the activation and the
+    packed ReLU mask it writes for the later readers (guard elements behind both stay untouched), the saved and the running statistics."""
+    import ctypes as C
+
+    class BnInput(C.Structure):
+        _fields_ = [("stat_acc", C.c_void_p), ("replicas", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                    ("running_var", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("coef", C.c_void_p)]
+
+    class BnRes(C.Structure):
+        _fields_ = [("res", C.c_void_p), ("y", C.c_void_p), ("relu_mask", C.c_void_p)]
+    N, H, W, Cc = shape
+    L = _lib.lib()
+    code, tdt = DT["bf16"]
+    if not L.clhip_conv_bn_input_supported(N, H, W, Cc, Cc, 3, 1, 1, code):
+        pytest.skip("layer outside the lazy-input kernels' domain")
+    M_ = N * H * W
+    zp = to_nhwc(quant(rnd((N, Cc, H, W), 81, 1.3), tdt), tdt)
+    rs_t = to_nhwc(quant(rnd((N, Cc, H, W), 82, 0.8), tdt), tdt)                   # the residual
+    zf = zp.float().reshape(-1, Cc).double()
+    rep_in = 4
+    acc_in = torch.zeros(rep_in, 2, Cc, dtype=torch.float64, device=DEV)
+    acc_in[0, 0], acc_in[3, 1] = zf.sum(0), (zf * zf).sum(0)
+    gamma, beta = (rnd((Cc,), 83) * 0.2 + 1.0).to(DEV), (rnd((Cc,), 84) * 0.3).to(DEV)
+    w = quant(rnd((Cc, 9, Cc), 85, 0.1), tdt).to(tdt).to(DEV).contiguous()
+    mom, eps, rep = 0.1, 1e-5, 8
+    nmask = M_ * Cc // 8
+
+    def fresh():
+        return dict(rm=torch.full((Cc,), 0.5, device=DEV), rv=torch.full((Cc,), 2.0, device=DEV), mean=torch.empty(Cc, device=DEV), invstd=torch.empty(Cc, device=DEV),
+                    coef=torch.full((2, Cc), float("nan"), device=DEV), z=torch.full((N, H, W, Cc), float("nan"), dtype=tdt, device=DEV),
+                    acc=torch.zeros(rep, 2, Cc, dtype=torch.float64, device=DEV), y=torch.full((M_ + 1, Cc), 7.0, dtype=tdt, device=DEV),
+                    mask=torch.full((nmask + 16,), 0xA5, dtype=torch.uint8, device=DEV))
+    e, l = fresh(), fresh()
+    call("clhip_bn_apply_train_mask", zp.data_ptr(), acc_in.data_ptr(), rep_in, M_, Cc, gamma.data_ptr(), beta.data_ptr(), e["rm"].data_ptr(), e["rv"].data_ptr(), mom, eps,
+         e["mean"].data_ptr(), e["invstd"].data_ptr(), rs_t.data_ptr(), e["y"].data_ptr(), e["mask"].data_ptr(), code, st())
+    call("clhip_conv_fwd_acc", e["y"].data_ptr(), w.data_ptr(), e["z"].data_ptr(), e["acc"].data_ptr(), rep, N, H, W, Cc, Cc, 3, 1, 1, code, st())
+    bi = BnInput(acc_in.data_ptr(), rep_in, gamma.data_ptr(), beta.data_ptr(), l["rm"].data_ptr(), l["rv"].data_ptr(), mom, eps, l["mean"].data_ptr(),
+                 l["invstd"].data_ptr(), l["coef"].data_ptr())
+    br = BnRes(rs_t.data_ptr(), l["y"].data_ptr(), l["mask"].data_ptr())
+    call("clhip_conv_fwd_acc_bn_res_input", zp.data_ptr(), C.byref(bi), C.byref(br), w.data_ptr(), l["z"].data_ptr(), l["acc"].data_ptr(), rep, N, H, W, Cc, Cc, 3, 1, 1,
+         code, st())
+    torch.cuda.synchronize()
+    assert torch.equal(l["y"], e["y"]) and float((l["y"][M_].float() - 7.0).abs().max()) == 0.0
+    assert torch.equal(l["mask"], e["mask"]) and bool((l["mask"][nmask:] == 0xA5).all())
+    assert int(e["mask"][:nmask].count_nonzero()) > 0 and int((e["y"][:M_] == 0).sum()) > 0      # both signs occur
+    assert torch.equal(l["z"], e["z"])
+    for k in ("rm", "rv", "mean", "invstd"):
+        assert torch.equal(l[k], e[k]), k
+    assert ((l["acc"].sum(0) - e["acc"].sum(0)).abs() <= 1e-12 * e["acc"].sum(0).abs().clamp(min=1.0)).all()
