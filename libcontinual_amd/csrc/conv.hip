@@ -740,16 +740,28 @@ size_t clhip_dgrad6_packed_bytes(int C, int K);
 int clhip_dgrad6_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C, int K, hipStream_t st);
 int clhip_dgrad6_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st);
 
+// conv7.hip: the same for 16 -> 32 and 32 -> 64 channels (CifarResNet-32), packed [C][10][K]
+bool clhip_dgrad7_supported(int N, int H, int W, int C, int K, int dtype);
+size_t clhip_dgrad7_packed_bytes(int C, int K);
+int clhip_dgrad7_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C, int K, hipStream_t st);
+int clhip_dgrad7_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st);
+static bool small_pair(int C, int K) { return (C == 16 || C == 32) && K == 2 * C; }
+
 extern "C" int clhip_conv_dgrad_pair_supported(int N, int H, int W, int C, int K, int dtype) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
     if (use_v1() || !use_v3()) return 0;
+    if (small_pair(C, K)) return clhip_dgrad7_supported(N, H, W, C, K, dtype) ? 1 : 0;
     return clhip_dgrad6_supported(N, H, W, C, K, dtype) ? 1 : 0;
 }
 
-extern "C" size_t clhip_conv_dgrad_pair_packed_bytes(int C, int K) { return (C > 0 && K > 0 && C % 64 == 0 && K % 16 == 0) ? clhip_dgrad6_packed_bytes(C, K) : 0; }
+extern "C" size_t clhip_conv_dgrad_pair_packed_bytes(int C, int K) {
+    if (small_pair(C, K)) return clhip_dgrad7_packed_bytes(C, K);
+    return (C > 0 && K > 0 && C % 64 == 0 && K % 16 == 0) ? clhip_dgrad6_packed_bytes(C, K) : 0;
+}
 
 extern "C" int clhip_conv_dgrad_pair_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C, int K, int dtype, void* stream) {
     CLHIP_CHECK_ARG(w_dg && packed && dtype == CLHIP_BF16 && clhip_conv_dgrad_pair_packed_bytes(C, K) > 0);
+    if (small_pair(C, K)) return clhip_dgrad7_pack(w_dg, w_sc_dg, packed, C, K, static_cast<hipStream_t>(stream));
     return clhip_dgrad6_pack(w_dg, w_sc_dg, packed, C, K, static_cast<hipStream_t>(stream));
 }
 
@@ -757,6 +769,7 @@ extern "C" int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const
                                      int dtype, void* stream) {
     CLHIP_CHECK_ARG(dz && w_packed && dx);
     CLHIP_CHECK_ARG(clhip_conv_dgrad_pair_supported(N, H, W, C, K, dtype));
+    if (small_pair(C, K)) return clhip_dgrad7_launch(dz, w_packed, dz_sc, dx, accumulate, N, H, W, C, K, static_cast<hipStream_t>(stream));
     return clhip_dgrad6_launch(dz, w_packed, dz_sc, dx, accumulate, N, H, W, C, K, static_cast<hipStream_t>(stream));
 }
 

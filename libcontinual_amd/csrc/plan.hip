@@ -459,7 +459,9 @@ constexpr int kPrepMax = 48;
 struct PrepEntry { int64_t w_off; int64_t wf_off, wd_off; int64_t wp_off; int wp_tap0; int K, taps, Creal, Cpad; unsigned first_block; };
 // third copy (wp_off >= 0): the packed dgrad layout of conv6.hip -- per (64-channel tile of C, 16-wide chunk of K) 64 rows x 21 sixteen-byte
 // slots, slot 2 * tap + (k % 16) / 8; the shortcut unit of a pair writes its single tap as tap 9 of its partner's buffer
-__device__ __forceinline__ size_t packed_index(int c, int tap, int k, int K) {
+// (fewer than 64 channels: conv7.hip's [C][10][K])
+__device__ __forceinline__ size_t packed_index(int c, int tap, int k, int K, int Cpad) {
+    if (Cpad < 64) return ((size_t)c * 10 + tap) * K + k;
     return ((((size_t)(c >> 6) * (K >> 4) + (k >> 4)) * 64 + (c & 63)) * 21 + tap * 2 + ((k >> 3) & 1)) * 8 + (k & 7);
 }
 struct PrepTable { int n; PrepEntry e[kPrepMax]; };
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* __r
         const int c = c0 + i, k = k0 + tx;
         if (c < d.Cpad && k < d.K) {
             Elem<T>::st(wd + ((size_t)c * d.taps + tap) * d.K + k, tile[tx][i]);
-            if (d.wp_off >= 0) Elem<T>::st(reinterpret_cast<T*>(shadow + d.wp_off) + packed_index(c, d.wp_tap0 + tap, k, d.K), tile[tx][i]);
+            if (d.wp_off >= 0) Elem<T>::st(reinterpret_cast<T*>(shadow + d.wp_off) + packed_index(c, d.wp_tap0 + tap, k, d.K, d.Cpad), tile[tx][i]);
         }
     }
 }
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi64_kernel(const float* _
         if (c < d.Cpad && k < d.K) {
             const uint2 v = make_uint2(pack_bf16x2(tile[tx][cc], tile[tx + 1][cc]), pack_bf16x2(tile[tx + 2][cc], tile[tx + 3][cc]));
             *reinterpret_cast<uint2*>(wd + ((size_t)c * d.taps + tap) * d.K + k) = v;
-            if (d.wp_off >= 0) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(shadow + d.wp_off) + packed_index(c, d.wp_tap0 + tap, k, d.K)) = v;
+            if (d.wp_off >= 0) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(shadow + d.wp_off) + packed_index(c, d.wp_tap0 + tap, k, d.K, d.Cpad)) = v;
         }
     }
 }

@@ -209,3 +209,28 @@ def test_lazy_residual_batchnorm_inputs_do_not_change_a_resnet32_run():
     assert d <= 1e-5 and dg <= 1e-4
     if b0 is not None:
         assert float((b0 - b1).abs().max()) <= 1e-5 * float(b0.abs().max())
+
+
+def test_fused_stage_entry_gradient_inside_a_resnet32_run():
+    """conv7.hip inside the plan: the input gradients of CifarResNet-32's two down-sampling entries (3x3 / s2 + 1x1 / s2 shortcut, 16 -> 32 and
+    32 -> 64 channels) as one launch each (CONV6_PAIR, default) against the two generic launches they replace -- the two forms differ by the bf16
+    rounding of the intermediate sum only."""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    out = []
+    try:
+        for on in (b"1", b"0"):
+            assert L.clhip_config(b"CONV6_PAIR", on) == 0
+            m = _make("ewc", 9)
+            o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+            T.train_steps(m, o, _batches(1, 64), None, "EWC", None, "cuda")      # ONE step: same weights, same forward; random-data training is chaotic beyond that
+            torch.cuda.synchronize()
+            out.append((m.network.backbone.flat_parameters()[0].clone(), m.network.backbone.flat_parameters()[1].clone()))
+    finally:
+        L.clhip_config(b"CONV6_PAIR", None)
+    (p0, g0), (p1, g1) = out
+    d = float((p0 - p1).abs().max()) / float(p0.abs().max())
+    dg = float((g0 - g1).abs().max()) / float(g0.abs().max())
+    rel = float((g0 - g1).norm()) / float(g0.norm())
+    print(f"fused vs separate stage-entry input gradients, one step: parameter deviation {d:.2e}, gradient max {dg:.2e}, norm {rel:.2e}")
+    assert 0.0 < dg <= 2e-2 and rel <= 1e-2 and d <= 1e-3          # (> 0: the fused launch is really in the plan)

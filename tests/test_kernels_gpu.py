@@ -909,7 +909,9 @@ def test_dgrad_with_fused_batchnorm_backward_reduction(shape, relu, accumulate):
 
 
 PAIR_CASES = [(256, 32, 32, 64, 128), (20, 32, 32, 64, 128), (3, 32, 32, 64, 128), (70, 16, 16, 128, 256), (256, 8, 8, 256, 512), (9, 8, 8, 256, 512),
-              (33, 4, 4, 64, 64), (9, 16, 8, 64, 32)]
+              (33, 4, 4, 64, 64), (9, 16, 8, 64, 32),
+              # conv7.hip: CifarResNet-32's entries (16 -> 32 at 32 x 32, 32 -> 64 at 16 x 16), ragged last tiles, one tile, non-square maps
+              (256, 32, 32, 16, 32), (256, 16, 16, 32, 64), (3, 32, 32, 16, 32), (5, 16, 16, 32, 64), (1, 4, 8, 16, 32), (7, 8, 4, 32, 64)]
 
 
 @pytest.mark.parametrize("case", PAIR_CASES)
