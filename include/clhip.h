@@ -385,12 +385,21 @@ int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const 
  * w_sc_dg [C][1][K] (nullable) of clhip_conv_weight_prep -- per (64-channel tile, 16-wide K chunk) the LDS image of that chunk's ten
  * taps (csrc/conv6.hip); a plan writes this layout in its own weight preparation.  Same result as clhip_conv_dgrad of the shortcut
  * followed by clhip_conv_dgrad(accumulate) of the 3x3 layer up to the bf16 rounding of the intermediate (here the two are summed
- * in fp32).  bf16, C % 64 == 0, K % 32 == 0, H/2 and W/2 powers of two, W/2 <= 16 (ResNet-18's three entries).  _supported: 1 / 0. */
+ * in fp32).  bf16, C % 64 == 0, K % 32 == 0, H/2 and W/2 powers of two, W/2 <= 16 (ResNet-18's three entries; csrc/conv6.hip), or
+ * C in {16, 32} with K = 2 C (CifarResNet-32's two; csrc/conv7.hip, packed [C][10][K]).  _supported: 1 / 0. */
 int clhip_conv_dgrad_pair_supported(int N, int H, int W, int C, int K, int dtype);
 size_t clhip_conv_dgrad_pair_packed_bytes(int C, int K);
 int clhip_conv_dgrad_pair_pack(const void* w_dg, const void* w_sc_dg /*nullable*/, void* packed, int C, int K, int dtype, void* stream);
 int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_sc /*nullable*/, void* dx, int accumulate, int N, int H,
                           int W, int C, int K, int dtype, void* stream);
+
+/* The WEIGHT gradients of the same two layers in one launch (csrc/conv7.hip): dw [K][9][C] += the 3x3/s2 layer's, dw_sc [K][1][C] += the
+ * shortcut's, both over the block input x [N,H,W,C]; dz, dz_sc [N,H/2,W/2,K].  ws / ws_sc: scratch of clhip_conv_wgrad_ws_bytes() bytes of
+ * the 3x3 / the 1x1 layer (partial blocks per image group, summed in a fixed order: bitwise reproducible).  bf16; CifarResNet-32's two
+ * entries (32 x 32 x 16 -> 32 channels, 16 x 16 x 32 -> 64).  _supported: 1 / 0. */
+int clhip_conv_wgrad_pair_supported(int N, int H, int W, int C, int K, int dtype);
+int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, float* dw, float* dw_sc, void* ws, void* ws_sc, int N, int H, int W,
+                          int C, int K, int dtype, void* stream);
 
 /* ---- run-time configuration ------------------------------------------------------------------------------------------------
  * ONE entry point for every dispatch switch, tuning value and micro-benchmark hook of the library (there are no other steering

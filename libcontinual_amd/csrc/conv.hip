@@ -14,6 +14,8 @@
 // reduced from the fp32 accumulators in the epilogue (per-tile partials, no atomics -> deterministic).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -773,7 +775,35 @@ extern "C" int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const
     return clhip_dgrad6_launch(dz, w_packed, dz_sc, dx, accumulate, N, H, W, C, K, static_cast<hipStream_t>(stream));
 }
 
+// conv7.hip: the weight gradients of a small-channel down-sampling entry (3x3/s2 + 1x1/s2 shortcut) in one launch
+bool clhip_wgrad7_supported(int N, int H, int W, int C, int K, int dtype);
+size_t clhip_wgrad7_ws_bytes(int N, int C, int K, int which);
+int clhip_wgrad7_launch(const void* x, const void* dz, const void* dz_sc, float* dw, float* dw_sc, float* ws3, float* ws_sc, int N, int C, hipStream_t st);
+static size_t wgrad_ws_bytes_single(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
+
+extern "C" int clhip_conv_wgrad_pair_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || use_v1() || !use_v3()) return 0;
+    return clhip_wgrad7_supported(N, H, W, C, K, dtype) ? 1 : 0;
+}
+
+extern "C" int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, float* dw, float* dw_sc, void* ws, void* ws_sc, int N, int H, int W, int C, int K,
+                                     int dtype, void* stream) {
+    CLHIP_CHECK_ARG(x && dz && dz_sc && dw && dw_sc && ws && ws_sc);
+    CLHIP_CHECK_ARG(clhip_conv_wgrad_pair_supported(N, H, W, C, K, dtype));
+    return clhip_wgrad7_launch(x, dz, dz_sc, dw, dw_sc, static_cast<float*>(ws), static_cast<float*>(ws_sc), N, C, static_cast<hipStream_t>(stream));
+}
+
+// (the scratch of a layer that can be half of such a pair is large enough for either form)
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
+    size_t b = wgrad_ws_bytes_single(N, H, W, C, Creal, K, ksize, stride, pad, dtype);
+    if (!use_v1() && use_v3() && Creal == C && stride == 2 && clhip_wgrad7_supported(N, H, W, C, K, dtype)) {
+        if (ksize == 3 && pad == 1) b = std::max(b, clhip_wgrad7_ws_bytes(N, C, K, 0));
+        if (ksize == 1 && pad == 0) b = std::max(b, clhip_wgrad7_ws_bytes(N, C, K, 1));
+    }
+    return b;
+}
+
+static size_t wgrad_ws_bytes_single(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     if (!use_v1() && use_v3() && clhip_stem_wgrad_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_stem_wgrad_ws_bytes(N, H, W, Creal, K);
     if (!use_v1() && use_v3() && clhip_wgrad64_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad64_ws_bytes(N);
     if (!use_v1() && use_v3() && clhip_wgrad4_supported(N, H, W, C, Creal, K, ksize, stride, pad, dtype)) return clhip_wgrad4_ws_bytes(N, H, W, C, K, ksize, stride);

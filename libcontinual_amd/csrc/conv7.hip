@@ -144,3 +144,152 @@ int clhip_dgrad7_launch(const void* dz, const void* w_packed, const void* dz_sc,
     if (C == 16) return sc ? launch7<16, true>(p, st) : launch7<16, false>(p, st);
     return sc ? launch7<32, true>(p, st) : launch7<32, false>(p, st);
 }
+
+// =========================================================================================================================================
+// The WEIGHT gradients of the same two layers in one launch:  dw3[k][tap][c] += sum_p dz[p][k] x[p @ tap][c]  (3x3 / s2 / p1) and
+// dwsc[k][c] += sum_p dz_sc[p][k] x[2 ho, 2 wo][c]  (1x1 / s2) -- both read the block input x.  On the generic kernel's deterministic form they
+// are 21.0 + 9.6 us (16 -> 32) and 21.0 + 9.6 us launches at batch 256 (profiles/r03_step_notes.md).  wgrad16 / wgrad32's scheme with a stride:
+// a workgroup walks a group of images; the zero-padded input image and the two gradient images sit in LDS; 32 output pixels are one MFMA K step;
+// both operands are pixel-major columns fetched with transposing reads (every lane of such a read has its own address, so the input pixels of a
+// step are simply two apart); the ten taps (nine + the shortcut, which shares tap (1, 1)'s input fragment) are constant offsets.  Every wave owns
+// its own output tiles over ALL pixels -- 16 -> 32: gradient-channel tile (wave & 1) x taps {0..4} / {5..9}; 32 -> 64: gradient-channel tile
+// `wave` x both input-channel tiles x ten taps -- so there is no cross-wave sum; a group's partial blocks go to two slabs that the fixed-order
+// reduce adds to the two gradients (bitwise reproducible).
+namespace {
+
+struct Wgrad7Params { const bf16_t* x; const bf16_t* dz; const bf16_t* dzs; float* slab3; float* slabsc; int N, ipg; };
+
+__device__ __forceinline__ uint4 tr8_7(const char* base, int addr, int second) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr + second));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void wgrad7_kernel(const Wgrad7Params p) {
+    constexpr int K = 2 * C, W = C == 16 ? 32 : 16, H = W, Wo = W / 2, Ho = H / 2, PW = W + 2;
+    constexpr int PXB = C * 2, PZB = K * 2;                  // bytes per input / gradient pixel
+    constexpr int XS = (H + 2) * PW * PXB, ZS = Ho * Wo * PZB;
+    constexpr int NCT = C / 16, NTW = C == 16 ? 5 : 10;      // input-channel tiles and taps per wave
+    constexpr int STEPS = Ho * Wo / 32, RS = 32 / Wo;        // K steps per image, output rows per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    char* zs = smem + XS;
+    char* zss = zs + ZS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kt = C == 16 ? (wave & 1) : wave;
+    const int t_lo = C == 16 ? (wave >> 1) * 5 : 0;
+    const int grp = blockIdx.x;
+    const int n_beg = grp * p.ipg, n_end = min(p.N, n_beg + p.ipg);
+
+    for (int i = tid; i < XS / 16; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);      // the border stays zero
+
+    f32x4 acc[NCT][NTW];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane (fr, fg) of a transposing read addresses reduction pixel k0 = 8 fg + (fr >> 2) of the step (+ 4 for the second read), 4-channel segment fr & 3
+    const int k0 = fg * 8 + (fr >> 2), seg = (fr & 3) * 8;
+    const int ho_l = k0 / Wo, wo = k0 % Wo;
+    const int zaddr = k0 * PZB + kt * 32 + seg;
+    const int xaddr = ((2 * ho_l) * PW + 2 * wo) * PXB + seg;           // padded coordinates of tap (0, 0) = input pixel (2 ho - 1, 2 wo - 1)
+    constexpr int CPX = C / 8, CPZ = K / 8;                  // 16-byte chunks per pixel
+
+    for (int n = n_beg; n < n_end; ++n) {
+        __syncthreads();                                     // the previous image has been multiplied (first trip: the zero fill is complete)
+        const bf16_t* xi = p.x + (size_t)n * H * W * C;
+        for (int i = tid; i < H * W * CPX; i += 256) {
+            const int px = i / CPX, ch = i - px * CPX, row = px / W, col = px - row * W;
+            *reinterpret_cast<uint4*>(xs + ((row + 1) * PW + col + 1) * PXB + ch * 16) = *reinterpret_cast<const uint4*>(xi + (size_t)px * C + ch * 8);
+        }
+        const bf16_t* zi = p.dz + (size_t)n * Ho * Wo * K;
+        const bf16_t* zsi = p.dzs + (size_t)n * Ho * Wo * K;
+        for (int i = tid; i < Ho * Wo * CPZ; i += 256) {
+            *reinterpret_cast<uint4*>(zs + i * 16) = *reinterpret_cast<const uint4*>(zi + (size_t)i * 8);
+            *reinterpret_cast<uint4*>(zss + i * 16) = *reinterpret_cast<const uint4*>(zsi + (size_t)i * 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const uint4 zf = tr8_7(zs, zaddr + s * 32 * PZB, 4 * PZB);
+            uint4 zsf = make_uint4(0, 0, 0, 0);
+            if (C == 32 || t_lo == 5) zsf = tr8_7(zss, zaddr + s * 32 * PZB, 4 * PZB);
+            const int xb = xaddr + s * RS * 2 * PW * PXB;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const int tap = t_lo + t;                // 9 = the shortcut: tap (1, 1)'s input fragment, the shortcut's gradient
+                    const int tt = tap == 9 ? 4 : tap;
+                    const int r = tt / 3, sx = tt - 3 * r;
+                    const uint4 xf = tr8_7(xs, xb + (r * PW + sx) * PXB + c * 32, 8 * PXB);
+                    acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, tap == 9 ? zsf : zf), __builtin_bit_cast(bf16x8_t, xf), acc[c][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[row = gradient channel kt * 16 + fg * 4 + e][col = input channel c * 16 + fr]
+    float* o3 = p.slab3 + (size_t)grp * K * 9 * C;
+    float* osc = p.slabsc + (size_t)grp * K * C;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int tap = t_lo + t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kt * 16 + fg * 4 + e;
+                if (tap == 9) osc[(size_t)k * C + c * 16 + fr] = acc[c][t][e];
+                else o3[((size_t)k * 9 + tap) * C + c * 16 + fr] = acc[c][t][e];
+            }
+        }
+}
+
+template <int C> int wgrad7_groups(int N) { const int ipg = C == 16 ? (N >= 256 ? N / 128 : 1) : (N >= 128 ? N / 64 : 1); return (N + ipg - 1) / ipg; }
+template <int C> int wgrad7_ipg(int N) { return C == 16 ? (N >= 256 ? N / 128 : 1) : (N >= 128 ? N / 64 : 1); }
+
+}  // namespace
+
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);      // conv3.hip
+
+// (N, H, W, C) = the block input; K = 2 C.  CifarResNet-32's two entries: 32 x 32 x 16 and 16 x 16 x 32
+bool clhip_wgrad7_supported(int N, int H, int W, int C, int K, int dtype) {
+    static const bool off = clhip_cfg("CONV7") != nullptr && atoi(clhip_cfg("CONV7")) == 0;
+    static const bool woff = clhip_cfg("WGRAD7") != nullptr && atoi(clhip_cfg("WGRAD7")) == 0;
+    if (off || woff || dtype != CLHIP_BF16 || N < 1) return false;
+    return (C == 16 && K == 32 && H == 32 && W == 32) || (C == 32 && K == 64 && H == 16 && W == 16);
+}
+// scratch of the 3x3 layer's partial blocks (which = 0) and of the shortcut's (which = 1)
+size_t clhip_wgrad7_ws_bytes(int N, int C, int K, int which) {
+    const int groups = C == 16 ? wgrad7_groups<16>(N) : wgrad7_groups<32>(N);
+    return (size_t)groups * K * (which == 0 ? 9 : 1) * C * sizeof(float);
+}
+
+int clhip_wgrad7_launch(const void* x, const void* dz, const void* dz_sc, float* dw, float* dw_sc, float* ws3, float* ws_sc, int N, int C, hipStream_t st) {
+    Wgrad7Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(dz_sc), ws3, ws_sc, N, 1};
+    const int K = 2 * C;
+    int groups;
+    if (C == 16) {
+        constexpr int lds = 34 * 34 * 32 + 2 * 256 * 64;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad7_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { clhip_set_error("wgrad7: cannot reserve %d bytes of LDS", lds); return CLHIP_EHIP; }
+            attr = true;
+        }
+        p.ipg = wgrad7_ipg<16>(N); groups = wgrad7_groups<16>(N);
+        hipLaunchKernelGGL(wgrad7_kernel<16>, dim3(groups), dim3(256), lds, st, p);
+    } else {
+        constexpr int lds = 18 * 18 * 64 + 2 * 64 * 128;
+        p.ipg = wgrad7_ipg<32>(N); groups = wgrad7_groups<32>(N);
+        hipLaunchKernelGGL(wgrad7_kernel<32>, dim3(groups), dim3(256), lds, st, p);
+    }
+    CLHIP_LAUNCH_CHECK();
+    if (int e = clhip_wgrad_reduce_launch(ws3, dw, (int64_t)K * 9 * C / 4, groups, st)) return e;
+    return clhip_wgrad_reduce_launch(ws_sc, dw_sc, (int64_t)K * C / 4, groups, st);
+}

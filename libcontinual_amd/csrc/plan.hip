@@ -55,6 +55,7 @@ struct Unit {
                                    // residual add and the ReLU on its operand load AND writes the activation + packed mask for the later readers
                                    // (clhip_conv_fwd_acc_bn_res_input): the training forward skips the apply launch
     int res_lazy_from;             // >= 0: this unit's input comes from such a unit
+    bool wpair;                    // ... and their two weight gradients are one launch too (clhip_conv_wgrad_pair, conv7.hip; set on both units)
     bool pair_acc;                 // the accumulate flag of that one launch (= the shortcut dgrad's, the first writer of the two)
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
     size_t a_fwd, a_bwd;                         // double offsets in the accumulator region ([rep][2][cout] each)
@@ -336,7 +337,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     }
     // down-sampling entries: a 3x3/s2/p1 unit a and a 1x1/s2/p0 unit b > a with the same source activation and channel counts, the only two
     // consumers of that activation -> their two input gradients are one launch at unit a (conv6.hip); the packed weights of both live at a.sh_pk
-    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; }
+    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; u.wpair = false; }
     const char* pair_cfg = clhip_cfg("CONV6_PAIR");             // (per plan: the tests build one with and one without)
     const bool pair_off = pair_cfg != nullptr && atoi(pair_cfg) == 0;
     for (int b = 0; b < n_units && !pair_off; ++b) {
@@ -356,6 +357,9 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         ua.pair = b; ub.pair = a;
         ua.pair_acc = ub.dx_acc;
         ua.sh_pk = p->shadow_bytes; p->shadow_bytes = align_up(p->shadow_bytes + clhip_conv_dgrad_pair_packed_bytes(ua.cin_pad, ua.d.cout));
+        // (own scratch regions per unit -- the deferred-reduce plans -- so that both partial-block slabs survive until the one reduce launch)
+        ua.wpair = ub.wpair = p->defer_reduce && ua.cin_pad == ua.d.cin && ub.cin_pad == ub.d.cin &&
+                              clhip_conv_wgrad_pair_supported(N, ua.H, ua.W, ua.cin_pad, ua.d.cout, dtype) != 0;
     }
     // lazy activations: unit a = conv -> BN -> ReLU whose activation has exactly one consumer b, a convolution that can apply the BatchNorm + ReLU
     // on its operand load (forward) and in its fused dgrad + weight-gradient launch (backward)
@@ -990,6 +994,13 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             if (prod) p->bwd_sums_ready[u.d.src - 1] = 1;
             continue;
         }
+        if (pair_b && u.wpair) {
+            // its weight gradient comes out of its 3x3 partner's launch (the next unit of this sweep)
+        } else if (pair_on && u.pair >= 0 && u.wpair && u.d.ksize == 3 && pair_dz != nullptr) {
+            const Unit& sc = p->units[u.pair];
+            TRY(clhip_conv_wgrad_pair(in, dz, pair_dz, grads + u.d.w_off, grads + sc.d.w_off, ws + u.wg_own, ws + sc.wg_own, p->N, u.H, u.W, u.cin_pad, u.d.cout,
+                                      p->dtype, wg_stream));
+        } else
         TRY(clhip_conv_wgrad(in, dz, grads + u.d.w_off, ws + u.wg_own, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, wg_stream));
         if (defer_side && on_side && ++side_deferred % p->defer_side == 0) TRY(clhip_wgrad_defer_flush(p->side, false));

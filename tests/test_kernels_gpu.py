@@ -1156,3 +1156,45 @@ def test_lazy_batchnorm_residual_input(shape):
     for k in ("rm", "rv", "mean", "invstd"):
         assert torch.equal(l[k], e[k]), k
     assert ((l["acc"].sum(0) - e["acc"].sum(0)).abs() <= 1e-12 * e["acc"].sum(0).abs().clamp(min=1.0)).all()
+
+
+@pytest.mark.parametrize("case", [(256, 32, 32, 16, 32), (256, 16, 16, 32, 64), (5, 32, 32, 16, 32), (3, 16, 16, 32, 64), (32, 32, 32, 16, 32), (130, 16, 16, 32, 64)])
+def test_stride2_wgrad_pair_one_launch(case):
+    """conv7.hip: the weight gradients of a down-sampling entry -- 3x3 / s2 / p1 and the 1x1 / s2 shortcut over the same block input -- in one
+    launch, against the fp64 reference and the two generic launches; accumulates into the gradients; bitwise reproducible (partial blocks per image
+    group + fixed-order reduce); image groups of one and of several images, a ragged last group."""
+    N, H, W, C, K = case
+    code, tdt = DT["bf16"]
+    L = _lib.lib()
+    assert L.clhip_conv_wgrad_pair_supported(N, H, W, C, K, code) == 1
+    Ho, Wo = H // 2, W // 2
+    x = quant(rnd((N, C, H, W), 11), tdt)
+    dz = quant(rnd((N, K, Ho, Wo), 12, 0.5), tdt)
+    dzs = quant(rnd((N, K, Ho, Wo), 13, 0.5), tdt)
+    w3 = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    w1 = torch.zeros(K, C, 1, 1, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w3, None, 2, 1).backward(dz.double())
+    F.conv2d(x.double(), w1, None, 2, 0).backward(dzs.double())
+    ref3 = w3.grad.permute(0, 2, 3, 1).reshape(K, 9, C)
+    ref1 = w1.grad.permute(0, 2, 3, 1).reshape(K, 1, C)
+    xd, dzd, dzsd = to_nhwc(x, tdt), to_nhwc(dz, tdt), to_nhwc(dzs, tdt)
+    ws3 = torch.empty(L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 3, 2, 1, code), dtype=torch.uint8, device=DEV)
+    ws1 = torch.empty(L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 1, 2, 0, code), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw3 = torch.full((K, 9, C), 0.25, device=DEV)
+        dw1 = torch.full((K, 1, C), -0.5, device=DEV)
+        ws3.fill_(0x7f); ws1.fill_(0x7f)
+        call("clhip_conv_wgrad_pair", xd.data_ptr(), dzd.data_ptr(), dzsd.data_ptr(), dw3.data_ptr(), dw1.data_ptr(), ws3.data_ptr(), ws1.data_ptr(), N, H, W, C, K, code, st())
+        torch.cuda.synchronize()
+        outs.append((dw3, dw1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert ((outs[0][0].cpu().double() - 0.25) - ref3).abs().max() <= 2e-3 * ref3.abs().max() + 1e-3
+    assert ((outs[0][1].cpu().double() + 0.5) - ref1).abs().max() <= 2e-3 * ref1.abs().max() + 1e-3
+    # the two generic launches it replaces
+    g3 = torch.full((K, 9, C), 0.25, device=DEV)
+    g1 = torch.full((K, 1, C), -0.5, device=DEV)
+    call("clhip_conv_wgrad", xd.data_ptr(), dzd.data_ptr(), g3.data_ptr(), ws3.data_ptr(), N, H, W, C, C, K, 3, 2, 1, code, st())
+    call("clhip_conv_wgrad", xd.data_ptr(), dzsd.data_ptr(), g1.data_ptr(), ws1.data_ptr(), N, H, W, C, C, K, 1, 2, 0, code, st())
+    torch.cuda.synchronize()
+    assert (outs[0][0] - g3).abs().max() <= 1e-3 * ref3.abs().max() + 1e-3 and (outs[0][1] - g1).abs().max() <= 1e-3 * ref1.abs().max() + 1e-3
