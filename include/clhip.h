@@ -398,6 +398,12 @@ int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_s
  * the 3x3 / the 1x1 layer (partial blocks per image group, summed in a fixed order: bitwise reproducible).  bf16; CifarResNet-32's two
  * entries (32 x 32 x 16 -> 32 channels, 16 x 16 x 32 -> 64).  _supported: 1 / 0. */
 int clhip_conv_wgrad_pair_supported(int N, int H, int W, int C, int K, int dtype);
+/* ... and their two FORWARD convolutions in one launch: z [N,H/2,W/2,K] = conv3x3/s2/p1(x, w_fwd [K][9][C]), z_sc = conv1x1/s2(x, w_sc_fwd [K][1][C]),
+ * each with its BatchNorm statistics added into its own fp64 accumulators exactly as clhip_conv_fwd_acc does.  Same domain as the small-channel
+ * clhip_conv_dgrad_pair (C in {16, 32}, K = 2 C). */
+int clhip_conv_fwd_acc_pair_supported(int N, int H, int W, int C, int K, int dtype);
+int clhip_conv_fwd_acc_pair(const void* x, const void* w_fwd, const void* w_sc_fwd, void* z, void* z_sc, double* stat_acc, int replicas,
+                            double* stat_acc_sc, int replicas_sc, int N, int H, int W, int C, int K, int dtype, void* stream);
 int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, float* dw, float* dw_sc, void* ws, void* ws_sc, int N, int H, int W,
                           int C, int K, int dtype, void* stream);
 

@@ -781,6 +781,24 @@ size_t clhip_wgrad7_ws_bytes(int N, int C, int K, int which);
 int clhip_wgrad7_launch(const void* x, const void* dz, const void* dz_sc, float* dw, float* dw_sc, float* ws3, float* ws_sc, int N, int C, hipStream_t st);
 static size_t wgrad_ws_bytes_single(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 
+bool clhip_fwd7_supported(int N, int H, int W, int C, int K, int dtype);
+int clhip_fwd7_launch(const void* x, const void* w3, const void* wsc, void* z3, void* zsc, double* acc3, int rep3, double* accsc, int repsc, int N, int H, int W, int C,
+                      hipStream_t st);
+
+// ... and their two FORWARD convolutions with the BatchNorm statistics of both (clhip_conv_fwd_acc twice) from one pass over x
+extern "C" int clhip_conv_fwd_acc_pair_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || use_v1() || !use_v3()) return 0;
+    return clhip_fwd7_supported(N, H, W, C, K, dtype) ? 1 : 0;
+}
+
+extern "C" int clhip_conv_fwd_acc_pair(const void* x, const void* w_fwd, const void* w_sc_fwd, void* z, void* z_sc, double* stat_acc, int replicas, double* stat_acc_sc,
+                                       int replicas_sc, int N, int H, int W, int C, int K, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(x && w_fwd && w_sc_fwd && z && z_sc && stat_acc && stat_acc_sc);
+    CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0 && replicas_sc >= 1 && replicas_sc <= 64 && (replicas_sc & (replicas_sc - 1)) == 0);
+    CLHIP_CHECK_ARG(clhip_conv_fwd_acc_pair_supported(N, H, W, C, K, dtype));
+    return clhip_fwd7_launch(x, w_fwd, w_sc_fwd, z, z_sc, stat_acc, replicas, stat_acc_sc, replicas_sc, N, H, W, C, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int clhip_conv_wgrad_pair_supported(int N, int H, int W, int C, int K, int dtype) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || use_v1() || !use_v3()) return 0;
     return clhip_wgrad7_supported(N, H, W, C, K, dtype) ? 1 : 0;

@@ -293,3 +293,134 @@ int clhip_wgrad7_launch(const void* x, const void* dz, const void* dz_sc, float*
     if (int e = clhip_wgrad_reduce_launch(ws3, dw, (int64_t)K * 9 * C / 4, groups, st)) return e;
     return clhip_wgrad_reduce_launch(ws_sc, dw_sc, (int64_t)K * C / 4, groups, st);
 }
+
+// =========================================================================================================================================
+// The FORWARD of the same two layers in one launch: z3 = conv3x3/s2/p1(x, W3), zsc = conv1x1/s2(x, Wsc), both with their BatchNorm statistics
+// (sum z, sum z^2 of the fp32 accumulators into the fp64 accumulators), from one pass over the block input.  Generic kernel: 9.6 + 5.9 us
+// (16 -> 32) and 7.9 + 4.6 us (32 -> 64) at batch 256.  dgrad7's scheme: no LDS -- a 16-pixel output tile, the weight fragments of two
+// 16-channel output tiles x ten taps in registers, the input fragments 16-byte global loads (16 channels: two taps per 32-deep MFMA K step, as in
+// conv16; 32 channels: one tap per step); out-of-image taps are zero fragments; the shortcut reads tap (1, 1)'s pixel.
+namespace {
+
+struct Fwd7Params {
+    const bf16_t* x; const bf16_t* w3; const bf16_t* wsc; bf16_t* z3; bf16_t* zsc;
+    double* acc3; double* accsc; int rep3, repsc;
+    int Ho, Wo, lgHo, lgWo, Mq, ntiles, tpw;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void fwd7_kernel(const Fwd7Params p) {
+    constexpr int K = 2 * C, NS = C == 16 ? 5 : 9;          // K steps of the 3x3 layer (16 channels: tap pairs)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int k0 = blockIdx.y * 32;                          // this wave's two 16-channel output tiles
+    const int cb = C == 16 ? (fg & 1) * 8 : fg * 8;          // the 8 input channels this lane feeds
+    const int tsel = fg >> 1;                                // 16 channels: which tap of the pair
+
+    uint4 w[2][NS], ws[2];
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + j * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tap = C == 16 ? 2 * s + tsel : s;
+            w[j][s] = tap < 9 ? *reinterpret_cast<const uint4*>(p.w3 + ((size_t)k * 9 + tap) * C + cb) : zero;
+        }
+        ws[j] = (C == 32 || tsel == 0) ? *reinterpret_cast<const uint4*>(p.wsc + (size_t)k * C + cb) : zero;
+    }
+    const int Wo = p.Wo, Ho = p.Ho, W = 2 * Wo, H = 2 * Ho;
+    float s1[2][2][4], s2[2][2][4];                          // [layer][tile][channel fg*4+e]
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[l][j][e] = s2[l][j][e] = 0.f;
+
+    const int t0 = (blockIdx.x * 4 + wave) * p.tpw;
+    for (int i = 0; i < p.tpw; ++i) {
+        const int tile = t0 + i;
+        if (tile >= p.ntiles) break;
+        const int q = tile * 16 + fr;
+        const bool qv = q < p.Mq;
+        const int wo = q & (Wo - 1), ho = (q >> p.lgWo) & (Ho - 1), n = q >> (p.lgWo + p.lgHo);
+        const bf16_t* xi = p.x + (size_t)n * H * W * C + cb;
+        uint4 xf[NS], xc;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tap = C == 16 ? 2 * s + tsel : s;
+            const int r = tap / 3, sx = tap - 3 * r;
+            const int hi = 2 * ho - 1 + r, wi = 2 * wo - 1 + sx;
+            const bool ok = qv && tap < 9 && hi >= 0 && wi >= 0 && hi < H && wi < W;
+            xf[s] = ok ? *reinterpret_cast<const uint4*>(xi + ((size_t)hi * W + wi) * C) : zero;
+        }
+        xc = (qv && (C == 32 || tsel == 0)) ? *reinterpret_cast<const uint4*>(xi + ((size_t)(2 * ho) * W + 2 * wo) * C) : zero;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 a3 = f32x4{0.f, 0.f, 0.f, 0.f}, as = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[j][s]), __builtin_bit_cast(bf16x8_t, xf[s]), a3, 0, 0, 0);
+            as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ws[j]), __builtin_bit_cast(bf16x8_t, xc), as, 0, 0, 0);
+            // D[row = output channel k0 + j * 16 + fg * 4 + e][col = pixel fr]
+            if (qv) {
+                const size_t at = (size_t)q * K + k0 + j * 16 + fg * 4;
+                *reinterpret_cast<uint2*>(p.z3 + at) = make_uint2(pack_bf16x2(a3[0], a3[1]), pack_bf16x2(a3[2], a3[3]));
+                *reinterpret_cast<uint2*>(p.zsc + at) = make_uint2(pack_bf16x2(as[0], as[1]), pack_bf16x2(as[2], as[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[0][j][e] += a3[e]; s2[0][j][e] = fmaf(a3[e], a3[e], s2[0][j][e]);
+                    s1[1][j][e] += as[e]; s2[1][j][e] = fmaf(as[e], as[e], s2[1][j][e]);
+                }
+            }
+        }
+    }
+    // per-channel sums over the wave's pixels (16-lane DPP sums), the four waves through LDS, then ONE fp64 atomic per channel and sum per workgroup
+    // (replica by workgroup, as the other kernels; a wave-level atomic each was 26 us of contention on the 16 -> 32 layer)
+    __shared__ float red[4][2][2][4][8];                     // [wave][layer][tile][fg][sum e, sum-of-squares e]
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float sv[8] = {s1[l][j][0], s1[l][j][1], s1[l][j][2], s1[l][j][3], s2[l][j][0], s2[l][j][1], s2[l][j][2], s2[l][j][3]};
+            row16_sum_n(sv);
+            if (fr == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[wave][l][j][fg][e] = sv[e];
+            }
+        }
+    __syncthreads();
+    if (tid < 128) {
+        const int e = tid & 7, g = (tid >> 3) & 3, j = (tid >> 5) & 1, l = tid >> 6;
+        const float v = red[0][l][j][g][e] + red[1][l][j][g][e] + red[2][l][j][g][e] + red[3][l][j][g][e];
+        double* base = l == 0 ? p.acc3 + (size_t)(blockIdx.x & (p.rep3 - 1)) * 2 * K : p.accsc + (size_t)(blockIdx.x & (p.repsc - 1)) * 2 * K;
+        const int k = k0 + j * 16 + g * 4 + (e & 3);
+        atomicAdd(base + (e >> 2) * K + k, (double)v);
+    }
+}
+
+}  // namespace
+
+bool clhip_fwd7_supported(int N, int H, int W, int C, int K, int dtype) {
+    static const bool foff = clhip_cfg("FWD7") != nullptr && atoi(clhip_cfg("FWD7")) == 0;
+    return !foff && clhip_dgrad7_supported(N, H, W, C, K, dtype);
+}
+
+int clhip_fwd7_launch(const void* x, const void* w3, const void* wsc, void* z3, void* zsc, double* acc3, int rep3, double* accsc, int repsc, int N, int H, int W, int C,
+                      hipStream_t st) {
+    Fwd7Params p;
+    p.x = static_cast<const bf16_t*>(x); p.w3 = static_cast<const bf16_t*>(w3); p.wsc = static_cast<const bf16_t*>(wsc);
+    p.z3 = static_cast<bf16_t*>(z3); p.zsc = static_cast<bf16_t*>(zsc); p.acc3 = acc3; p.accsc = accsc; p.rep3 = rep3 > 0 ? rep3 : 1; p.repsc = repsc > 0 ? repsc : 1;
+    p.Ho = H / 2; p.Wo = W / 2; p.lgHo = ilog2_7(p.Ho); p.lgWo = ilog2_7(p.Wo);
+    p.Mq = N * p.Ho * p.Wo; p.ntiles = (p.Mq + 15) / 16;
+    const int ny = 2 * C / 32;
+    int tpw = 4;
+    while (tpw > 1 && (p.ntiles / tpw / 4) * ny < 256) tpw >>= 1;
+    p.tpw = tpw;
+    const int waves = (p.ntiles + tpw - 1) / tpw;
+    if (C == 16) hipLaunchKernelGGL(fwd7_kernel<16>, dim3((waves + 3) / 4, ny), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(fwd7_kernel<32>, dim3((waves + 3) / 4, ny), dim3(256), 0, st, p);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}

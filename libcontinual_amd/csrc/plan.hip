@@ -55,6 +55,7 @@ struct Unit {
                                    // residual add and the ReLU on its operand load AND writes the activation + packed mask for the later readers
                                    // (clhip_conv_fwd_acc_bn_res_input): the training forward skips the apply launch
     int res_lazy_from;             // >= 0: this unit's input comes from such a unit
+    bool fpair;                    // ... their two forward convolutions are one launch (clhip_conv_fwd_acc_pair, conv7.hip; set on both units)
     bool wpair;                    // ... and their two weight gradients are one launch too (clhip_conv_wgrad_pair, conv7.hip; set on both units)
     bool pair_acc;                 // the accumulate flag of that one launch (= the shortcut dgrad's, the first writer of the two)
     size_t f_mean, f_invstd, f_scale, f_shift;   // float offsets in the fp32 region
@@ -337,7 +338,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     }
     // down-sampling entries: a 3x3/s2/p1 unit a and a 1x1/s2/p0 unit b > a with the same source activation and channel counts, the only two
     // consumers of that activation -> their two input gradients are one launch at unit a (conv6.hip); the packed weights of both live at a.sh_pk
-    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; u.wpair = false; }
+    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; u.wpair = u.fpair = false; }
     const char* pair_cfg = clhip_cfg("CONV6_PAIR");             // (per plan: the tests build one with and one without)
     const bool pair_off = pair_cfg != nullptr && atoi(pair_cfg) == 0;
     for (int b = 0; b < n_units && !pair_off; ++b) {
@@ -358,6 +359,8 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         ua.pair_acc = ub.dx_acc;
         ua.sh_pk = p->shadow_bytes; p->shadow_bytes = align_up(p->shadow_bytes + clhip_conv_dgrad_pair_packed_bytes(ua.cin_pad, ua.d.cout));
         // (own scratch regions per unit -- the deferred-reduce plans -- so that both partial-block slabs survive until the one reduce launch)
+        ua.fpair = ub.fpair = ua.rep_fwd > 0 && ub.rep_fwd > 0 && ua.cin_pad == ua.d.cin &&
+                              clhip_conv_fwd_acc_pair_supported(N, ua.H, ua.W, ua.cin_pad, ua.d.cout, dtype) != 0;
         ua.wpair = ub.wpair = p->defer_reduce && ua.cin_pad == ua.d.cin && ub.cin_pad == ub.d.cin &&
                               clhip_conv_wgrad_pair_supported(N, ua.H, ua.W, ua.cin_pad, ua.d.cout, dtype) != 0;
     }
@@ -661,6 +664,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const char* rlazy_cfg = clhip_cfg("BN_RES_INPUT");
     const bool rlazy_on = lazy_on && !(rlazy_cfg != nullptr && atoi(rlazy_cfg) == 0);
     for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = 0;
+    int fwd_pair_done = -1;                                  // the 3x3/s2 unit whose launch also ran its shortcut partner's convolution
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
@@ -703,6 +707,13 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 TRY(clhip_conv_fwd_acc_bn_res_input(ws + a.z_off, &bi, &rs, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad,
                                                     u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, us));
                 p->res_pending[u.res_lazy_from] = 0;
+            } else if (u.fpair && u.d.ksize == 1 && fwd_pair_done == u.pair) {
+                // z and the statistics of this shortcut came out of its 3x3 partner's launch
+            } else if (u.fpair && u.d.ksize == 3 && !br_on && !on_br && !u.raw_src) {
+                const Unit& sc = p->units[u.pair];
+                TRY(clhip_conv_fwd_acc_pair(in, sh + u.sh_fwd, sh + sc.sh_fwd, ws + u.z_off, ws + sc.z_off, acc + u.a_fwd, u.rep_fwd, acc + sc.a_fwd, sc.rep_fwd, p->N, u.H,
+                                            u.W, u.cin_pad, u.d.cout, p->dtype, us));
+                fwd_pair_done = (int)i;
             } else if (u.lazy_from >= 0 && p->lazy_live[u.lazy_from]) {
                 // the producer's BatchNorm + ReLU happen on this convolution's operand load: scale / shift, the saved statistics and the running
                 // statistics of the producer are this launch's by-products

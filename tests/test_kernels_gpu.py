@@ -1198,3 +1198,44 @@ def test_stride2_wgrad_pair_one_launch(case):
     call("clhip_conv_wgrad", xd.data_ptr(), dzsd.data_ptr(), g1.data_ptr(), ws1.data_ptr(), N, H, W, C, C, K, 1, 2, 0, code, st())
     torch.cuda.synchronize()
     assert (outs[0][0] - g3).abs().max() <= 1e-3 * ref3.abs().max() + 1e-3 and (outs[0][1] - g1).abs().max() <= 1e-3 * ref1.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("case", [(256, 32, 32, 16, 32), (256, 16, 16, 32, 64), (5, 32, 32, 16, 32), (3, 16, 16, 32, 64), (1, 4, 8, 16, 32), (7, 8, 4, 32, 64)])
+def test_stride2_forward_pair_one_launch(case):
+    """conv7.hip: the forward of a down-sampling entry -- 3x3 / s2 / p1 and the 1x1 / s2 shortcut over the same block input, each with its BatchNorm
+    sums -- in one launch, against the fp64 convolutions (outputs and the sums of the unrounded outputs) and against the two generic launches."""
+    N, H, W, C, K = case
+    code, tdt = DT["bf16"]
+    L = _lib.lib()
+    assert L.clhip_conv_fwd_acc_pair_supported(N, H, W, C, K, code) == 1
+    Ho, Wo = H // 2, W // 2
+    x = quant(rnd((N, C, H, W), 21), tdt)
+    w3 = quant(rnd((K, C, 3, 3), 22, 1.0 / (C * 9) ** 0.5), tdt)
+    w1 = quant(rnd((K, C, 1, 1), 23, 1.0 / C ** 0.5), tdt)
+    r3 = F.conv2d(x.double(), w3.double(), None, 2, 1)
+    r1 = F.conv2d(x.double(), w1.double(), None, 2, 0)
+    xd = to_nhwc(x, tdt)
+    w3d = w3.permute(0, 2, 3, 1).contiguous().to(tdt).to(DEV)          # [K][9][C]
+    w1d = w1.permute(0, 2, 3, 1).contiguous().to(tdt).to(DEV)
+    z3 = torch.full((N * Ho * Wo + 1, K), 7.0, dtype=tdt, device=DEV)
+    z1 = torch.full((N * Ho * Wo + 1, K), 7.0, dtype=tdt, device=DEV)
+    a3 = torch.zeros(8, 2, K, dtype=torch.float64, device=DEV)
+    a1 = torch.zeros(4, 2, K, dtype=torch.float64, device=DEV)
+    call("clhip_conv_fwd_acc_pair", xd.data_ptr(), w3d.data_ptr(), w1d.data_ptr(), z3.data_ptr(), z1.data_ptr(), a3.data_ptr(), 8, a1.data_ptr(), 4, N, H, W, C, K, code, st())
+    torch.cuda.synchronize()
+    M_ = N * Ho * Wo
+    for z, r, a in ((z3, r3, a3), (z1, r1, a1)):
+        got = z[:M_].reshape(N, Ho, Wo, K).permute(0, 3, 1, 2).cpu().double()
+        assert (got - r).abs().max() <= tol("bf16", r)
+        assert float((z[M_].float() - 7.0).abs().max()) == 0.0
+        s = a.sum(0).cpu()
+        rs, rq = r.sum((0, 2, 3)), (r * r).sum((0, 2, 3))
+        assert (s[0] - rs).abs().max() <= 1e-4 * r.abs().sum((0, 2, 3)).max() + 1e-6
+        assert (s[1] - rq).abs().max() <= 1e-4 * rq.max() + 1e-6
+    g3 = torch.empty(M_, K, dtype=tdt, device=DEV)
+    g1 = torch.empty(M_, K, dtype=tdt, device=DEV)
+    b3, b1 = torch.zeros_like(a3), torch.zeros_like(a1)
+    call("clhip_conv_fwd_acc", xd.data_ptr(), w3d.data_ptr(), g3.data_ptr(), b3.data_ptr(), 8, N, H, W, C, K, 3, 2, 1, code, st())
+    call("clhip_conv_fwd_acc", xd.data_ptr(), w1d.data_ptr(), g1.data_ptr(), b1.data_ptr(), 4, N, H, W, C, K, 1, 2, 0, code, st())
+    torch.cuda.synchronize()
+    assert (z3[:M_].float() - g3.float()).abs().max() <= 2 ** -7 * float(r3.abs().max()) and (z1[:M_].float() - g1.float()).abs().max() <= 2 ** -7 * float(r1.abs().max())
