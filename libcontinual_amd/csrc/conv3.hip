@@ -1692,21 +1692,24 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(Wgrad32Params p) {
 // multiplied.  Partial blocks per group + the fixed-order reduce: bitwise reproducible.
 struct Wgrad64Params { const bf16_t* x; const bf16_t* dz; float* slab; int N, H, img_per_group; const float* x_coef = nullptr; LazyDz lz; };
 
-template <bool LZ = false>
+constexpr int WG64_IPI = 2;      // (default; WGRAD64_IPI2=1 keeps one) images staged and multiplied per barrier pair: an image is two K steps (18 MFMAs per wave) -- the per-image cost was the two barriers and the
+                                 // LDS round trip, eight times in a row per workgroup at batch 256
+template <bool LZ = false, int IPI = WG64_IPI>
 __device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int ot, const int grp, char* smem) {
     constexpr int W = 8, PW = 10, PX = 144, PZ = 32, C = 64;  // image width, padded width, bytes per staged input pixel (128 + pad), per gradient pixel (this tile's 16 channels)
     const int H = p.H, HW = H * W;
-    char* xs = smem;                                          // (H + 2) x 10 pixels
-    char* zs = smem + (H + 2) * PW * PX;                      // H x 8 pixels
+    const int xsz = (H + 2) * PW * PX, zsz = HW * PZ;
+    char* xs = smem;                                          // IPI x (H + 2) x 10 pixels
+    char* zs = smem + IPI * xsz;                              // IPI x H x 8 pixels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int it = wave;                                      // in-channel tile
     const int n_beg = grp * p.img_per_group, n_end = min(p.N, n_beg + p.img_per_group);
-    for (int i = tid; i < (H + 2) * PW * 9; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < IPI * xsz / 16; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     const int nx = HW * 8, nz = HW * 2;                       // 16-byte chunks per image: input (8 per pixel), gradient slice (2 per pixel)
     constexpr int NXI = 4;                                    // input chunks per thread (H <= 16)
-    uint4 rx[NXI], rz, ry;
-    unsigned rm = 0u;
+    uint4 rx[IPI][NXI], rz[IPI], ry[IPI];
+    unsigned rm[IPI];
     constexpr bool lzd = LZ;
     LazyDz8 lt;
     if constexpr (lzd) {                                      // gradient chunk q = tid covers channels ot * 16 + (tid & 1) * 8
@@ -1721,36 +1724,45 @@ __device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int o
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xsc[e] = p.x_coef[(tid & 7) * 8 + e]; xsh[e] = p.x_coef[C + (tid & 7) * 8 + e]; }
     }
-    auto gload = [&](int n) {
-        const size_t base = (size_t)n * HW;
+    auto gload = [&](int n0) {
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int q = tid + 256 * i;
-            rx[i] = q < nx ? *reinterpret_cast<const uint4*>(p.x + (base + (q >> 3)) * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
-        }
-        const int q = tid;
-        if constexpr (lzd) {
-            rz = q < nz ? *reinterpret_cast<const uint4*>(p.lz.dy + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
-            ry = q < nz ? *reinterpret_cast<const uint4*>(p.lz.z + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
-            rm = (q < nz && p.lz.mask != nullptr) ? p.lz.mask[(base + (q >> 1)) * 8 + ot * 2 + (q & 1)] : 0u;
-        } else {
-            rz = q < nz ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto sstore = [&]() {
+        for (int j = 0; j < IPI; ++j) {
+            const bool iv = n0 + j < n_end;
+            const size_t base = (size_t)(iv ? n0 + j : n0) * HW;
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int q = tid + 256 * i;
-            if (q < nx) {
-                const int px = q >> 3;
-                *reinterpret_cast<uint4*>(xs + ((px / W + 1) * PW + (px % W) + 1) * PX + (q & 7) * 16) = p.x_coef != nullptr ? bn_relu8_bf16(rx[i], xsc, xsh) : rx[i];
+            for (int i = 0; i < NXI; ++i) {
+                const int q = tid + 256 * i;
+                rx[j][i] = (iv && q < nx) ? *reinterpret_cast<const uint4*>(p.x + (base + (q >> 3)) * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
+            }
+            const int q = tid;
+            rm[j] = 0u;
+            if constexpr (lzd) {
+                rz[j] = (iv && q < nz) ? *reinterpret_cast<const uint4*>(p.lz.dy + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+                ry[j] = (iv && q < nz) ? *reinterpret_cast<const uint4*>(p.lz.z + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
+                rm[j] = (iv && q < nz && p.lz.mask != nullptr) ? p.lz.mask[(base + (q >> 1)) * 8 + ot * 2 + (q & 1)] : 0u;
+            } else {
+                rz[j] = (iv && q < nz) ? *reinterpret_cast<const uint4*>(p.dz + (base + (q >> 1)) * C + ot * 16 + (q & 1) * 8) : make_uint4(0, 0, 0, 0);
             }
         }
-        const int q = tid;
-        if (q < nz) {
-            uint4 v = rz;
-            if constexpr (lzd) v = lazy_dz8(rz, ry, lt, p.lz.mask != nullptr, rm);
-            *reinterpret_cast<uint4*>(zs + (q >> 1) * PZ + (q & 1) * 16) = v;
+    };
+    auto sstore = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < IPI; ++j) {
+            if (n0 + j >= n_end) break;                       // (its K steps are skipped as well)
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) {
+                const int q = tid + 256 * i;
+                if (q < nx) {
+                    const int px = q >> 3;
+                    *reinterpret_cast<uint4*>(xs + j * xsz + ((px / W + 1) * PW + (px % W) + 1) * PX + (q & 7) * 16) = p.x_coef != nullptr ? bn_relu8_bf16(rx[j][i], xsc, xsh) : rx[j][i];
+                }
+            }
+            const int q = tid;
+            if (q < nz) {
+                uint4 v = rz[j];
+                if constexpr (lzd) v = lazy_dz8(rz[j], ry[j], lt, p.lz.mask != nullptr, rm[j]);
+                *reinterpret_cast<uint4*>(zs + j * zsz + (q >> 1) * PZ + (q & 1) * 16) = v;
+            }
         }
     };
     f32x4 acc[9];
@@ -1760,19 +1772,23 @@ __device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int o
     // 8-byte segment fr & 3 of the 16-channel tile
     const int prow = fg, pcol = fr >> 2, seg = (fr & 3) * 8;
     if (n_beg < n_end) gload(n_beg);
-    for (int n = n_beg; n < n_end; ++n) {
+    for (int n = n_beg; n < n_end; n += IPI) {
         __syncthreads();
-        sstore();
+        sstore(n);
         __syncthreads();
-        if (n + 1 < n_end) gload(n + 1);
-        for (int h0 = 0; h0 < H; h0 += 4) {
-            const uint4 zf = tr8(zs, ((h0 + prow) * W + pcol) * PZ + seg, 4 * PZ);
-            const int xb = ((h0 + prow) * PW + pcol) * PX + it * 32 + seg;       // padded coordinates: tap (r, s) adds r rows, s columns
+        if (n + IPI < n_end) gload(n + IPI);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, sx = t - 3 * r;
-                const uint4 xf = tr8(xs, xb + (r * PW + sx) * PX, 4 * PX);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[t], 0, 0, 0);
+        for (int j = 0; j < IPI; ++j) {
+            if (n + j >= n_end) break;
+            for (int h0 = 0; h0 < H; h0 += 4) {
+                const uint4 zf = tr8(zs + j * zsz, ((h0 + prow) * W + pcol) * PZ + seg, 4 * PZ);
+                const int xb = ((h0 + prow) * PW + pcol) * PX + it * 32 + seg;       // padded coordinates: tap (r, s) adds r rows, s columns
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int r = t / 3, sx = t - 3 * r;
+                    const uint4 xf = tr8(xs + j * xsz, xb + (r * PW + sx) * PX, 4 * PX);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -1783,9 +1799,10 @@ __device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int o
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[((ot * 16 + fg * 4 + e) * 9 + t) * C + it * 16 + fr] = acc[t][e];
 }
+template <int IPI>
 __global__ __launch_bounds__(256) void wgrad64_kernel(Wgrad64Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    wgrad64_body(p, blockIdx.x, blockIdx.y, smem);
+    wgrad64_body<false, IPI>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 int wgrad32_ipg(int N) {
@@ -1821,6 +1838,7 @@ bool clhip_wgrad64_supported(int N, int H, int W, int C, int Creal, int K, int k
     return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && C == 64 && Creal == 64 && K == 64 && W == 8 && H >= 4 && H <= 16 && (H & 3) == 0 && N >= 1;
 }
 
+static bool wgrad64_pair_images() { static const bool one = clhip_cfg("WGRAD64_IPI2") != nullptr && atoi(clhip_cfg("WGRAD64_IPI2")) == 1; return !one; }
 static int wgrad64_ipg(int N) {
     static const int forced = clhip_cfg("WGRAD64_IPG") ? atoi(clhip_cfg("WGRAD64_IPG")) : 0;
     if (forced > 0) return forced < N ? forced : N;
@@ -1835,8 +1853,9 @@ size_t clhip_wgrad64_ws_bytes(int N) { return (size_t)wgrad64_groups(N) * 36864 
 int clhip_wgrad64_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, const float* x_coef, hipStream_t st) {
     const int groups = wgrad64_groups(N);
     Wgrad64Params p{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad64_ipg(N), x_coef};
-    const size_t lds = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
-    hipLaunchKernelGGL(wgrad64_kernel, dim3(4, groups), dim3(256), lds, st, p);
+    const size_t lds = WG64_IPI * ((size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32) + 2048;
+    if (wgrad64_pair_images()) hipLaunchKernelGGL(wgrad64_kernel<WG64_IPI>, dim3(4, groups), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(wgrad64_kernel<1>, dim3(4, groups), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
     return clhip_wgrad_reduce_launch(ws, dw, 9216, groups, st);
 }
@@ -1927,10 +1946,10 @@ __global__ __launch_bounds__(256) void bwd32_fused_kernel(Conv3Params pd, Wgrad3
 }
 }  // namespace
 
-template <bool LZ>
+template <bool LZ, int IPI = WG64_IPI>
 __global__ __launch_bounds__(256) void bwd64_fused_kernel(Conv3Params pd, Wgrad64Params pw, int nw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nw) wgrad64_body<LZ>(pw, blockIdx.x & 3, blockIdx.x >> 2, smem);
+    if ((int)blockIdx.x < nw) wgrad64_body<LZ, IPI>(pw, blockIdx.x & 3, blockIdx.x >> 2, smem);
     else conv64_body<1, LZ>(pd, (int)blockIdx.x - nw, smem);
 }
 
@@ -1965,10 +1984,13 @@ int clhip_bwd_fused_launch(const void* x, const void* dz, const void* w_dg, void
         const int nd64 = (pd.M + 63) / 64, groups = wgrad64_groups(N);
         Wgrad64Params pw{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(dz), ws, N, H, wgrad64_ipg(N), x_coef, lzd};
         size_t lds64 = (size_t)pd.patch_bytes + 2048;
-        const size_t wl = (size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32 + 2048;
+        const size_t wl = WG64_IPI * ((size_t)(H + 2) * 10 * 144 + (size_t)H * 8 * 32) + 2048;
         if (wl > lds64) lds64 = wl;
-        if (lz != nullptr) hipLaunchKernelGGL(bwd64_fused_kernel<true>, dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
-        else hipLaunchKernelGGL(bwd64_fused_kernel<false>, dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
+        if (!wgrad64_pair_images()) {
+            if (lz != nullptr) hipLaunchKernelGGL((bwd64_fused_kernel<true, 1>), dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
+            else hipLaunchKernelGGL((bwd64_fused_kernel<false, 1>), dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
+        } else if (lz != nullptr) hipLaunchKernelGGL((bwd64_fused_kernel<true>), dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
+        else hipLaunchKernelGGL((bwd64_fused_kernel<false>), dim3(4 * groups + nd64), dim3(256), lds64, st, pd, pw, 4 * groups);
         CLHIP_LAUNCH_CHECK();
         return clhip_wgrad_reduce_launch(ws, dw, 9216, groups, st);
     }
