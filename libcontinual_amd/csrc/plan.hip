@@ -655,7 +655,10 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     // alternating runs each on one box, ms per step): off 2.157 / 2.153, forward only 2.148 / 2.144, both 2.160 / 2.163, backward only 2.197 /
     // 2.205 -- in the backward the chip is already shared with the weight-gradient stream and a third stream only adds contention and
     // barrier packets; in the forward nothing else runs beside the chain (profiles/r03_step_notes.md)
-    static const int br_mode_f = clhip_cfg("BRANCH_STREAM") ? atoi(clhip_cfg("BRANCH_STREAM")) : 2;
+    // (looked up per call: a caller that runs a second network beside this one -- ops.TeacherPass: the frozen teacher on a stream of its own -- switches
+    //  the branch streams of both off for that step; five streams on four hardware queues made the LwF ResNet-18 task >= 1 step 6.36 ms instead of 2.70)
+    const char* br_cfg_f = clhip_cfg("BRANCH_STREAM");
+    const int br_mode_f = br_cfg_f ? atoi(br_cfg_f) : 2;
     const bool br_on = use_acc && (br_mode_f == 1 || br_mode_f == 2) && branch_stream_on(p, (hipStream_t)stream);
     struct FwdStopGuard { ~FwdStopGuard() { clhip_bn_set_fwd_stop_event(nullptr); } } fwd_stop_guard;
     const char* lazy_cfg = clhip_cfg("BN_INPUT");            // (looked up per call: the tests flip it between two models of one process)
@@ -820,7 +823,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     struct DeferGuard { bool on; ~DeferGuard() { if (on) clhip_wgrad_defer_abort(); } } defer_guard{p->defer_reduce || defer_side};
     if (p->defer_reduce || defer_side) clhip_wgrad_defer_begin();
     int side_deferred = 0;
-    static const int br_mode_b = clhip_cfg("BRANCH_STREAM") ? atoi(clhip_cfg("BRANCH_STREAM")) : 2;
+    const char* br_cfg_b = clhip_cfg("BRANCH_STREAM");
+    const int br_mode_b = br_cfg_b ? atoi(br_cfg_b) : 2;
     const bool br_on = two_streams && (br_mode_b == 1 || br_mode_b == 3) && branch_stream_on(p, main_s);
     bool br_used = false;
     p->br_act = -1;

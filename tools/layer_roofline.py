@@ -88,6 +88,34 @@ def pair_row(tag, N, H, W, C, K):
         (dz.numel() + dzs.numel() + dx.numel()) * 2 + pk.numel())
 
 
+def entry_rows(tag, N, H, W, C, K):
+    """the step's three launches for a FEW-channel down-sampling entry (conv7.hip): forward pair, input-gradient pair, weight-gradient pair"""
+    Ho, Wo = H // 2, W // 2
+    x = torch.randn(N, H, W, C, device=dev).to(tdt)
+    w3f = (torch.randn(K, 9, C, device=dev) * 0.05).to(tdt)
+    w1f = (torch.randn(K, 1, C, device=dev) * 0.05).to(tdt)
+    z3 = torch.empty(N, Ho, Wo, K, device=dev, dtype=tdt)
+    z1 = torch.empty_like(z3)
+    a3 = torch.zeros(8, 2, K, dtype=torch.float64, device=dev)
+    a1 = torch.zeros(8, 2, K, dtype=torch.float64, device=dev)
+    act = (x.numel() + 2 * z3.numel()) * 2
+    us = timed(lambda: _lib.call("clhip_conv_fwd_acc_pair", x.data_ptr(), w3f.data_ptr(), w1f.data_ptr(), z3.data_ptr(), z1.data_ptr(), a3.data_ptr(), 8, a1.data_ptr(), 8,
+                                 N, H, W, C, K, code, st))
+    row(f"{tag} {C}->{K} {H}x{W}: fwd of k3 s2 + shortcut k1 s2 with both BatchNorm sums, ONE launch (the step's form)", us, 2.0 * N * Ho * Wo * K * C * 10, act)
+    pair_row(tag, N, H, W, C, K)
+    dz = torch.randn(N, Ho, Wo, K, device=dev).to(tdt)
+    dzs = torch.randn(N, Ho, Wo, K, device=dev).to(tdt)
+    dw3 = torch.zeros(K, 9, C, device=dev)
+    dw1 = torch.zeros(K, 1, C, device=dev)
+    L = _lib.lib()
+    ws3 = torch.empty(L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 3, 2, 1, code), dtype=torch.uint8, device=dev)
+    ws1 = torch.empty(L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, K, 1, 2, 0, code), dtype=torch.uint8, device=dev)
+    us = timed(lambda: _lib.call("clhip_conv_wgrad_pair", x.data_ptr(), dz.data_ptr(), dzs.data_ptr(), dw3.data_ptr(), dw1.data_ptr(), ws3.data_ptr(), ws1.data_ptr(),
+                                 N, H, W, C, K, code, st))
+    row(f"{tag} {C}->{K} {H}x{W}: wgrad of k3 s2 + shortcut k1 s2, ONE launch + the two reduces (the step's form)", us, 2.0 * N * Ho * Wo * K * C * 10,
+        act + (dw3.numel() + dw1.numel()) * 4)
+
+
 def gemm_row(tag, M, N, K, epi):
     A = torch.randn(M, K, device=dev).to(tdt)
     B = (torch.randn(N, K, device=dev) * 0.03).to(tdt)
@@ -121,8 +149,12 @@ print("\n## CifarResNet-32, batch 256, bf16\n\n" + HEAD)
 conv_rows("stem", 256, 32, 32, 3, 16, 3, 1, 1)
 conv_rows("stage1", 256, 32, 32, 16, 16, 3, 1, 10)
 conv_rows("stage2.0", 256, 32, 32, 16, 32, 3, 2, 1)
+conv_rows("stage2.0 shortcut", 256, 32, 32, 16, 32, 1, 2, 1)
+entry_rows("stage2.0", 256, 32, 32, 16, 32)
 conv_rows("stage2", 256, 16, 16, 32, 32, 3, 1, 9)
 conv_rows("stage3.0", 256, 16, 16, 32, 64, 3, 2, 1)
+conv_rows("stage3.0 shortcut", 256, 16, 16, 32, 64, 1, 2, 1)
+entry_rows("stage3.0", 256, 16, 16, 32, 64)
 conv_rows("stage3", 256, 8, 8, 64, 64, 3, 1, 9)
 for tag, rows in (("InfLoRA_OPT b128", 128 * 197), ("L2P b16", 16 * 222)):
     print(f"\n## ViT-B/16 block GEMMs, {tag} ({rows} token rows), bf16\n\n" + HEAD)
