@@ -656,7 +656,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     // 2.205 -- in the backward the chip is already shared with the weight-gradient stream and a third stream only adds contention and
     // barrier packets; in the forward nothing else runs beside the chain (profiles/r03_step_notes.md)
     // (looked up per call: a caller that runs a second network beside this one -- ops.TeacherPass: the frozen teacher on a stream of its own -- switches
-    //  the branch streams of both off for that step; five streams on four hardware queues made the LwF ResNet-18 task >= 1 step 6.36 ms instead of 2.70)
+    //  the branch streams of both off for that step; five streams in one step made the LwF ResNet-18 task >= 1 step 6.36 ms instead of 2.60, profiles/r03_step_notes.md)
     const char* br_cfg_f = clhip_cfg("BRANCH_STREAM");
     const int br_mode_f = br_cfg_f ? atoi(br_cfg_f) : 2;
     const bool br_on = use_acc && (br_mode_f == 1 || br_mode_f == 2) && branch_stream_on(p, (hipStream_t)stream);

@@ -435,7 +435,7 @@ class TeacherPass:
                 side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))        # x (and the teacher's weights) are ready
             # two networks on two streams: their plans keep to ONE stream each in the forward while this pass is in flight (the shortcut
-            # branch streams of both would make five streams on four hardware queues: 6.36 ms per LwF ResNet-18 step instead of 2.70)
+            # branch streams of both make five streams in one step: measured 6.36 ms per LwF ResNet-18 step instead of 2.60, profiles/r03_step_notes.md)
             self._branch_off = _env_unset("CLHIP_BRANCH_STREAM")
             if self._branch_off:
                 _lib.lib().clhip_config(b"BRANCH_STREAM", b"0")
