@@ -202,6 +202,15 @@ def attach(model, optimizer, reducer):
     own = reducer is not None and bool(getattr(model, "reduces_own_gradients", False))
     if reducer is not None:
         reducer.optimizer = optimizer
+        if reducer.world > 1 and os.environ.get("CLHIP_BRANCH_STREAM") is None:
+            # multi-rank steps already run main + weight-gradient + the collective's stream(s): the plans' shortcut-branch stream (+0.5 % on one GPU)
+            # stays off -- a fifth stream in one step is what made the LwF teacher step 2.4x slower (profiles/r03_step_notes.md), and the multi-GPU
+            # combination cannot be measured on the 1-GPU boxes this was built on
+            from . import _lib
+            try:
+                _lib.lib().clhip_config(b"BRANCH_STREAM", b"0")
+            except Exception:
+                pass                                          # CPU-only processes (gloo tests) have no library to steer
     if hasattr(model, "grad_reducer") or own:
         model.grad_reducer = reducer if own else None
     if hasattr(optimizer, "grad_scale"):
