@@ -393,6 +393,13 @@ int clhip_conv_dgrad_pair_pack(const void* w_dg, const void* w_sc_dg /*nullable*
 int clhip_conv_dgrad_pair(const void* dz, const void* w_packed, const void* dz_sc /*nullable*/, void* dx, int accumulate, int N, int H,
                           int W, int C, int K, int dtype, void* stream);
 
+/* clhip_conv_dgrad_pair whose epilogue also reduces the BatchNorm backward of the layer that PRODUCED the block input (z_prod, y_prod, mean, invstd,
+ * acc, replicas exactly as clhip_conv_dgrad_bn_reduce; valid when this launch completes dx, i.e. the two layers are the activation's only readers).
+ * The small-channel entries (C in {16, 32}, K = 2 C).  _supported: 1 / 0. */
+int clhip_conv_dgrad_pair_bn_reduce_supported(int N, int H, int W, int C, int K, int dtype);
+int clhip_conv_dgrad_pair_bn_reduce(const void* dz, const void* w_packed, const void* dz_sc /*nullable*/, void* dx, int accumulate, const void* z_prod,
+                                    const void* y_prod /*nullable*/, const float* mean, const float* invstd, double* acc, int replicas, int N, int H,
+                                    int W, int C, int K, int dtype, void* stream);
 /* The WEIGHT gradients of the same two layers in one launch (csrc/conv7.hip): dw [K][9][C] += the 3x3/s2 layer's, dw_sc [K][1][C] += the
  * shortcut's, both over the block input x [N,H,W,C]; dz, dz_sc [N,H/2,W/2,K].  ws / ws_sc: scratch of clhip_conv_wgrad_ws_bytes() bytes of
  * the 3x3 / the 1x1 layer (partial blocks per image group, summed in a fixed order: bitwise reproducible).  bf16; CifarResNet-32's two

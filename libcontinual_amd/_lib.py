@@ -80,6 +80,8 @@ _PROTOS = {
     "clhip_conv_dgrad_pair_packed_bytes": (_sz, [_i, _i]),
     "clhip_conv_dgrad_pair_pack": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clhip_conv_dgrad_pair": (_i, [_p, _p, _p, _p, _i] + [_i] * 6 + [_p]),
+    "clhip_conv_dgrad_pair_bn_reduce_supported": (_i, [_i] * 6),
+    "clhip_conv_dgrad_pair_bn_reduce": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i] + [_i] * 6 + [_p]),
     "clhip_conv_wgrad_pair_supported": (_i, [_i] * 6),
     "clhip_conv_fwd_acc_pair_supported": (_i, [_i] * 6),
     "clhip_conv_fwd_acc_pair": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i] + [_i] * 6 + [_p]),

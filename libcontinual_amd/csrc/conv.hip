@@ -746,7 +746,9 @@ int clhip_dgrad6_launch(const void* dz, const void* w_packed, const void* dz_sc,
 bool clhip_dgrad7_supported(int N, int H, int W, int C, int K, int dtype);
 size_t clhip_dgrad7_packed_bytes(int C, int K);
 int clhip_dgrad7_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C, int K, hipStream_t st);
-int clhip_dgrad7_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st);
+int clhip_dgrad7_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st,
+                        const void* bn_z = nullptr, const void* bn_y = nullptr, const float* bn_mean = nullptr, const float* bn_invstd = nullptr, double* bn_acc = nullptr,
+                        int bn_rep = 1);
 static bool small_pair(int C, int K) { return (C == 16 || C == 32) && K == 2 * C; }
 
 extern "C" int clhip_conv_dgrad_pair_supported(int N, int H, int W, int C, int K, int dtype) {
@@ -812,6 +814,22 @@ extern "C" int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* 
 }
 
 // (the scratch of a layer that can be half of such a pair is large enough for either form)
+// ... with the BatchNorm-backward sums of the layer that produced the block input in the epilogue (clhip_conv_dgrad_bn_reduce's contract; the
+// small-channel kernel only)
+extern "C" int clhip_conv_dgrad_pair_bn_reduce_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || use_v1() || !use_v3()) return 0;
+    return (small_pair(C, K) && clhip_dgrad7_supported(N, H, W, C, K, dtype)) ? 1 : 0;
+}
+
+extern "C" int clhip_conv_dgrad_pair_bn_reduce(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, const void* z_prod, const void* y_prod,
+                                               const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C, int K, int dtype,
+                                               void* stream) {
+    CLHIP_CHECK_ARG(dz && w_packed && dx && z_prod && mean && invstd && acc);
+    CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    CLHIP_CHECK_ARG(clhip_conv_dgrad_pair_bn_reduce_supported(N, H, W, C, K, dtype));
+    return clhip_dgrad7_launch(dz, w_packed, dz_sc, dx, accumulate, N, H, W, C, K, static_cast<hipStream_t>(stream), z_prod, y_prod, mean, invstd, acc, replicas);
+}
+
 extern "C" size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype) {
     size_t b = wgrad_ws_bytes_single(N, H, W, C, Creal, K, ksize, stride, pad, dtype);
     if (!use_v1() && use_v3() && Creal == C && stride == 2 && clhip_wgrad7_supported(N, H, W, C, K, dtype)) {

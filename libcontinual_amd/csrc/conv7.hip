@@ -24,9 +24,16 @@ struct Dgrad7Params {
     const bf16_t* wpk;   // [C][10][K]
     bf16_t* dx;          // [N,2Ho,2Wo,C]
     int Ho, Wo, lgHo, lgWo, Mq, accumulate, ntiles, tpw;      // Mq = N*Ho*Wo quads, tiles of 16 quads, tiles per wave
+    // BN: the BatchNorm-backward sums of the layer that PRODUCED the block input (sum g, sum g * xhat; g = dx masked by that layer's ReLU), from the
+    // fp32 results before their rounding -- clhip_conv_dgrad_bn_reduce's epilogue (conv4.hip / conv3.hip) for this launch
+    const bf16_t* bn_z = nullptr;    // [N,2Ho,2Wo,C] the producer's pre-BatchNorm output
+    const bf16_t* bn_y = nullptr;    // its activation (mask y > 0), or nullptr: no ReLU
+    const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
+    double* bn_acc = nullptr;        // [bn_rep][2][C]
+    int bn_rep = 1;
 };
 
-template <int C, bool SC>
+template <int C, bool SC, bool BN = false>
 __global__ __launch_bounds__(256) void dgrad7_kernel(const Dgrad7Params p) {
     constexpr int K = 2 * C, KS = K / 32, NTAP = SC ? 10 : 9;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -41,6 +48,7 @@ __global__ __launch_bounds__(256) void dgrad7_kernel(const Dgrad7Params p) {
         for (int ks = 0; ks < KS; ++ks) w[t][ks] = *reinterpret_cast<const uint4*>(p.wpk + ((size_t)(ct * 16 + fr) * 10 + t) * K + ks * 32 + fg * 8);
 
     const int Wo = p.Wo, Ho = p.Ho, W2 = 2 * Wo;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};      // BN: sum g, sum g z' of channels ct * 16 + fg * 4 + e over this lane's pixels
     const int t0 = (blockIdx.x * 4 + wave) * p.tpw;
     for (int i = 0; i < p.tpw; ++i) {
         const int tile = t0 + i;
@@ -86,7 +94,41 @@ __global__ __launch_bounds__(256) void dgrad7_kernel(const Dgrad7Params p) {
                     v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
                 }
                 *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                if constexpr (BN) {
+                    const size_t at = o - p.dx;
+                    const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + at);
+                    uint2 yy = make_uint2(0x3f803f80u, 0x3f803f80u);
+                    if (p.bn_y != nullptr) yy = *reinterpret_cast<const uint2*>(p.bn_y + at);
+                    const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
+                    const float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
+                    const float v4[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = y4[e] > 0.f ? v4[e] : 0.f;
+                        s1[e] += g; s2[e] = fmaf(g, z4[e], s2[e]);
+                    }
+                }
             }
+        }
+    }
+    if constexpr (BN) {
+        // 16-lane sums, the four waves through LDS, one fp64 atomic per channel and sum per workgroup; the centred form
+        // sum g xhat = invstd (sum g z' - mean sum g) is taken once per channel
+        __shared__ float red[4][4][8];                       // [wave][fg][sum e, sum-z e]
+        float sv[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+        row16_sum_n(sv);
+        if (fr == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave][fg][e] = sv[e];
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int g = tid >> 2, e = tid & 3, c = ct * 16 + g * 4 + e;
+            const float a1 = red[0][g][e] + red[1][g][e] + red[2][g][e] + red[3][g][e];
+            const float a2 = red[0][g][4 + e] + red[1][g][4 + e] + red[2][g][4 + e] + red[3][g][4 + e];
+            double* acc = p.bn_acc + (size_t)(blockIdx.x & (p.bn_rep - 1)) * 2 * C;
+            atomicAdd(acc + c, (double)a1);
+            atomicAdd(acc + C + c, (double)(p.bn_invstd[c] * (a2 - p.bn_mean[c] * a1)));
         }
     }
 }
@@ -104,7 +146,8 @@ int ilog2_7(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ?
 template <int C, bool SC>
 int launch7(const Dgrad7Params& p, hipStream_t st) {
     const int waves = (p.ntiles + p.tpw - 1) / p.tpw;
-    hipLaunchKernelGGL((dgrad7_kernel<C, SC>), dim3((waves + 3) / 4, C / 16), dim3(256), 0, st, p);
+    if (p.bn_z != nullptr) hipLaunchKernelGGL((dgrad7_kernel<C, SC, true>), dim3((waves + 3) / 4, C / 16), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dgrad7_kernel<C, SC>), dim3((waves + 3) / 4, C / 16), dim3(256), 0, st, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -129,8 +172,11 @@ int clhip_dgrad7_pack(const void* w_dg, const void* w_sc_dg, void* packed, int C
     return CLHIP_OK;
 }
 
-int clhip_dgrad7_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st) {
+int clhip_dgrad7_launch(const void* dz, const void* w_packed, const void* dz_sc, void* dx, int accumulate, int N, int H, int W, int C, int K, hipStream_t st,
+                        const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep) {
     Dgrad7Params p;
+    p.bn_z = static_cast<const bf16_t*>(bn_z); p.bn_y = static_cast<const bf16_t*>(bn_y); p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_acc = bn_acc;
+    p.bn_rep = bn_rep > 0 ? bn_rep : 1;
     p.dz = static_cast<const bf16_t*>(dz); p.dzs = static_cast<const bf16_t*>(dz_sc); p.wpk = static_cast<const bf16_t*>(w_packed); p.dx = static_cast<bf16_t*>(dx);
     p.Ho = H / 2; p.Wo = W / 2; p.lgHo = ilog2_7(p.Ho); p.lgWo = ilog2_7(p.Wo);
     p.Mq = N * p.Ho * p.Wo; p.accumulate = accumulate; p.ntiles = (p.Mq + 15) / 16;

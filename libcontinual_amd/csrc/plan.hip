@@ -55,6 +55,7 @@ struct Unit {
                                    // residual add and the ReLU on its operand load AND writes the activation + packed mask for the later readers
                                    // (clhip_conv_fwd_acc_bn_res_input): the training forward skips the apply launch
     int res_lazy_from;             // >= 0: this unit's input comes from such a unit
+    bool pair_fuse_bn;             // ... that one launch also reduces the BatchNorm backward of the unit that produced the activation (its only readers are the pair)
     bool fpair;                    // ... their two forward convolutions are one launch (clhip_conv_fwd_acc_pair, conv7.hip; set on both units)
     bool wpair;                    // ... and their two weight gradients are one launch too (clhip_conv_wgrad_pair, conv7.hip; set on both units)
     bool pair_acc;                 // the accumulate flag of that one launch (= the shortcut dgrad's, the first writer of the two)
@@ -338,7 +339,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     }
     // down-sampling entries: a 3x3/s2/p1 unit a and a 1x1/s2/p0 unit b > a with the same source activation and channel counts, the only two
     // consumers of that activation -> their two input gradients are one launch at unit a (conv6.hip); the packed weights of both live at a.sh_pk
-    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; u.wpair = u.fpair = false; }
+    for (auto& u : p->units) { u.pair = -1; u.pair_acc = false; u.sh_pk = 0; u.wpair = u.fpair = u.pair_fuse_bn = false; }
     const char* pair_cfg = clhip_cfg("CONV6_PAIR");             // (per plan: the tests build one with and one without)
     const bool pair_off = pair_cfg != nullptr && atoi(pair_cfg) == 0;
     for (int b = 0; b < n_units && !pair_off; ++b) {
@@ -359,6 +360,11 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         ua.pair_acc = ub.dx_acc;
         ua.sh_pk = p->shadow_bytes; p->shadow_bytes = align_up(p->shadow_bytes + clhip_conv_dgrad_pair_packed_bytes(ua.cin_pad, ua.d.cout));
         // (own scratch regions per unit -- the deferred-reduce plans -- so that both partial-block slabs survive until the one reduce launch)
+        {
+            const Unit& prod = p->units[ua.d.src - 1];       // users == 2: the pair's launch is the only writer of that activation's gradient
+            ua.pair_fuse_bn = fuse_on && !prod.no_bn && !prod.pre_res && !prod.raw_src && !prod.has_dzr && prod.rep_bwd > 0 && (long long)prod.M <= fuse_max_m &&
+                              clhip_conv_dgrad_pair_bn_reduce_supported(N, ua.H, ua.W, ua.cin_pad, ua.d.cout, dtype) != 0;
+        }
         ua.fpair = ub.fpair = ua.rep_fwd > 0 && ub.rep_fwd > 0 && ua.cin_pad == ua.d.cin &&
                               clhip_conv_fwd_acc_pair_supported(N, ua.H, ua.W, ua.cin_pad, ua.d.cout, dtype) != 0;
         ua.wpair = ub.wpair = p->defer_reduce && ua.cin_pad == ua.d.cin && ub.cin_pad == ub.d.cin &&
@@ -1036,6 +1042,14 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         } else if (pair_b) {
             pair_dz = dz;                                      // its partner is the next unit of this sweep
         } else if (pair_on && u.pair >= 0 && u.d.ksize == 3 && pair_dz != nullptr) {
+            static const bool pfb_off = clhip_cfg("PAIR_BN_FUSE") != nullptr && atoi(clhip_cfg("PAIR_BN_FUSE")) == 0;
+            if (u.pair_fuse_bn && !pfb_off) {
+                const Unit& prod = p->units[u.d.src - 1];
+                TRY(clhip_conv_dgrad_pair_bn_reduce(dz, sh + u.sh_pk, pair_dz, ws + src.dy_off, u.pair_acc, ws + prod.z_off, prod.relu ? ws + src.y_off : nullptr,
+                                                    fr + prod.f_mean, fr + prod.f_invstd, reinterpret_cast<double*>(ws + p->acc_off) + prod.a_bwd, prod.rep_bwd, p->N, u.H, u.W,
+                                                    u.cin_pad, u.d.cout, p->dtype, stream));
+                p->bwd_sums_ready[u.d.src - 1] = 1;
+            } else
             TRY(clhip_conv_dgrad_pair(dz, sh + u.sh_pk, pair_dz, ws + src.dy_off, u.pair_acc, p->N, u.H, u.W, u.cin_pad, u.d.cout, p->dtype, stream));
             pair_dz = nullptr;
         } else if (u.d.src != 0) {

@@ -951,6 +951,27 @@ def test_stride2_dgrad_pair_one_launch(case):
     call("clhip_conv_dgrad", dzsd.data_ptr(), w1d.data_ptr(), two.data_ptr(), 0, N, H, W, C, K, 1, 2, 0, code, st())
     call("clhip_conv_dgrad", dzd.data_ptr(), w3d.data_ptr(), two.data_ptr(), 1, N, H, W, C, K, 3, 2, 1, code, st())
     assert (dx.float() - two.float()).abs().max() <= 2 ** -6 * ref.abs().max()
+    if L.clhip_conv_dgrad_pair_bn_reduce_supported(N, H, W, C, K, code):
+        # the same launch with the BatchNorm-backward sums of the layer that produced the block input in its epilogue: dx bit-identical, the sums
+        # against fp64 from the unrounded reference (sum g, sum g xhat; g = dx masked by that layer's ReLU)
+        zp = quant(rnd((N, C, H, W), 31, 1.2), tdt)
+        yp = quant(torch.relu(rnd((N, C, H, W), 32) + 0.1), tdt)
+        mean, var = zp.double().mean((0, 2, 3)), zp.double().var((0, 2, 3), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        meand, invd = mean.float().to(DEV), invstd.float().to(DEV)
+        acc = torch.zeros(4, 2, C, dtype=torch.float64, device=DEV)
+        dxb = torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+        zpd, ypd = to_nhwc(zp, tdt), to_nhwc(yp, tdt)
+        call("clhip_conv_dgrad_pair_bn_reduce", dzd.data_ptr(), pk.data_ptr(), dzsd.data_ptr(), dxb.data_ptr(), 0, zpd.data_ptr(), ypd.data_ptr(),
+             meand.data_ptr(), invd.data_ptr(), acc.data_ptr(), 4, N, H, W, C, K, code, st())
+        torch.cuda.synchronize()
+        assert torch.equal(dxb, dx)
+        g = ref * (yp.double() > 0)
+        xhat = (zp.double() - meand.cpu().double().view(1, C, 1, 1)) * invd.cpu().double().view(1, C, 1, 1)
+        s = acc.sum(0).cpu()
+        scale = g.abs().sum((0, 2, 3)).max()
+        assert (s[0] - g.sum((0, 2, 3))).abs().max() <= 1e-5 * scale + 1e-6
+        assert (s[1] - (g * xhat).sum((0, 2, 3))).abs().max() <= 1e-5 * (g.abs() * xhat.abs()).sum((0, 2, 3)).max() + 1e-6
     # without the shortcut operand; with accumulation
     dx3 = torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
     call("clhip_conv_dgrad_pair", dzd.data_ptr(), pk3.data_ptr(), None, dx3.data_ptr(), 0, N, H, W, C, K, code, st())
