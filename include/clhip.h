@@ -149,6 +149,12 @@ int clhip_bn_bwd(const void* dy, const void* y, const void* z, const float* mean
 /* global average pool: feat[N,C] (fp32) = mean_hw a[N,HW,C]; backward broadcasts dfeat/HW           */
 int clhip_avgpool_fwd(const void* a, float* feat, int N, int HW, int C, int dtype, void* stream);
 int clhip_avgpool_bwd(const float* dfeat, void* da, int N, int HW, int C, int dtype, void* stream);
+/* clhip_avgpool_bwd that also reduces the BatchNorm backward of the layer that PRODUCED the pooled activation (the backbone's last unit; the pooling
+ * is that activation's only reader): z_prod, y_prod (nullable: no ReLU), mean, invstd, acc [replicas][2][C] fp64 as clhip_conv_dgrad_bn_reduce.
+ * C a power of two in [8, 256].  _supported: 1 / 0. */
+int clhip_avgpool_bwd_bn_reduce_supported(int N, int HW, int C, int dtype);
+int clhip_avgpool_bwd_bn_reduce(const float* dfeat, void* da, const void* z_prod, const void* y_prod /*nullable*/, const float* mean, const float* invstd,
+                                double* acc, int replicas, int N, int HW, int C, int dtype, void* stream);
 
 /* AvgPool2d(win) + NCHW flatten: feat[n][(c*Ph + ph)*Pw + pw] (fp32), Ph = H/win, Pw = W/win (resnet.py:643, 675-676) */
 int clhip_avgpool_win_fwd(const void* a, float* feat, int N, int H, int W, int C, int win, int dtype, void* stream);

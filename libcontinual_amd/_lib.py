@@ -96,6 +96,8 @@ _PROTOS = {
     "clhip_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "clhip_avgpool_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "clhip_avgpool_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "clhip_avgpool_bwd_bn_reduce_supported": (_i, [_i] * 4),
+    "clhip_avgpool_bwd_bn_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_avgpool_win_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "clhip_avgpool_win_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "clhip_add_stats_blocks": (_i, [_l, _i]),

@@ -570,6 +570,51 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, T* __restric
     }
 }
 
+// avgpool backward that also reduces the BatchNorm backward of the LAST unit (whose activation the pooling is the only reader of): sum g and
+// sum g * xhat per channel, g = da masked by that unit's ReLU -- the first pass of clhip_bn_bwd_acc over a tensor this kernel has in registers.
+// A thread's 8 channels are fixed (the grid stride is a multiple of C / 8); threads of a workgroup with the same channels are summed through LDS,
+// then one fp64 atomic per channel and sum (centred form as in the dgrad epilogues).
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_bn_kernel(const float* __restrict__ dfeat, T* __restrict__ da, int N, int HW, int C, const T* __restrict__ z,
+                                                             const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             double* __restrict__ acc, int rep) {
+    __shared__ float red[256][17];
+    const int64_t nchunks = (int64_t)N * HW * C / 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float inv = 1.f / (float)HW;
+    float s[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int64_t e0 = i * 8;
+        const int c0 = (int)(e0 % C);
+        const int n = (int)(e0 / ((int64_t)HW * C));
+        float v[8], zz[8], yy[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dfeat[(size_t)n * C + c0 + e] * inv;
+        store8<T>(da + e0, v);
+        load8<T>(z + e0, zz);
+        if (y != nullptr) load8<T>(y + e0, yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = (y == nullptr || yy[e] > 0.f) ? v[e] : 0.f;
+            s[e] += g; s[8 + e] = fmaf(g, zz[e], s[8 + e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    const int cpp = C / 8;                                   // chunks per pixel = distinct channel groups among the workgroup's threads
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x, grp = c >> 3, e = c & 7;
+        float a1 = 0.f, a2 = 0.f;
+        for (int t = grp; t < 256; t += cpp) { a1 += red[t][e]; a2 += red[t][8 + e]; }
+        double* a = acc + (size_t)(blockIdx.x & (rep - 1)) * 2 * C;
+        atomicAdd(a + c, (double)a1);
+        atomicAdd(a + C + c, (double)(invstd[c] * (a2 - mean[c] * a1)));
+    }
+}
+
 // ------------------------------------------------------------------------------ layout converts
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int Cpad) {
@@ -847,6 +892,25 @@ extern "C" int clhip_avgpool_fwd(const void* a, float* feat, int N, int HW, int 
     if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, (const bf16_t*)a, feat, N, HW, C);
     else if (dtype == CLHIP_F32) hipLaunchKernelGGL((avgpool_fwd_kernel<float>), g, b, 0, (hipStream_t)stream, (const float*)a, feat, N, HW, C);
     else { CLHIP_CHECK_ARG(!"dtype"); }
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+// C a power of two in [8, 256] (a workgroup's threads then cover whole channel groups: thread t feeds channels (t mod C/8) * 8 ..), bf16 / f32
+extern "C" int clhip_avgpool_bwd_bn_reduce_supported(int N, int HW, int C, int dtype) {
+    return (N > 0 && HW > 0 && C >= 8 && C <= 256 && (C & (C - 1)) == 0 && (dtype == CLHIP_BF16 || dtype == CLHIP_F32)) ? 1 : 0;
+}
+extern "C" int clhip_avgpool_bwd_bn_reduce(const float* dfeat, void* da, const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc,
+                                           int replicas, int N, int HW, int C, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(dfeat && da && z_prod && mean && invstd && acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    CLHIP_CHECK_ARG(clhip_avgpool_bwd_bn_reduce_supported(N, HW, C, dtype));
+    const int64_t nch = (int64_t)N * HW * C / 8;
+    int blocks = (int)((nch + 256 * 4 - 1) / (256 * 4));     // ~4 chunks per thread: enough workgroups to fill the chip on the small last stages
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    dim3 g(blocks), b(256);
+    if (dtype == CLHIP_BF16) hipLaunchKernelGGL((avgpool_bwd_bn_kernel<bf16_t>), g, b, 0, (hipStream_t)stream, dfeat, (bf16_t*)da, N, HW, C, (const bf16_t*)z_prod, (const bf16_t*)y_prod, mean, invstd, acc, replicas);
+    else hipLaunchKernelGGL((avgpool_bwd_bn_kernel<float>), g, b, 0, (hipStream_t)stream, dfeat, (float*)da, N, HW, C, (const float*)z_prod, (const float*)y_prod, mean, invstd, acc, replicas);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

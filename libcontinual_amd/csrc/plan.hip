@@ -792,7 +792,21 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     if (unit_hi == (int)p->units.size()) {
         const Act& last = p->acts.back();
         if (p->pool_win > 0) TRY(clhip_avgpool_win_bwd(dfeat, ws + last.dy_off, p->N, last.H, last.W, last.C, p->pool_win, p->dtype, stream));
-        else TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
+        else {
+            // the pooling is the last activation's only reader: its backward completes that gradient and reduces the last unit's BatchNorm backward on the way
+            const Unit& lu = p->units.back();
+            static const bool pool_fuse_off = clhip_cfg("POOL_BN_FUSE") != nullptr && atoi(clhip_cfg("POOL_BN_FUSE")) == 0;
+            const char* fe = clhip_cfg("BN_FUSE");
+            bool sole = true;
+            for (const Unit& o : p->units) if (o.d.src == (int)p->units.size() || o.d.res == (int)p->units.size()) sole = false;
+            const bool fuse = !pool_fuse_off && p->use_acc && (fe == nullptr || atoi(fe) != 0) && sole && !lu.no_bn && !lu.pre_res && !lu.raw_src && !lu.has_dzr && lu.rep_bwd > 0 &&
+                              lu.d.cout == last.C && clhip_avgpool_bwd_bn_reduce_supported(p->N, last.H * last.W, last.C, p->dtype) != 0;
+            if (fuse) {
+                TRY(clhip_avgpool_bwd_bn_reduce(dfeat, ws + last.dy_off, ws + lu.z_off, lu.relu ? ws + last.y_off : nullptr, fr + lu.f_mean, fr + lu.f_invstd,
+                                                reinterpret_cast<double*>(ws + p->acc_off) + lu.a_bwd, lu.rep_bwd, p->N, last.H * last.W, last.C, p->dtype, stream));
+                p->bwd_sums_ready[p->units.size() - 1] = 1;
+            } else TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
+        }
     }
     // The weight gradients hang off the backward chain (BN backward -> dgrad -> next unit) as leaves: they run on a second stream,
     // so their kernels fill the load / store phases of the chain's kernels instead of queueing behind them.  dz is double-buffered;

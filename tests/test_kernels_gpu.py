@@ -1260,3 +1260,35 @@ def test_stride2_forward_pair_one_launch(case):
     call("clhip_conv_fwd_acc", xd.data_ptr(), w1d.data_ptr(), g1.data_ptr(), b1.data_ptr(), 4, N, H, W, C, K, 1, 2, 0, code, st())
     torch.cuda.synchronize()
     assert (z3[:M_].float() - g3.float()).abs().max() <= 2 ** -7 * float(r3.abs().max()) and (z1[:M_].float() - g1.float()).abs().max() <= 2 ** -7 * float(r1.abs().max())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(256, 64, 64), (33, 16, 512 // 2), (5, 49, 64), (7, 1, 128)])
+def test_avgpool_backward_with_batchnorm_sums(shape, dt):
+    """clhip_avgpool_bwd_bn_reduce = clhip_avgpool_bwd (bit-identical gradient) + the BatchNorm-backward sums of the layer that produced the pooled
+    activation (sum g, sum g xhat with g = da masked by y > 0), against fp64; with and without a ReLU."""
+    N, HW, C = shape
+    code, tdt = DT[dt]
+    L = _lib.lib()
+    assert L.clhip_avgpool_bwd_bn_reduce_supported(N, HW, C, code) == 1
+    dfeat = rnd((N, C), 41).to(DEV)
+    z = quant(rnd((N, HW, C), 42, 1.1), tdt).to(tdt).to(DEV)
+    y = quant(torch.relu(rnd((N, HW, C), 43) + 0.2), tdt).to(tdt).to(DEV)
+    mean = z.double().mean((0, 1)).float()
+    invstd = (1.0 / torch.sqrt(z.double().var((0, 1), unbiased=False) + 1e-5)).float()
+    ref_da = torch.empty(N, HW, C, dtype=tdt, device=DEV)
+    call("clhip_avgpool_bwd", dfeat.data_ptr(), ref_da.data_ptr(), N, HW, C, code, st())
+    for relu in (True, False):
+        da = torch.full((N, HW, C), float("nan"), dtype=tdt, device=DEV)
+        acc = torch.zeros(8, 2, C, dtype=torch.float64, device=DEV)
+        call("clhip_avgpool_bwd_bn_reduce", dfeat.data_ptr(), da.data_ptr(), z.data_ptr(), y.data_ptr() if relu else None, mean.data_ptr(), invstd.data_ptr(),
+             acc.data_ptr(), 8, N, HW, C, code, st())
+        torch.cuda.synchronize()
+        assert torch.equal(da, ref_da)
+        g = (dfeat.double() / HW).view(N, 1, C).expand(N, HW, C)
+        if relu:
+            g = g * (y.double() > 0)
+        xhat = (z.double() - mean.double()) * invstd.double()
+        s = acc.sum(0)
+        assert (s[0] - g.sum((0, 1))).abs().max() <= 1e-5 * g.abs().sum((0, 1)).max() + 1e-7
+        assert (s[1] - (g * xhat).sum((0, 1))).abs().max() <= 1e-5 * (g.abs() * xhat.abs()).sum((0, 1)).max() + 1e-7
