@@ -8,6 +8,9 @@
 //
 // These are tiny (B x <=100 logits); each is one launch with one wavefront per row and fuses forward
 // value, gradient, prediction and accuracy so the step needs no host synchronisation.
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -175,18 +178,24 @@ __device__ __forceinline__ int row16_min_i(int v) {
     return v;
 }
 
+// Several workgroups (gridDim.x = G <= 8, workgroup g owns rows g * 64 RPG ..): each leaves its fixed-order partial loss / count in a scratch slot, the
+// LAST one to arrive (a ticket counter) adds the G partials in index order -- still no data-dependent summation order, no zeroing launch; the slot's
+// counter is reset by that workgroup.  256 rows on four CUs: 13 -> 6.5 us.
+struct CeSlot { float part[8]; int cpart[8]; unsigned count; unsigned pad[15]; };
+
 template <int NC, int RPG>
 __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B, int O, int lo, int hi,
                                                        int pred_lo, int pred_hi, float weight, float* loss_out, float* __restrict__ dlogits, int grad_acc,
-                                                       int64_t* pred, int32_t* correct, int loss_acc) {
+                                                       int64_t* pred, int32_t* correct, int loss_acc, CeSlot* slot) {
     __shared__ float gl[64];
     __shared__ int gc[64];
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int row0 = blockIdx.x * 64 * RPG;
     float v[RPG][NC];
     int yy[RPG];
 #pragma unroll
     for (int i = 0; i < RPG; ++i) {
-        const int row = grp + 64 * i;
+        const int row = row0 + grp + 64 * i;
         const bool rv = row < B;
         yy[i] = rv ? (int)labels[row] : -1;
 #pragma unroll
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
     const float sc = weight / (float)B;
 #pragma unroll
     for (int i = 0; i < RPG; ++i) {
-        const int row = grp + 64 * i;
+        const int row = row0 + grp + 64 * i;
         if (row >= B) continue;                                   // uniform over the 16-lane group
         float bv = -INFINITY; int bi = 0x7fffffff;
         float mx = -INFINITY;
@@ -254,8 +263,25 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o, 64); c += __shfl_xor(c, o, 64); }
         if (threadIdx.x == 0) {
-            *loss_out = loss_acc ? *loss_out + t : t;
-            if (correct) *correct = c;
+            const int G = gridDim.x;
+            if (G == 1) {
+                *loss_out = loss_acc ? *loss_out + t : t;
+                if (correct) *correct = c;
+            } else {
+                __hip_atomic_store(&slot->part[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot->cpart[blockIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned ticket = __hip_atomic_fetch_add(&slot->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket == (unsigned)G - 1) {                 // every other workgroup's partial is visible (release / acquire on the counter)
+                    float tt = 0.f; int cc = 0;
+                    for (int g = 0; g < G; ++g) {
+                        tt += __hip_atomic_load(&slot->part[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cc += __hip_atomic_load(&slot->cpart[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    *loss_out = loss_acc ? *loss_out + tt : tt;
+                    if (correct) *correct = cc;
+                    __hip_atomic_store(&slot->count, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }
@@ -538,9 +564,26 @@ extern "C" int clhip_ce_window(const float* logits, const int64_t* labels, int B
     CLHIP_CHECK_ARG(pred_lo >= 0 && pred_hi > pred_lo && pred_hi <= O);
     static const bool rows_off = clhip_cfg("CE_ROWS") != nullptr && atoi(clhip_cfg("CE_ROWS")) == 0;      // A/B switch: the one-wave-per-row form
     if (B <= 512 && (O <= 128 || (O <= 256 && B <= 256)) && !rows_off) {      // (16 columns x 8 rows per lane would spill)
-#define CE_ROWS(NC, RPG) hipLaunchKernelGGL((ce_rows_kernel<NC, RPG>), dim3(1), dim3(1024), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out, \
-                                            dlogits, grad_accumulate, pred, correct, loss_accumulate)
-        const int rpg = (B + 63) / 64;
+#define CE_ROWS(NC, RPG) hipLaunchKernelGGL((ce_rows_kernel<NC, RPG>), dim3(G), dim3(1024), 0, ST, logits, labels, B, O, lo, hi, pred_lo, pred_hi, weight, loss_out, \
+                                            dlogits, grad_accumulate, pred, correct, loss_accumulate, slot)
+        // 64 rows per workgroup from 128 rows up (at most 8 workgroups); a launch takes the next slot of a small ring, so launches in flight on
+        // different streams do not share one
+        static const bool one_wg = clhip_cfg("CE_ONE_WG") != nullptr && atoi(clhip_cfg("CE_ONE_WG")) != 0;
+        static CeSlot* ring = nullptr;
+        static std::atomic<unsigned> next{0};
+        int G = (B >= 128 && !one_wg) ? (B + 63) / 64 : 1;
+        if (G > 8) G = 8;
+        if (G > 1 && ring == nullptr) {
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lk(mu);
+            if (ring == nullptr) {
+                CeSlot* r = nullptr;
+                if (hipMalloc(&r, 64 * sizeof(CeSlot)) != hipSuccess || hipMemset(r, 0, 64 * sizeof(CeSlot)) != hipSuccess) { clhip_set_error("clhip_ce_window: cannot allocate the partial-sum ring"); return CLHIP_EHIP; }
+                ring = r;
+            }
+        }
+        CeSlot* slot = G > 1 ? ring + (next.fetch_add(1) & 63u) : nullptr;
+        const int rpg = (B + 64 * G - 1) / (64 * G);
         if (O <= 128) { if (rpg <= 1) CE_ROWS(8, 1); else if (rpg <= 2) CE_ROWS(8, 2); else if (rpg <= 4) CE_ROWS(8, 4); else CE_ROWS(8, 8); }
         else { if (rpg <= 1) CE_ROWS(16, 1); else if (rpg <= 2) CE_ROWS(16, 2); else CE_ROWS(16, 4); }
 #undef CE_ROWS
