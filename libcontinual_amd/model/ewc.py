@@ -68,10 +68,14 @@ class _EwcLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         dlog, head_w, head_b = ctx.saved_tensors
         owner = ctx.owner
+        unit = gout.is_cuda and gout.data_ptr() in ops.UNIT_GRAD_PTRS      # the trainer's cached unit root gradient: no scaling launch
         gout = gout.reshape(1).float().contiguous()
         st = torch.cuda.current_stream().cuda_stream
-        dl = torch.empty_like(dlog)
-        call("clhip_scale_dev", dlog.data_ptr(), dl.data_ptr(), dlog.numel(), 1.0, gout.data_ptr(), st)
+        if unit:
+            dl = dlog
+        else:
+            dl = torch.empty_like(dlog)
+            call("clhip_scale_dev", dlog.data_ptr(), dl.data_ptr(), dlog.numel(), 1.0, gout.data_ptr(), st)
         bb = owner.network.backbone
         gflat = bb.begin_grad_write()              # zeroes the buffer if this is the first write after zero_grad()
         flat, _ = bb.flat_parameters()

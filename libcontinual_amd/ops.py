@@ -8,6 +8,7 @@ from . import _lib
 from ._lib import call, require_gpu
 
 _NULL = None
+UNIT_GRAD_PTRS = set()      # data pointers of the trainer's cached unit root gradients (trainer._backward)
 
 
 def _st():
@@ -208,6 +209,8 @@ class _ClassifyLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (dlog,) = ctx.saved_tensors
+        if gout.is_cuda and gout.data_ptr() in UNIT_GRAD_PTRS:      # the trainer's cached unit root gradient: d(loss)/d(logits) as computed
+            return (dlog,) + (None,) * 11
         gout = _f32c(gout.reshape(1))
         out = torch.empty_like(dlog)
         call("clhip_scale_dev", _ptr(dlog), _ptr(out), dlog.numel(), 1.0, _ptr(gout), _st())

@@ -39,6 +39,7 @@ def _backward(loss):
         one = _UNIT_GRADS.get(loss.device)
         if one is None:
             one = _UNIT_GRADS[loss.device] = torch.ones((), device=loss.device, dtype=torch.float32)
+            ops.UNIT_GRAD_PTRS.add(one.data_ptr())             # the fused loss nodes skip their "scale by the upstream gradient" launch for it
         torch.autograd.backward(loss, grad_tensors=one)
     else:
         loss.backward()
