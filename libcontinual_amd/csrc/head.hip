@@ -56,6 +56,59 @@ __global__ void linear_bwd_dx_kernel(const float* __restrict__ dout, const float
     for (int o = 0; o < O; ++o) s = fmaf(dout[(size_t)b * O + o], w[(size_t)o * D + d], s);
     dx[idx] = acc ? dx[idx] + s : s;
 }
+// dx and dw / db of a linear head in ONE launch (the two bodies behind one grid, input-gradient workgroups first: it is the one the backbone's
+// backward waits for): workgroup < ndx -> 256 elements of dx with eight weight rows in flight per trip (the plain loop was one dependent
+// load -> fma chain per output: 14-20 us inside the ResNet-18 step for 256 x 512 x 50), else -> one (output row, 64 columns) tile of dw as
+// linear_bwd_dw_kernel below.  Same summation orders as the two kernels: bitwise reproducible.
+__global__ __launch_bounds__(256) void linear_bwd_fused_kernel(const float* __restrict__ dout, const float* __restrict__ w, const float* __restrict__ x,
+                                                               float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int B, int D, int O,
+                                                               int accumulate, int ndx, int ndwx) {
+    __shared__ float red[4][64], redb[4];
+    if ((int)blockIdx.x < ndx) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= B * D) return;
+        const int b = idx / D, d = idx - b * D;
+        const float* dr = dout + (size_t)b * O;
+        const float* wc = w + d;
+        float s = 0.f;
+        int o = 0;
+        for (; o + 8 <= O; o += 8) {
+            float g[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { g[u] = dr[o + u]; wv[u] = wc[(size_t)(o + u) * D]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(g[u], wv[u], s);
+        }
+        for (; o < O; ++o) s = fmaf(dr[o], wc[(size_t)o * D], s);
+        dx[idx] = s;
+        return;
+    }
+    const int t = (int)blockIdx.x - ndx;
+    const int bx = t % ndwx, o = t / ndwx;
+    const int dl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    const int d = bx * 64 + dl;
+    const bool in = d < D;
+    float s = 0.f, sb = 0.f;
+    for (int b0 = bg; b0 < B; b0 += 32) {
+        float g[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 4 * u;
+            g[u] = b < B ? dout[(size_t)b * O + o] : 0.f;
+            xv[u] = (b < B && in) ? x[(size_t)b * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s = fmaf(g[u], xv[u], s); sb += g[u]; }
+    }
+    red[bg][dl] = s;
+    if (dl == 0) redb[bg] = sb;
+    __syncthreads();
+    if (bg == 0) {
+        const float tt = (red[0][dl] + red[1][dl]) + (red[2][dl] + red[3][dl]);
+        if (in) { float* q = dw + (size_t)o * D + d; *q = accumulate ? *q + tt : tt; }
+        if (db != nullptr && bx == 0 && dl == 0) { const float tb = (redb[0] + redb[1]) + (redb[2] + redb[3]); db[o] = accumulate ? db[o] + tb : tb; }
+    }
+}
 // dw[o][d] (+)= sum_b dout[b][o] x[b][d] ; db[o] (+)= sum_b dout[b][o].  One workgroup = one output row o x 64 columns d; its four
 // waves take every fourth batch row (eight independent loads in flight each) and are summed through LDS in a fixed order: no atomics,
 // no zeroing launches, bitwise reproducible (the batch-split atomic version was the last fp32-atomic kernel of the ResNet step).
@@ -548,6 +601,13 @@ extern "C" int clhip_linear_fwd(const float* x, const float* w, const float* b, 
 extern "C" int clhip_linear_bwd(const float* x, const float* w, const float* dout, float* dx, float* dw, float* db, int B, int D,
                                 int O, int accumulate, void* stream) {
     CLHIP_CHECK_ARG(x && w && dout && dw && B > 0 && D > 0 && O > 0);
+    static const bool split = clhip_cfg("LINEAR_BWD_SPLIT") != nullptr && atoi(clhip_cfg("LINEAR_BWD_SPLIT")) != 0;
+    if (dx && !split) {
+        const int ndx = (B * D + 255) / 256, ndwx = (D + 63) / 64;
+        hipLaunchKernelGGL(linear_bwd_fused_kernel, dim3(ndx + ndwx * O), dim3(256), 0, ST, dout, w, x, dx, dw, db, B, D, O, accumulate, ndx, ndwx);
+        CLHIP_LAUNCH_CHECK();
+        return CLHIP_OK;
+    }
     if (dx) {
         hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST, dout, w, dx, B, D, O, 0);
         CLHIP_LAUNCH_CHECK();
