@@ -288,6 +288,10 @@ int clhip_fisher_accum(float* fisher, const float* g, int64_t n, float scale, vo
 int clhip_fisher_merge(float* new_f, const float* old_f, int64_t n, float alpha, void* stream);
 int clhip_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, float weight_decay,
                    float grad_scale, const float* ewc_ref, const float* ewc_fisher, float ewc_weight, void* stream);
+/* the same update (without the EWC term) over `count` <= 8 tensors in ONE launch: p[k], g[k], mom[k] (mom NULL when momentum == 0), n[k] elements each.
+ * Element for element the arithmetic of clhip_sgd_step. */
+int clhip_sgd_step_multi(int count, float* const* p, const float* const* g, float* const* mom /*nullable*/, const int64_t* n, float lr, float momentum,
+                         float weight_decay, float grad_scale, void* stream);
 int clhip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float grad_scale, int step, void* stream);
 int clhip_sq_norm(const float* g, int64_t n, float* out, int accumulate, void* stream);

@@ -111,6 +111,29 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// the same update over several tensors in one launch (a backbone's flat buffer + the head's weight and bias: three launches per step otherwise)
+constexpr int kSgdSegs = 8;
+struct SgdSeg { float* p; const float* g; float* m; long long n; unsigned first_block, blocks; };
+struct SgdTable { int n; SgdSeg s[kSgdSegs]; };
+template <bool MOM>
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float lr, float momentum, float wd, float gscale) {
+    int u = 0;
+    while (u + 1 < t.n && blockIdx.x >= t.s[u + 1].first_block) ++u;
+    const SgdSeg& e = t.s[u];
+    const long long stride = (long long)e.blocks * 256;
+    for (long long i = (long long)(blockIdx.x - e.first_block) * 256 + threadIdx.x; i < e.n; i += stride) {
+        float pv = e.p[i];
+        float d = e.g[i] * gscale;
+        d = fmaf(wd, pv, d);
+        if (MOM) {
+            float b = fmaf(momentum, e.m[i], d);
+            e.m[i] = b;
+            d = b;
+        }
+        e.p[i] = fmaf(-lr, d, pv);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                                                    float gscale, float bc1, float bc2s) {
@@ -269,6 +292,28 @@ extern "C" int clhip_sgd_step(float* p, const float* g, float* mom, int64_t n, f
 #define SGD(M, E) hipLaunchKernelGGL((sgd_kernel<M, E>), gr, b, 0, st, p, g, mom, n, lr, momentum, weight_decay, grad_scale, ewc_ref, ewc_fisher, ewc_weight)
     if (mo && ew) SGD(true, true); else if (mo) SGD(true, false); else if (ew) SGD(false, true); else SGD(false, false);
 #undef SGD
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_sgd_step_multi(int count, float* const* p, const float* const* g, float* const* mom, const int64_t* n, float lr, float momentum,
+                                    float weight_decay, float grad_scale, void* stream) {
+    CLHIP_CHECK_ARG(count >= 1 && count <= kSgdSegs && p && g && n);
+    CLHIP_CHECK_ARG(momentum == 0.f || mom != nullptr);
+    SgdTable t;
+    t.n = 0;
+    unsigned blocks = 0;
+    for (int k = 0; k < count; ++k) {
+        CLHIP_CHECK_ARG(n[k] >= 0 && (n[k] == 0 || (p[k] && g[k] && (momentum == 0.f || mom[k]))));
+        if (n[k] == 0) continue;
+        SgdSeg& e = t.s[t.n++];
+        e.p = p[k]; e.g = g[k]; e.m = momentum != 0.f ? mom[k] : nullptr; e.n = n[k];
+        e.first_block = blocks; e.blocks = (unsigned)ew_blocks4(n[k]);
+        blocks += e.blocks;
+    }
+    if (t.n == 0) return CLHIP_OK;
+    if (momentum != 0.f) hipLaunchKernelGGL(sgd_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, lr, momentum, weight_decay, grad_scale);
+    else hipLaunchKernelGGL(sgd_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, lr, momentum, weight_decay, grad_scale);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

@@ -116,6 +116,9 @@ class SGD(_FusedBase):
             lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
             whole, rest = self._split(group)
             self._check_unconsumed_shards(rest)
+            # every tensor of the group goes into ONE launch (clhip_sgd_step_multi, up to eight per launch): a backbone's flat buffer + the head's
+            # weight and bias were three launches per step
+            items, after = [], []
             for o in whole:
                 require_gpu(o._flat)
                 st = self.state[o._params[0]]
@@ -127,12 +130,8 @@ class SGD(_FusedBase):
                         if buf is None or buf.data_ptr() == 0 or buf.numel() != flat.numel() or buf.device != flat.device:
                             buf = torch.zeros_like(flat)
                             st["flat_momentum" + sfx] = buf
-                    ops.sgd_step(flat, gflat, buf, lr, mom, wd, self.grad_scale)
-                if shard is not None:
-                    o._dp_shard = shard
-                    shard["reducer"].gather_params(o)
-                    o._dp_shard = None
-                o.mark_params_modified()
+                    items.append((flat, gflat, buf))
+                after.append((o, shard))
             for p in rest:
                 require_gpu(p)
                 st = self.state[p]
@@ -144,10 +143,23 @@ class SGD(_FusedBase):
                     if buf is None:
                         buf = torch.zeros(pd.numel(), device=p.device, dtype=torch.float32)
                         st["momentum_buffer"] = buf
-                ops.sgd_step(pd, gd, buf, lr, mom, wd, self.grad_scale)
+                items.append((pd, gd, buf))
                 o = _owner_of(p)
                 if o is not None:
-                    o.mark_params_modified()
+                    after.append((o, None))
+            same_dev = len({it[0].device for it in items}) <= 1
+            if len(items) >= 2 and same_dev:
+                for k in range(0, len(items), 8):
+                    ops.sgd_step_multi(items[k:k + 8], lr, mom, wd, self.grad_scale)
+            else:
+                for pd, gd, buf in items:
+                    ops.sgd_step(pd, gd, buf, lr, mom, wd, self.grad_scale)
+            for o, shard in after:
+                if shard is not None:
+                    o._dp_shard = shard
+                    shard["reducer"].gather_params(o)
+                    o._dp_shard = None
+                o.mark_params_modified()
         return None
 
 

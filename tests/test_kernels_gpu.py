@@ -1292,3 +1292,23 @@ def test_avgpool_backward_with_batchnorm_sums(shape, dt):
         s = acc.sum(0)
         assert (s[0] - g.sum((0, 1))).abs().max() <= 1e-5 * g.abs().sum((0, 1)).max() + 1e-7
         assert (s[1] - (g * xhat).sum((0, 1))).abs().max() <= 1e-5 * (g.abs() * xhat.abs()).sum((0, 1)).max() + 1e-7
+
+
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_sgd_step_over_several_tensors_in_one_launch(momentum):
+    """clhip_sgd_step_multi = clhip_sgd_step on each tensor, bit for bit (parameters and momentum buffers), sizes that are not multiples of 4, an empty one"""
+    from libcontinual_amd import ops
+    sizes = [446_042, 6400, 100, 0, 7]
+    ps = [rnd((n,), 50 + i).to(DEV) for i, n in enumerate(sizes)]
+    gs = [rnd((n,), 60 + i, 0.1).to(DEV) for i, n in enumerate(sizes)]
+    ms = [rnd((n,), 70 + i, 0.05).to(DEV) for i, n in enumerate(sizes)]
+    p1, m1 = [p.clone() for p in ps], [m.clone() for m in ms]
+    p2, m2 = [p.clone() for p in ps], [m.clone() for m in ms]
+    for p, g, m in zip(p1, gs, m1):
+        if p.numel():
+            ops.sgd_step(p, g, m if momentum else None, 0.05, momentum, 5e-4, 0.5)
+    ops.sgd_step_multi([(p, g, m if momentum else None) for p, g, m in zip(p2, gs, m2)], 0.05, momentum, 5e-4, 0.5)
+    torch.cuda.synchronize()
+    for a, b, c, d in zip(p1, p2, m1, m2):
+        assert torch.equal(a, b) and torch.equal(c, d)
+    assert not torch.equal(p1[0], ps[0])
