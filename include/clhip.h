@@ -151,7 +151,7 @@ int clhip_avgpool_fwd(const void* a, float* feat, int N, int HW, int C, int dtyp
 int clhip_avgpool_bwd(const float* dfeat, void* da, int N, int HW, int C, int dtype, void* stream);
 /* clhip_avgpool_bwd that also reduces the BatchNorm backward of the layer that PRODUCED the pooled activation (the backbone's last unit; the pooling
  * is that activation's only reader): z_prod, y_prod (nullable: no ReLU), mean, invstd, acc [replicas][2][C] fp64 as clhip_conv_dgrad_bn_reduce.
- * C a power of two in [8, 256].  _supported: 1 / 0. */
+ * C a power of two in [8, 2048].  _supported: 1 / 0. */
 int clhip_avgpool_bwd_bn_reduce_supported(int N, int HW, int C, int dtype);
 int clhip_avgpool_bwd_bn_reduce(const float* dfeat, void* da, const void* z_prod, const void* y_prod /*nullable*/, const float* mean, const float* invstd,
                                 double* acc, int replicas, int N, int HW, int C, int dtype, void* stream);

@@ -605,8 +605,8 @@ __global__ __launch_bounds__(256) void avgpool_bwd_bn_kernel(const float* __rest
     for (int e = 0; e < 16; ++e) red[threadIdx.x][e] = s[e];
     __syncthreads();
     const int cpp = C / 8;                                   // chunks per pixel = distinct channel groups among the workgroup's threads
-    if ((int)threadIdx.x < C) {
-        const int c = threadIdx.x, grp = c >> 3, e = c & 7;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int grp = c >> 3, e = c & 7;
         float a1 = 0.f, a2 = 0.f;
         for (int t = grp; t < 256; t += cpp) { a1 += red[t][e]; a2 += red[t][8 + e]; }
         double* a = acc + (size_t)(blockIdx.x & (rep - 1)) * 2 * C;
@@ -896,9 +896,9 @@ extern "C" int clhip_avgpool_fwd(const void* a, float* feat, int N, int HW, int 
     return CLHIP_OK;
 }
 
-// C a power of two in [8, 256] (a workgroup's threads then cover whole channel groups: thread t feeds channels (t mod C/8) * 8 ..), bf16 / f32
+// C a power of two in [8, 2048] (a workgroup's threads then cover whole channel groups: thread t feeds channels (t mod C/8) * 8 ..), bf16 / f32
 extern "C" int clhip_avgpool_bwd_bn_reduce_supported(int N, int HW, int C, int dtype) {
-    return (N > 0 && HW > 0 && C >= 8 && C <= 256 && (C & (C - 1)) == 0 && (dtype == CLHIP_BF16 || dtype == CLHIP_F32)) ? 1 : 0;
+    return (N > 0 && HW > 0 && C >= 8 && C <= 2048 && (C & (C - 1)) == 0 && (dtype == CLHIP_BF16 || dtype == CLHIP_F32)) ? 1 : 0;
 }
 extern "C" int clhip_avgpool_bwd_bn_reduce(const float* dfeat, void* da, const void* z_prod, const void* y_prod, const float* mean, const float* invstd, double* acc,
                                            int replicas, int N, int HW, int C, int dtype, void* stream) {

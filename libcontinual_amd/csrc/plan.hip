@@ -800,7 +800,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             bool sole = true;
             for (const Unit& o : p->units) if (o.d.src == (int)p->units.size() || o.d.res == (int)p->units.size()) sole = false;
             const bool fuse = !pool_fuse_off && p->use_acc && (fe == nullptr || atoi(fe) != 0) && sole && !lu.no_bn && !lu.pre_res && !lu.raw_src && !lu.has_dzr && lu.rep_bwd > 0 &&
-                              lu.d.cout == last.C && clhip_avgpool_bwd_bn_reduce_supported(p->N, last.H * last.W, last.C, p->dtype) != 0;
+                              lu.d.cout == last.C && last.C <= 256 /* wider: one fp64 atomic per channel and workgroup is 262 k atomics on ResNet-18's 512-channel map -- measured 0.5 % slower */ &&
+                              clhip_avgpool_bwd_bn_reduce_supported(p->N, last.H * last.W, last.C, p->dtype) != 0;
             if (fuse) {
                 TRY(clhip_avgpool_bwd_bn_reduce(dfeat, ws + last.dy_off, ws + lu.z_off, lu.relu ? ws + last.y_off : nullptr, fr + lu.f_mean, fr + lu.f_invstd,
                                                 reinterpret_cast<double*>(ws + p->acc_off) + lu.a_bwd, lu.rep_bwd, p->N, last.H * last.W, last.C, p->dtype, stream));

@@ -1263,7 +1263,7 @@ def test_stride2_forward_pair_one_launch(case):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
-@pytest.mark.parametrize("shape", [(256, 64, 64), (33, 16, 512 // 2), (5, 49, 64), (7, 1, 128)])
+@pytest.mark.parametrize("shape", [(256, 64, 64), (33, 16, 512 // 2), (5, 49, 64), (7, 1, 128), (256, 16, 512), (3, 4, 2048)])
 def test_avgpool_backward_with_batchnorm_sums(shape, dt):
     """clhip_avgpool_bwd_bn_reduce = clhip_avgpool_bwd (bit-identical gradient) + the BatchNorm-backward sums of the layer that produced the pooled
     activation (sum g, sum g xhat with g = da masked by y > 0), against fp64; with and without a ReLU."""
