@@ -31,6 +31,10 @@ FLOP_FWD_PER_IMG = {"resnet18": 1.1108e9, "cifar_resnet32": 0.13825e9}     # 2*M
 # whole-step algorithmic FLOP per image of the ViT-B/16 methods: L2P = query fwd (N=197) + prompted
 # fwd (N=222) + activation-only bwd; InfLoRA_OPT = fwd + activation bwd + rank-10 dB (the reference's dense qkv dW not counted)
 FLOP_STEP_PER_IMG = {"l2p_vitb16": 116.2e9, "inflora_vitb16": 71.5e9}
+# whole-step ALGORITHMIC HBM bytes per image, ideal-fused bf16 (every conv output written once and read once in the
+# forward, read once + its gradient written / read once in the backward); the frozen teacher's forward adds one write + one read
+HBM_BYTES_STEP_PER_IMG = {"cifar_resnet32": 3.2e6, "resnet18": 6.0e6}
+HBM_BYTES_TEACHER_PER_IMG = {"cifar_resnet32": 1.3e6, "resnet18": 2.4e6}
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -44,7 +48,9 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: per-GPU batch fixed as N grows; strong: global batch fixed, per-GPU batch = batch // N")
     ap.add_argument("--workload", default="lwf_resnet18_b50_task0",
                     choices=["lwf_resnet18_b50_task0", "lwf_resnet18_b50_task1", "icarl_resnet32_b50_task1", "ewc_resnet32_b50_task1",
-                             "l2p_vitb16_b10_task1", "inflora_vitb16_b20_task1"])
+                             "lucir_resnet32_b50_task1", "l2p_vitb16_b10_task1", "inflora_vitb16_b20_task1",
+                             # the single-GPU per-task work north_star names (a "step" = one batch of the Fisher pass / one class of the herding)
+                             "ewc_fisher_pass", "herding_b50"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' launches (what the PMC passes sample) and print their block")
@@ -88,6 +94,19 @@ def build_method(workload, dtype, dev):
             lo, hi = 50, 55
         opt = optim.SGD(m.get_parameters({}), lr=0.1)                      # config/lwf.yaml:14-17
         arch, teacher = "resnet18", workload.endswith("task1")
+    elif workload.startswith("lucir_resnet32"):
+        # config/lucir-resnet32-cifar100-b50-5-10.yaml: resnet32_V2 + cosine head, task 1 = 50 old + 5 new classes, the frozen previous model's
+        # features (less-forget), CE and the hard-negative margin ranking loss (core/model/lucir.py:175-210); fc2 keeps its fresh
+        # initialisation here (the imprint of lucir.py:134-159 needs the task's data)
+        bb = M.resnet32_V2(dtype=dtype)
+        m = M.LUCIR(bb, 64, 100, device=dev, init_cls_num=50, inc_cls_num=5, dist=0.5, lamda=5, K=2, lw_mr=1).to(dev)
+        m.before_task(0, None, None, None)
+        m._init_new_fc = lambda *a, **k: None
+        m.before_task(1, None, None, None)
+        lo, hi = 0, 55
+        pg = m.get_parameters({})
+        opt = optim.SGD(pg, lr=0.1, momentum=0.9, weight_decay=5e-4)
+        arch, teacher = "cifar_resnet32", True
     elif workload.startswith("icarl_resnet32"):
         bb = M.cifar_resnet32(dtype=dtype)
         m = M.ICarl(bb, 64, 100, device=dev, init_cls_num=50, inc_cls_num=5, task_num=11).to(dev)
@@ -234,7 +253,7 @@ def _time_launches(run, reps, warm=5):
 def _profile_lookup(workload, symbol):
     """in-step average duration of a kernel symbol from the committed rocprofv3 --kernel-trace --stats summary of THIS command
     (profiles/r02_bench_kernel_stats.json, written by tools/bench_profile.sh); None if absent"""
-    for name in ("r03_bench_kernel_stats.json", "r02_bench_kernel_stats.json"):
+    for name in ("r04_bench_kernel_stats.json", "r03_bench_kernel_stats.json", "r02_bench_kernel_stats.json"):
         pj = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pj):
             break
@@ -252,7 +271,7 @@ def _profile_lookup(workload, symbol):
 
 
 def _pmc_lookup(key):
-    for name in ("r03_roofline_pmc.json", "r02_roofline_pmc.json"):
+    for name in ("r04_roofline_pmc.json", "r03_roofline_pmc.json", "r02_roofline_pmc.json"):
         pj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pj):
             continue
@@ -314,6 +333,42 @@ def conv_rooflines(dev, dtype, B, workload):
         return lambda: _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), buf.data_ptr(), N, H, W, C, C, K, 3, stride, 1, code, st)
 
     r18 = "resnet18" in workload
+    if not r18 and dtype == "bf16":
+        # CifarResNet-32 / resnet32_V2 steps: the symbol with the largest share of the committed in-step traces is the fused backward of a
+        # 16 -> 16-channel layer (bwd16_fused_kernel<true>: BatchNorm backward on the operand loads + dgrad + weight gradient, one launch,
+        # conv3.hip) -- timed here through its C entry point at the stage-1 shape.  Algorithmic bytes: x, dy, z read once, dx written once
+        # (+ the 9 KB of dW); FLOPs: dgrad + wgrad = 2 x 2 M 9 C K.  HBM-bound (AI = 18 FLOP/B).
+        import ctypes as Ct
+
+        class BnGrad(Ct.Structure):
+            _fields_ = [("dy", Ct.c_void_p), ("z", Ct.c_void_p), ("sums", Ct.c_void_p), ("replicas", Ct.c_int), ("mean", Ct.c_void_p), ("invstd", Ct.c_void_p),
+                        ("gamma", Ct.c_void_p), ("beta", Ct.c_void_p), ("dgamma", Ct.c_void_p), ("dbeta", Ct.c_void_p), ("relu_mask", Ct.c_void_p), ("dres", Ct.c_void_p),
+                        ("dres_accumulate", Ct.c_int)]
+        N, H, W, C = B, 32, 32, 16
+        M = N * H * W
+        if L.clhip_conv_bn_input_supported(N, H, W, C, C, 3, 1, 1, code) and L.clhip_conv_dgrad_wgrad_supported(N, H, W, C, C, C, 3, 1, 1, code):
+            xin = torch.randn(N, H, W, C, device=dev).to(tdt)
+            dy = (torch.randn(N, H, W, C, device=dev) * 0.5).to(tdt)
+            zp = torch.randn(N, H, W, C, device=dev).to(tdt)
+            wd = (torch.randn(C, 9, C, device=dev) * 0.1).to(tdt)
+            dx = torch.empty(N, H, W, C, device=dev, dtype=tdt)
+            dw = torch.zeros(C, 9, C, device=dev)
+            ws_ = torch.empty(max(L.clhip_conv_wgrad_ws_bytes(N, H, W, C, C, C, 3, 1, 1, code), 16), dtype=torch.uint8, device=dev)
+            mean, invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            zf = zp.float().reshape(-1, C)
+            g = (zf > 0).float() * dy.float().reshape(-1, C)
+            gsum = torch.zeros(4, 2, C, dtype=torch.float64, device=dev)
+            gsum[0, 0], gsum[0, 1] = g.double().sum(0), (g * zf).double().sum(0)
+            bg = BnGrad(dy.data_ptr(), zp.data_ptr(), gsum.data_ptr(), 4, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+                        None, None, 0)
+            keep = (xin, dy, zp, wd, dx, dw, ws_, mean, invstd, gamma, beta, dgam, dbet, gsum, bg)
+            entry("bwd", "bwd16_fused_kernel<true>", f"bwd16_fused_kernel<true>: BatchNorm backward + dX + dW of 3x3/s1 16->16 in one launch @ [{N},{H},{W},{C}]", N, H, W, C, C,
+                  lambda: _lib.call("clhip_conv_dgrad_wgrad_bn_grad", xin.data_ptr(), None, Ct.byref(bg), wd.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), ws_.data_ptr(), None, None,
+                                    None, None, None, 1, N, H, W, C, C, C, 3, 1, 1, code, st),
+                  2 * 2.0 * M * 9 * C * C, 4 * M * C * es + C * 9 * C * 4, f"bwd16/{N}x{H}x{W}x{C}")
+            del keep
     # the 64 -> 64-channel forward runs on the weight-stationary kernel (conv5.hip) from 512 tiles of 256 pixels up (batch >= 128 at 32 x 32)
     l1_sym = "conv5_kernel<0, 12>" if B * 32 * 32 >= 512 * 256 else "conv4_kernel<4, 1, 1, 32, 32, 0>"
     shapes = ((32, 64, l1_sym), (16, 128, "conv4_kernel<4, 2, 1, 64, 32, 0>")) if r18 else ((8, 64, "conv4_kernel<2, 1, 2, 64, 8, 0>"),)
@@ -329,7 +384,7 @@ def conv_rooflines(dev, dtype, B, workload):
         wsbuf = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         acc = torch.zeros(64, 2, K, dtype=torch.float64, device=dev)
         flops = 2.0 * M * 9 * C * K
-        if i == 0:
+        if i == 0 and r18:         # (the CifarResNet-32 steps contain no wgrad4 launch: their weight gradients are part of the fused backward kernels)
             _lib.call("clhip_conv_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), wsbuf.data_ptr(), N, H, W, C, C, K, 3, 1, 1, code, st)
             entry("wgrad", [f"conv_wgrad4_kernel<{W}, 1, 3>", "wgrad3_reduce_kernel"], f"conv_wgrad4_kernel<{W},1,3> + wgrad3_reduce_kernel: dW of 3x3/s1 @ [{N},{H},{W},{C}] x [{N},{H},{W},{K}]",
                   N, H, W, C, K,
@@ -464,8 +519,92 @@ def dp_breakdown(model, opt, reducer, batches, method_name, dev, steps=12):
     return out
 
 
+def task_work_main(a):
+    """The single-GPU per-task work north_star names (Fisher-diagonal accumulation and buffer herding stay on one GPU): same contract,
+    a "step" = one batch of EWC's Fisher pass (core/model/ewc.py:147-205: train-mode forward, CE over all logits, backward, fisher += g^2 * len(y),
+    in fp32 whatever the training dtype) or one class of the herding after a task (core/model/buffer/linearherdingbuffer.py:77-161: eval-mode
+    features of the class's 500 images, L2-normalised, greedy mean matching for buffer_size // classes = 40 exemplars)."""
+    import libcontinual_amd.model as M
+    from libcontinual_amd import _lib, ops
+    assert a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1, "the per-task passes are single-GPU by design (SURVEY.md section 8(e))"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1993)
+    fisher = a.workload == "ewc_fisher_pass"
+    bb = M.cifar_resnet32(dtype=a.dtype)
+    if fisher:
+        B = a.batch or 32                                                  # config/ewc-resnet32-cifar100-b50-5-10.yaml: batch_size 32
+        steps, warm = a.steps or 200, a.warmup if a.warmup is not None else 20
+        m = M.EWC(bb, 64, 100, device=dev, init_cls_num=50, inc_cls_num=5, lamda=1000).to(dev)
+        m.before_task(0, None, None, None)
+        batches = [synthetic_batch(B, 0, 50, 100 + i, dev) for i in range(4)]
+
+        class Loader:                                                        # what getFisher reads: batch_size, len(), iteration
+            def __init__(self, n): self.n, self.batch_size = n, B
+            def __len__(self): return self.n
+            def __iter__(self): return (batches[i % 4] for i in range(self.n))
+        run = lambda n: m.getFisher(Loader(n))
+        per_step_imgs = B
+        desc = dict(workload=a.workload, method="EWC.getFisher", backbone="cifar_resnet32", per_gpu_batch=B, global_batch=B, image="3x32x32", parallelism="dp1",
+                    pass_images=25000, compute_dtype="f32 (the Fisher pass runs in fp32 whatever the training dtype)")
+        metric = "images/sec (EWC Fisher pass after task 0: 25000 images), CIFAR-100 B50-5x10"
+    else:
+        B = a.batch or 500                                                   # images of one class
+        steps, warm = a.steps or 100, a.warmup if a.warmup is not None else 5
+        net = M.ICarl(bb, 64, 100, device=dev, init_cls_num=50, inc_cls_num=5, task_num=11).to(dev)
+        net.before_task(0, None, None, None)
+        net.eval()
+        xs = [synthetic_batch(B, 0, 50, 200 + i, dev)["image"] for i in range(4)]
+
+        def one_class(i):
+            feats = []
+            with torch.no_grad():
+                for j in range(0, B, 256):                                   # the reference's DataLoader(batch_size=256) over the class's images
+                    feats.append(ops.l2_normalize_rows(net.network.backbone(xs[i % 4][j:j + 256])["features"]))
+            return ops.herding_select(torch.cat(feats), 2000 // 50)
+        run = lambda n: [one_class(i) for i in range(n)]
+        per_step_imgs = B
+        desc = dict(workload=a.workload, method="LinearHerdingBuffer.herding_select", backbone="cifar_resnet32", per_gpu_batch=B, global_batch=B, image="3x32x32",
+                    parallelism="dp1", classes=50, exemplars_per_class=40)
+        metric = "images/sec (herding after task 0: 50 classes x 500 images -> 40 exemplars each), CIFAR-100 B50-5x10"
+    run(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ips = per_step_imgs * steps / dt
+    # roofline of the pass's own elementwise / selection kernel, timed live (the convolution kernels are priced by the training workloads)
+    st = torch.cuda.current_stream().cuda_stream
+    if fisher:
+        flat, gflat = bb.flat_parameters()
+        f = torch.zeros_like(flat)
+        ms = _time_launches(lambda: ops.fisher_accum(f, gflat, 1.0 / 25000), 50)
+        nbytes = 12.0 * flat.numel()
+        roof = dict(bound="hbm", kernel=f"fisher_accum_kernel: f += s * g^2 over the flat parameter buffer ({flat.numel()} fp32)", launch_ms=ms, algorithmic_bytes_per_launch=nbytes,
+                    achieved=nbytes / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=None,
+                    note="5.6 MB per launch: a launch at its latency floor, not a bandwidth-bound one")
+        step_flops = 3 * FLOP_FWD_PER_IMG["cifar_resnet32"]
+    else:
+        cf = ops.l2_normalize_rows(torch.randn(B, 64, device=dev))
+        ms = _time_launches(lambda: ops.herding_select(cf, 40), 50)
+        nbytes = 40.0 * B * 64 * 4                                           # every pick re-reads the class's features
+        roof = dict(bound="hbm", kernel=f"herding_kernel: 40 greedy picks over [{B}, 64] normalised features, one workgroup", launch_ms=ms, algorithmic_bytes_per_launch=nbytes,
+                    achieved=nbytes / (ms * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=None,
+                    note="a sequential 40-step selection on 128 KB of features: latency-bound by construction (one workgroup, LDS-resident)")
+        step_flops = FLOP_FWD_PER_IMG["cifar_resnet32"]
+    out = {"metric": metric, "value": ips, "unit": "images/sec", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if fisher else a.dtype, "data": "synthetic", "config": desc,
+           "whole_pass_seconds": (25000.0 / ips), "step_tflops_algorithmic": step_flops * ips / 1e12,
+           "step_frac_of_hbm_peak": (HBM_BYTES_STEP_PER_IMG["cifar_resnet32"] * (2.0 if fisher else 0.4)) * ips / 1e9 / PEAK_HBM_GBS,
+           "roofline": roof}
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.workload in ("ewc_fisher_pass", "herding_b50"):
+        return task_work_main(a)
     vit = "vitb16" in a.workload
     if a.batch is None:
         a.batch = 16 if a.workload.startswith("l2p") else (128 if vit else 256)
@@ -565,6 +704,12 @@ def main():
         "step_tflops_algorithmic": step_flops_per_img * ips / 1e12,
         "step_frac_of_bf16_mfma_peak": step_flops_per_img * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
     }
+    if not vit:
+        # the HBM-roofline reading of the whole step (primary for CifarResNet-32, AI ~ 130 FLOP/B; secondary for ResNet-18)
+        hb = HBM_BYTES_STEP_PER_IMG[arch] + (HBM_BYTES_TEACHER_PER_IMG[arch] if teacher else 0.0)
+        out["step_hbm_gbs_algorithmic"] = hb * ips / 1e9
+        out["step_frac_of_hbm_peak"] = hb * ips / 1e9 / (PEAK_HBM_GBS * world)
+        out["step_bound"] = "hbm" if arch == "cifar_resnet32" else "mfma"
     if dp is not None:
         out["dp"] = dp
     out["roofline"] = roofline

@@ -384,6 +384,15 @@ typedef struct clhip_bn_res_input {
 int clhip_conv_fwd_acc_bn_res_input(const void* z_in, const clhip_bn_input* bn /*host*/, const clhip_bn_res_input* rs /*host*/, const void* w_fwd, void* z,
                                     double* stat_acc, int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype,
                                     void* stream);
+/* The write-through form for the LDS-DMA kernels of the wide layers (64 ... 512 channels, 3x3 / stride 1: ResNet-18's BasicBlocks,
+ * resnet.py:289-316; conv4.hip / conv5.hip): LDS-DMA has no arithmetic on the way, so the patch lands RAW (z_in) and the wave that issued a
+ * DMA piece rewrites its slots in LDS with relu(scale * z_in + shift [+ res]) before the patch is published; the workgroup that owns a pixel
+ * writes rs->y (always: the consumer's weight gradient reads it) and, for a conv -> BN -> +res -> ReLU producer, rs->relu_mask.
+ * rs->res / rs->relu_mask NULL: plain relu(bn(z_in)).  Values bit for bit those of clhip_bn_apply_train[_mask]; bf16 only. */
+int clhip_conv_bn_input_wt_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
+int clhip_conv_fwd_acc_bn_input_wt(const void* z_in, const clhip_bn_input* bn /*host*/, const clhip_bn_res_input* rs /*host*/, const void* w_fwd, void* z,
+                                   double* stat_acc, int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype,
+                                   void* stream);
 int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw,
                                     void* ws, const float* mean, const float* invstd, double* acc /*nullable*/, int replicas, int N, int H, int W,
                                     int C, int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream);
@@ -432,7 +441,7 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
  * pin a code path, tools/ to sweep.
  *   dispatch (0 / 1 unless noted):
- *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV64 (0: 64 -> 64 channels on small maps stay on conv4 / wgrad4; CONV64_FWD 0: only their backward; CONV64_BM 64 | 128), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV7 (0: no small-channel entry kernels; FWD7 0 / WGRAD7 0: not their forward / weight-gradient pairs; CONV7_TPW n: tiles per wave), BN_INPUT (0: no lazy BatchNorm inputs), BN_RES_INPUT (0: block outputs keep their own apply launch), BN_GRAD (0: no BatchNorm backward on the operand loads; BN_GRAD_MINC n: only for layers of >= n channels, BN_GRAD_RES 0: not for the +res layers), CONV_V1,
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV64 (0: 64 -> 64 channels on small maps stay on conv4 / wgrad4; CONV64_FWD 0: only their backward; CONV64_BM 64 | 128), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV7 (0: no small-channel entry kernels; FWD7 0 / WGRAD7 0: not their forward / weight-gradient pairs; CONV7_TPW n: tiles per wave), BN_INPUT (0: no lazy BatchNorm inputs), BN_INPUT_WT (0: not on the LDS-DMA kernels of the wide layers), BN_RES_INPUT (0: block outputs keep their own apply launch), BN_GRAD (0: no BatchNorm backward on the operand loads; BN_GRAD_MINC n: only for layers of >= n channels, BN_GRAD_RES 0: not for the +res layers), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
  *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
@@ -440,12 +449,15 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), BRANCH_STREAM (shortcut branches on a third stream: 0 never, 1 forward and backward, 2 forward only = default, 3 backward only), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD
  *   tuning values:
  *     WGRAD_TARGET (workgroups of the weight-gradient kernels), WGRAD_NET_GFLOP, WGRAD4_MIN_STEPS, WGRAD4_MIN_TOTAL, CONV3_CFG "wm,wn",
- *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
+ *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, PLAN_SKIP (timing ablations: 1 no forward BatchNorm apply, 2 no BatchNorm backward, 4 no weight gradients -- results invalid), IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
  *     STEM_WGRAD_GRID, SHORTCUT_MIN_PIXELS, BN_ACC_CPT, BN_BWD_ITERS
  *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG, CONV6_DEBUG (read once),
  *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE (device address of
  *     a stamp buffer as a number; ablation builds only) */
 int clhip_config(const char* key, const char* value);
+/* the value clhip_config() last set for `key` (NULL: never set or erased -- the environment's value applies).  For callers that flip a
+ * switch around a region and must put back what was there (ops.TeacherPass).  The pointer stays valid for the process' life. */
+const char* clhip_config_get(const char* key);
 /* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never, 1 where it wins (default: N >= 2048,
  * >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
 void clhip_gemm5_config(int mode);
@@ -499,6 +511,9 @@ int clhip_lora_grad(const void* x, const void* dqkv, const float* lora_a_k, cons
                     float* d_b_v, void* ws, int M, int D, int rank, int dtype, void* stream);
 /* G [D, D] fp32 += X^T X  (MultiHeadAttention_LoRA get_input_matrix, transformer.py:241-244; the running mean is the caller's) */
 int clhip_gram_accum(const void* x, float* G, int M, int D, int dtype, void* stream);
+/* the same for n_layers inputs of one pass in ONE launch: layer l reads x + l * layer_stride_elems and adds into G + l * D * D.  bf16: an
+ * MFMA "TN" product, one workgroup per (layer, 128 x 128 tile) over all rows -- no atomics, bitwise reproducible; fp32: the scalar kernel per layer */
+int clhip_gram_accum_batched(const void* x, size_t layer_stride_elems, int n_layers, float* G, int M, int D, int dtype, void* stream);
 /* prompt.L2P.forward (prompt.py:369-406): cosine top-k per sample, batch-majority top-k ids (ties: lowest id), gathered
  * prompt tokens [top_k*length, D], reduce_sim (scalar) and d reduce_sim / d prompt_key [pool, D].  scratch: B+pool+D+B*pool floats. */
 int clhip_l2p_select(const float* cls_feat, const float* prompt_key, const float* prompt, int B, int D, int pool, int top_k, int length,

@@ -148,6 +148,10 @@ _PROTOS = {
     "clhip_augment_rrc_aa": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_gemm_nt": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "clhip_config": (_i, [C.c_char_p, C.c_char_p]),
+    "clhip_config_get": (C.c_char_p, [C.c_char_p]),
+    "clhip_conv_bn_input_wt_supported": (_i, [_i] * 9),
+    "clhip_conv_fwd_acc_bn_input_wt": (_i, [_p, _p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
+    "clhip_gram_accum_batched": (_i, [_p, C.c_size_t, _i, _p, _i, _i, _i, _p]),
     "clhip_gemm5_config": (None, [_i]),
     "clhip_wgrad4_config": (None, [_i]),
     "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -28,11 +28,11 @@ const char* const kKeys[] = {
     // dispatch switches (A/B runs, tests that pin a code path)
     "ATTN_GENERIC", "BN_FUSE", "BN_FUSE_MAX_M", "BN_MASK_BITS", "BN_MASK_FROM_Y", "BN_PARTIALS", "CE_ROWS", "CE_ONE_WG", "LINEAR_BWD_SPLIT", "CONV3G", "CONV4", "CONV_V1",
     "GEMM5", "GEMM_NO_SPLIT", "GEMM_TAIL", "NO_CONV16", "NO_CONV3", "NO_PARITY_DGRAD", "NO_SHORTCUT", "NO_STEM", "PREP_NARROW", "WGRAD4",
-    "WGRAD_NO_TR", "WGRAD2_ATOMIC", "WGRAD_DEFER", "WGRAD_DEFER_SIDE", "BWD_FUSED", "WGRAD_STREAM", "BRANCH_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "CONV6", "WGRAD16_PARTS", "WGRAD32_IPG", "WGRAD64_IPG", "WGRAD64_IPI2", "CONV64", "CONV64_BM", "CONV64_FWD", "CONV6_PAIR", "CONV7", "CONV7_TPW", "WGRAD7", "FWD7", "PAIR_BN_FUSE", "POOL_BN_FUSE", "BN_INPUT", "BN_RES_INPUT", "BN_GRAD", "BN_GRAD_MINC", "BN_GRAD_RES", "CONV6_DEBUG", "BN_ONEPASS", "WGRAD5", "WGRAD32",
+    "WGRAD_NO_TR", "WGRAD2_ATOMIC", "WGRAD_DEFER", "WGRAD_DEFER_SIDE", "BWD_FUSED", "WGRAD_STREAM", "BRANCH_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "CONV6", "WGRAD16_PARTS", "WGRAD32_IPG", "WGRAD64_IPG", "WGRAD64_IPI2", "CONV64", "CONV64_BM", "CONV64_FWD", "CONV6_PAIR", "CONV7", "CONV7_TPW", "WGRAD7", "FWD7", "PAIR_BN_FUSE", "POOL_BN_FUSE", "BN_INPUT", "BN_INPUT_WT", "BN_RES_INPUT", "BN_GRAD", "BN_GRAD_MINC", "BN_GRAD_RES", "CONV6_DEBUG", "BN_ONEPASS", "WGRAD5", "WGRAD32",
     // tuning values
     "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
-    "CONV5_MIN_TILES", "CONV5_GRID",
+    "CONV5_MIN_TILES", "CONV5_GRID", "PLAN_SKIP", "WT_DEBUG",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
     "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE", "CONV6_TRACE",
 };
@@ -67,6 +67,14 @@ const char* clhip_cfg(const char* name) {
     char env[96];
     snprintf(env, sizeof(env), "CLHIP_%s", name);
     return getenv(env);
+}
+
+extern "C" const char* clhip_config_get(const char* key) {
+    if (key == nullptr) return nullptr;
+    if (strncmp(key, "CLHIP_", 6) == 0) key += 6;
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
+    auto it = cfg_map().find(key);
+    return it != cfg_map().end() ? it->second : nullptr;
 }
 
 extern "C" int clhip_config(const char* key, const char* value) {

@@ -17,7 +17,7 @@ namespace {
 __global__ __launch_bounds__(256) void crop_flip_kernel(const uint8_t* __restrict__ store, const int64_t* __restrict__ index,
                                                         const int32_t* __restrict__ params /* [B,3]: dy, dx, flip */,
                                                         const float* __restrict__ bright /* [B] or null */, float* __restrict__ out, int B, int H,
-                                                        int W, int S, int pad, float m0, float m1, float m2, float i0, float i1, float i2) {
+                                                        int W, int S, int pad, float m0, float m1, float m2, float i0 /* std, not its reciprocal: ToTensor + Normalize divide (v / 255, (x - mean) / std), and so does this -- bit for bit */, float i1, float i2) {
     const int64_t total = (int64_t)B * S * S;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int x = (int)(t % S), y = (int)((t / S) % S), b = (int)(t / ((int64_t)S * S));
@@ -35,9 +35,9 @@ __global__ __launch_bounds__(256) void crop_flip_kernel(const uint8_t* __restric
         }
         const size_t plane = (size_t)S * S;
         float* o = out + (size_t)b * 3 * plane + (size_t)y * S + x;
-        o[0] = (r * (1.f / 255.f) - m0) * i0;
-        o[plane] = (g * (1.f / 255.f) - m1) * i1;
-        o[2 * plane] = (bl * (1.f / 255.f) - m2) * i2;
+        o[0] = (r / 255.f - m0) / i0;
+        o[plane] = (g / 255.f - m1) / i1;
+        o[2 * plane] = (bl / 255.f - m2) / i2;
     }
 }
 
@@ -72,9 +72,9 @@ __global__ __launch_bounds__(256) void rrc_flip_kernel(const uint8_t* __restrict
         }
         const size_t plane = (size_t)S * S;
         float* o = out + (size_t)b * 3 * plane + (size_t)y * S + x;
-        o[0] = (v[0] * (1.f / 255.f) - m0) * i0;
-        o[plane] = (v[1] * (1.f / 255.f) - m1) * i1;
-        o[2 * plane] = (v[2] * (1.f / 255.f) - m2) * i2;
+        o[0] = (v[0] / 255.f - m0) / i0;
+        o[plane] = (v[1] / 255.f - m1) / i1;
+        o[2 * plane] = (v[2] / 255.f - m2) / i2;
     }
 }
 
@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void rrc_aa_kernel(const uint8_t* __restrict__
         }
         const size_t plane = (size_t)S * S;
         float* o = out + (size_t)b * 3 * plane + (size_t)y * S + x;
-        o[0] = ((float)clip8(v0 >> AA_BITS) * (1.f / 255.f) - m0) * i0;
-        o[plane] = ((float)clip8(v1 >> AA_BITS) * (1.f / 255.f) - m1) * i1;
-        o[2 * plane] = ((float)clip8(v2 >> AA_BITS) * (1.f / 255.f) - m2) * i2;
+        o[0] = ((float)clip8(v0 >> AA_BITS) / 255.f - m0) / i0;
+        o[plane] = ((float)clip8(v1 >> AA_BITS) / 255.f - m1) / i1;
+        o[2 * plane] = ((float)clip8(v2 >> AA_BITS) / 255.f - m2) / i2;
     }
 }
 
@@ -176,7 +176,7 @@ extern "C" int clhip_augment_crop_flip(const uint8_t* store, const int64_t* inde
     CLHIP_CHECK_ARG(store && index && params && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && S > 0 && pad >= 0);
     CLHIP_CHECK_ARG(S <= H + 2 * pad && S <= W + 2 * pad);
     hipLaunchKernelGGL(crop_flip_kernel, dim3(blocks_for((int64_t)B * S * S)), dim3(256), 0, static_cast<hipStream_t>(stream), store, index, params,
-                       brightness, out, B, H, W, S, pad, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+                       brightness, out, B, H, W, S, pad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -185,7 +185,7 @@ extern "C" int clhip_augment_rrc_flip(const uint8_t* store, const int64_t* index
                                       const float* mean3, const float* std3, void* stream) {
     CLHIP_CHECK_ARG(store && index && params && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && S > 0);
     hipLaunchKernelGGL(rrc_flip_kernel, dim3(blocks_for((int64_t)B * S * S)), dim3(256), 0, static_cast<hipStream_t>(stream), store, index, params, out,
-                       B, H, W, S, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+                       B, H, W, S, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -205,7 +205,7 @@ extern "C" int clhip_augment_rrc_aa(const uint8_t* store, const int64_t* offsets
     hipLaunchKernelGGL(aa_coef_kernel, dim3((B * 2 * S + 255) / 256), dim3(256), 0, st, params, static_cast<int32_t*>(ws), B, S, T);
     CLHIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(rrc_aa_kernel, dim3(blocks_for((int64_t)B * S * S)), dim3(256), 0, st, store, offsets, hw, index, params,
-                       static_cast<const int32_t*>(ws), out, B, H, W, S, T, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+                       static_cast<const int32_t*>(ws), out, B, H, W, S, T, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

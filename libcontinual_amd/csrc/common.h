@@ -204,6 +204,74 @@ __device__ __forceinline__ uint4 bn_res_relu8_bf16(uint4 v, uint4 r, const float
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
+// ---- "lazy" BatchNorm input of the LDS-DMA convolution kernels (conv4.hip / conv5.hip, round 4): the consumer's patch arrives in LDS as the RAW
+// pre-BatchNorm output z' of the producing layer (LDS-DMA has no arithmetic on the way), and the wave that issued a DMA piece rewrites the
+// slots it landed IN PLACE with relu(scale * z' + shift [+ r]) before the workgroup barrier publishes the patch.  The workgroup that owns a
+// pixel also writes that activation (and, for a conv -> BN -> +res -> ReLU producer, its packed ReLU mask) to global memory -- the weight
+// gradient of the consumer and the backward of the producer read it -- so the producer's BatchNorm-apply launch disappears and the
+// convolution's read of the activation becomes the read of z' [and r].  Values bit for bit what bn_apply_train_kernel stores.
+struct LazyIn {
+    const double* acc = nullptr;    // the producer's [rep][2][C] fp64 statistics accumulators; nullptr: the source is an ordinary activation
+    int rep = 1;
+    const float* gamma = nullptr; const float* beta = nullptr;
+    float* rm = nullptr; float* rv = nullptr;           // running statistics (updated by workgroup 0), or both nullptr
+    float momentum = 0.f, eps = 0.f;
+    double invM = 0.0, unbias = 1.0;
+    float* mean_o = nullptr; float* invstd_o = nullptr; float* coef_o = nullptr;      // [C], [C], [2][C]: what the backward reads (workgroup 0)
+    const bf16_t* res = nullptr;    // r [N,H,W,C] or nullptr
+    bf16_t* y = nullptr;            // out [N,H,W,C]
+    unsigned char* mask = nullptr;  // out [N*H*W*C/8] or nullptr
+};
+
+// scale / shift of a lazy input into coefs[2][C] (LDS): the arithmetic of bn_apply_train_kernel's prologue (bn.hip), bf16 mode.  Called by
+// every thread of a workgroup of >= 256 threads; sred = 256 doubles of LDS; ends with a workgroup barrier.
+__device__ inline void lazy_in_coefs(const LazyIn& L, int C, float* coefs, double* sred, bool first) {
+    const bool narrow = 2 * C <= 128;
+    if (narrow) {
+        if (threadIdx.x < 256) {
+            const int n2 = 2 * C, parts = 256 / n2;
+            const int col = threadIdx.x % n2, part = threadIdx.x / n2;
+            const int n = (L.rep - part + parts - 1) / parts;
+            double s = 0.0;
+            for (int r0 = 0; r0 < n; r0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = r0 + i < n ? L.acc[(size_t)(part + (r0 + i) * parts) * n2 + col] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[i];
+            }
+            sred[threadIdx.x] = s;
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const bool upd = first && L.rm != nullptr;
+        const float rm_old = upd ? L.rm[c] : 0.f, rv_old = upd ? L.rv[c] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+        if (narrow) { for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; } }
+        else sum_strided2(L.acc + c, L.acc + C + c, L.rep, 2 * (size_t)C, s1, s2);
+        const double mean = s1 * L.invM;
+        double var = s2 * L.invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float istd = rsqrtf((float)var + L.eps);
+        const float sc = L.gamma[c] * istd;
+        const float sh = L.beta[c] - (float)mean * sc;
+        coefs[c] = sc;
+        coefs[C + c] = sh;
+        if (first) {
+            L.mean_o[c] = (float)mean;
+            L.invstd_o[c] = istd;
+            L.coef_o[c] = sc;
+            L.coef_o[C + c] = sh;
+            if (upd) {
+                L.rm[c] = (1.f - L.momentum) * rm_old + L.momentum * (float)mean;
+                L.rv[c] = (1.f - L.momentum) * rv_old + L.momentum * (float)(var * L.unbias);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ uint4 bn_relu8_bf16(uint4 v, const float* sc, const float* sh) {
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
     unsigned o[4];

@@ -696,6 +696,46 @@ static int conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, con
                                   static_cast<hipStream_t>(stream), rs);
 }
 
+// ---- the same for the LDS-DMA kernels of the wide layers (conv5.hip: 64 -> 64 channels at >= 512 tiles; conv4.hip: C, K multiples of 64): the
+//      transform happens IN LDS on the landed patch and the launch always writes the activation (common.h LazyIn)
+int clhip_conv5_launch_in(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, const LazyIn* in,
+                          hipStream_t st);
+bool clhip_conv4_in_supported(int N, int H, int W, int Cs, int Cd);
+int clhip_conv4_launch_in(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, const LazyIn* in, hipStream_t st);
+
+extern "C" int clhip_conv_bn_input_wt_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
+    if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
+    if (use_v1() || !use_v3() || dtype != CLHIP_BF16) return 0;
+    // OFF by default (BN_INPUT_WT=1 enables it): measured on ResNet-18 layer1 at batch 256 the fused launch is 41.5 us against 47.2 us for the two it
+    // replaces stand-alone, but inside the step the apply launches run at 10-11 us out of the Infinity Cache and the step got SLOWER (2.095 ->
+    // 2.14 ms with the four layer-1 units fused; the +res form loses stand-alone as well: 59 vs 55 us) -- profiles/r04_wt_notes.md
+    const char* cfg = clhip_cfg("BN_INPUT_WT");
+    if (cfg == nullptr || atoi(cfg) == 0) return 0;
+    if (conv64_fwd_on() && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 0;      // (that layer runs on the register-staged kernel)
+    if (clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 1;
+    if (clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype) && clhip_conv4_in_supported(N, H, W, C, K)) return 1;
+    return 0;
+}
+
+extern "C" int clhip_conv_fwd_acc_bn_input_wt(const void* z_in, const clhip_bn_input* bn, const clhip_bn_res_input* rs, const void* w_fwd, void* z, double* stat_acc,
+                                              int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream) {
+    if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
+    CLHIP_CHECK_ARG(z_in && bn && rs && rs->y && w_fwd && z && stat_acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+    CLHIP_CHECK_ARG(bn->stat_acc && bn->gamma && bn->beta && bn->mean && bn->invstd && bn->coef && bn->replicas >= 1 && bn->replicas <= 64);
+    CLHIP_CHECK_ARG((bn->running_mean == nullptr) == (bn->running_var == nullptr));
+    CLHIP_CHECK_ARG(rs->relu_mask == nullptr || rs->res != nullptr);
+    CLHIP_CHECK_ARG(clhip_conv_bn_input_wt_supported(N, H, W, C, K, ksize, stride, pad, dtype));
+    LazyIn in;
+    in.acc = bn->stat_acc; in.rep = bn->replicas; in.gamma = bn->gamma; in.beta = bn->beta; in.rm = bn->running_mean; in.rv = bn->running_var;
+    in.momentum = bn->momentum; in.eps = bn->eps; in.mean_o = bn->mean; in.invstd_o = bn->invstd; in.coef_o = bn->coef;
+    const double M = (double)N * H * W;
+    in.invM = 1.0 / M; in.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
+    in.res = static_cast<const bf16_t*>(rs->res); in.y = static_cast<bf16_t*>(rs->y); in.mask = static_cast<unsigned char*>(rs->relu_mask);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return clhip_conv5_launch_in(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, &in, st);
+    return clhip_conv4_launch_in(z_in, w_fwd, z, stat_acc, replicas, N, H, W, C, K, &in, st);
+}
+
 extern "C" int clhip_conv_dgrad_wgrad_bn_input(const void* x_z, const float* x_coef, const void* dz, const void* w_dg, void* dx, int accumulate, float* dw,
                                                void* ws, const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C,
                                                int Creal, int K, int ksize, int stride, int pad, int dtype, void* stream) {

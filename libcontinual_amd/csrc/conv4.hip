@@ -671,3 +671,11 @@ void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck) { g_force4[0] = wm; g_f
 void clhip_conv4_enable(int on) { g_enable4 = on; }
 void clhip_conv4_set_debug(int bits) { g_debug4 = bits; }
 void clhip_conv4_set_trace(unsigned long long* dev_buf) { g_trace4 = dev_buf; }
+
+// ---- lazy BatchNorm input (common.h LazyIn): not built for this kernel family yet
+bool clhip_conv4_in_supported(int N, int H, int W, int Cs, int Cd) { (void)N; (void)H; (void)W; (void)Cs; (void)Cd; return false; }
+int clhip_conv4_launch_in(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int Cs, int Cd, const LazyIn* in, hipStream_t st) {
+    (void)src; (void)wt; (void)dst; (void)stat_acc; (void)stat_rep; (void)N; (void)H; (void)W; (void)Cs; (void)Cd; (void)in; (void)st;
+    clhip_set_error("conv4: lazy inputs are not supported");
+    return CLHIP_EINVAL;
+}

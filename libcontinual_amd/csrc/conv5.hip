@@ -40,6 +40,8 @@ struct Conv5Params {
     int patch_bytes;
     int zoff;
     int n_tiles;
+    LazyIn in;           // XF != 0 (forward only): src is the producer's pre-BatchNorm output, see common.h
+    int in_debug;        // WT_DEBUG (timing experiments, results invalid): 1 no activation / mask stores, 2 no transform at all
 };
 
 int g_enable5 = -1, g_min_tiles5 = -1;      // clhip_config("CONV5" / "CONV5_MIN_TILES"): take effect at once (tests and tools/ubench flip them between launches)
@@ -67,8 +69,12 @@ __device__ __forceinline__ unsigned tap_mask5(int g, const Conv5Params& p) {
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0070 | 0xF00); }          // vmcnt(0), lgkmcnt / expcnt untouched
 __device__ __forceinline__ void wait_lds5() { __builtin_amdgcn_s_waitcnt(0xC07F); }                // lgkmcnt(0)
 
-template <int MODE, int PINST>
+// XF: 0 = the source is an activation; 1 = lazy input relu(bn(z')); 2 = lazy input relu(bn(z') + r) with the packed ReLU mask written as well
+// (common.h LazyIn; both forms write the activation for the pixels the workgroup owns).  LDS with XF: | patch 0 | patch 1 | statistics |
+// coefficient table [2][64] | fp64 scratch of the coefficient prologue / (XF == 2) the landed patch of r |
+template <int MODE, int PINST, int XF = 0>
 __global__ __launch_bounds__(256, 1) void conv5_kernel(const Conv5Params p) {
+    static_assert(XF == 0 || MODE == 0, "lazy inputs exist in the forward only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,6 +141,56 @@ __global__ __launch_bounds__(256, 1) void conv5_kernel(const Conv5Params p) {
 #endif
     };
 
+    // ---- lazy input: coefficient table, the residual's patch (same slots, same lanes as the z' patch), the in-place transform of the slots
+    //      THIS wave's DMA pieces landed (legal right after the wave's own vmcnt wait; the tile barrier publishes the result)
+    float* coefs = reinterpret_cast<float*>(smem + 2 * p.patch_bytes + 2 * 8 * 2 * C5 * sizeof(float));
+    char* rbuf = reinterpret_cast<char*>(coefs + 2 * C5);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(XF == 2 ? p.in.res : p.src), 0, p.M * C5 * 2, 0x00020000);
+    auto rdma = [&](int tile) {
+        if constexpr (XF == 2) {
+            const int base = (tile * BM5 - halo) * (C5 * 2);
+            char* l = rbuf + wv * (PINST * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int i = 0; i < PINST; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lvoid_t*)(l + i * 1024), 16, prel[i] + base, 0, 0, 0);
+#else
+            (void)base; (void)l;
+#endif
+        }
+    };
+    auto transform = [&](int tile, int buf) {
+        if constexpr (XF != 0) {
+            if (p.in_debug & 2) return;
+            const int pix0 = tile * BM5 - halo;                       // global pixel of patch pixel 0
+            char* l = patch + buf * p.patch_bytes + (wv * PINST) * 1024 + lane * 16;
+            const char* lr = rbuf + (wv * PINST) * 1024 + lane * 16;
+#pragma unroll 2
+            for (int i = 0; i < PINST; ++i) {
+                const int pr = prel[i];
+                if (pr == OOB) continue;                              // pad slot / zero area / behind the patch: stays zero
+                const int q = pr >> 7, sub = (pr >> 4) & 7;
+                const int g = pix0 + q;
+                if (g < 0 || g >= p.M) continue;                      // outside the tensor: the DMA wrote zeros, and zeros they stay
+                const uint4 v = *reinterpret_cast<const uint4*>(l + i * 1024);
+                float sc[8], sh[8];
+                *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(coefs + sub * 8);
+                *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(coefs + sub * 8 + 4);
+                *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(coefs + C5 + sub * 8);
+                *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(coefs + C5 + sub * 8 + 4);
+                uint4 o;
+                unsigned mk = 0;
+                if constexpr (XF == 2) o = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(lr + i * 1024), sc, sh, mk);
+                else o = bn_relu8_bf16(v, sc, sh);
+                *reinterpret_cast<uint4*>(l + i * 1024) = o;
+                if (q >= halo && q < halo + BM5 && !(p.in_debug & 1)) {      // a pixel of this workgroup's tile: the activation's one writer
+                    *reinterpret_cast<uint4*>(p.in.y + (size_t)g * C5 + sub * 8) = o;
+                    if (XF == 2 && p.in.mask != nullptr) p.in.mask[(size_t)g * (C5 / 8) + sub] = (unsigned char)mk;
+                }
+            }
+        }
+    };
+
     // ---- pixel fragment addresses: tile i of this wave = pixels wv*64 + i*32 + l31, K half kh
     int xaddr[2];
 #pragma unroll
@@ -156,11 +212,22 @@ __global__ __launch_bounds__(256, 1) void conv5_kernel(const Conv5Params p) {
         t_first = blockIdx.x; t_step = G;
         nmy = (p.n_tiles - t_first + G - 1) / G;
     }
-    if (nmy <= 0) return;
+    if (nmy <= 0) {
+        // (a lazy input's by-products -- saved statistics, running-statistics update -- are workgroup 0's, which always has a tile)
+        return;
+    }
     // prologue: patch of the first tile -> buffer 1, filter rows 0-31 -> buffer 0 -> registers, rows 32-63 likewise
     pdma(t_first, 1);
+    rdma(t_first);
     wdma(0);
+    if constexpr (XF != 0) {
+        // scale / shift of the producer's BatchNorm from its fp64 sums while the first DMAs fly (the fp64 scratch is the residual buffer's tail:
+        // nothing lands there -- the DMA pieces cover PINST * 4 KB from its start, the scratch sits behind the zero area of that image)
+        lazy_in_coefs(p.in, C5, coefs, reinterpret_cast<double*>(coefs + 2 * C5 + (XF == 2 ? p.patch_bytes / 4 : 0)), blockIdx.x == 0);
+    }
     wait_vm0();
+    transform(t_first, 1);
+    wait_lds5();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     wread(0);
@@ -180,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv5_kernel(const Conv5Params p) {
         const int tile = t_first + k * t_step;
         const int m0 = tile * BM5;
         const char* pb = patch + ((k + 1) & 1) * p.patch_bytes;         // the first tile sits in buffer 1 (buffer 0 staged the filter rows)
-        if (k + 1 < nmy) pdma(tile + t_step, k & 1);           // lands under this tile's 144 MFMAs
+        if (k + 1 < nmy) { pdma(tile + t_step, k & 1); rdma(tile + t_step); }     // lands under this tile's 144 MFMAs
         unsigned tmask[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -278,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void conv5_kernel(const Conv5Params p) {
                 }
             }
         }
+        if (k + 1 < nmy) transform(tile + t_step, k & 1);       // this wave's slots of the next patch: raw z' -> the activation, in place
         // one barrier per tile: every wave is done reading this tile's patch buffer (the DMA of tile k + 2 may overwrite it), every wave's
         // part of the next patch has landed (waited for above), and the statistics rows of this tile are visible
         wait_lds5();
@@ -293,10 +361,12 @@ __global__ __launch_bounds__(256, 1) void conv5_kernel(const Conv5Params p) {
     }
 }
 
-template <int MODE, int PINST>
+template <int MODE, int PINST, int XF = 0>
 int launch5(Conv5Params& p, hipStream_t st) {
-    const size_t lds = (size_t)2 * p.patch_bytes + 2 * 8 * 2 * C5 * sizeof(float);
-    auto kern = conv5_kernel<MODE, PINST>;
+    size_t lds = (size_t)2 * p.patch_bytes + 2 * 8 * 2 * C5 * sizeof(float);
+    if (XF != 0) lds += 2 * C5 * sizeof(float) + (XF == 2 ? p.patch_bytes : 0) + 256 * sizeof(double);
+    if (lds > 160 * 1024) { clhip_set_error("conv5: %zu bytes of LDS", lds); return CLHIP_EINVAL; }
+    auto kern = conv5_kernel<MODE, PINST, XF>;
     static size_t attr = 0;
     if (lds > attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -333,8 +403,23 @@ void clhip_conv5_min_tiles(int n) { g_min_tiles5 = n; }
 
 int clhip_conv5_tiles_m(int M) { return (M + BM5 - 1) / BM5; }
 
+int clhip_conv5_launch_in(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, const LazyIn* in,
+                          hipStream_t st);
+
 int clhip_conv5_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, hipStream_t st) {
+    return clhip_conv5_launch_in(src, wt, dst, stat_acc, stat_rep, N, H, W, accumulate, mode, nullptr, st);
+}
+
+// in != nullptr (forward only): src is the producer's pre-BatchNorm output, the operand relu(bn(src) [+ in->res]) is formed in LDS and written to in->y
+int clhip_conv5_launch_in(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, const LazyIn* in,
+                          hipStream_t st) {
     Conv5Params p;
+    if (in != nullptr) {
+        if (mode != 0 || in->acc == nullptr || in->y == nullptr) { clhip_set_error("conv5: a lazy input needs the forward mode, the producer's sums and an output activation"); return CLHIP_EINVAL; }
+        p.in = *in;
+    }
+    static const int wt_debug = clhip_cfg("WT_DEBUG") ? atoi(clhip_cfg("WT_DEBUG")) : 0;
+    p.in_debug = wt_debug;
     p.src = static_cast<const bf16_t*>(src); p.wt = static_cast<const bf16_t*>(wt); p.dst = static_cast<bf16_t*>(dst);
     p.stat_acc = stat_acc; p.stat_rep = stat_rep > 0 ? stat_rep : 1;
     p.H = H; p.W = W; p.M = N * H * W; p.accumulate = accumulate;
@@ -345,7 +430,7 @@ int clhip_conv5_launch(const void* src, const void* wt, void* dst, double* stat_
     p.patch_bytes = pinst * 4 * 1024;
     p.n_tiles = (p.M + BM5 - 1) / BM5;
     if (p.zoff + 512 > p.patch_bytes) { clhip_set_error("conv5: patch geometry"); return CLHIP_EINVAL; }
-#define L5(PI) (mode == 0 ? launch5<0, PI>(p, st) : launch5<1, PI>(p, st))
+#define L5(PI) (mode == 0 ? (in == nullptr ? launch5<0, PI>(p, st) : (in->res != nullptr ? launch5<0, PI, 2>(p, st) : launch5<0, PI, 1>(p, st))) : launch5<1, PI>(p, st))
     switch (pinst) {
         case 10: return L5(10);
         case 11: return L5(11);

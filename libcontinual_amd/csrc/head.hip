@@ -629,17 +629,33 @@ extern "C" int clhip_ce_window(const float* logits, const int64_t* labels, int B
         // 64 rows per workgroup from 128 rows up (at most 8 workgroups); a launch takes the next slot of a small ring, so launches in flight on
         // different streams do not share one
         static const bool one_wg = clhip_cfg("CE_ONE_WG") != nullptr && atoi(clhip_cfg("CE_ONE_WG")) != 0;
-        static CeSlot* ring = nullptr;
+        // one ring PER DEVICE (a process that drives several GPUs must not hand device 0's memory to a kernel on device 1: ADVICE r3).  The first
+        // multi-workgroup call on a device allocates it -- a synchronous hipMalloc + hipMemset, which a stream capture cannot contain: a capturing
+        // stream that finds no ring yet takes the one-workgroup form instead (a different grouping of the same fixed-order sums; the trainer's
+        // two eager warm steps allocate the ring before any capture, so a replayed step and an eager one group alike)
+        constexpr int kMaxDev = 16;
+        static std::atomic<CeSlot*> rings[kMaxDev];
         static std::atomic<unsigned> next{0};
         int G = (B >= 128 && !one_wg) ? (B + 63) / 64 : 1;
         if (G > 8) G = 8;
+        int devid = 0;
+        (void)hipGetDevice(&devid);
+        if (devid < 0 || devid >= kMaxDev) G = 1;
+        CeSlot* ring = G > 1 ? rings[devid].load(std::memory_order_acquire) : nullptr;
         if (G > 1 && ring == nullptr) {
-            static std::mutex mu;
-            std::lock_guard<std::mutex> lk(mu);
-            if (ring == nullptr) {
-                CeSlot* r = nullptr;
-                if (hipMalloc(&r, 64 * sizeof(CeSlot)) != hipSuccess || hipMemset(r, 0, 64 * sizeof(CeSlot)) != hipSuccess) { clhip_set_error("clhip_ce_window: cannot allocate the partial-sum ring"); return CLHIP_EHIP; }
-                ring = r;
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(ST, &cap);
+            if (cap != hipStreamCaptureStatusNone) G = 1;
+            else {
+                static std::mutex mu;
+                std::lock_guard<std::mutex> lk(mu);
+                ring = rings[devid].load(std::memory_order_acquire);
+                if (ring == nullptr) {
+                    CeSlot* r = nullptr;
+                    if (hipMalloc(&r, 64 * sizeof(CeSlot)) != hipSuccess || hipMemset(r, 0, 64 * sizeof(CeSlot)) != hipSuccess) { clhip_set_error("clhip_ce_window: cannot allocate the partial-sum ring"); return CLHIP_EHIP; }
+                    rings[devid].store(r, std::memory_order_release);
+                    ring = r;
+                }
             }
         }
         CeSlot* slot = G > 1 ? ring + (next.fetch_add(1) & 63u) : nullptr;

@@ -55,6 +55,10 @@ struct Unit {
                                    // residual add and the ReLU on its operand load AND writes the activation + packed mask for the later readers
                                    // (clhip_conv_fwd_acc_bn_res_input): the training forward skips the apply launch
     int res_lazy_from;             // >= 0: this unit's input comes from such a unit
+    int wt_to;                     // >= 0 (round 4, the LDS-DMA kernels of the wide layers): this unit's BatchNorm [+ residual] + ReLU is applied by convolution
+                                   // `wt_to` -- the FIRST reader of its activation in unit order -- on the patch it has landed in LDS, and that launch WRITES the
+                                   // activation [+ packed mask] for every later reader (clhip_conv_fwd_acc_bn_input_wt): the training forward skips the apply launch
+    int wt_from;                   // >= 0: this unit's input comes from such a unit
     bool pair_fuse_bn;             // ... that one launch also reduces the BatchNorm backward of the unit that produced the activation (its only readers are the pair)
     bool fpair;                    // ... their two forward convolutions are one launch (clhip_conv_fwd_acc_pair, conv7.hip; set on both units)
     bool wpair;                    // ... and their two weight gradients are one launch too (clhip_conv_wgrad_pair, conv7.hip; set on both units)
@@ -108,6 +112,7 @@ struct clhip_plan {
     size_t acc_off, acc_bytes;   // fp64 BN accumulators of all units (forward sums, backward sums): zeroed once per training forward
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
     std::vector<char> res_pending;      // per unit: its forward skipped the (+res) apply launch and its consumer has not run yet
+    std::vector<char> wt_pending;       // ... likewise for the write-through form of the wide layers
     std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
     int feat_dim;
@@ -414,6 +419,31 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (!clhip_conv_bn_input_supported(N, ub.H, ub.W, ub.cin_pad, ub.d.cout, ub.d.ksize, ub.d.stride, ub.d.pad, dtype)) continue;
         ua.res_lazy_to = b; ub.res_lazy_from = a;
     }
+    // the write-through form on the LDS-DMA kernels (conv4 / conv5): unit a = conv -> BN [-> +res] -> ReLU whose FIRST reader in unit order is a
+    // convolution b that can transform its landed patch in LDS; every other reader (a later residual add, b's weight gradient, a's backward) finds the
+    // activation b's launch wrote.  Producers that start a branch stream with their apply launch keep it.
+    for (auto& u : p->units) { u.wt_to = u.wt_from = -1; }
+    p->wt_pending.assign(p->units.size(), 0);
+    for (int a = 0; a + 1 < n_units && want_acc && !mask_y; ++a) {
+        Unit& ua = p->units[a];
+        if (!ua.relu || ua.pre_res || ua.no_bn || ua.has_dzr || ua.raw_src || ua.rep_fwd <= 0 || ua.branch >= 0 || ua.forks >= 0 || ua.lazy_to >= 0 || ua.res_lazy_to >= 0) continue;
+        if (ua.d.res >= 0 && ua.mask_off == 0) continue;
+        int b = -1;
+        bool ok = true;
+        for (int k = 0; k < n_units; ++k) {
+            const Unit& o = p->units[k];
+            const bool reads = o.d.src == a + 1 || o.d.res == a + 1;
+            if (!reads) continue;
+            if (k <= a) { ok = false; break; }
+            if (b < 0) { if (o.d.src != a + 1 || o.raw_src) { ok = false; break; } b = k; }
+            else if (o.d.src == a + 1 && o.raw_src) { ok = false; break; }
+        }
+        if (!ok || b < 0) continue;
+        Unit& ub = p->units[b];
+        if (ub.no_bn || ub.pre_res || ub.rep_fwd <= 0 || ub.cin_pad != ub.d.cin || ub.branch >= 0 || ub.pair >= 0 || ub.lazy_from >= 0 || ub.res_lazy_from >= 0) continue;
+        if (!clhip_conv_bn_input_wt_supported(N, ub.H, ub.W, ub.cin_pad, ub.d.cout, ub.d.ksize, ub.d.stride, ub.d.pad, dtype)) continue;
+        ua.wt_to = b; ub.wt_from = a;
+    }
     return p;
 }
 
@@ -435,6 +465,9 @@ extern "C" void clhip_plan_destroy(clhip_plan* p) {
 extern "C" size_t clhip_plan_workspace_bytes(const clhip_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" size_t clhip_plan_shadow_bytes(const clhip_plan* p) { return p ? p->shadow_bytes : 0; }
 extern "C" int clhip_plan_feat_dim(const clhip_plan* p) { return p ? p->feat_dim : 0; }
+
+// PLAN_SKIP (timing ablations only, results invalid): 1 no forward BatchNorm apply, 2 no BatchNorm backward, 4 no weight gradients
+static int plan_skip() { static const int v = clhip_cfg("PLAN_SKIP") ? atoi(clhip_cfg("PLAN_SKIP")) : 0; return v; }
 
 #define TRY(call)            \
     do {                     \
@@ -672,7 +705,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const bool lazy_on = lazy_env && training && use_acc;
     const char* rlazy_cfg = clhip_cfg("BN_RES_INPUT");
     const bool rlazy_on = lazy_on && !(rlazy_cfg != nullptr && atoi(rlazy_cfg) == 0);
-    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = 0;
+    const char* wt_cfg = clhip_cfg("BN_INPUT_WT");
+    const bool wt_on = training && use_acc && wt_cfg != nullptr && atoi(wt_cfg) != 0;          // (off by default: conv.hip clhip_conv_bn_input_wt_supported)
+    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = 0;
     int fwd_pair_done = -1;                                  // the 3x3/s2 unit whose launch also ran its shortcut partner's convolution
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
@@ -702,7 +737,21 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 (void)hipStreamWaitEvent(p->br, p->ev_fork[u.branch], 0);
                 us = p->br;
             }
-            if (u.res_lazy_from >= 0 && p->res_pending[u.res_lazy_from]) {
+            if (u.wt_from >= 0 && p->wt_pending[u.wt_from]) {
+                // the producer's BatchNorm [+ residual] + ReLU happen on this convolution's landed patch (in LDS), and this launch writes the activation
+                // [+ packed mask] for the readers that follow; mean / invstd / coefficients and the running statistics are its by-products
+                const Unit& a = p->units[u.wt_from];
+                clhip_bn_input bi;
+                bi.stat_acc = acc + a.a_fwd; bi.replicas = a.rep_fwd; bi.gamma = params + a.d.gamma_off; bi.beta = params + a.d.beta_off;
+                bi.running_mean = bn_stats + a.d.rm_off; bi.running_var = bn_stats + a.d.rv_off; bi.momentum = kBnMomentum; bi.eps = kBnEps;
+                bi.mean = fr + a.f_mean; bi.invstd = fr + a.f_invstd; bi.coef = fr + a.f_scale;
+                clhip_bn_res_input rs;
+                rs.res = a.d.res >= 0 ? ws + p->acts[a.d.res].y_off : nullptr; rs.y = ws + src.y_off; rs.relu_mask = a.mask_off != 0 ? ws + a.mask_off : nullptr;
+                if (br_on && a.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)us, p->ev_join[a.joins], 0);      // the residual comes from the branch stream
+                TRY(clhip_conv_fwd_acc_bn_input_wt(ws + a.z_off, &bi, &rs, sh + u.sh_fwd, ws + u.z_off, acc + u.a_fwd, u.rep_fwd, p->N, u.H, u.W, u.cin_pad, u.d.cout,
+                                                   u.d.ksize, u.d.stride, u.d.pad, p->dtype, us));
+                p->wt_pending[u.wt_from] = 0;
+            } else if (u.res_lazy_from >= 0 && p->res_pending[u.res_lazy_from]) {
                 // the producer is a block's last unit: its BatchNorm + residual add + ReLU happen on this convolution's operand load, and this launch
                 // writes the activation and the packed mask for the readers that follow
                 const Unit& a = p->units[u.res_lazy_from];
@@ -738,9 +787,11 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                                        u.d.stride, u.d.pad, p->dtype, us));
             }
             p->lazy_live[i] = 0;
+            if (wt_on && u.wt_to >= 0) { p->wt_pending[i] = 1; continue; }              // its first reader applies it in LDS and writes the activation [+ mask]
             if (lazy_on && u.lazy_to >= 0) { p->lazy_live[i] = 1; continue; }          // its one consumer applies the BatchNorm: no apply launch, no activation
             if (rlazy_on && u.res_lazy_to >= 0) { p->res_pending[i] = 1; continue; }   // its first consumer applies it and writes the activation + mask
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
+            if (plan_skip() & 1) continue;                       // timing ablation: no forward BatchNorm apply (results invalid)
             if (br_on && u.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)stream, p->ev_join[u.joins], 0);      // the residual comes from the branch stream
             if (br_on && u.forks >= 0) clhip_bn_set_fwd_stop_event(p->ev_fork[u.forks]);                           // this launch's completion starts the branch
             if (u.mask_off != 0)
@@ -934,6 +985,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                                 u.relu && !mask_from_y && u.cin_pad == u.d.cin &&                                 clhip_conv_bn_input_supported(p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype);
         const bool bn_grad = bn_grad_ok && (dres == nullptr ? true : (u.mask_off != 0 && lazy_res_on));
         if (u.no_bn || bn_grad) {
+        } else if ((plan_skip() & 2) && u.rep_bwd > 0) {         // timing ablation: no BatchNorm backward (results invalid)
         } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
             // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
             const bool zmask = u.relu && dres == nullptr && !mask_from_y;
@@ -1036,7 +1088,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             const Unit& sc = p->units[u.pair];
             TRY(clhip_conv_wgrad_pair(in, dz, pair_dz, grads + u.d.w_off, grads + sc.d.w_off, ws + u.wg_own, ws + sc.wg_own, p->N, u.H, u.W, u.cin_pad, u.d.cout,
                                       p->dtype, wg_stream));
-        } else
+        } else if (!(plan_skip() & 4))
         TRY(clhip_conv_wgrad(in, dz, grads + u.d.w_off, ws + u.wg_own, p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout,
                              u.d.ksize, u.d.stride, u.d.pad, p->dtype, wg_stream));
         if (defer_side && on_side && ++side_deferred % p->defer_side == 0) TRY(clhip_wgrad_defer_flush(p->side, false));

@@ -491,6 +491,84 @@ __global__ __launch_bounds__(256) void gram_kernel(const T* __restrict__ x, floa
         }
 }
 
+// bf16: G_l [D, D] += X_l^T X_l on the matrix cores, all layers of a pass in ONE launch (the Gram of every
+// attention input on the device, resident, instead of transformer.py:241-244's bmm + 2.4-MB transfer per layer and batch).  A "TN" product:
+// the reduction runs over the ROWS of X, so both MFMA operands come out of row-major LDS tiles through the transposing read (the
+// slot order of lora_db_mfma_kernel: k-slot j of lane group g <-> row 4 g + (j & 3) + 16 (j >> 2) on both operands).  Workgroup =
+// one 128 x 128 tile of one layer over ALL rows (no row split: every element of G has one owner per launch, plain fp32 read-modify-
+// write, bitwise reproducible); 2 x 2 waves of 64 x 64 = 16 accumulator tiles each; 32 rows per step, register-staged, double-buffered.
+constexpr int GP = 544;               // LDS row pitch: 256 bf16 (the i panel, then the j panel) + 32 bytes -> rows 0..7 fall in disjoint 32-byte bank groups
+
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const bf16_t* __restrict__ x0, size_t layer_stride, float* __restrict__ G0, int M, int D, int tiles) {
+    __shared__ __attribute__((aligned(16))) char xs[2][32 * GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int layer = blockIdx.x / (tiles * tiles), t = blockIdx.x - layer * tiles * tiles;
+    const int i0 = (t / tiles) * 128, j0 = (t % tiles) * 128;
+    const bf16_t* x = x0 + (size_t)layer * layer_stride;
+    float* G = G0 + (size_t)layer * D * D;
+    const int wi = wave >> 1, wj = wave & 1;
+    // staging: chunk c = tid + 256 q (q = 0..3) is (row c >> 5, 16-byte column c & 31); columns 0..15 = the i panel, 16..31 = the j panel
+    uint4 rg[4];
+    int srow[4], scol[4], gcol[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = tid + 256 * q, cc = c & 31;
+        srow[q] = c >> 5; scol[q] = cc * 16;
+        const int col = cc < 16 ? i0 + cc * 8 : j0 + (cc - 16) * 8;
+        gcol[q] = col < D ? col : -1;                  // D % 8 == 0: a chunk is inside or outside
+    }
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = mb + srow[q];
+            rg[q] = (m < M && gcol[q] >= 0) ? *reinterpret_cast<const uint4*>(x + (size_t)m * D + gcol[q]) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(xs[st] + srow[q] * GP + scol[q]) = rg[q];
+    };
+    const int ra = (g * 4 + (l15 >> 2)) * GP + (l15 & 3) * 8;
+    const int aa = ra + (wi * 64) * 2, ba = ra + 256 + (wj * 64) * 2;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int st = 0;
+    for (int mb = 0; mb < M; mb += 32, st ^= 1) {
+        const bool more = mb + 32 < M;
+        if (more) gload(mb + 32);
+        uint4 af[4], bfr[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) af[a] = tr8v(xs[st], aa + a * 32, 16 * GP);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bfr[b] = tr8v(xs[st], ba + b * 32, 16 * GP);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[a]), __builtin_bit_cast(bf16x8_t, bfr[b]), acc[a][b], 0, 0, 0);
+        if (more) sstore(st ^ 1);
+        __syncthreads();
+    }
+    // D[row = i (4 g + e)][col = j (l15)] of tile (a, b)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + wj * 64 + b * 16 + l15;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + wi * 64 + a * 16 + g * 4 + e;
+                if (i < D && j < D) G[(size_t)i * D + j] += acc[a][b][e];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------- L2P
 // One block.  q [B, D] (cls features), key [pool, D].  Per-sample cosine top-k, batch-majority top-k (ties -> lowest id),
 // gathered prompt tokens, reduce_sim = sum_b sum_{k in ids} <kn_k, qn_b> / B and its gradient w.r.t. key.
@@ -763,9 +841,25 @@ extern "C" int clhip_lora_grad(const void* x, const void* dqkv, const float* lor
     return CLHIP_OK;
 }
 
+extern "C" int clhip_gram_accum_batched(const void* x, size_t layer_stride_elems, int n_layers, float* G, int M, int D, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(x && G && M > 0 && D > 0 && n_layers > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CLHIP_BF16 && D % 8 == 0) {
+        const int tiles = (D + 127) / 128;
+        hipLaunchKernelGGL(gram_mfma_kernel, dim3(n_layers * tiles * tiles), dim3(256), 0, s, (const bf16_t*)x, layer_stride_elems, G, M, D, tiles);
+        CLHIP_LAUNCH_CHECK();
+        return CLHIP_OK;
+    }
+    const size_t esz = dtype == CLHIP_BF16 ? 2 : 4;
+    for (int l = 0; l < n_layers; ++l)
+        if (int rc = clhip_gram_accum(static_cast<const char*>(x) + (size_t)l * layer_stride_elems * esz, G + (size_t)l * D * D, M, D, dtype, stream)) return rc;
+    return CLHIP_OK;
+}
+
 extern "C" int clhip_gram_accum(const void* x, float* G, int M, int D, int dtype, void* stream) {
     CLHIP_CHECK_ARG(x && G && M > 0 && D > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CLHIP_BF16 && D % 8 == 0) return clhip_gram_accum_batched(x, 0, 1, G, M, D, dtype, stream);
     const int rows = 1024;
     dim3 grid((D + 63) / 64, (D + 63) / 64, (M + rows - 1) / rows);
     DT_DISPATCH(dtype, hipLaunchKernelGGL(gram_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, G, M, D, rows),

@@ -40,9 +40,12 @@ struct clhip_vit {
     hipEvent_t ev_q, ev_l;
 };
 
-static void make_layout(const clhip_vit* v, int B, int P, int save, Layout& L) {
+// `flags`: bit 0 = keep what the backward needs; bit 1 (CLHIP_VIT_KEEP_ATTN_IN) = keep every layer's attention input (LN1 output) until the
+// end of the forward -- the Gram pass multiplies all of them in one launch
+static void make_layout(const clhip_vit* v, int B, int P, int flags, Layout& L) {
     const clhip_vit_desc& d = v->d;
     const size_t e = v->esize;
+    const int save = flags & 1;
     L.B = B; L.P = P; L.N = P + 1 + v->np; L.M = B * L.N; L.save = save;
     const size_t M = L.M, D = d.dim;
     size_t off = 0;
@@ -74,6 +77,10 @@ static void make_layout(const clhip_vit* v, int B, int P, int save, Layout& L) {
             L.x_mid[l] = L.x_mid[0]; L.qkv[l] = L.qkv[0]; L.attn_o[l] = L.attn_o[0]; L.hpre[l] = 0; L.h1[l] = L.ln_out;
             L.st1[l] = L.st1[0]; L.st2[l] = L.st2[0]; L.lse[l] = L.lse[0];
         }
+    }
+    if ((flags & 2) && !keep_h1) {                       // one contiguous region, layer stride M * D elements
+        const size_t base = take((size_t)d.depth * al(M * D * e));
+        for (int l = 0; l < d.depth; ++l) L.h1[l] = base + (size_t)l * al(M * D * e);
     }
     if (save) {
         L.g = take(M * D * e);
@@ -177,7 +184,7 @@ extern "C" int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const 
     CLHIP_CHECK_ARG(n_prompt + 1 + v->np <= 256);
     const clhip_vit_desc& d = v->d;
     Layout& L = v->last;
-    make_layout(v, B, n_prompt, save, L);
+    make_layout(v, B, n_prompt, (save ? 1 : 0) | (gram ? 2 : 0), L);
     v->have_last = true;
     char* ws = static_cast<char*>(workspace);
     const char* sh = static_cast<const char*>(shadow);
@@ -194,7 +201,6 @@ extern "C" int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const 
         float* st2 = reinterpret_cast<float*>(ws + L.st2[l]);
         char* h1 = ws + L.h1[l];
         TRY(clhip_ln_fwd(ws + L.x_in[l], p.ln1_w, p.ln1_b, h1, st1, st1 + M, M, D, beps, dt, stream));
-        if (gram) TRY(clhip_gram_accum(h1, gram + (size_t)l * D * D, M, D, dt, stream));
         TRY(clhip_gemm_nt(h1, sh + s.qkv_f, ws + L.qkv[l], p.qkv_b, nullptr, nullptr, M, 3 * D, D, D, D, 3 * D, 0, 0, EPI_BIAS, dt, stream));
         TRY(clhip_attn_fwd(ws + L.qkv[l], ws + L.attn_o[l], reinterpret_cast<float*>(ws + L.lse[l]), B, N, d.heads, D, dt, stream));
         TRY(clhip_gemm_nt(ws + L.attn_o[l], sh + s.proj_f, ws + L.x_mid[l], p.proj_b, ws + L.x_in[l], nullptr, M, D, D, D, D, D, D, 0, EPI_BIAS_RES, dt, stream));
@@ -202,6 +208,13 @@ extern "C" int clhip_vit_forward(clhip_vit* v, const clhip_vit_params* P, const 
         TRY(clhip_gemm_nt(ws + L.ln_out, sh + s.fc1_f, ws + L.act, p.fc1_b, nullptr, save ? ws + L.hpre[l] : nullptr, M, Hm, D, D, D, Hm, 0, Hm, EPI_BIAS_GELU, dt,
                           stream));
         TRY(clhip_gemm_nt(ws + L.act, sh + s.fc2_f, ws + L.x_in[l + 1], p.fc2_b, ws + L.x_mid[l], nullptr, M, D, Hm, Hm, Hm, D, D, 0, EPI_BIAS_RES, dt, stream));
+    }
+    if (gram) {
+        // every layer's attention input is still there (make_layout bit 1, or the backward's own copies): X_l^T X_l of all layers, one launch
+        bool strided = true;
+        for (int l = 1; l < d.depth; ++l) strided = strided && (L.h1[l] - L.h1[l - 1]) == (L.h1[1] - L.h1[0]) && (L.h1[1] - L.h1[0]) % v->esize == 0;
+        if (strided && d.depth > 1) TRY(clhip_gram_accum_batched(ws + L.h1[0], (L.h1[1] - L.h1[0]) / v->esize, d.depth, gram, M, D, dt, stream));
+        else for (int l = 0; l < d.depth; ++l) TRY(clhip_gram_accum(ws + L.h1[l], gram + (size_t)l * D * D, M, D, dt, stream));
     }
     return clhip_ln_pool_fwd(ws + L.x_in[d.depth], P->norm_w, P->norm_b, feat, B, N, D, n_prompt > 0 ? n_prompt : 1, 1e-6f, dt, stream);
 }

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ..heads import HipLinear
-from .vit import Mlp, VisionTransformer, _P, _PatchEmbed
+from .vit import LazyGram, Mlp, VisionTransformer, _P, _PatchEmbed, lazy_gram_attrs
 
 __all__ = ["Attention_LoRA", "ViT_lora_co", "SiNet_vit"]
 
@@ -36,8 +36,11 @@ class Attention_LoRA(nn.Module):
         self.lora_B_k = nn.ModuleList([_P((dim, r), False) for _ in range(n_tasks)])
         self.lora_A_v = nn.ModuleList([_P((r, dim), False) for _ in range(n_tasks)])
         self.lora_B_v = nn.ModuleList([_P((dim, r), False) for _ in range(n_tasks)])
-        self.matrix, self.n_matrix = torch.zeros(dim, dim), 0              # CPU running means of x^T x, like the reference
-        self.cur_matrix, self.n_cur_matrix = torch.zeros(dim, dim), 0
+        # CPU running means of x^T x like the reference's -- read lazily: the per-batch sums stay in the backbone's device buffers
+        self.__dict__["_gram_all"], self.__dict__["_gram_cur"] = LazyGram(dim), LazyGram(dim)
+
+    matrix, n_matrix = lazy_gram_attrs("matrix", "n_matrix", "_gram_all")
+    cur_matrix, n_cur_matrix = lazy_gram_attrs("cur_matrix", "n_cur_matrix", "_gram_cur")
 
     def init_param(self):
         for t in range(len(self.lora_A_k)):
@@ -170,22 +173,46 @@ class ViT_lora_co(nn.Module):
         ex = self._ex
         self._select_task(task_id)
         want_gram = get_feat or get_cur_feat
-        if want_gram:            # the executor accumulates the per-layer Gram of the attention input into its holders' cur_matrix
-            for mine, his in zip(self.blocks, ex.transformer.blocks):
-                his.attn.cur_matrix, his.attn.n_cur_matrix = torch.zeros_like(mine.attn.cur_matrix), 0
-        feat = ex.features(x, None, get_input_matrix=want_gram)
+        gram = None
         if want_gram:
-            for mine, his in zip(self.blocks, ex.transformer.blocks):
-                g, n = his.attn.cur_matrix, his.attn.n_cur_matrix          # mean over this batch's n tokens
-                a = mine.attn
-                if get_feat:
-                    a.matrix = (a.matrix * a.n_matrix + g * n) / (a.n_matrix + n)
-                    a.n_matrix += n
-                if get_cur_feat:
-                    a.cur_matrix = (a.cur_matrix * a.n_cur_matrix + g * n) / (a.n_cur_matrix + n)
-                    a.n_cur_matrix += n
+            # the executor ADDS every layer's X^T X into a resident [depth, D, D] buffer (one MFMA launch per forward); the running means of
+            # vit_inflora.py:205-212 are taken when `matrix` / `cur_matrix` are read.  Both at once (never in the reference's plugin): the batch's
+            # sums go through a scratch buffer and are added to both.
+            both = get_feat and get_cur_feat
+            gram = self._gram_buffer("_tmp" if both else ("_gram_all" if get_feat else "_gram_cur"), x.device)
+            if both:
+                gram.zero_()
+        feat = ex.features(x, None, get_input_matrix=want_gram, gram_out=gram)
+        if want_gram:
+            n = x.shape[0] * (self.patch_embed.num_patches + 1)
+            for slot, on in (("_gram_all", get_feat), ("_gram_cur", get_cur_feat)):
+                if not on:
+                    continue
+                if both:
+                    self._gram_buffer(slot, x.device).add_(gram)
+                for blk in self.blocks:
+                    blk.attn.__dict__[slot].n_dev += n
         prompt_loss = torch.zeros((1,), device=feat.device, requires_grad=True)
         return feat.unsqueeze(1), prompt_loss
+
+    def _gram_buffer(self, slot, dev):
+        """resident [depth, D, D] fp32 sums behind the blocks' `matrix` (slot "_gram_all") / `cur_matrix` ("_gram_cur") attributes"""
+        bufs = self.__dict__.setdefault("_gram_bufs", {})
+        b = bufs.get(slot)
+        if b is not None and slot != "_tmp":             # (a deep copy of the module carries the buffers but detached holders)
+            g0 = self.blocks[0].attn.__dict__[slot]
+            if g0.dev is None or g0.dev.data_ptr() != b[0].data_ptr():
+                b = None
+        if b is None or b.device != dev:
+            if slot != "_tmp":
+                for blk in self.blocks:
+                    blk.attn.__dict__[slot].fold()
+            b = bufs[slot] = torch.zeros(self.depth, self.embed_dim, self.embed_dim, device=dev)
+            if slot != "_tmp":
+                for i, blk in enumerate(self.blocks):
+                    g = blk.attn.__dict__[slot]
+                    g.dev, g.n_dev = b[i], 0
+        return b
 
     def load_timm_state_dict(self, sd):
         """timm `vit_base_patch16_224_in21k` keys are this module's keys: load what matches in name and shape"""

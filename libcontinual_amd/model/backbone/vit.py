@@ -45,6 +45,64 @@ class _P(nn.Module):
         raise RuntimeError("parameter holder: the HIP executor (VisionTransformer.features) runs the layer")
 
 
+class LazyGram:
+    """running mean of X^T X over the tokens seen so far (transformer.py:241-244) whose per-batch sums stay ON THE DEVICE: the executor adds
+    every batch's X^T X into `dev` (a [D, D] fp32 view of the backbone's resident [depth, D, D] buffer) and `n_dev` counts the tokens in it;
+    the host tensor the reference keeps (`cur_matrix`, the SVD's input) is brought up to date when somebody READS it --
+    (host * n_host + dev) / (n_host + n_dev), the reference's per-batch update with all pending batches as one -- i.e. one transfer per
+    task boundary instead of one per batch and layer."""
+
+    def __init__(self, dim):
+        self.host, self.n_host = torch.zeros(dim, dim), 0
+        self.dev, self.n_dev = None, 0
+
+    def fold(self):
+        if self.n_dev:
+            self.host = (self.host * self.n_host + self.dev.cpu()) / (self.n_host + self.n_dev)
+            self.n_host += self.n_dev
+            self.drop_pending()
+
+    def drop_pending(self):
+        if self.n_dev:
+            self.dev.zero_()
+        self.n_dev = 0
+
+    def __deepcopy__(self, memo):          # a copied module starts from the folded host state (device views are never shared)
+        self.fold()
+        c = LazyGram(self.host.shape[0])
+        c.host, c.n_host = self.host.clone(), self.n_host
+        return c
+
+
+def lazy_gram_attrs(matrix_name, count_name, slot):
+    """(matrix, count) properties over a LazyGram kept in `self.__dict__[slot]`: reads fold the pending device sums, `x = zeros` /
+    `n = 0` drop them -- the plugin code written against the reference's plain attributes runs unchanged"""
+
+    def get_m(self):
+        g = self.__dict__[slot]
+        g.fold()
+        return g.host
+
+    def set_m(self, v):
+        g = self.__dict__[slot]
+        g.drop_pending()
+        g.host = v
+
+    def get_n(self):
+        g = self.__dict__[slot]
+        return g.n_host + g.n_dev
+
+    def set_n(self, v):
+        g = self.__dict__[slot]
+        if v == 0:
+            g.drop_pending()
+        else:
+            g.fold()
+        g.n_host = v
+
+    return property(get_m, set_m), property(get_n, set_n)
+
+
 class MultiHeadAttention(nn.Module):
     def __init__(self, dim, num_heads, **kw):
         super().__init__()
@@ -64,8 +122,9 @@ class MultiHeadAttention_LoRA(MultiHeadAttention):
         self.lora_A_k, self.lora_B_k = _P((lora_rank, dim), False), _P((dim, lora_rank), False)
         self.lora_A_v, self.lora_B_v = _P((lora_rank, dim), False), _P((dim, lora_rank), False)
         self.apply_lora = False
-        self.cur_matrix = torch.zeros(dim, dim)          # CPU, like the reference (SVD input)
-        self.n_cur_matrix = 0
+        self.__dict__["_gram"] = LazyGram(dim)           # `cur_matrix` (CPU, the SVD input, like the reference) / `n_cur_matrix` live in it
+
+    cur_matrix, n_cur_matrix = lazy_gram_attrs("cur_matrix", "n_cur_matrix", "_gram")
 
     def init_param(self):
         nn.init.kaiming_uniform_(self.lora_A_k.weight, a=math.sqrt(5))
@@ -84,8 +143,8 @@ class MultiHeadAttention_LoRA(MultiHeadAttention):
         self.apply_lora = False
 
     def reset_input_matrix(self):
+        self.n_cur_matrix = 0                            # (drops the pending device sums first: nothing is transferred for a reset)
         self.cur_matrix.zero_()
-        self.n_cur_matrix = 0
 
 
 class Mlp(nn.Module):
@@ -130,6 +189,7 @@ class _Scratch:
         self.sig = None
         self.cparams = None
         self.keep = None
+        self.gram = None
 
     def __deepcopy__(self, memo):
         return _Scratch()
@@ -263,7 +323,8 @@ class VisionTransformer(nn.Module):
         return s
 
     def _workspace(self, s, B, n_prompt, save, dev):
-        key = (B, n_prompt, bool(save))
+        """`save`: bit 0 = keep what the backward needs, bit 1 = keep every layer's attention input for the Gram launch"""
+        key = (B, n_prompt, int(save))
         need = _lib.lib().clhip_vit_workspace_bytes(s.handle, B, n_prompt, int(save))
         if need == 0:
             raise _lib.ClhipError(f"invalid ViT launch: batch {B}, {n_prompt} prompt tokens (max 256 tokens)")
@@ -285,7 +346,7 @@ class VisionTransformer(nn.Module):
         if prompt_tokens is not None:
             prompt_tokens = prompt_tokens.detach().float().contiguous()
             n_prompt = prompt_tokens.shape[0]
-        ws = self._workspace(s, B, n_prompt, save, dev)
+        ws = self._workspace(s, B, n_prompt, int(bool(save)) | (2 if gram is not None else 0), dev)
         feat = torch.empty(B, self.embed_dim, device=dev, dtype=torch.float32)
         call("clhip_vit_forward", s.handle, C.byref(s.cparams), s.shadow.data_ptr(), ws.data_ptr(), images.data_ptr(), B,
              prompt_tokens.data_ptr() if n_prompt else None, n_prompt, int(save), gram.data_ptr() if gram is not None else None,
@@ -309,26 +370,46 @@ class VisionTransformer(nn.Module):
         return dprompt, dl
 
     # --------------------------------------------------------------------------------------- public forward
-    def features(self, images, prompt_tokens=None, get_input_matrix=False):
+    def _gram_buffer(self, dev):
+        """the resident [depth, D, D] fp32 sums of X^T X; layer i's LazyGram (if its attention module has one) owns row i"""
+        s = self._s
+        if s.gram is not None:                           # (holders re-created or detached since: a deep copy, a new attention module)
+            g0 = self.attention_modules()[0].__dict__.get("_gram")
+            if g0 is not None and (g0.dev is None or g0.dev.data_ptr() != s.gram[0].data_ptr()):
+                s.gram = None
+        if s.gram is None or s.gram.device != dev:
+            for a in self.attention_modules():
+                g = a.__dict__.get("_gram")
+                if g is not None:
+                    g.fold()
+            s.gram = torch.zeros(self.depth, self.embed_dim, self.embed_dim, device=dev)
+            for i, a in enumerate(self.attention_modules()):
+                g = a.__dict__.get("_gram")
+                if g is not None:
+                    g.dev, g.n_dev = s.gram[i], 0
+        return s.gram
+
+    def features(self, images, prompt_tokens=None, get_input_matrix=False, gram_out=None):
         """[B, D] fp32: final-LN output at the cls token, or (with L2P prompt tokens [P, D]) the mean over the P prompt
-        token outputs (transformer.py:2254-2261).  Differentiable w.r.t. prompt_tokens and the lora_B weights."""
+        token outputs (transformer.py:2254-2261).  Differentiable w.r.t. prompt_tokens and the lora_B weights.
+        get_input_matrix: every layer's X^T X (X = the attention input) is ADDED to a device-resident [depth, D, D] fp32 buffer by one
+        MFMA launch at the end of the forward -- the modules' own (`cur_matrix`, read lazily) or the caller's `gram_out`."""
         gram = None
         if get_input_matrix:
-            gram = torch.zeros(self.depth, self.embed_dim, self.embed_dim, device=images.device)
+            gram = gram_out if gram_out is not None else self._gram_buffer(images.device)
         lora_b = []
         if self.lora_rank and any(a.apply_lora for a in self.attention_modules()):
             for a in self.attention_modules():
                 lora_b += [a.lora_B_k.weight, a.lora_B_v.weight]
         need = torch.is_grad_enabled() and ((prompt_tokens is not None and prompt_tokens.requires_grad) or any(b.requires_grad for b in lora_b))
         feat = _VitFn.apply(self, images, prompt_tokens, gram, need, *lora_b)
-        if get_input_matrix:
-            # running mean over tokens, on the host like the reference (transformer.py:241-244)
+        if get_input_matrix and gram_out is None:
+            # the running mean over tokens (transformer.py:241-244) is taken when `cur_matrix` is read; here only the token count moves
             cnt = images.shape[0] * (self.patch_embed.num_patches + 1 + (0 if prompt_tokens is None else prompt_tokens.shape[0]))
-            g = gram.cpu()
-            for i, a in enumerate(self.attention_modules()):
-                if hasattr(a, "cur_matrix"):
-                    a.cur_matrix = (a.cur_matrix * a.n_cur_matrix + g[i]) / (a.n_cur_matrix + cnt)
-                    a.n_cur_matrix += cnt
+            for a in self.attention_modules():
+                g = a.__dict__.get("_gram")
+                if g is not None:
+                    g.n_dev += cnt
         return feat
 
     def forward(self, x, prompt=None, prompt_flag="", cls_features=None, get_input_matrix=False, **kwargs):

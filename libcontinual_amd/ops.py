@@ -450,8 +450,10 @@ class TeacherPass:
             side.wait_stream(torch.cuda.current_stream(x.device))        # x (and the teacher's weights) are ready
             # two networks on two streams: their plans keep to ONE stream each in the forward while this pass is in flight (the shortcut
             # branch streams of both make five streams in one step: measured 6.36 ms per LwF ResNet-18 step instead of 2.60, profiles/r03_step_notes.md)
+            # (whatever was configured before -- parallel.attach()'s "0" of a multi-rank run, a caller's own choice -- is put back by result())
             self._branch_off = _env_unset("CLHIP_BRANCH_STREAM")
             if self._branch_off:
+                self._branch_prev = _lib.lib().clhip_config_get(b"BRANCH_STREAM")
                 _lib.lib().clhip_config(b"BRANCH_STREAM", b"0")
             with torch.cuda.stream(side), torch.no_grad():
                 self._out = fn()
@@ -464,7 +466,7 @@ class TeacherPass:
         main = torch.cuda.current_stream()
         main.wait_stream(self._side)
         if getattr(self, "_branch_off", False):
-            _lib.lib().clhip_config(b"BRANCH_STREAM", None)               # back to the default for the launches that follow (the backward)
+            _lib.lib().clhip_config(b"BRANCH_STREAM", self._branch_prev)   # back to what it was for the launches that follow (the backward)
             self._branch_off = False
         outs = self._out if isinstance(self._out, (tuple, list)) else (self._out,)
         for t in outs:

@@ -57,8 +57,17 @@ class GraphedStep:
         workspaces, the autograd graph's buffers) must not happen inside a capture -- and are REAL steps; the capture itself
         executes nothing, its first replay is the next real step;
       * a new key (ragged last batch of an epoch, a scheduler step) captures a new graph; the last few keys are kept;
-      * only single-process runs of methods that declare `cuda_graph_safe` (a step without data-dependent host control flow)."""
+      * only single-process runs of methods that declare `cuda_graph_safe` (a step without data-dependent host control flow);
+      * a replay re-runs the captured LAUNCHES only: the host-side bookkeeping of the plans behind them (plan.hip `lazy_live`, `res_pending`,
+        `wt_pending`, `bwd_sums_ready`: which activations a consumer applies lazily, whose BatchNorm-backward sums a dgrad epilogue produced) and
+        ops.TeacherPass's clhip_config toggles stay as the capture left them.  That is consistent as long as every replay has the structure of the
+        captured step, so everything that changes the structure is part of the graph key: input shapes, optimizer hyper-parameters, train / eval
+        mode, and the values of the clhip_config switches that steer a plan's launch sequence (`_PLAN_SWITCHES`) -- flipping one between two
+        steps captures a new graph instead of replaying a stale one.  Reading a lazily applied activation between two replays
+        (clhip_plan_read_act: debugging hooks) materialises it with a launch of its own and does not disturb the next replay: the replayed
+        forward rewrites every buffer it reads."""
     WARM, KEEP = 2, 4
+    _PLAN_SWITCHES = (b"BN_INPUT", b"BN_INPUT_WT", b"BN_RES_INPUT", b"BN_GRAD", b"BN_GRAD_RES", b"BN_FUSE", b"BRANCH_STREAM", b"WGRAD_STREAM", b"CONV6_PAIR")
 
     def __init__(self, model, optimizer, method_name):
         self.model, self.optimizer, self.method_name = model, optimizer, method_name
@@ -83,7 +92,10 @@ class GraphedStep:
     def _key(self, batch):
         shapes = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
         lrs = tuple((g.get("lr"), g.get("momentum"), g.get("weight_decay")) for g in self.optimizer.param_groups)
-        return shapes, lrs, self.model.training
+        from . import _lib
+        L = _lib.lib()
+        cfg = tuple(L.clhip_config_get(k) for k in self._PLAN_SWITCHES)
+        return shapes, lrs, self.model.training, cfg
 
     def _step(self, batch):
         if self.method_name in _OBSERVE_DOES_BACKWARD:
@@ -128,7 +140,7 @@ class GraphedStep:
 
 
 def _graph_mode(model, reducer, device, optimizer=None):
-    """CLHIP_CUDA_GRAPH = 1: replay where legal; anything else: never.  Legal = single process, a plugin that declares
+    """CLHIP_CUDA_GRAPH = 1: replay where legal; 0: never; unset: replay where legal AND the batch is small (see below).  Legal = single process, a plugin that declares
     `cuda_graph_safe`, and an optimizer whose step is capture-safe (class attribute `capture_safe`: the fused SGD -- every argument of
     its launches is a device pointer or a value covered by the graph key; the fused Adam passes its step count by value, torch.optim
     fallbacks synchronise or allocate).  Opt-in because it only pays when the HOST is the limit: with an
@@ -138,17 +150,31 @@ def _graph_mode(model, reducer, device, optimizer=None):
     env = os.environ.get("CLHIP_CUDA_GRAPH")
     legal = (device is not None and torch.device(device).type == "cuda" and reducer is None and getattr(model, "grad_reducer", None) is None
              and getattr(model, "cuda_graph_safe", False) and getattr(optimizer, "capture_safe", False))
-    if not legal or env != "1":
+    if not legal or env == "0":
         return None
-    return "always"
+    # Round 4: replay is the DEFAULT for small per-GPU batches (<= GRAPH_AUTO_MAX_BATCH rows; CLHIP_CUDA_GRAPH=0 opts out, =1 replays every
+    # size).  With ~100 launches left in a 32-image CifarResNet-32 step the replay is never slower than the best eager run and takes the host
+    # out of the picture (eager 0.985 ... 1.106 ms box to box and run to run, replayed 0.846-0.849 ms: profiles/r03_step_notes.md); the large
+    # batches keep the eager path -- their steps are GPU-bound and use side streams a capture keeps on one stream.
+    return "always" if env == "1" else "auto"
+
+
+GRAPH_AUTO_MAX_BATCH = 64
+
+
+def _batch_rows(batch):
+    for v in batch.values():
+        if torch.is_tensor(v) and v.dim() >= 1:
+            return int(v.shape[0])
+    return 0
 
 
 def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=None, device=None):
     """The per-batch hot path (core/trainer.py:585-612): observe -> zero_grad -> backward -> [grad all-reduce]
     -> step -> meters.  Shared by Trainer._train and bench.py so that the benchmark times exactly what
     training runs.  Loss / accuracy stay on the device (ops.Deferred): no host sync inside the loop.
-    With CLHIP_CUDA_GRAPH=1, graph-safe methods under the fused SGD replay a captured HIP graph of the step (GraphedStep; opt-in,
-    see _graph_mode)."""
+    Graph-safe methods under the fused SGD replay a captured HIP graph of the step (GraphedStep) -- by default for per-GPU batches of at most
+    GRAPH_AUTO_MAX_BATCH rows, for every size with CLHIP_CUDA_GRAPH=1, never with =0 (see _graph_mode)."""
     on_gpu = device is not None and torch.device(device).type == "cuda"
     import contextlib
     overlap = reducer.overlap(model) if (reducer is not None and hasattr(reducer, "overlap")) else contextlib.nullcontext()
@@ -164,10 +190,12 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
     with ops.deferred_metrics(on_gpu), overlap, (torch.cuda.stream(gs.stream) if gs is not None else contextlib.nullcontext()):
         for b, batch in enumerate(batches):
             batch["batch_id"] = b
-            if gs is not None:
+            if gs is not None and (mode == "always" or _batch_rows(batch) <= GRAPH_AUTO_MAX_BATCH):
                 gs.stream.wait_stream(caller)                  # loaders that produce their batches on the caller's stream
                 output, acc, loss = gs({k: v for k, v in batch.items() if k != "batch_id"})
             else:
+                if gs is not None:
+                    gs.stream.wait_stream(caller)
                 if method_name in _OBSERVE_DOES_BACKWARD:
                     optimizer.zero_grad()
                     output, acc, loss = model.observe(batch)

@@ -234,3 +234,60 @@ def test_fused_stage_entry_gradient_inside_a_resnet32_run():
     rel = float((g0 - g1).norm()) / float(g0.norm())
     print(f"fused vs separate stage-entry input gradients, one step: parameter deviation {d:.2e}, gradient max {dg:.2e}, norm {rel:.2e}")
     assert 0.0 < dg <= 2e-2 and rel <= 1e-2 and d <= 1e-3          # (> 0: the fused launch is really in the plan)
+
+
+def test_small_batches_replay_by_default_and_a_config_flip_recaptures(monkeypatch):
+    """Round 4: without CLHIP_CUDA_GRAPH the step replays for per-GPU batches of at most GRAPH_AUTO_MAX_BATCH rows and stays
+    eager above; CLHIP_CUDA_GRAPH=0 opts out.  ADVICE r3: the clhip_config switches that steer a plan's launch sequence are part of the graph
+    key -- a flip between two steps captures a NEW graph instead of replaying one whose host-side plan state no longer matches."""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    monkeypatch.delenv("CLHIP_CUDA_GRAPH", raising=False)
+    m = _make("ewc", 21)
+    o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+    T.train_steps(m, o, _batches(5, 32), None, "EWC", None, "cuda")
+    gs = m._graphed_step
+    assert gs is not None and len(gs.graphs) == 1
+    T.train_steps(m, o, _batches(4, 128), None, "EWC", None, "cuda")            # above the limit: eager, nothing captured for that shape
+    assert len(gs.graphs) == 1 and not any(k[0][0][1][0] == 128 for k in gs.graphs)
+    try:
+        assert L.clhip_config(b"BN_INPUT", b"0") == 0
+        T.train_steps(m, o, _batches(4, 32), None, "EWC", None, "cuda")        # same shapes, another launch sequence: two warm steps, a new capture
+        assert len(gs.graphs) == 2
+    finally:
+        L.clhip_config(b"BN_INPUT", None)
+    T.train_steps(m, o, _batches(2, 32), None, "EWC", None, "cuda")            # back on the first key: replayed, no further capture
+    assert len(gs.graphs) == 2
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.backbone.flat_parameters()[0]).all())
+    monkeypatch.setenv("CLHIP_CUDA_GRAPH", "0")
+    m2 = _make("ewc", 22)
+    o2 = optim.SGD(m2.get_parameters({}), lr=0.02, momentum=0.9)
+    T.train_steps(m2, o2, _batches(4, 32), None, "EWC", None, "cuda")
+    assert getattr(m2, "_graphed_step", None) is None
+
+
+def test_write_through_batchnorm_inputs_do_not_change_a_resnet18_run():
+    """Round 4: ResNet-18's 64-channel BasicBlocks with the producer's BatchNorm [+ residual] + ReLU applied by the consuming convolution on its
+    landed patch in LDS (clhip_conv_fwd_acc_bn_input_wt, conv5.hip; opt-in BN_INPUT_WT=1): the activation, mask and statistics the launch
+    writes are the apply launch's bit for bit, so six steps with the switch on end where six steps with it off end (fp64-atomic tolerance)."""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    out = []
+    try:
+        for wt in (b"1", b"0"):
+            assert L.clhip_config(b"BN_INPUT_WT", wt) == 0
+            m = _make("lwf", 9)
+            o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+            T.train_steps(m, o, _batches(6, 160), None, "LWF", None, "cuda")      # 640 tiles of 256 pixels at 32 x 32: the weight-stationary kernel's domain
+            torch.cuda.synchronize()
+            bb = m.backbone
+            out.append((bb.flat_parameters()[0].clone(), bb.flat_parameters()[1].clone(), bb._stats.clone()))
+    finally:
+        L.clhip_config(b"BN_INPUT_WT", None)
+    (p0, g0, s0), (p1, g1, s1) = out
+    d = float((p0 - p1).abs().max()) / float(p0.abs().max())
+    dg = float((g0 - g1).abs().max()) / float(g0.abs().max())
+    print(f"write-through vs separate BatchNorm apply, six ResNet-18 steps: parameter deviation {d:.2e}, last gradient {dg:.2e}")
+    assert d <= 1e-5 and dg <= 1e-4
+    assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max())

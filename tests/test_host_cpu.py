@@ -46,6 +46,37 @@ def test_clhip_config_round_trip(monkeypatch):
     assert L.clhip_config(b"BN_ACC_CPT", b"4") == 0 and L.clhip_config(b"CLHIP_BN_ACC_CPT", None) == 0      # prefix accepted, NULL = default
     assert L.clhip_config(b"CONV4_FORCE_CFG", b"nonsense") == -1
     assert L.clhip_config(b"CONV4_FORCE_CFG", None) == 0
+    # the getter returns what clhip_config() set (not the environment): callers that flip a switch around a region restore through it
+    monkeypatch.setenv("CLHIP_BRANCH_STREAM", "1")
+    assert L.clhip_config_get(b"BRANCH_STREAM") is None
+    assert L.clhip_config(b"BRANCH_STREAM", b"0") == 0 and L.clhip_config_get(b"BRANCH_STREAM") == b"0" and L.clhip_config_get(b"CLHIP_BRANCH_STREAM") == b"0"
+    assert L.clhip_config(b"BRANCH_STREAM", None) == 0 and L.clhip_config_get(b"BRANCH_STREAM") is None
+
+
+def test_teacher_pass_restores_the_branch_stream_switch(monkeypatch):
+    """TeacherPass.result() must put back what was configured (parallel.attach()'s "0"), not erase it"""
+    import torch
+    from libcontinual_amd import ops
+    monkeypatch.delenv("CLHIP_BRANCH_STREAM", raising=False)
+    L = _lib.lib()
+
+    class FakeStream:
+        def wait_stream(self, other): pass
+    class FakeX:
+        is_cuda = True
+        class device: index = 0
+    monkeypatch.setattr(ops, "_SIDE_STREAMS", {0: FakeStream()})
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: FakeStream())
+    import contextlib
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    seen = {}
+    for prev in (b"0", None, b"2"):
+        assert L.clhip_config(b"BRANCH_STREAM", prev) == 0
+        tp = ops.TeacherPass(FakeX(), lambda: seen.setdefault("during", L.clhip_config_get(b"BRANCH_STREAM")) and 7)
+        assert seen.pop("during") == b"0"
+        assert tp.result() == 7
+        assert L.clhip_config_get(b"BRANCH_STREAM") == prev
+    L.clhip_config(b"BRANCH_STREAM", None)
 
 
 def test_invalid_arguments_return_error_codes_not_exceptions():

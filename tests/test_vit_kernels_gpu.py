@@ -290,6 +290,31 @@ def test_gram(dt):
     assert relerr(G, 1 + x.double().T @ x.double()) < 1e-4
 
 
+@pytest.mark.parametrize("M,D,L", [(2500, 192, 3), (197 * 4, 768, 2), (33, 64, 1)])
+def test_gram_batched_mfma(M, D, L):
+    """clhip_gram_accum_batched: X_l^T X_l of all layers in one MFMA launch (transformer.py:241-244) -- ragged row
+    count, a partial 128-tile (D = 192), a layer stride larger than M * D, accumulation onto existing sums, bitwise reproducible"""
+    stride = M * D + 256
+    buf = torch.zeros(L * stride, device=DEV, dtype=torch.bfloat16)
+    xs = []
+    for l in range(L):
+        x = rnd(M, D, seed=10 + l).to(torch.bfloat16)
+        buf[l * stride:l * stride + M * D] = x.reshape(-1)
+        xs.append(x.double())
+    outs = []
+    for _ in range(2):
+        G = torch.full((L, D, D), 0.5, device=DEV)
+        call("clhip_gram_accum_batched", p(buf), stride, L, p(G), M, D, CODE["bf16"], st())
+        call("clhip_gram_accum_batched", p(buf), stride, L, p(G), M, D, CODE["bf16"], st())      # resident sums: a second batch adds on top
+        torch.cuda.synchronize()
+        outs.append(G.clone())
+    assert torch.equal(outs[0], outs[1])
+    for l in range(L):
+        want = 0.5 + 2 * (xs[l].T @ xs[l])
+        assert relerr(outs[0][l], want) < 1e-5
+        assert torch.equal(outs[0][l], outs[0][l].T) or relerr(outs[0][l], outs[0][l].T) < 1e-6
+
+
 def test_l2p_select():
     B, D, pool, top_k, length = 16, 128, 10, 5, 5
     q = rnd(B, D, seed=1)
