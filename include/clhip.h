@@ -312,6 +312,11 @@ int clhip_l2_normalize_rows(const float* x, float* out, int R, int D, void* stre
 int clhip_ncm_classify(const float* feats, const float* means, int B, int M, int D, int64_t* pred, void* stream);
 int clhip_herding_select(const float* feats /*[n,D], L2-normalised*/, int n, int D, int m, int32_t* chosen /*[m]*/,
                          float* ws /*[2*D + n]*/, void* stream);
+/* the same for every class of a task in ONE launch (one block per class): class c = rows [offsets[c], offsets[c+1]) of feats (offsets: n_classes + 1
+ * int32 on the device, max_rows = the largest class), picks are class-local indices in chosen[c * m ...] (-1 beyond a class's row count);
+ * ws: 2 * D * n_classes + offsets[n_classes] floats.  Same arithmetic, same picks as n_classes calls of clhip_herding_select. */
+int clhip_herding_select_batched(const float* feats, const int32_t* offsets, int n_classes, int max_rows, int D, int m, int32_t* chosen, float* ws,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ViT path: frozen ViT-B/16 backbone with L2P prompt tokens or InfLoRA's

@@ -142,6 +142,7 @@ _PROTOS = {
     "clhip_l2_normalize_rows": (_i, [_p, _p, _i, _i, _p]),
     "clhip_ncm_classify": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "clhip_herding_select": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "clhip_herding_select_batched": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "clhip_augment_crop_flip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_augment_rrc_flip": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "clhip_augment_rrc_aa_ws_bytes": (_sz, [_i, _i, _i]),

@@ -539,19 +539,27 @@ __global__ __launch_bounds__(256) void ncm_kernel(const float* __restrict__ f, c
     if (lane == 0) pred[row] = bi;
 }
 
-// herding: single block; ws = [mu(D) | run(D) | taken(n)]
-__global__ __launch_bounds__(256) void herding_kernel(const float* __restrict__ f, int n, int D, int m, int32_t* chosen, float* ws) {
+// herding: one block per class; ws = [mu(D) | run(D) | taken(n)].  `fl` (nullable): the class's rows staged in LDS at a pitch of D + 1 floats
+// (row i of thread i, coordinate d: bank (i + d) % 32 -- conflict-free), the arithmetic and its order are those of the global-memory form
+__device__ __forceinline__ void herding_body(const float* __restrict__ f, int n, int D, int m, int32_t* chosen, float* ws, float* fl) {
     __shared__ float sv[256];
     __shared__ int si[256];
     float* mu = ws; float* run = ws + D; float* taken = ws + 2 * D;
     const int tid = threadIdx.x;
+    const int P = fl != nullptr ? D + 1 : D;
+    if (fl != nullptr) {
+        for (int e = tid; e < n * D; e += 256) { const int i = e / D, d = e - i * D; fl[i * P + d] = f[e]; }
+        __syncthreads();
+        f = fl;
+    }
     for (int d = tid; d < D; d += 256) {
         float s = 0.f;
-        for (int i = 0; i < n; ++i) s += f[(size_t)i * D + d];
+        for (int i = 0; i < n; ++i) s += f[(size_t)i * P + d];
         mu[d] = s / (float)n;
         run[d] = 0.f;
     }
     for (int i = tid; i < n; i += 256) taken[i] = 0.f;
+    for (int k = n + tid; k < m; k += 256) chosen[k] = -1;      // fewer rows than picks: the tail stays marked
     __syncthreads();
     for (int k = 0; k < m && k < n; ++k) {
         float bv = INFINITY; int bi = 0x7fffffff;
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256) void herding_kernel(const float* __restrict__ 
             float s = 0.f;
             // a selected row is "removed" by +1e6 on every coordinate (linearherdingbuffer.py:160)
             const float off = taken[i] * 1e6f;
-            for (int d = 0; d < D; ++d) { float t = mu[d] - (f[(size_t)i * D + d] + off + run[d]) * inv; s = fmaf(t, t, s); }
+            for (int d = 0; d < D; ++d) { float t = mu[d] - (f[(size_t)i * P + d] + off + run[d]) * inv; s = fmaf(t, t, s); }
             if (s < bv) { bv = s; bi = i; }
         }
         sv[tid] = bv; si[tid] = bi;
@@ -574,11 +582,28 @@ __global__ __launch_bounds__(256) void herding_kernel(const float* __restrict__ 
         }
         const int best = si[0];
         if (tid == 0) { chosen[k] = best; }
-        for (int d = tid; d < D; d += 256) run[d] += f[(size_t)best * D + d] + taken[best] * 1e6f;
+        for (int d = tid; d < D; d += 256) run[d] += f[(size_t)best * P + d] + taken[best] * 1e6f;
         __syncthreads();
         if (tid == 0) taken[best] += 1.f;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void herding_kernel(const float* __restrict__ f, int n, int D, int m, int32_t* chosen, float* ws, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float herd_lds[];
+    herding_body(f, n, D, m, chosen, ws, use_lds ? herd_lds : nullptr);
+}
+
+// every class of a task in ONE launch (round 4): class c = rows [offsets[c], offsets[c + 1]) of f, its picks (class-local indices) in
+// chosen[c * m ...], its scratch at ws + 2 D c + offsets[c].  The 50 classes of a B50 task: one launch of 50 blocks instead of 50 launches
+// of one block (0.86 ms each: tools / bench.py --workload herding_b50)
+__global__ __launch_bounds__(256) void herding_batched_kernel(const float* __restrict__ f, const int32_t* __restrict__ offsets, int D, int m, int32_t* chosen, float* ws,
+                                                              int lds_rows) {
+    extern __shared__ __attribute__((aligned(16))) float herd_lds[];
+    const int c = blockIdx.x;
+    const int o0 = offsets[c], n = offsets[c + 1] - o0;
+    if (n <= 0) { for (int k = threadIdx.x; k < m; k += 256) chosen[(size_t)c * m + k] = -1; return; }
+    herding_body(f + (size_t)o0 * D, n, D, m, chosen + (size_t)c * m, ws + (size_t)2 * D * c + o0, n <= lds_rows ? herd_lds : nullptr);
 }
 
 }  // namespace
@@ -747,7 +772,33 @@ extern "C" int clhip_ncm_classify(const float* feats, const float* means, int B,
 
 extern "C" int clhip_herding_select(const float* feats, int n, int D, int m, int32_t* chosen, float* ws, void* stream) {
     CLHIP_CHECK_ARG(feats && chosen && ws && n > 0 && D > 0 && m > 0);
-    hipLaunchKernelGGL(herding_kernel, dim3(1), dim3(256), 0, ST, feats, n, D, m, chosen, ws);
+    // the class's rows in LDS when they fit (500 x 64 features: 130 KB): every pick re-reads all of them
+    const size_t lds = (size_t)n * (D + 1) * sizeof(float);
+    const bool in_lds = lds <= 150 * 1024;
+    if (in_lds) {
+        static size_t attr = 0;
+        if (lds > attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(herding_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { clhip_set_error("clhip_herding_select: cannot reserve LDS"); return CLHIP_EHIP; }
+            attr = 150 * 1024;
+        }
+    }
+    hipLaunchKernelGGL(herding_kernel, dim3(1), dim3(256), in_lds ? lds : 0, ST, feats, n, D, m, chosen, ws, in_lds ? 1 : 0);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_herding_select_batched(const float* feats, const int32_t* offsets, int n_classes, int max_rows, int D, int m, int32_t* chosen, float* ws,
+                                            void* stream) {
+    CLHIP_CHECK_ARG(feats && offsets && chosen && ws && n_classes > 0 && max_rows > 0 && D > 0 && m > 0);
+    int lds_rows = (int)((150 * 1024) / ((size_t)(D + 1) * sizeof(float)));
+    if (lds_rows > max_rows) lds_rows = max_rows;
+    const size_t lds = (size_t)lds_rows * (D + 1) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(herding_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { clhip_set_error("clhip_herding_select_batched: cannot reserve LDS"); return CLHIP_EHIP; }
+        attr = 150 * 1024;
+    }
+    hipLaunchKernelGGL(herding_batched_kernel, dim3(n_classes), dim3(256), lds, ST, feats, offsets, D, m, chosen, ws, lds_rows);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }

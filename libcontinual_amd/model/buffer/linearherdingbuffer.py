@@ -81,10 +81,15 @@ class LinearHerdingBuffer:
                 targets.append(data["label"].to(device))
         feats = torch.cat(feats)
         targets = torch.cat(targets).cpu().numpy()
+        # class samples are contiguous after the filtering above: all classes of the task in ONE launch, one block per class (the reference's
+        # per-class loop, :140-161; picks identical to per-class ops.herding_select calls)
+        classes, firsts, counts = np.unique(targets, return_index=True, return_counts=True)
+        order = np.argsort(firsts)
+        firsts, counts = firsts[order], counts[order]
+        assert int(firsts[0]) == 0 and all(int(firsts[i]) + int(counts[i]) == int(firsts[i + 1]) for i in range(len(firsts) - 1))
+        picks = ops.herding_select_classes(feats, counts.tolist(), spc)
+        chosen_of = {int(classes[order[i]]): (picks[i].cpu().numpy() + int(firsts[i])) for i in range(len(counts))}
         result = []
         for c in np.unique(targets):
-            ind = np.where(targets == c)[0]
-            cf = feats[int(ind[0]): int(ind[-1]) + 1]          # class samples are contiguous after the filtering above
-            chosen = ops.herding_select(cf, spc).cpu().numpy()
-            result.extend((chosen + int(ind[0])).tolist())
+            result.extend(chosen_of[int(c)].tolist())
         return result

@@ -398,6 +398,24 @@ def herding_select(feats_normed, m):
     return chosen
 
 
+def herding_select_classes(feats_normed, counts, m):
+    """herding_select for every class of a task in ONE launch: `feats_normed` [sum(counts), D] holds the classes' rows back to back,
+    `counts` their row counts.  Returns a list of int32 tensors (class-local indices, min(m, count) each) -- the picks of
+    len(counts) herding_select calls (linearherdingbuffer.py:140-161 per class)."""
+    f = _f32c(feats_normed)
+    N, D = f.shape
+    counts = [int(c) for c in counts]
+    assert sum(counts) == N and len(counts) > 0
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    offsets = torch.tensor(offs, dtype=torch.int32, device=f.device)
+    chosen = torch.empty(len(counts), int(m), device=f.device, dtype=torch.int32)
+    ws = torch.empty(2 * D * len(counts) + N, device=f.device, dtype=torch.float32)
+    call("clhip_herding_select_batched", _ptr(f), _ptr(offsets), len(counts), max(counts), D, int(m), _ptr(chosen), _ptr(ws), _st())
+    return [chosen[i, : min(int(m), c)] for i, c in enumerate(counts)]
+
+
 def clip_grad_norm_(params, max_norm, eps=1e-6):
     """torch.nn.utils.clip_grad_norm_ (l2p.py:104) without a host sync: total = sqrt(sum ||g||^2) over the given
     parameters, every gradient scaled by min(1, max_norm / (total + eps)) on the device.  Returns the norm tensor."""

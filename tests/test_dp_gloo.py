@@ -154,3 +154,83 @@ def test_gradient_reducer_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_w(rank, world, port, q):
+    """world-size-generic checks (run at world 8): shard arithmetic with a ragged tail (n % (4 * world) != 0), the all-reduce with the early tail
+    hand-over, the reduce-scatter -> shard update -> all-gather exchange, the BatchNorm-buffer broadcast that precedes after_task"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    import libcontinual_amd.model as M
+    from libcontinual_amd import optim as fused, parallel
+    from libcontinual_amd.optim import _dp_plan
+    parallel.init_distributed(device_is_cuda=False)
+    torch.manual_seed(100 + rank)
+    bb = M.cifar_resnet32()
+    head = torch.nn.Linear(64, 55)
+    net = torch.nn.ModuleDict({"backbone": bb, "classifier": head})
+    bb._stats.copy_(torch.full_like(bb._stats, float(rank)))             # per-rank running statistics (DDP-faithful BatchNorm)
+    parallel.broadcast_module_state(net)
+    flat, gflat = bb.flat_parameters()
+    ref = flat.clone()
+    ok = bool((bb._stats == 0).all())                                       # rank 0's buffers everywhere
+    n = flat.numel()
+    pattern = torch.arange(n, dtype=torch.float32) % 11 - 5
+    ranks_sum = float(sum(r + 1 for r in range(world)))
+    total = ranks_sum * pattern + 5.0 * world
+    scale = 1.0 / world
+    # ---- all-reduce, the tail of the buffer handed over early
+    red = parallel.GradientReducer()
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    bb.attach_grads()
+    head.weight.grad = torch.full_like(head.weight, float(rank + 1))
+    head.bias.grad = torch.full_like(head.bias, 2.0 * (rank + 1))
+    with red.overlap(net, fraction=0.5):
+        k = bb.grad_cut_for_fraction(0.5)
+        cut = bb._unit_off[k]
+        bb._grad_segment_hook(bb, cut, bb._nflat)
+        bb._grad_segment_hook(bb, 0, cut)
+        red.reduce(net)
+    ok = ok and torch.allclose(gflat, total) and torch.allclose(head.weight.grad, torch.full_like(head.weight, ranks_sum))
+    ok = ok and torch.allclose(head.bias.grad, torch.full_like(head.bias, 2.0 * ranks_sum))
+    # ---- reduce-scatter with a ragged tail
+    rs = parallel.GradientReducer(exchange="reduce_scatter")
+    per, prefix = rs.shard_bounds(n)
+    ok = ok and per % 4 == 0 and prefix == per * world and 0 < n - prefix < 4 * world          # 466256 = 8 * 58280 + 16
+    whole_opt = fused.SGD(net.parameters(), lr=0.1)
+    parallel.attach(net, whole_opt, rs)
+    gflat.copy_((rank + 1) * pattern + 5.0)
+    head.weight.grad = torch.full_like(head.weight, float(rank + 1))
+    flat.copy_(ref)
+    rs.reduce(net)
+    d = bb._dp_shard
+    ok = ok and d is not None and d["lo"] == rank * per and d["hi"] == (rank + 1) * per and d["prefix"] == prefix
+    ok = ok and torch.allclose(d["grad"], total[d["lo"]:d["hi"]]) and torch.allclose(gflat[prefix:], total[prefix:])
+    parts, shard = _dp_plan(bb)
+    ok = ok and [sfx for _, _, sfx in parts] == ["_shard", "_tail"]
+    for pslice, gslice, _ in parts:
+        pslice.sub_(0.1 * scale * gslice)
+    bb._dp_shard = shard
+    rs.gather_params(bb)
+    ok = ok and torch.allclose(flat, ref - 0.1 * scale * total, atol=1e-6)
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)
+    ok = ok and abs(rs.mean_scalar(float(rank), "cpu") - (world - 1) / 2.0) < 1e-12
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_world8():
+    """the world-size > 2 arithmetic (8 ranks = the node BASELINE configs[2] / [4] name) on CPU over gloo"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_w, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=420) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)]

@@ -26,9 +26,9 @@ def _free_port():
     return p
 
 
-def _launch(script_args, timeout=600, **extra):
-    env = dict(os.environ, CLHIP_DIST_BACKEND="gloo", CLHIP_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **extra)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+def _launch(script_args, timeout=600, nproc=2, **extra):
+    env = dict(os.environ, CLHIP_DIST_BACKEND="gloo", CLHIP_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **dict({"OMP_NUM_THREADS": "4"}, **extra))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -144,3 +144,40 @@ def test_bench_strong_scaling_and_step_breakdown_at_two_ranks():
         assert abs(rk["bucket_mb"] - 44.7) < 0.2                                                      # ResNet-18's flat gradient buffer
     r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "65", "--scaling", "strong", "--no-cpu-baseline"])
     assert r.returncode != 0 and "does not divide" in r.stderr
+
+
+def test_eight_ranks_train_in_lockstep(tmp_path):
+    """the world-8 path (the node BASELINE configs[2] / [4] name) with eight processes sharing the one GPU over gloo --
+    rank-0 broadcast, per-rank batches, the segmented backward with the early tail hand-over, 1/8 folded into the fused SGD step: all eight
+    replicas end with bit-identical parameters, per-rank BatchNorm statistics until the end-of-task broadcast"""
+    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path), "2"], timeout=900, nproc=8, OMP_NUM_THREADS="1")
+    assert r.returncode == 0, r.stderr[-3000:]
+    ranks = [np.load(tmp_path / f"rank{k}.npz") for k in range(8)]
+    for k in range(1, 8):
+        np.testing.assert_array_equal(ranks[0]["flat"], ranks[k]["flat"])
+        np.testing.assert_array_equal(ranks[0]["head"], ranks[k]["head"])
+        np.testing.assert_array_equal(ranks[0]["rm_synced"], ranks[k]["rm_synced"])
+        assert np.abs(ranks[0]["rm"] - ranks[k]["rm"]).max() > 0
+    np.testing.assert_array_equal(ranks[0]["rm_synced"], ranks[0]["rm"])
+    assert np.isfinite(ranks[0]["flat"]).all()
+
+
+@pytest.mark.parametrize("exchange", ["all_reduce", "reduce_scatter"])
+def test_bench_icarl_strong_scaling_at_eight_ranks(exchange):
+    """BASELINE configs[2] as the driver will launch it on an 8-GPU node, strong-scaling series (x[256 global -> 32 / GPU], SURVEY.md section
+    8(d), core/trainer.py:229-241): eight ranks (sharing cuda:0 over gloo here), 32 images each, the flat 1.9-MB gradient bucket reduced per
+    step -- with the ragged reduce-scatter shards of a 466 256-element buffer (n % 32 = 16) in the second form; ONE json line, whole-job rate,
+    one `dp` entry per rank with the step breakdown"""
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "2", "--workload", "icarl_resnet32_b50_task1", "--batch", "256",
+                 "--scaling", "strong", "--no-cpu-baseline"], timeout=900, nproc=8, OMP_NUM_THREADS="1", CLHIP_DP_EXCHANGE=exchange)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["global_batch"] == 256 and out["config"]["per_gpu_batch"] == 32
+    assert out["config"]["parallelism"] == "dp8" and np.isfinite(out["config"]["final_loss"])
+    assert abs(out["value"] - 256 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    dp = out["dp"]
+    assert dp["world_size"] == 8 and sorted(r_["rank"] for r_ in dp["ranks"]) == list(range(8)) and dp["exchange"] == exchange
+    for rk in dp["ranks"]:
+        assert rk["backward_ms"] > 0 and abs(rk["bucket_mb"] - 1.865) < 0.01, rk

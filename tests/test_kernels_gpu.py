@@ -751,6 +751,24 @@ def test_herding_at_benchmark_size(n, D, m):
     assert d_got <= 1.25 * d_ref + 1e-6
 
 
+def test_herding_all_classes_in_one_launch():
+    """ops.herding_select_classes: every class of a task by one workgroup each in ONE launch (round 4) -- the picks of per-class
+    ops.herding_select calls, exactly (same arithmetic, same order), for classes of different sizes: one larger than the LDS staging
+    limit (global-memory form), one smaller than the number of picks (the tail stays unpicked)."""
+    from libcontinual_amd import ops
+    torch.manual_seed(5)
+    D, m = 64, 40
+    counts = [500, 37, 700, 1, 640, 500]
+    feats = ops.l2_normalize_rows(torch.randn(sum(counts), D, device=DEV))
+    got = ops.herding_select_classes(feats, counts, m)
+    o = 0
+    for c, g in zip(counts, got):
+        want = ops.herding_select(feats[o:o + c], m)
+        assert g.shape[0] == min(m, c)
+        assert torch.equal(g, want), (c, g.tolist(), want.tolist())
+        o += c
+
+
 @pytest.mark.parametrize("rep", [1, 2, 8, 16, 32, 64])
 @pytest.mark.parametrize("shape", [(5, 6, 6, 16), (3, 7, 9, 64), (3, 5, 5, 128), (2, 3, 3, 512), (2, 2, 3, 2048)])
 def test_batchnorm_accumulator_replicas(shape, rep):
