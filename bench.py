@@ -21,6 +21,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (must be set before the HIP runtime starts)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")               # see libcontinual_amd/__init__.py: more than four busy hardware queues are time-sliced
 
 import torch
 

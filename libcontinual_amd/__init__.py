@@ -6,6 +6,19 @@ The per-task inner loop (ResNet forward/backward, BatchNorm, EWC / KD / LUCIR te
 fused SGD/Adam) runs as hand-written gfx950 HIP kernels in `libclhip.so` behind the C ABI of
 `include/clhip.h`; this Python package is host orchestration only and has no CPU fallback.
 """
-from . import _lib  # noqa: F401
+import os as _os
+
+# Hardware-queue cap (round 4, the cause behind DESIGN.md lesson 11 "count the streams"): the HIP runtime gives every stream a hardware queue of its
+# own until GPU_MAX_HW_QUEUES (default 4) are in use and multiplexes the rest.  A step that keeps FIVE queues busy at once -- LwF task >= 1 with
+# the shortcut-branch streams on: caller + weight-gradient + branch + teacher + teacher-branch -- runs 6.15 ms instead of 2.61 ms whenever the cap
+# allows five queues (GPU_MAX_HW_QUEUES >= 5; 2.90 ms at 4, 2.61 ms at 3 -- the time of the same step WITHOUT the extra streams): the chip's
+# command processor serves four compute pipes, a fifth busy queue is time-sliced against the others and every cross-stream event wait behind it
+# pays the slice.  Three queues cost nothing measurable on any workload (kernels of different streams still overlap inside one hardware queue --
+# only same-stream packets carry the barrier bit: ResNet-18 task-0 step 2.1135 / 2.1025 / 2.098 / 2.096 ms at 1 / 3 / 4 / 8 queues), so the cap is
+# set here for every process that imports the package before the HIP runtime starts; an explicit GPU_MAX_HW_QUEUES in the environment wins.
+# Measurements: profiles/r04_stream_stall.md.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
+from . import _lib  # noqa: E402,F401
 
 __version__ = "0.1.0"
