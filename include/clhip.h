@@ -292,6 +292,11 @@ int clhip_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, fl
  * Element for element the arithmetic of clhip_sgd_step. */
 int clhip_sgd_step_multi(int count, float* const* p, const float* const* g, float* const* mom /*nullable*/, const int64_t* n, float lr, float momentum,
                          float weight_decay, float grad_scale, void* stream);
+/* ... and, for the tensors whose bit is set in zero_grad_mask, g <- 0 once it has been consumed: the flat gradient buffer of a backbone then
+ * enters the next backward already zeroed (every writer of it accumulates) and the per-step 44.7-MB fill launch of ResNet-18 disappears
+ * (trainer.train_steps opts in: between optimizer.step() and the next zero_grad() nothing reads the gradients there). */
+int clhip_sgd_step_multi_zero(int count, float* const* p, float* const* g, float* const* mom /*nullable*/, const int64_t* n, float lr, float momentum,
+                              float weight_decay, float grad_scale, unsigned zero_grad_mask, void* stream);
 int clhip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float grad_scale, int step, void* stream);
 int clhip_sq_norm(const float* g, int64_t n, float* out, int accumulate, void* stream);

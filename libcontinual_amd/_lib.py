@@ -133,6 +133,7 @@ _PROTOS = {
     "clhip_fisher_merge": (_i, [_p, _p, _l, _f, _p]),
     "clhip_sgd_step": (_i, [_p, _p, _p, _l, _f, _f, _f, _f, _p, _p, _f, _p]),
     "clhip_sgd_step_multi": (_i, [_i, _p, _p, _p, _p, _f, _f, _f, _f, _p]),
+    "clhip_sgd_step_multi_zero": (_i, [_i, _p, _p, _p, _p, _f, _f, _f, _f, C.c_uint, _p]),
     "clhip_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _i, _p]),
     "clhip_sq_norm": (_i, [_p, _l, _p, _i, _p]),
     "clhip_scale": (_i, [_p, _l, _f, _p]),

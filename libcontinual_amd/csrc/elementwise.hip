@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 // the same update over several tensors in one launch (a backbone's flat buffer + the head's weight and bias: three launches per step otherwise)
 constexpr int kSgdSegs = 8;
-struct SgdSeg { float* p; const float* g; float* m; long long n; unsigned first_block, blocks; };
+struct SgdSeg { float* p; float* g; float* m; long long n; unsigned first_block, blocks; int zero; };
 struct SgdTable { int n; SgdSeg s[kSgdSegs]; };
 template <bool MOM>
 __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float lr, float momentum, float wd, float gscale) {
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float lr, fl
             d = b;
         }
         e.p[i] = fmaf(-lr, d, pv);
+        if (e.zero) e.g[i] = 0.f;          // the consumed gradient leaves zeroed: the next backward accumulates into it without a fill launch
     }
 }
 
@@ -298,6 +299,11 @@ extern "C" int clhip_sgd_step(float* p, const float* g, float* mom, int64_t n, f
 
 extern "C" int clhip_sgd_step_multi(int count, float* const* p, const float* const* g, float* const* mom, const int64_t* n, float lr, float momentum,
                                     float weight_decay, float grad_scale, void* stream) {
+    return clhip_sgd_step_multi_zero(count, p, const_cast<float* const*>(reinterpret_cast<const float* const*>(g)), mom, n, lr, momentum, weight_decay, grad_scale, 0u, stream);
+}
+
+extern "C" int clhip_sgd_step_multi_zero(int count, float* const* p, float* const* g, float* const* mom, const int64_t* n, float lr, float momentum,
+                                         float weight_decay, float grad_scale, unsigned zero_grad_mask, void* stream) {
     CLHIP_CHECK_ARG(count >= 1 && count <= kSgdSegs && p && g && n);
     CLHIP_CHECK_ARG(momentum == 0.f || mom != nullptr);
     SgdTable t;
@@ -307,7 +313,7 @@ extern "C" int clhip_sgd_step_multi(int count, float* const* p, const float* con
         CLHIP_CHECK_ARG(n[k] >= 0 && (n[k] == 0 || (p[k] && g[k] && (momentum == 0.f || mom[k]))));
         if (n[k] == 0) continue;
         SgdSeg& e = t.s[t.n++];
-        e.p = p[k]; e.g = g[k]; e.m = momentum != 0.f ? mom[k] : nullptr; e.n = n[k];
+        e.p = p[k]; e.g = g[k]; e.m = momentum != 0.f ? mom[k] : nullptr; e.n = n[k]; e.zero = (zero_grad_mask >> k) & 1u;
         e.first_block = blocks; e.blocks = (unsigned)ew_blocks4(n[k]);
         blocks += e.blocks;
     }

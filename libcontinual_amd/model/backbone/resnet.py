@@ -406,7 +406,9 @@ class HipResNet(nn.Module):
         writer attaches the views, so the later ones see live gradients and add).  Returns the gradient buffer."""
         _, g = self.flat_parameters()
         if all(p.grad is None for p in self._params):
-            g.zero_()
+            if not getattr(self, "_gflat_zeroed", False):           # (the fused SGD left it zeroed: optim._FusedBase.zero_grads_in_step)
+                g.zero_()
+        self._gflat_zeroed = False                                   # whoever called is about to write into it
         return g
 
     # ------------------------------------------------------------------------------ execution

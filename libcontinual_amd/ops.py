@@ -346,15 +346,16 @@ def sgd_step(p, g, mom, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0, ewc_
          float(grad_scale), _ptr(ewc_ref), _ptr(ewc_fisher), float(ewc_weight), _st())
 
 
-def sgd_step_multi(items, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
-    """items: [(p, g, mom or None), ...] (<= 8 flat fp32 tensors on one device): clhip_sgd_step on each, ONE launch"""
+def sgd_step_multi(items, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0, zero_mask=0):
+    """items: [(p, g, mom or None), ...] (<= 8 flat fp32 tensors on one device): clhip_sgd_step on each, ONE launch; bit k of `zero_mask`: the
+    gradient of item k is zeroed once consumed"""
     import ctypes as C
     for p, g, m in items:
         _dev(p, g, m)
     n = (C.c_int64 * len(items))(*[it[0].numel() for it in items])
     moms = _ptr_array([it[2] for it in items]) if momentum != 0 else None
-    call("clhip_sgd_step_multi", len(items), _ptr_array([it[0] for it in items]), _ptr_array([it[1] for it in items]), moms, n, float(lr), float(momentum),
-         float(weight_decay), float(grad_scale), _st())
+    call("clhip_sgd_step_multi_zero", len(items), _ptr_array([it[0] for it in items]), _ptr_array([it[1] for it in items]), moms, n, float(lr), float(momentum),
+         float(weight_decay), float(grad_scale), int(zero_mask), _st())
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):

@@ -33,6 +33,10 @@ def _tag_backbones(params):
 class _FusedBase(torch.optim.Optimizer):
     grad_scale = 1.0
     capture_safe = False        # may trainer.GraphedStep capture step() into a HIP graph?
+    # the fused SGD may leave a backbone's flat gradient buffer ZEROED after consuming it (the next backward then needs no fill launch: 44.7 MB per
+    # ResNet-18 step).  Off by default -- torch semantics: p.grad still holds the gradient after step() -- and switched on by trainer.train_steps
+    # for its loop, where zero_grad() follows every step() and nothing reads the gradients in between.
+    zero_grads_in_step = False
 
     def whole_backbones(self):
         """the backbones this optimizer updates with ONE launch over their flat buffer (and whose `_dp_shard` it therefore honours):
@@ -118,11 +122,15 @@ class SGD(_FusedBase):
             self._check_unconsumed_shards(rest)
             # every tensor of the group goes into ONE launch (clhip_sgd_step_multi, up to eight per launch): a backbone's flat buffer + the head's
             # weight and bias were three launches per step
-            items, after = [], []
+            items, after, zero_mask = [], [], 0
             for o in whole:
                 require_gpu(o._flat)
                 st = self.state[o._params[0]]
                 parts, shard = _dp_plan(o)
+                if self.zero_grads_in_step and shard is None and len(parts) == 1 and len(items) < 8:
+                    # the whole flat gradient buffer is consumed by this launch: it leaves zeroed, and the backbone skips its fill at the next backward
+                    zero_mask |= 1 << len(items)
+                    o._gflat_zeroed = True
                 for flat, gflat, sfx in parts:
                     buf = None
                     if mom != 0:
@@ -148,9 +156,9 @@ class SGD(_FusedBase):
                 if o is not None:
                     after.append((o, None))
             same_dev = len({it[0].device for it in items}) <= 1
-            if len(items) >= 2 and same_dev:
+            if (len(items) >= 2 or zero_mask) and same_dev:
                 for k in range(0, len(items), 8):
-                    ops.sgd_step_multi(items[k:k + 8], lr, mom, wd, self.grad_scale)
+                    ops.sgd_step_multi(items[k:k + 8], lr, mom, wd, self.grad_scale, zero_mask if k == 0 else 0)
             else:
                 for pd, gd, buf in items:
                     ops.sgd_step(pd, gd, buf, lr, mom, wd, self.grad_scale)

@@ -88,6 +88,8 @@ class GraphedStep:
         # every step of a graphed loop -- warm-up, capture, replay -- runs on this stream: autograd binds a parameter's gradient
         # accumulation to the stream of its first backward, and a capture cannot depend on the legacy default stream
         self.stream = torch.cuda.Stream()
+        self.disabled = False       # a capture failed under the auto mode: this loop stays eager
+        self.fallback_ok = True     # ... which only the auto mode allows (train_steps sets it)
 
     def _key(self, batch):
         shapes = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
@@ -109,6 +111,8 @@ class GraphedStep:
         return out
 
     def __call__(self, batch):
+        if self.disabled:
+            return self._step(batch)
         key = self._key(batch)
         ent = self.graphs.get(key)
         if ent is None:
@@ -121,8 +125,25 @@ class GraphedStep:
             static = {k: (v.to(dev, copy=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
-                out = self._step(static)
+            try:
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                    out = self._step(static)
+            except Exception as e:
+                # the step is NOT capturable after all (a wrapper around observe() that reads a loss on the host, a plugin whose class-level
+                # `cuda_graph_safe` promise an instance breaks).  Under the default (auto) mode that must not cost the user the run: nothing of
+                # the captured step has executed, so drop the capture, stay eager for the rest of this loop's life and say so once.  With
+                # CLHIP_CUDA_GRAPH=1 the caller asked for replay explicitly: fail loudly.
+                del g
+                if not self.fallback_ok:
+                    raise
+                torch.cuda.synchronize()
+                self.disabled = True
+                for o in self.owners:             # launches "made" during the dropped capture never ran: the weight copies they were to refresh are stale
+                    o.mark_params_modified()
+                import warnings
+                warnings.warn(f"libcontinual_amd: the training step of {self.method_name or type(self.model).__name__} could not be captured into a HIP graph "
+                              f"({type(e).__name__}: {str(e).splitlines()[0][:120]}); continuing eagerly (CLHIP_CUDA_GRAPH=0 silences the attempt)")
+                return self._step(batch)
             while len(self.graphs) >= self.KEEP:
                 self.graphs.pop(next(iter(self.graphs)))
             ent = self.graphs[key] = (g, static, out)
@@ -184,9 +205,26 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
         gs = getattr(model, "_graphed_step", None)
         if gs is None or gs.optimizer is not optimizer:
             gs = model._graphed_step = GraphedStep(model, optimizer, method_name)
+        gs.fallback_ok = mode == "auto"
     caller = torch.cuda.current_stream() if gs is not None else None
     if gs is not None:
         gs.stream.wait_stream(caller)
+    # in this loop zero_grad() follows every step() and nothing reads the gradients in between: the fused SGD may hand the flat gradient buffer
+    # back zeroed (no fill launch in front of the next backward); single-process only -- the sharded exchange consumes slices
+    zero_prev = getattr(optimizer, "zero_grads_in_step", None)
+    if zero_prev is not None and reducer is None and os.environ.get("CLHIP_SGD_ZERO", "1") != "0":
+        optimizer.zero_grads_in_step = True
+    try:
+        _train_loop(model, optimizer, batches, reducer, method_name, meter, on_gpu, overlap, mode, gs, caller)
+    finally:
+        if zero_prev is not None:
+            optimizer.zero_grads_in_step = zero_prev
+    if gs is not None:
+        caller.wait_stream(gs.stream)
+
+
+def _train_loop(model, optimizer, batches, reducer, method_name, meter, on_gpu, overlap, mode, gs, caller):
+    import contextlib
     with ops.deferred_metrics(on_gpu), overlap, (torch.cuda.stream(gs.stream) if gs is not None else contextlib.nullcontext()):
         for b, batch in enumerate(batches):
             batch["batch_id"] = b
@@ -209,8 +247,6 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
             if meter is not None:
                 meter.update("acc1", 100 * acc)
                 meter.update("loss", loss.detach() if on_gpu else loss.item())
-    if gs is not None:
-        caller.wait_stream(gs.stream)
 
 
 class Trainer:

@@ -13,6 +13,13 @@ from libcontinual_amd import trainer as T              # noqa: E402
 from libcontinual_amd.utils import AverageMeter        # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _gradients_survive_the_step(monkeypatch):
+    """these tests read the flat gradient buffer AFTER train_steps: keep the fused SGD from handing it back zeroed (CLHIP_SGD_ZERO, the round-4
+    default inside train_steps); test_sgd_hands_back_a_zeroed_gradient_buffer switches it on again"""
+    monkeypatch.setenv("CLHIP_SGD_ZERO", "0")
+
+
 def _make(kind, seed):
     torch.manual_seed(seed)
     if kind == "lwf":
@@ -291,3 +298,74 @@ def test_write_through_batchnorm_inputs_do_not_change_a_resnet18_run():
     print(f"write-through vs separate BatchNorm apply, six ResNet-18 steps: parameter deviation {d:.2e}, last gradient {dg:.2e}")
     assert d <= 1e-5 and dg <= 1e-4
     assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max())
+
+
+def test_sgd_hands_back_a_zeroed_gradient_buffer(monkeypatch):
+    """inside train_steps the fused SGD zeroes the flat gradient buffer while it consumes it, and the next backward skips its
+    fill launch (the last torch kernel of the ResNet-18 step).  Same parameters as the run with the fill (f32 parity mode: bit for bit), the
+    buffer reads zero afterwards; outside train_steps (the flag's default) optimizer.step() leaves the gradients in place."""
+    monkeypatch.setenv("CLHIP_CUDA_GRAPH", "0")
+    outs = []
+    for z in ("1", "0"):
+        monkeypatch.setenv("CLHIP_SGD_ZERO", z)
+        torch.manual_seed(31)
+        bb = M.resnet18(args={"dataset": "cifar100"}, dtype="f32")
+        m = M.LWF(bb, 512, 100, device="cuda", init_cls_num=50, inc_cls_num=5).to("cuda")
+        m.before_task(0, None, None, None)
+        m.train()
+        o = optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        T.train_steps(m, o, _batches(4, 32), None, "LWF", None, "cuda")
+        torch.cuda.synchronize()
+        outs.append((m.backbone.flat_parameters()[0].clone(), m.backbone.flat_parameters()[1].clone(), m.classifier.weight.detach().clone()))
+        assert o.zero_grads_in_step is False                                   # the loop's opt-in does not outlive it
+    (p1, g1, h1), (p0, g0, h0) = outs
+    assert torch.equal(p1, p0) and torch.equal(h1, h0)
+    assert float(g1.abs().max()) == 0.0 and float(g0.abs().max()) > 0.0
+    # a plain step outside the loop keeps torch's semantics
+    _, _, loss = m.observe(_batches(1, 32)[0])
+    o.zero_grad()
+    loss.backward()
+    o.step()
+    torch.cuda.synchronize()
+    assert float(m.backbone.flat_parameters()[1].abs().max()) > 0.0
+
+
+def test_a_step_that_cannot_be_captured_falls_back_to_eager_under_the_default_mode(monkeypatch):
+    """the default (auto) replay of small batches must not break a loop whose observe() turns out to synchronise with the host (a recorder
+    wrapped around the plugin, as tests/test_trainer_trace_gpu.py does): the failed capture is dropped, the loop continues eagerly with a
+    warning and ends where the eager run ends; with CLHIP_CUDA_GRAPH=1 the same loop fails loudly"""
+    import warnings
+    outs = []
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("CLHIP_CUDA_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("CLHIP_CUDA_GRAPH", mode)
+        m = _make("ewc", 41)
+        seen = []
+        inner = m.observe
+
+        def observe(batch, inner=inner, seen=seen):
+            out = inner(batch)
+            seen.append(float(out[2].detach().float().item()))             # a host read inside the step
+            return out
+        m.observe = observe
+        o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            T.train_steps(m, o, _batches(6, 32), None, "EWC", None, "cuda")
+        torch.cuda.synchronize()
+        if mode is None:
+            assert m._graphed_step.disabled and any("could not be captured" in str(x.message) for x in w)
+        assert len(seen) == 6
+        outs.append((m.network.backbone.flat_parameters()[0].clone(), list(seen)))
+    d = float((outs[0][0] - outs[1][0]).abs().max()) / float(outs[1][0].abs().max())
+    assert d <= 1e-5 and max(abs(a - b) for a, b in zip(outs[0][1], outs[1][1])) <= 1e-4 * abs(outs[1][1][0])
+    monkeypatch.setenv("CLHIP_CUDA_GRAPH", "1")
+    m = _make("ewc", 41)
+    inner = m.observe
+    m.observe = lambda batch: (lambda out: (out[2].item(), out)[1])(inner(batch))
+    o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9)
+    with pytest.raises(Exception):
+        T.train_steps(m, o, _batches(6, 32), None, "EWC", None, "cuda")
+    torch.cuda.synchronize()
