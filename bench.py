@@ -371,7 +371,7 @@ def conv_rooflines(dev, dtype, B, workload):
                   2 * 2.0 * M * 9 * C * C, 4 * M * C * es + C * 9 * C * 4, f"bwd16/{N}x{H}x{W}x{C}")
             del keep
     # the 64 -> 64-channel forward runs on the weight-stationary kernel (conv5.hip) from 512 tiles of 256 pixels up (batch >= 128 at 32 x 32)
-    l1_sym = "conv5_kernel<0, 12>" if B * 32 * 32 >= 512 * 256 else "conv4_kernel<4, 1, 1, 32, 32, 0>"
+    l1_sym = "conv5_kernel<0, 12, 0>" if B * 32 * 32 >= 512 * 256 else "conv4_kernel<4, 1, 1, 32, 32, 0>"
     shapes = ((32, 64, l1_sym), (16, 128, "conv4_kernel<4, 2, 1, 64, 32, 0>")) if r18 else ((8, 64, "conv4_kernel<2, 1, 2, 64, 8, 0>"),)
     for i, (H, C, sym) in enumerate(shapes):
         N, W, K = B, H, C

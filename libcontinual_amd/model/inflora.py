@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from .. import ops
 from .backbone.sinet import Attention_LoRA
 from .finetune import Finetune
+from ..utils import device_svd
 
 
 class InfLoRA(Finetune):
@@ -76,7 +77,7 @@ class InfLoRA(Finetune):
             if self._cur_task > 0:
                 fm = self.feature_mat[kk].to(cur.dtype)
                 cur = cur - fm @ cur if self.project_type[kk] == "remove" else fm @ cur
-            U = torch.linalg.svd(cur, full_matrices=self._cur_task == 0)[0]
+            U = torch.from_numpy(device_svd(cur, full_matrices=self._cur_task == 0)[0]).to(cur.dtype)            # fp64 on the GPU (utils.device_svd)
             A = (U[:, : module.rank].T / math.sqrt(3)).to(module.lora_A_k[self._cur_task].weight)
             module.lora_A_k[self._cur_task].weight.copy_(A)
             module.lora_A_v[self._cur_task].weight.copy_(A)
@@ -100,16 +101,16 @@ class InfLoRA(Finetune):
         first = len(self.feature_list) == 0
         for i, activation in enumerate(np.asarray(m) for m in mat_list):
             if first:
-                U, S, _ = np.linalg.svd(activation, full_matrices=False)
+                U, S, _ = device_svd(activation, full_matrices=False)
                 r = int(np.sum(np.cumsum(S ** 2 / (S ** 2).sum()) < threshold))
                 self.feature_list.append(U[:, : max(r, 1)])
                 self.project_type.append("remove" if r < activation.shape[0] / 2 else "retain")
                 continue
-            total = (np.linalg.svd(activation, compute_uv=False) ** 2).sum()
+            total = (device_svd(activation, compute_uv=False) ** 2).sum()
             f = self.feature_list[i]
             proj = f @ (f.T @ activation)
             if self.project_type[i] == "remove":
-                U, S, _ = np.linalg.svd(activation - proj, full_matrices=False)
+                U, S, _ = device_svd(activation - proj, full_matrices=False)
                 ratio, acc, r = S ** 2 / total, (total - (S ** 2).sum()) / total, 0
                 while r < ratio.shape[0] and acc < threshold:
                     acc += ratio[r]
@@ -118,17 +119,17 @@ class InfLoRA(Finetune):
                     Ui = np.hstack((f, U[:, :r]))
                     self.feature_list[i] = Ui[:, : Ui.shape[0]] if Ui.shape[1] > Ui.shape[0] else Ui
             else:
-                U, S, _ = np.linalg.svd(proj, full_matrices=False)
+                U, S, _ = device_svd(proj, full_matrices=False)
                 ratio, acc, r = S ** 2 / total, (S ** 2).sum() / total, 0
                 while r < ratio.shape[0] and acc >= 1 - threshold:
                     acc -= ratio[r]
                     r += 1
                 if r:
                     rest = f - U[:, :r] @ (U[:, :r].T @ f)
-                    self.feature_list[i] = np.linalg.svd(rest)[0][:, : f.shape[1] - r]
+                    self.feature_list[i] = device_svd(rest, full_matrices=True)[0][:, : f.shape[1] - r]
         for i, f in enumerate(self.feature_list):
             if self.project_type[i] == "remove" and f.shape[1] > f.shape[0] / 2:
-                self.feature_list[i] = np.linalg.svd(f)[0][:, f.shape[1]:]
+                self.feature_list[i] = device_svd(f, full_matrices=True)[0][:, f.shape[1]:]
                 self.project_type[i] = "retain"
             elif self.project_type[i] == "retain":
                 assert f.shape[1] <= f.shape[0] / 2

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils import device_svd
 from .backbone.vit import MultiHeadAttention_LoRA, ViTZoo
 from .heads import HipLinear
 
@@ -110,7 +111,7 @@ class InfLoRA_OPT(nn.Module):
                 assert self.project_type[i] in ("remove", "retain")
                 feature_mat = torch.as_tensor(self.feature_list[i] @ self.feature_list[i].T, dtype=cur_matrix.dtype)
                 cur_matrix = cur_matrix - feature_mat @ cur_matrix if self.project_type[i] == "remove" else feature_mat @ cur_matrix
-            U, _, _ = torch.linalg.svd(cur_matrix, full_matrices=False)
+            U = torch.from_numpy(device_svd(cur_matrix, full_matrices=False)[0]).to(cur_matrix.dtype)      # fp64 on the GPU (utils.device_svd)
             A = (U[:, : module.lora_rank].T / math.sqrt(3)).to(module.lora_A_k.weight)
             module.lora_A_k.weight.copy_(A)          # in-place on the Parameter (not .data): bumps its version, which the
             module.lora_A_v.weight.copy_(A)          # executor watches to refresh its [A_k; A_v] copy
@@ -130,18 +131,18 @@ class InfLoRA_OPT(nn.Module):
         for i, module in enumerate(self.attention_modules):
             activation = module.cur_matrix.numpy().astype(np.float64)
             if task_idx == 0:
-                U, S, _ = np.linalg.svd(activation, full_matrices=False)
+                U, S, _ = device_svd(activation, full_matrices=False)
                 ratio = (S ** 2) / (S ** 2).sum()
                 r = max(np.sum(np.cumsum(ratio) < threshold), 1)
                 assert r < activation.shape[0] / 2
                 self.feature_list.append(U[:, :r])
                 self.project_type.append("remove")
             else:
-                _, S, _ = np.linalg.svd(activation, full_matrices=False)
+                _, S, _ = device_svd(activation, full_matrices=False)
                 total = (S ** 2).sum()
                 fm = self.feature_list[i] @ self.feature_list[i].T
                 if self.project_type[i] == "remove":
-                    U, S, _ = np.linalg.svd(activation - fm @ activation, full_matrices=False)
+                    U, S, _ = device_svd(activation - fm @ activation, full_matrices=False)
                     ratio = (S ** 2) / total
                     acc = (total - (S ** 2).sum()) / total
                     if acc < threshold:
@@ -149,19 +150,19 @@ class InfLoRA_OPT(nn.Module):
                         Ui = np.hstack((self.feature_list[i], U[:, :r]))
                         self.feature_list[i] = Ui[:, : min(Ui.shape[0], Ui.shape[1])]
                 else:
-                    U, S, _ = np.linalg.svd(fm @ activation, full_matrices=False)
+                    U, S, _ = device_svd(fm @ activation, full_matrices=False)
                     ratio = (S ** 2) / total
                     acc = (S ** 2).sum() / total
                     if acc >= 1 - threshold:
                         r = np.sum(acc - np.cumsum(ratio) >= 1 - threshold) + 1
                         af = self.feature_list[i] - U[:, :r] @ U[:, :r].T @ self.feature_list[i]
-                        U, _, _ = np.linalg.svd(af)
+                        U, _, _ = device_svd(af, full_matrices=True)
                         self.feature_list[i] = U[:, : self.feature_list[i].shape[1] - r]
             module.reset_input_matrix()
         for i in range(len(self.feature_list)):
             f = self.feature_list[i]
             if self.project_type[i] == "remove" and f.shape[1] > f.shape[0] / 2:
-                U, _, _ = np.linalg.svd(f)
+                U, _, _ = device_svd(f, full_matrices=True)
                 self.feature_list[i] = U[:, f.shape[1]:]
                 self.project_type[i] = "retain"
             elif self.project_type[i] == "retain":

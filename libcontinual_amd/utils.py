@@ -115,3 +115,25 @@ def compute_frgt(acc_table, curr_acc, task_idx):
     if task_idx > 1:
         return sum(np.diag(acc_table)[: task_idx - 1] - np.asarray(curr_acc)[: task_idx + 1][:-2]) / task_idx
     return 0.0
+
+
+# ------------------------------------------------------------------------------------------------ per-task SVDs (InfLoRA / DualGPM)
+def device_svd(a, full_matrices=False, compute_uv=True, device=None):
+    """numpy.linalg.svd semantics (float64 in, float64 out) with the factorisation done ON THE GPU in fp64 through torch.linalg
+    (rocSOLVER) when one is there -- SURVEY.md section 8(f) rank 3 ("768 x 768 SVD (rocSOLVER)").  This is per-task host math of the reference
+    (core/model/InfLoRA_opt.py:251-369, InfLoRA.py:108-308), not the training step: measured on the MI355X box a 768 x 768 factorisation takes 138 ms
+    on the device in fp64 (reconstruction error 1.7e-13) against 0.5 s in numpy (fp64) and 1.2-10 s in torch's CPU fp32 driver (the reference's
+    `torch.linalg.svd(cur_matrix)`, 128 host threads; error 1.7e-6) -- before_task of a 2 400-image ImageNet-R task 15.3 s -> 2 s
+    (profiles/r04_inflora_task_boundary.md).  CLHIP_SVD=host keeps numpy.  `a`: numpy array or CPU / device tensor."""
+    import numpy as np
+    import torch
+    arr = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    use_dev = os.environ.get("CLHIP_SVD", "device") != "host" and torch.cuda.is_available()
+    if not use_dev:
+        return np.linalg.svd(arr.astype(np.float64), full_matrices=full_matrices, compute_uv=compute_uv)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    t = torch.as_tensor(arr, dtype=torch.float64).to(dev)
+    if not compute_uv:
+        return torch.linalg.svdvals(t).cpu().numpy()
+    U, S, Vh = torch.linalg.svd(t, full_matrices=full_matrices)
+    return U.cpu().numpy(), S.cpu().numpy(), Vh.cpu().numpy()

@@ -98,6 +98,6 @@ if __name__ == "__main__":
         stats[w] = kernel_stats(w)
         json.dump(stats, open(pj, "w"), indent=1)
         print(w, "kernel stats done", flush=True)
-    if not any("vitb16" in w for w in wl[:1]):
+    if not any(("vitb16" in w or w in ("ewc_fisher_pass", "herding_b50")) for w in wl[:1]):
         json.dump(pmc(wl[0]), open(os.path.join(OUT, "roofline_pmc.json"), "w"), indent=1)
         print("pmc done")

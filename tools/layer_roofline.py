@@ -166,3 +166,34 @@ for tag, rows in (("InfLoRA_OPT b128", 128 * 197), ("L2P b16", 16 * 222)):
     gemm_row("d fc1", rows, 768, 3072, 0)
     gemm_row("d proj", rows, 768, 768, 0)
     gemm_row("d qkv", rows, 768, 2304, 0)
+
+
+def attn_rows(tag, B, N):
+    """softmax(q k^T / 8) v and its backward on the packed qkv (attn.hip).  Algorithmic bytes: qkv read once + the output written (forward);
+    qkv, out, d out read + d qkv written (backward).  AI = 99 / 125 FLOP per byte at 197 tokens: HBM-bound, not MFMA-bound."""
+    H, D = 12, 768
+    M = B * N
+    qkv = torch.randn(M, 3 * D, device=dev).to(tdt)
+    out = torch.empty(M, D, device=dev, dtype=tdt)
+    lse = torch.empty(B * H * N, device=dev)
+    dout = torch.randn(M, D, device=dev).to(tdt)
+    dqkv = torch.empty(M, 3 * D, device=dev, dtype=tdt)
+    dsum = torch.empty(B * H * N, device=dev)
+    us = timed(lambda: _lib.call("clhip_attn_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, D, code, st))
+    row(f"{tag} attention forward, {B} x {H} heads x {N} tokens", us, 4.0 * B * H * N * N * 64, (M * 3 * D + M * D) * 2)
+    us = timed(lambda: _lib.call("clhip_attn_bwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dsum.data_ptr(), B, N, H, D, code, st))
+    row(f"{tag} attention backward", us, 10.0 * B * H * N * N * 64, (M * 3 * D * 2 + M * D * 2) * 2)
+
+
+def gram_row(tag, B, N):
+    M, D, Lr = B * N, 768, 12
+    h = torch.randn(Lr, M, D, device=dev).to(tdt)
+    G = torch.zeros(Lr, D, D, device=dev)
+    us = timed(lambda: _lib.call("clhip_gram_accum_batched", h.data_ptr(), M * D, Lr, G.data_ptr(), M, D, code, st))
+    row(f"{tag} Gram X^T X of the 12 attention inputs, one launch", us, Lr * 2.0 * M * D * D, Lr * (M * D * 2 + 2 * D * D * 4))
+
+
+print("\n## ViT-B/16 attention and the InfLoRA Gram launch, bf16\n\n" + HEAD)
+attn_rows("InfLoRA_OPT b128", 128, 197)
+attn_rows("L2P b16", 16, 222)
+gram_row("InfLoRA_OPT b128", 128, 197)
