@@ -110,6 +110,10 @@ int clhip_bn_eval_affine(const float* gamma, const float* beta, const float* run
                          float eps, int C, float* scale, float* shift, void* stream);
 int clhip_bn_apply(const void* z, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C,
                    int relu, int dtype, void* stream);
+/* eval-mode BatchNorm (running statistics) [+ residual] [+ ReLU] in ONE launch: clhip_bn_eval_affine + clhip_bn_apply with the per-channel
+ * scale / shift derived per workgroup (same expressions, same values).  nn.BatchNorm2d.eval() of the reference backbones (resnet.py:296-316). */
+int clhip_bn_apply_eval(const void* z, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                        const void* res /*nullable*/, void* y, int64_t M, int C, int relu, int dtype, void* stream);
 /* training-mode BatchNorm straight from the fp64 sums of clhip_conv_fwd_acc: y = relu?(bn(z) + res?), batch mean / invstd saved
  * for the backward, running statistics updated (momentum, unbiased variance) -- bn_stats_finalize + bn_apply in ONE launch.
  * C must be a power of two. */

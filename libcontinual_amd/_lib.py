@@ -91,6 +91,7 @@ _PROTOS = {
     "clhip_bn_stats_finalize": (_i, [_p, _i, _l, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "clhip_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "clhip_bn_apply": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),
+    "clhip_bn_apply_eval": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _i, _p]),
     "clhip_bn_bwd_blocks": (_i, [_l, _i]),
     "clhip_bn_bwd_ws_floats": (_sz, [_l, _i]),
     "clhip_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),

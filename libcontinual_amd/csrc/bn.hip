@@ -82,6 +82,38 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, 
     }
 }
 
+// the eval-mode form in ONE launch (round 4): scale / shift of the running statistics are derived per workgroup into LDS -- bn_eval_affine_kernel's
+// expressions, so the values equal the two-launch form bit for bit -- and applied; an eval forward of CifarResNet-32 was 33 affine launches of
+// 4.7 us (25 % of its kernel time, profiles/r04_bench_kernel_stats_herding_b50.txt) in front of 33 apply launches
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_eval_kernel(const T* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ rm, const float* __restrict__ rv, float eps, const T* __restrict__ res,
+                                                            T* __restrict__ y, int64_t nchunks, int C) {
+    extern __shared__ __attribute__((aligned(16))) float ecoefs[];      // [2][C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float istd = 1.f / sqrtf(rv[c] + eps);
+        const float sc = gamma[c] * istd;
+        ecoefs[c] = sc;
+        ecoefs[C + c] = beta[c] - rm[c] * sc;
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        const int c0 = (int)((i * 8) % C);
+        float v[8], r[8];
+        load8<T>(z + i * 8, v);
+        if (RES) load8<T>(res + i * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = fmaf(v[e], ecoefs[c0 + e], ecoefs[C + c0 + e]);
+            if (RES) o += r[e];
+            if (RELU) o = fmaxf(o, 0.f);
+            v[e] = o;
+        }
+        store8<T>(y + i * 8, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------- backward
 // pass 1: per-channel partial sums of g = dy*mask and g*xhat over a slab of rows.
 // thread layout: cpr = C/8 chunk columns per row, rpi = 256/cpr rows per iteration.
@@ -698,6 +730,30 @@ extern "C" int clhip_bn_apply(const void* z, const float* scale, const float* sh
     CLHIP_CHECK_ARG(z && scale && shift && y && M > 0 && C >= 8 && C % 8 == 0);
     if (dtype == CLHIP_BF16) return bn_apply_t<bf16_t>(z, scale, shift, res, y, M, C, relu, (hipStream_t)stream);
     if (dtype == CLHIP_F32) return bn_apply_t<float>(z, scale, shift, res, y, M, C, relu, (hipStream_t)stream);
+    CLHIP_CHECK_ARG(!"dtype");
+    return CLHIP_EINVAL;
+}
+
+template <typename T>
+static int bn_apply_eval_t(const void* z, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, const void* res, void* y, int64_t M, int C,
+                           int relu, hipStream_t st) {
+    const int64_t nch = M * C / 8;
+    dim3 g(ew_blocks(nch)), b(256);
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    const T* zz = (const T*)z; const T* rr = (const T*)res; T* yy = (T*)y;
+    if (res && relu) hipLaunchKernelGGL((bn_apply_eval_kernel<T, true, true>), g, b, lds, st, zz, gamma, beta, rm, rv, eps, rr, yy, nch, C);
+    else if (res) hipLaunchKernelGGL((bn_apply_eval_kernel<T, true, false>), g, b, lds, st, zz, gamma, beta, rm, rv, eps, rr, yy, nch, C);
+    else if (relu) hipLaunchKernelGGL((bn_apply_eval_kernel<T, false, true>), g, b, lds, st, zz, gamma, beta, rm, rv, eps, rr, yy, nch, C);
+    else hipLaunchKernelGGL((bn_apply_eval_kernel<T, false, false>), g, b, lds, st, zz, gamma, beta, rm, rv, eps, rr, yy, nch, C);
+    CLHIP_LAUNCH_CHECK();
+    return CLHIP_OK;
+}
+
+extern "C" int clhip_bn_apply_eval(const void* z, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                   const void* res, void* y, int64_t M, int C, int relu, int dtype, void* stream) {
+    CLHIP_CHECK_ARG(z && gamma && beta && running_mean && running_var && y && M > 0 && C >= 8 && C % 8 == 0 && C <= 8192);
+    if (dtype == CLHIP_BF16) return bn_apply_eval_t<bf16_t>(z, gamma, beta, running_mean, running_var, eps, res, y, M, C, relu, (hipStream_t)stream);
+    if (dtype == CLHIP_F32) return bn_apply_eval_t<float>(z, gamma, beta, running_mean, running_var, eps, res, y, M, C, relu, (hipStream_t)stream);
     CLHIP_CHECK_ARG(!"dtype");
     return CLHIP_EINVAL;
 }

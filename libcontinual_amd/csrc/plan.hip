@@ -723,9 +723,8 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                                          bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean, fr + u.f_invstd, nullptr,
                                          ws + dst.y_off, u.relu, p->dtype, stream));
             } else {
-                TRY(clhip_bn_eval_affine(params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnEps, u.d.cout,
-                                         fr + u.f_scale, fr + u.f_shift, stream));
-                TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, nullptr, ws + dst.y_off, u.M, u.d.cout, u.relu, p->dtype, stream));
+                TRY(clhip_bn_apply_eval(ws + u.z_off, params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnEps, nullptr,
+                                        ws + dst.y_off, u.M, u.d.cout, u.relu, p->dtype, stream));
             }
             continue;
         }
@@ -812,11 +811,14 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
             TRY(clhip_bn_stats_finalize(part, u.tiles, u.M, u.d.cout, params + u.d.gamma_off, params + u.d.beta_off,
                                         bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnMomentum, kBnEps, fr + u.f_mean,
                                         fr + u.f_invstd, fr + u.f_scale, fr + u.f_shift, stream));
-        } else {
-            TRY(clhip_bn_eval_affine(params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off,
-                                     kBnEps, u.d.cout, fr + u.f_scale, fr + u.f_shift, stream));
         }
         const void* res = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
+        if (!training) {
+            // eval mode: scale / shift of the running statistics are derived inside the apply launch (one launch per unit instead of two)
+            TRY(clhip_bn_apply_eval(ws + u.z_off, params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnEps, res, ws + dst.y_off,
+                                    u.M, u.d.cout, u.relu, p->dtype, stream));
+            continue;
+        }
         TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, res, ws + dst.y_off, u.M, u.d.cout, u.relu, p->dtype, stream));
     }
     const Act& last = p->acts.back();

@@ -1412,3 +1412,30 @@ def test_sgd_step_over_several_tensors_in_one_launch(momentum):
     for a, b, c, d in zip(p1, p2, m1, m2):
         assert torch.equal(a, b) and torch.equal(c, d)
     assert not torch.equal(p1[0], ps[0])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("M_,Cc,with_res,relu", [(4096, 64, True, 1), (1000, 16, False, 1), (777, 512, False, 0), (256 * 64, 256, True, 1)])
+def test_batchnorm_eval_apply_in_one_launch(dt, M_, Cc, with_res, relu):
+    """clhip_bn_apply_eval = clhip_bn_eval_affine + clhip_bn_apply, bit for bit (the eval-mode forward of the reference backbones,
+    resnet.py:296-316 under .eval()): one launch per unit instead of two"""
+    code, tdt = DT[dt]
+    z = (rnd((M_, Cc), 201) * 1.5).to(tdt).to(DEV)
+    r = (rnd((M_, Cc), 202)).to(tdt).to(DEV) if with_res else None
+    gamma, beta = (rnd((Cc,), 203) * 0.2 + 1.0).to(DEV), (rnd((Cc,), 204) * 0.3).to(DEV)
+    rm, rv = (rnd((Cc,), 205) * 0.1).to(DEV), (rnd((Cc,), 206).abs() + 0.5).to(DEV)
+    sc, sh = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    y0 = torch.full((M_ + 1, Cc), 3.0, dtype=tdt, device=DEV)
+    y1 = torch.full((M_ + 1, Cc), 3.0, dtype=tdt, device=DEV)
+    call("clhip_bn_eval_affine", gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 1e-5, Cc, sc.data_ptr(), sh.data_ptr(), st())
+    call("clhip_bn_apply", z.data_ptr(), sc.data_ptr(), sh.data_ptr(), r.data_ptr() if with_res else None, y0.data_ptr(), M_, Cc, relu, code, st())
+    call("clhip_bn_apply_eval", z.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 1e-5, r.data_ptr() if with_res else None, y1.data_ptr(),
+         M_, Cc, relu, code, st())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and float((y1[M_].float() - 3.0).abs().max()) == 0.0
+    want = z.double() * (gamma.double() / (rv.double() + 1e-5).sqrt()) + (beta.double() - rm.double() * gamma.double() / (rv.double() + 1e-5).sqrt())
+    if with_res:
+        want = want + r.double()
+    if relu:
+        want = want.clamp(min=0)
+    assert float((y1[:M_].double() - want).abs().max()) <= (2e-2 if dt == "bf16" else 1e-4) * float(want.abs().max())

@@ -93,7 +93,9 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     wl = sys.argv[1:] or ["lwf_resnet18_b50_task0"]
     pj = os.path.join(OUT, "bench_kernel_stats.json")
-    stats = json.load(open(pj)) if os.path.exists(pj) else {}
+    # (the GPU box starts with an empty gpurun_out/: begin from the committed table so that a partial re-run keeps the other workloads)
+    committed = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.json")
+    stats = json.load(open(pj)) if os.path.exists(pj) else (json.load(open(committed)) if os.path.exists(committed) else {})
     for w in wl:
         stats[w] = kernel_stats(w)
         json.dump(stats, open(pj, "w"), indent=1)
