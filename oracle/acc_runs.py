@@ -14,8 +14,15 @@ import time
 import numpy as np
 
 
+def _cache_path(cache, name, perturb):
+    return os.path.join(cache, f"{name}_run{perturb:03d}.npz")
+
+
 def _one(job):
-    name, perturb, threads = job
+    name, perturb, threads, cache = job
+    if cache and os.path.exists(_cache_path(cache, name, perturb)):          # an interrupted batch of runs resumes where it stopped
+        d = np.load(_cache_path(cache, name, perturb), allow_pickle=False)
+        return name, perturb, {k: d[k] for k in d.files}
     import torch
     torch.set_num_threads(threads)
     from . import fixtures, gen_golden, trainer_scenarios as ts
@@ -23,6 +30,11 @@ def _one(job):
     with fixtures.use_dtype(torch.float32):
         out = ts.run_reference(name, gen_golden.reference_namespace(), ts.common_of(name), perturb=perturb)
     out["seconds"] = np.asarray([time.time() - t0])
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        tmp = _cache_path(cache, name, perturb) + ".tmp.npz"
+        np.savez_compressed(tmp, **{k: np.asarray(v) for k, v in out.items()})
+        os.replace(tmp, _cache_path(cache, name, perturb))
     return name, perturb, out
 
 
@@ -33,9 +45,10 @@ def main():
     ap.add_argument("--procs", type=int, default=4)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--explore", action="store_true")
+    ap.add_argument("--cache", default=None, help="directory of per-run results: finished runs are re-used, so an interrupted batch resumes")
     a = ap.parse_args()
     import multiprocessing as mp
-    jobs = [(n, k, a.threads) for n in a.names for k in range(a.runs)]
+    jobs = [(n, k, a.threads, a.cache) for n in a.names for k in range(a.runs)]
     res = {n: {} for n in a.names}
     with mp.get_context("spawn").Pool(a.procs) as pool:
         for name, k, out in pool.imap_unordered(_one, jobs):

@@ -2,7 +2,8 @@
 imported reference classes on the same step, same threads -- SURVEY.md section 8(d): "the restatement is additionally timed side-by-side with
 the imported reference classes to show they cost the same".  LwF task-0 step (forward + CE + backward + SGD), fp32, torch CPU.
 
-    python tools/cpu_restatement_vs_reference.py [batch=64] [steps=4] > profiles/r04_cpu_restatement_vs_reference.md
+    python -m oracle.cpu_vs_reference [batch=64] [steps=4] > profiles/r04_cpu_restatement_vs_reference.md
+(TEST INFRASTRUCTURE: lives under oracle/ like acc_runs.py; nothing of the product imports it)
 """
 import os
 import sys

@@ -133,6 +133,50 @@ def test_backbone_vs_oracle_random_init(arch, dtype):
     assert [tuple(t.shape[1:]) for t in fm][-1] == (nets.arch(arch)[1], 32 // 2 ** (len(fm) - 1), 32 // 2 ** (len(fm) - 1))
 
 
+@pytest.mark.parametrize("arch", ["cifar_resnet32", "resnet18"])
+def test_bf16_gradient_sits_at_the_storage_format_floor(arch):
+    """the bf16 mode's parameter gradient is 1.3 x the operand-rounding yardstick away from the fp64 oracle -- is the extra
+    third a kernel defect or the price of the format?  `oracle/bf16_floor_study.py` evaluates the fp64 oracle with every tensor the HIP path
+    STORES in bf16 rounded at its storage site (conv outputs z, activations y, their gradients; arithmetic fp64): that format floor is 1.30 x
+    the yardstick on CifarResNet-32 (0.528 vs 0.406; the forward tensors z and y account for all of it, rounding dy / dz adds nothing --
+    profiles/r04_bf16_floor_study.md).  The product must sit AT that floor: whole-gradient deviation <= 1.06 x the floor's (1.01 observed),
+    per-layer median <= 1.1 x, and it must be closer to the format-faithful oracle than to the unrounded one."""
+    from oracle import bf16_floor_study as fs
+    B = 64
+    g = torch.Generator().manual_seed(3)
+    P = nets.init_params(arch, g)
+    Bf = nets.init_buffers(arch)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    cw = torch.randn(B, nets.arch(arch)[1], generator=g).double()
+
+    def oracle(sites, round_operands):
+        Pg_ = {k: ((fs.rb(v.double()) if (round_operands and v.dim() == 4) else v.double()).clone().requires_grad_(True)) for k, v in P.items()}
+        xin = fs.rb(x.double()) if round_operands else x.double()
+        Bo_ = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in Bf.items()}
+        f_ = fs.forward(arch, Pg_, Bo_, xin, sites)
+        (f_ * cw).sum().backward()
+        return {k: v.grad.reshape(-1) for k, v in Pg_.items() if v.grad is not None}
+    ref = oracle((), False)
+    floor = oracle(("z", "y", "dy", "dz"), True)
+    bb = adapter("bf16").backbone(arch, P, Bf)
+    bb.train()
+    f = bb(x.to(DEV))["features"]
+    (f * cw.float().to(DEV)).sum().backward()
+    got = {n: p.grad.cpu().double().reshape(-1) for n, p in bb.named_parameters() if p.grad is not None}
+    names = sorted(got)
+    cat = lambda d: torch.cat([d[k] for k in names])       # noqa: E731
+    w_prod, w_floor = relnorm(cat(got), cat(ref)), relnorm(cat(floor), cat(ref))
+    to_floor = relnorm(cat(got), cat(floor))
+    med_prod = float(np.median([relnorm(got[k], ref[k]) for k in names]))
+    med_floor = float(np.median([relnorm(floor[k], ref[k]) for k in names]))
+    cos = float(torch.dot(cat(got), cat(floor)) / (cat(got).norm() * cat(floor).norm()))
+    print(f"{arch}: product vs fp64 oracle {w_prod:.3f}, format floor vs fp64 oracle {w_floor:.3f} (ratio {w_prod / w_floor:.3f}); per-layer median {med_prod:.3f} / {med_floor:.3f}; "
+          f"product vs the format-faithful oracle {to_floor:.3f} (cosine {cos:.4f})")
+    assert w_prod <= 1.06 * w_floor, (w_prod, w_floor)
+    assert med_prod <= 1.1 * med_floor, (med_prod, med_floor)
+    assert to_floor < w_prod, (to_floor, w_prod)
+
+
 @pytest.mark.parametrize("size", [64, 32])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_preactivation_backbone_vs_oracle_random_init(dtype, size):
