@@ -393,6 +393,78 @@ __global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict
         if (lane == 0) out[(size_t)row * O + o] = s / (xn[row] * wn[o]);
     }
 }
+// round 4: the whole forward in ONE launch for the head sizes of the in-scope nets (the weight matrix fits LDS): a block owns eight rows of x, keeps
+// w [O, D] and its rows in LDS (pitch D + 1: conflict-free for consecutive outputs), derives both sets of norms itself (block 0 stores wnorm) and
+// writes the cosines -- the three launches it replaces cost 5 + 5 + 30 us at 256 x 64 -> 55 (55 dependent wave reductions per row)
+constexpr int kCosRows = 8;
+__global__ __launch_bounds__(256) void cosine_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ xn_o, float* __restrict__ wn_o,
+                                                               float* __restrict__ out, int B, int D, int O) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];
+    const int P = D + 1;
+    float* ws = cs;                       // [O][P]
+    float* xs = ws + (size_t)O * P;       // [kCosRows][P]
+    float* wn = xs + kCosRows * P;        // [O]
+    float* xn = wn + O;                   // [kCosRows]
+    const int tid = threadIdx.x, r0 = blockIdx.x * kCosRows;
+    for (int e = tid; e < O * D; e += 256) { const int o = e / D, d = e - o * D; ws[o * P + d] = w[e]; }
+    for (int e = tid; e < kCosRows * D; e += 256) { const int r = e / D, d = e - r * D; xs[r * P + d] = (r0 + r) < B ? x[(size_t)(r0 + r) * D + d] : 0.f; }
+    __syncthreads();
+    for (int i = tid; i < O + kCosRows; i += 256) {
+        const float* v = i < O ? ws + (size_t)i * P : xs + (i - O) * P;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s = fmaf(v[d], v[d], s);
+        const float n = fmaxf(sqrtf(s), 1e-12f);                 // F.normalize eps
+        if (i < O) { wn[i] = n; if (blockIdx.x == 0) wn_o[i] = n; }
+        else { xn[i - O] = n; if (r0 + i - O < B) xn_o[r0 + i - O] = n; }
+    }
+    __syncthreads();
+    for (int i = tid; i < kCosRows * O; i += 256) {
+        const int r = i / O, o = i - r * O;
+        if (r0 + r >= B) continue;
+        const float* a = xs + r * P;
+        const float* b = ws + (size_t)o * P;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s = fmaf(a[d], b[d], s);
+        out[(size_t)(r0 + r) * O + o] = s / (xn[r] * wn[o]);
+    }
+}
+
+// dw[o][d] (+)= (1 / wn[o]) sum_b dout[b,o] (x[b,d] / xn[b] - out[b,o] wh[o,d]): one block per output row o, the batch split over four thread groups
+// whose partial sums are added in group order (fixed order: reproducible); the one-thread-per-element form walked the batch as 256 dependent loads
+// per thread on 14 workgroups (76 us at 256 x 64 -> 55)
+__global__ __launch_bounds__(256) void cosine_bwd_dw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ out,
+                                                                 const float* __restrict__ xn, const float* __restrict__ wn, const float* __restrict__ dout,
+                                                                 float* __restrict__ dw, int B, int D, int O, int acc) {
+    __shared__ float part[4][64];
+    const int o = blockIdx.x, dl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const float wno = wn[o];
+    const int per = (B + 3) / 4, b0 = grp * per, b1 = min(B, b0 + per);
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + dl;
+        const float wh = d < D ? w[(size_t)o * D + d] / wno : 0.f;
+        float s = 0.f;
+        if (d < D) {
+            int b = b0;
+            for (; b + 4 <= b1; b += 4) {
+                float g[4], xv[4], ov[4], nv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { g[u] = dout[(size_t)(b + u) * O + o]; xv[u] = x[(size_t)(b + u) * D + d]; ov[u] = out[(size_t)(b + u) * O + o]; nv[u] = xn[b + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += g[u] * (xv[u] / nv[u] - ov[u] * wh);
+            }
+            for (; b < b1; ++b) s += dout[(size_t)b * O + o] * (x[(size_t)b * D + d] / xn[b] - out[(size_t)b * O + o] * wh);
+        }
+        part[grp][dl] = s;
+        __syncthreads();
+        if (grp == 0 && d < D) {
+            const float t = (((part[0][dl] + part[1][dl]) + part[2][dl]) + part[3][dl]) / wno;
+            const size_t idx = (size_t)o * D + d;
+            dw[idx] = acc ? dw[idx] + t : t;
+        }
+        __syncthreads();
+    }
+}
+
 // dx[b][d] = sum_o dout[b,o] * (wh[o][d] - s[b,o]*xh[b][d]) / xn[b]
 __global__ void cosine_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ out,
                                      const float* __restrict__ xn, const float* __restrict__ wn, const float* __restrict__ dout,
@@ -408,21 +480,6 @@ __global__ void cosine_bwd_dx_kernel(const float* __restrict__ x, const float* _
     }
     s /= xn[b];
     dx[idx] = acc ? dx[idx] + s : s;
-}
-__global__ void cosine_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ out,
-                                     const float* __restrict__ xn, const float* __restrict__ wn, const float* __restrict__ dout,
-                                     float* __restrict__ dw, int B, int D, int O, int acc) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * D) return;
-    int o = idx / D, d = idx - o * D;
-    float wh = w[idx] / wn[o];
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float g = dout[(size_t)b * O + o];
-        s += g * (x[(size_t)b * D + d] / xn[b] - out[(size_t)b * O + o] * wh);
-    }
-    s /= wn[o];
-    dw[idx] = acc ? dw[idx] + s : s;
 }
 
 // nn.CosineEmbeddingLoss(target=1): mean_b (1 - cos(a_b, b_b)), cos = a.b / sqrt((|a|^2+eps)(|b|^2+eps)), eps=1e-8
@@ -724,6 +781,12 @@ extern "C" int clhip_kd_loss(const float* pred, int pred_stride, const float* so
 extern "C" int clhip_cosine_linear_fwd(const float* x, const float* w, float* out, float* xnorm, float* wnorm, int B, int D, int O,
                                        void* stream) {
     CLHIP_CHECK_ARG(x && w && out && xnorm && wnorm && B > 0 && D > 0 && O > 0);
+    const size_t lds = ((size_t)(O + kCosRows) * (D + 1) + O + kCosRows) * sizeof(float);
+    if (lds <= 60 * 1024) {           // every in-scope head (64 x 100, 512 x 100 needs 224 KB: the three-launch form below)
+        hipLaunchKernelGGL(cosine_fwd_fused_kernel, dim3((B + kCosRows - 1) / kCosRows), dim3(256), lds, ST, x, w, xnorm, wnorm, out, B, D, O);
+        CLHIP_LAUNCH_CHECK();
+        return CLHIP_OK;
+    }
     hipLaunchKernelGGL(row_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, x, xnorm, B, D);
     hipLaunchKernelGGL(row_norm_kernel, dim3((O + 3) / 4), dim3(256), 0, ST, w, wnorm, O, D);
     hipLaunchKernelGGL(cosine_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, x, w, xnorm, wnorm, out, B, D, O);
@@ -735,7 +798,7 @@ extern "C" int clhip_cosine_linear_bwd(const float* x, const float* w, const flo
                                        const float* dout, float* dx, float* dw, int B, int D, int O, int accumulate, void* stream) {
     CLHIP_CHECK_ARG(x && w && out && xnorm && wnorm && dout && B > 0 && D > 0 && O > 0);
     if (dx) hipLaunchKernelGGL(cosine_bwd_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST, x, w, out, xnorm, wnorm, dout, dx, B, D, O, 0);
-    if (dw) hipLaunchKernelGGL(cosine_bwd_dw_kernel, dim3((O * D + 255) / 256), dim3(256), 0, ST, x, w, out, xnorm, wnorm, dout, dw, B, D, O, accumulate);
+    if (dw) hipLaunchKernelGGL(cosine_bwd_dw_rows_kernel, dim3(O), dim3(256), 0, ST, x, w, out, xnorm, wnorm, dout, dw, B, D, O, accumulate);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
