@@ -33,20 +33,27 @@ from test_trainer_trace_gpu import run_product   # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 N_RUNS = 10
+# round 4: the LwF scenario with 40 runs per side (its after-one-increment figure is chaotic in the reference itself: std 4.3
+# points -- ten runs could not tell a -4-point bf16 bias from nothing), and an UNSATURATED rehearsal scenario (acc_icarl11_hard: the reference's own
+# runs sit at 99.3 +- 0.6, not at 99.9) with 24 runs per side.  A scenario runs as many product runs as its fixture holds reference runs, up to this cap.
+RUN_CAP = {"acc_lwf": 40, "acc_icarl11": 10, "acc_icarl11_hard": 24}
 # first optimisation steps of the unperturbed run: these scenarios step at lr 0.05 (the short ones at 0.02), so the chaotic amplification
 # sets in one step earlier -- f32 mode observed 1.5e-7, 1.8e-5, then 9e-4 at the third step
 FIRST_STEPS_ACC = {"f32": (2, 2e-4), "bf16": (2, 3e-2)}
 
 
-@pytest.mark.parametrize("name", ["acc_icarl11", "acc_lwf"])
+@pytest.mark.parametrize("name", ["acc_icarl11", "acc_lwf", "acc_icarl11_hard"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
     path = os.path.join(HERE, "golden", f"trainer_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"no fixture for {name} (python -m oracle.acc_runs {name} in the build container)")
     ref = np.load(path)
     ref_final, ref_overall = ref["runs_final_avg_acc"], ref["runs_overall_avg_acc"]
     assert len(ref_final) >= N_RUNS
+    n_runs = min(len(ref_final), RUN_CAP[name])
     prod_final, prod_overall, prod_task0 = [], [], []
-    for q in range(N_RUNS):
+    for q in range(n_runs):
         got, _ = run_product(name, dtype, str(tmp_path / f"r{q}"), perturb=q)
         if q == 0:
             assert got["trace"].tolist() == ref["trace"].tolist()
@@ -71,16 +78,26 @@ def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
                            product_mean=float(pr.mean()), product_std=float(pr.std(ddof=1)))
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    jp = os.path.join(out, "accuracy_parity_r03.json")
+    jp = os.path.join(out, "accuracy_parity_r04.json")
     prev = json.load(open(jp)) if os.path.exists(jp) else {}
     prev[f"{name}/{dtype}"] = report
     json.dump(prev, open(jp, "w"), indent=1)
     print(json.dumps({k: report[k] for k in ("final_avg_acc", "overall_avg_acc", "task0_avg_acc")}))
-    gated = {"acc_icarl11": ("final_avg_acc", "overall_avg_acc", "task0_avg_acc"), "acc_lwf": ("task0_avg_acc",)}[name]
+    gated = {"acc_icarl11": ("final_avg_acc", "overall_avg_acc", "task0_avg_acc"), "acc_lwf": ("task0_avg_acc",),
+             "acc_icarl11_hard": ("final_avg_acc", "overall_avg_acc", "task0_avg_acc")}[name]
+    se_cap = 0.2 if name == "acc_icarl11_hard" else 0.15                   # (the unsaturated scenario: 24 + 24 runs of a std-0.6 quantity)
     for key in gated:
         r = report[key]
-        assert r["se"] <= 0.15, (key, r)                                   # the runs resolve the band
+        assert r["se"] <= se_cap, (key, r)                                 # the runs resolve the band
         assert abs(r["gap_points"]) <= r["band"] + 1e-9, (key, r)          # BASELINE.json: within +-0.3 points of the CPU reference
+    if name == "acc_lwf":
+        # the after-one-increment figure with 40 + 40 runs: a gate if they resolve it (SE <= 0.5), the measured bias with its interval otherwise
+        r = report["final_avg_acc"]
+        r["ci95_points"] = [r["gap_points"] - 1.96 * r["se"], r["gap_points"] + 1.96 * r["se"]]
+        json.dump(prev, open(jp, "w"), indent=1)
+        print("LwF after one increment, product - reference:", r["gap_points"], "+-", 1.96 * r["se"], f"({n_runs} + {R} runs)")
+        if r["se"] <= 0.5:
+            assert abs(r["gap_points"]) <= 0.3 + 2 * r["se"] + 1e-9, r
     for key in ("final_avg_acc", "overall_avg_acc"):                       # recorded quantities the reference itself cannot pin to 0.3: 3 SE
         r = report[key]
         assert abs(r["gap_points"]) <= 0.3 + 3 * r["se"] + 1e-9, (key, r)
