@@ -369,3 +369,24 @@ def test_a_step_that_cannot_be_captured_falls_back_to_eager_under_the_default_mo
     with pytest.raises(Exception):
         T.train_steps(m, o, _batches(6, 32), None, "EWC", None, "cuda")
     torch.cuda.synchronize()
+
+
+def test_lucir_replays_like_eager(monkeypatch):
+    """LUCIR (cosine head, frozen previous model on a side stream, CE + less-forget + margin ranking: core/model/lucir.py:175-210) declared
+    graph-safe in round 4: eight steps of which six are replays end where eight eager steps end (bit for bit observed; bounded at the run-to-run
+    tolerance of the fp64-atomic BatchNorm sums)"""
+    import bench
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLHIP_CUDA_GRAPH", mode)
+        torch.manual_seed(1993)
+        m, o, arch, teacher, (lo, hi) = bench.build_method("lucir_resnet32_b50_task1", "bf16", torch.device("cuda:0"))
+        m.train()
+        batches = [bench.synthetic_batch(32, lo, hi, 100 + i, "cuda", 32) for i in range(4)]
+        T.train_steps(m, o, (dict(batches[i % 4]) for i in range(8)), None, "LUCIR", None, "cuda")
+        torch.cuda.synchronize()
+        res.append((m.network.backbone.flat_parameters()[0].clone(), m.network.classifier.fc2.weight.detach().clone(), getattr(m, "_graphed_step", None)))
+    (p0, h0, g0), (p1, h1, g1) = res
+    assert g0 is None and g1 is not None and len(g1.graphs) == 1 and not g1.disabled
+    assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max())
+    assert float((h0 - h1).abs().max()) <= 1e-5 * float(h0.abs().max())
