@@ -36,12 +36,17 @@ struct LazyDz {
 template <int C>
 __device__ __forceinline__ void lazy_dz_coefs(const LazyDz& lz, bool first, float* coef) {
     __shared__ double sred[256];
-    replica_parts(lz.sums, lz.rep, C, sred);
     const int c = threadIdx.x;
+    // the per-channel parameters are fetched BEFORE the replica sum: its barrier would otherwise put a second memory round trip on the launch's critical path
+    float db_old = 0.f, dg_old = 0.f, m = 0.f, is_c = 0.f, ga_c = 0.f, be_c = 0.f;
     if (c < C) {
-        const float db_old = first ? lz.dbeta[c] : 0.f, dg_old = first ? lz.dgamma[c] : 0.f;
-        const float m = lz.mean[c], is_c = lz.invstd[c], gi_c = lz.gamma[c] * is_c;
-        const float sh_c = lz.beta[c] - m * gi_c;
+        if (first) { db_old = lz.dbeta[c]; dg_old = lz.dgamma[c]; }
+        m = lz.mean[c]; is_c = lz.invstd[c]; ga_c = lz.gamma[c]; be_c = lz.beta[c];
+    }
+    replica_parts(lz.sums, lz.rep, C, sred);
+    if (c < C) {
+        const float gi_c = ga_c * is_c;
+        const float sh_c = be_c - m * gi_c;
         double s1 = 0.0, s2 = 0.0;
         for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; }
         coef[c] = (float)(s1 * lz.invM);
@@ -148,20 +153,24 @@ struct Conv3Params {
 template <int C>
 __device__ __forceinline__ void lazy_input_coefs(const Conv3Params& p, int bx, float* coef) {
     __shared__ double sred[256];
-    replica_parts(p.in_acc, p.in_rep, C, sred);
     const int c = threadIdx.x;
+    const bool first = bx == 0;
+    const bool upd = first && p.in_rm != nullptr;
+    float rm_old = 0.f, rv_old = 0.f, ga_c = 0.f, be_c = 0.f;       // fetched before the replica sum (see lazy_dz_coefs)
     if (c < C) {
-        const bool first = bx == 0;
-        const bool upd = first && p.in_rm != nullptr;
-        const float rm_old = upd ? p.in_rm[c] : 0.f, rv_old = upd ? p.in_rv[c] : 0.f;
+        if (upd) { rm_old = p.in_rm[c]; rv_old = p.in_rv[c]; }
+        ga_c = p.in_gamma[c]; be_c = p.in_beta[c];
+    }
+    replica_parts(p.in_acc, p.in_rep, C, sred);
+    if (c < C) {
         double s1 = 0.0, s2 = 0.0;
         for (int q = 0; q < 256 / (2 * C); ++q) { s1 += sred[q * 2 * C + c]; s2 += sred[q * 2 * C + C + c]; }
         const double mean = s1 * p.in_invM;
         double var = s2 * p.in_invM - mean * mean;
         if (var < 0.0) var = 0.0;
         const float istd = rsqrtf((float)var + p.in_eps);
-        const float sc = p.in_gamma[c] * istd;
-        const float sh = p.in_beta[c] - (float)mean * sc;
+        const float sc = ga_c * istd;
+        const float sh = be_c - (float)mean * sc;
         coef[c] = sc;
         coef[C + c] = sh;
         if (first) {
@@ -682,6 +691,92 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3g_kernel(Conv3Params p) {
     }
 }
 
+// The patch of a register-staged kernel (conv16 / conv32 / conv64): pixels [m0 - halo, m0 + BM + halo) as 16-byte chunks into LDS at pitch PP,
+// plus the zero row.  With a lazy operand (LI: BatchNorm input, LZ: BatchNorm-backward gradient) the RAW chunks of the first PF rounds are
+// fetched BEFORE the coefficient prologue: that prologue is a memory round trip of its own (the fp64 replicas) behind two barriers, and with
+// the loads after it a launch at its latency floor paid launch -> replicas -> patch -> MFMA in series (batch 32: 6.7-10.6 us per launch for
+// 0.3 us of MFMAs).  Same arithmetic, same stores: bit-identical results.
+struct RawChunk { uint4 a, b; unsigned m; };
+template <int MODE, bool LZ, int LI, int C, int PP, int BM, int PF>
+__device__ __forceinline__ void stage_patch(const Conv3Params& p, const int bx, const int m0, const int halo, char* smem) {
+    constexpr int CPP = C / 8, LOG = CPP == 2 ? 1 : (CPP == 4 ? 2 : 3);
+    constexpr bool lazy = MODE == 0 && LI != 0;
+    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out
+    constexpr bool lzd = MODE == 1 && LZ;                    // (template parameters: as run-time tests the tables' registers and the branches slowed EVERY launch)
+    const int tid = threadIdx.x;
+    const int nchunks = p.np * CPP;
+    const int ch = tid & (CPP - 1);                          // chunk idx = tid + 256 * round: the same 8 channels in every round
+    auto fetch = [&](int idx, RawChunk& rc) {
+        rc.a = make_uint4(0, 0, 0, 0); rc.b = rc.a; rc.m = 0u;
+        const int q = idx >> LOG;
+        const long long g = (long long)m0 - halo + q;
+        if (idx < nchunks && g >= 0 && g < p.M) {
+            const size_t at = (size_t)g * C + ch * 8;
+            if constexpr (lzd) {
+                rc.a = *reinterpret_cast<const uint4*>(p.lz.dy + at);
+                rc.b = *reinterpret_cast<const uint4*>(p.lz.z + at);
+                if (p.lz.mask != nullptr) rc.m = p.lz.mask[(size_t)g * CPP + ch];
+            } else {
+                rc.a = *reinterpret_cast<const uint4*>(p.src + at);
+                if constexpr (lres) rc.b = *reinterpret_cast<const uint4*>(p.in_res + at);
+            }
+        }
+    };
+    RawChunk raw[PF];
+    if constexpr (lazy || lzd) {
+#pragma unroll
+        for (int it = 0; it < PF; ++it) fetch(tid + it * 256, raw[it]);
+    }
+    float isc[8], ish[8];
+    LazyDz8 lt;
+    float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
+    if constexpr (lazy) {
+        lazy_input_coefs<C>(p, bx, coef);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { isc[e] = coef[ch * 8 + e]; ish[e] = coef[C + ch * 8 + e]; }
+    }
+    if constexpr (lzd) {                                     // the gradient operand = this layer's BatchNorm backward, from dy and z
+        lazy_dz_coefs<C>(p.lz, bx == 0, coef);
+        lazy_dz_load<C>(coef, ch * 8, lt);
+    }
+    auto stage = [&](int idx, const RawChunk& rc) {
+        const int q = idx >> LOG;
+        const long long g = (long long)m0 - halo + q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g < p.M) {
+            const size_t at = (size_t)g * C + ch * 8;
+            if constexpr (lzd) {
+                float gg[8];
+                v = lazy_dz8(rc.a, rc.b, lt, p.lz.mask != nullptr, rc.m, gg);
+                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + at, gg, p.lz.dres_acc);
+            } else if constexpr (lres) {
+                unsigned mb;
+                v = bn_res_relu8_bf16(rc.a, rc.b, isc, ish, mb);
+                if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + at) = v; p.in_mask[(size_t)g * CPP + ch] = (unsigned char)mb; }
+            } else if constexpr (lazy) {
+                v = bn_relu8_bf16(rc.a, isc, ish);
+            } else {
+                v = rc.a;
+            }
+        }
+        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
+    };
+    int idx = tid;
+    if constexpr (lazy || lzd) {
+#pragma unroll
+        for (int it = 0; it < PF; ++it)
+            if (tid + it * 256 < nchunks) stage(tid + it * 256, raw[it]);
+        idx = tid + PF * 256;
+    }
+    for (; idx < nchunks; idx += 256) {
+        RawChunk rc;
+        fetch(idx, rc);
+        stage(idx, rc);
+    }
+    if (tid < CPP) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // conv16: 3x3 / stride 1 / pad 1 with 16 input and 16 output channels (ResNet-32 stage 1: 11 of its 33 convolutions, on the
 // largest maps).  The generic implicit-GEMM kernel spent 26 us (forward) / 40 us (dgrad) on [256,32,32,16] -- 2 % of the MFMA
@@ -712,47 +807,7 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
         bit[ks] = tap < 9 ? 1u << tap : 0u;
     }
     // patch: pixels [m0 - halo, m0 + BM + halo) as 16-byte half rows, plus one zero row for the out-of-image taps
-    const int nchunks = p.np * 2;
-    constexpr bool lazy = MODE == 0 && LI != 0;
-    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out                    // lazy BatchNorm input (template parameter for the same reason as LZ)
-    float isc[8], ish[8];
-    if constexpr (lazy) {                                    // this thread stages channels (tid & 1) * 8 .. + 8 of every pixel it touches
-        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
-        lazy_input_coefs<16>(p, bx, coef);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 1) * 8 + e]; ish[e] = coef[16 + (tid & 1) * 8 + e]; }
-    }
-    constexpr bool lzd = MODE == 1 && LZ;                    // (a template parameter: the table's 48 registers and the branch in the staging loop slowed EVERY dgrad launch when this was a run-time test)
-    LazyDz8 lt;
-    if constexpr (lzd) {                                     // the gradient operand = this layer's BatchNorm backward, from dy and z
-        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
-        lazy_dz_coefs<16>(p.lz, bx == 0, coef);
-        lazy_dz_load<16>(coef, (tid & 1) * 8, lt);
-    }
-    for (int idx = tid; idx < nchunks; idx += 256) {
-        const int q = idx >> 1, ch = idx & 1;
-        const long long g = (long long)m0 - halo + q;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g >= 0 && g < p.M) {
-            if constexpr (lzd) {
-                const bool bits = p.lz.mask != nullptr;
-                const unsigned mb = bits ? p.lz.mask[(size_t)g * 2 + ch] : 0u;
-                float gg[8];
-                v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 16 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 16 + ch * 8), lt, bits, mb, gg);
-                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * 16 + ch * 8, gg, p.lz.dres_acc);
-            } else {
-                v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 16 + ch * 8);
-                if constexpr (lres) {
-                    unsigned mb;
-                    v = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(p.in_res + (size_t)g * 16 + ch * 8), isc, ish, mb);
-                    if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + (size_t)g * 16 + ch * 8) = v; p.in_mask[(size_t)g * 2 + ch] = (unsigned char)mb; }
-                } else if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
-            }
-        }
-        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
-    }
-    if (tid < 2) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    stage_patch<MODE, LZ, LI, 16, PP, BM, 3>(p, bx, m0, halo, smem);
 
     const int zaddr = p.np * PP + half * 16;
     f32x4 acc[4];
@@ -838,47 +893,7 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 2; ++j) wreg[t][j] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(j * 16 + fr) * 288 + t * 32 + fg * 8);
-    const int nchunks = p.np * 4;
-    constexpr bool lazy = MODE == 0 && LI != 0;
-    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out                    // lazy BatchNorm input (template parameter for the same reason as LZ)
-    float isc[8], ish[8];
-    if constexpr (lazy) {                                    // this thread stages channels (tid & 3) * 8 .. + 8
-        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
-        lazy_input_coefs<32>(p, bx, coef);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 3) * 8 + e]; ish[e] = coef[32 + (tid & 3) * 8 + e]; }
-    }
-    constexpr bool lzd = MODE == 1 && LZ;
-    LazyDz8 lt;
-    if constexpr (lzd) {
-        float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
-        lazy_dz_coefs<32>(p.lz, bx == 0, coef);
-        lazy_dz_load<32>(coef, (tid & 3) * 8, lt);
-    }
-    for (int idx = tid; idx < nchunks; idx += 256) {
-        const int q = idx >> 2, ch = idx & 3;
-        const long long g = (long long)m0 - halo + q;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g >= 0 && g < p.M) {
-            if constexpr (lzd) {
-                const bool bits = p.lz.mask != nullptr;
-                const unsigned mb = bits ? p.lz.mask[(size_t)g * 4 + ch] : 0u;
-                float gg[8];
-                v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * 32 + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * 32 + ch * 8), lt, bits, mb, gg);
-                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * 32 + ch * 8, gg, p.lz.dres_acc);
-            } else {
-                v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * 32 + ch * 8);
-                if constexpr (lres) {
-                    unsigned mb;
-                    v = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(p.in_res + (size_t)g * 32 + ch * 8), isc, ish, mb);
-                    if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + (size_t)g * 32 + ch * 8) = v; p.in_mask[(size_t)g * 4 + ch] = (unsigned char)mb; }
-                } else if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
-            }
-        }
-        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
-    }
-    if (tid < 4) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    stage_patch<MODE, LZ, LI, 32, PP, BM, 5>(p, bx, m0, halo, smem);
 
     const int zaddr = p.np * PP + fg * 16;
     f32x4 acc[4][2];
@@ -980,46 +995,7 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wreg[t][ks] = *reinterpret_cast<const uint4*>(p.wt + (size_t)(wave * 16 + fr) * 576 + t * 64 + ks * 32 + fg * 8);
-    const int nchunks = p.np * 8;
-    constexpr bool lazy = MODE == 0 && LI != 0;
-    constexpr bool lres = MODE == 0 && LI == 2;              // ... of a +res producer: two tensors in, the activation and its mask out
-    constexpr bool lzd = MODE == 1 && LZ;
-    float isc[8], ish[8];
-    LazyDz8 lt;
-    float* coef = reinterpret_cast<float*>(smem + (p.np + 1) * PP);
-    if constexpr (lazy) {                                    // this thread stages channels (tid & 7) * 8 .. + 8
-        lazy_input_coefs<C>(p, bx, coef);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { isc[e] = coef[(tid & 7) * 8 + e]; ish[e] = coef[C + (tid & 7) * 8 + e]; }
-    }
-    if constexpr (lzd) {
-        lazy_dz_coefs<C>(p.lz, bx == 0, coef);
-        lazy_dz_load<C>(coef, (tid & 7) * 8, lt);
-    }
-    for (int idx = tid; idx < nchunks; idx += 256) {
-        const int q = idx >> 3, ch = idx & 7;
-        const long long g = (long long)m0 - halo + q;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g >= 0 && g < p.M) {
-            if constexpr (lzd) {
-                const bool bits = p.lz.mask != nullptr;
-                const unsigned mb = bits ? p.lz.mask[(size_t)g * 8 + ch] : 0u;
-                float gg[8];
-                v = lazy_dz8(*reinterpret_cast<const uint4*>(p.lz.dy + (size_t)g * C + ch * 8), *reinterpret_cast<const uint4*>(p.lz.z + (size_t)g * C + ch * 8), lt, bits, mb, gg);
-                if (p.lz.dres != nullptr && q >= halo && q < halo + BM) lazy_dres_store(p.lz.dres + (size_t)g * C + ch * 8, gg, p.lz.dres_acc);
-            } else {
-                v = *reinterpret_cast<const uint4*>(p.src + (size_t)g * C + ch * 8);
-                if constexpr (lres) {
-                    unsigned mb;
-                    v = bn_res_relu8_bf16(v, *reinterpret_cast<const uint4*>(p.in_res + (size_t)g * C + ch * 8), isc, ish, mb);
-                    if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + (size_t)g * C + ch * 8) = v; p.in_mask[(size_t)g * 8 + ch] = (unsigned char)mb; }
-                } else if constexpr (lazy) v = bn_relu8_bf16(v, isc, ish);
-            }
-        }
-        *reinterpret_cast<uint4*>(smem + q * PP + ch * 16) = v;
-    }
-    if (tid < 8) *reinterpret_cast<uint4*>(smem + p.np * PP + tid * 16) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    stage_patch<MODE, LZ, LI, C, PP, BM, (BM == 64 ? 3 : 6)>(p, bx, m0, halo, smem);
 
     const int zaddr = p.np * PP + fg * 16;
     f32x4 acc[NT];
@@ -1507,13 +1483,24 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
     for (int i = tid; i < xchunks; i += 256) *reinterpret_cast<uint4*>(xs + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     constexpr bool lzd = LZ;
-    LazyDz8 lt;
-    if constexpr (lzd) {                                     // (the staging area is still free: the coefficient table sits at its start until the fill)
-        float* coef = reinterpret_cast<float*>(zs);
-        __syncthreads();
-        lazy_dz_coefs<16>(p.lz, false, coef);
-        lazy_dz_load<16>(coef, (tid & 1) * 8, lt);
-        __syncthreads();
+    // lazy gradient: the band's raw dy / z chunks (RH = 16 rows: four rounds) are fetched first and the input band is staged next, so that the
+    // coefficient prologue (a memory round trip of its own behind two barriers) overlaps them instead of preceding them
+    constexpr int PFZ = 4;
+    const int nzc = RH * W * 2;
+    uint4 pdy[PFZ], pz[PFZ];
+    unsigned pm[PFZ];
+    if constexpr (lzd) {
+#pragma unroll
+        for (int it = 0; it < PFZ; ++it) {
+            const int i = tid + it * 256;
+            pdy[it] = make_uint4(0, 0, 0, 0); pz[it] = pdy[it]; pm[it] = 0u;
+            if (i < nzc) {
+                const size_t pix = img + (size_t)r0 * W + (i >> 1);
+                pdy[it] = *reinterpret_cast<const uint4*>(p.lz.dy + pix * 16 + (i & 1) * 8);
+                pz[it] = *reinterpret_cast<const uint4*>(p.lz.z + pix * 16 + (i & 1) * 8);
+                if (p.lz.mask != nullptr) pm[it] = p.lz.mask[pix * 2 + (i & 1)];
+            }
+        }
     }
     float xsc[8], xsh[8];
     if (p.x_coef != nullptr) {
@@ -1528,7 +1515,19 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Params& p, const int b
         if (p.x_coef != nullptr) xv = bn_relu8_bf16(xv, xsc, xsh);
         *reinterpret_cast<uint4*>(xs + (lr * PW + c + 1) * PX + half * 16) = xv;
     }
-    for (int i = tid; i < RH * W * 2; i += 256) {
+    LazyDz8 lt;
+    if constexpr (lzd) {                                     // (the gradient staging area is still free: the coefficient table sits at its start until the fill)
+        float* coef = reinterpret_cast<float*>(zs);
+        lazy_dz_coefs<16>(p.lz, false, coef);
+        lazy_dz_load<16>(coef, (tid & 1) * 8, lt);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < PFZ; ++it) {
+            const int i = tid + it * 256;
+            if (i < nzc) *reinterpret_cast<uint4*>(zs + (i >> 1) * PX + (i & 1) * 16) = lazy_dz8(pdy[it], pz[it], lt, p.lz.mask != nullptr, pm[it]);
+        }
+    }
+    for (int i = lzd ? tid + PFZ * 256 : tid; i < nzc; i += 256) {
         const int lp = i >> 1, half = i & 1;
         const size_t pix = img + (size_t)r0 * W + lp;
         uint4 zv;
@@ -1600,13 +1599,6 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
     unsigned rm[2] = {0u, 0u};
     constexpr bool lzd = LZ;
     LazyDz8 lt;
-    if constexpr (lzd) {                                      // gradient chunk q = tid + 256 i covers channels ot * 16 + (tid & 1) * 8
-        float* coef = reinterpret_cast<float*>(zs);
-        __syncthreads();
-        lazy_dz_coefs<32>(p.lz, false, coef);
-        lazy_dz_load<32>(coef, ot * 16 + (tid & 1) * 8, lt);
-        __syncthreads();
-    }
     float xsc[8], xsh[8];                                     // chunk q = tid + 256 i covers channels (q & 3) * 8 = (tid & 3) * 8 of its pixel
     if (p.x_coef != nullptr) {
 #pragma unroll
@@ -1654,7 +1646,12 @@ __device__ __forceinline__ void wgrad32_body(const Wgrad32Params& p, const int o
     // column 8 (fg & 1) + (fr >> 2)), 8-byte segment fr & 3 of the 16-channel tile
     const int prow = fg >> 1, pcol = (fg & 1) * 8 + (fr >> 2), seg = (fr & 3) * 8;
     const int t0 = th * 5, nt = th == 0 ? 5 : 4;
-    if (n_beg < n_end) gload(n_beg);
+    if (n_beg < n_end) gload(n_beg);                          // the first image's raw operands are in flight while the coefficient prologue (a round trip of its own) runs
+    if constexpr (lzd) {                                      // gradient chunk q = tid + 256 i covers channels ot * 16 + (tid & 1) * 8
+        float* coef = reinterpret_cast<float*>(zs);
+        lazy_dz_coefs<32>(p.lz, false, coef);
+        lazy_dz_load<32>(coef, ot * 16 + (tid & 1) * 8, lt);
+    }
     for (int n = n_beg; n < n_end; ++n) {
         __syncthreads();                                      // the previous image's reads are done (first pass: the zero fill)
         sstore();
@@ -1712,13 +1709,6 @@ __device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int o
     unsigned rm[IPI];
     constexpr bool lzd = LZ;
     LazyDz8 lt;
-    if constexpr (lzd) {                                      // gradient chunk q = tid covers channels ot * 16 + (tid & 1) * 8
-        float* coef = reinterpret_cast<float*>(zs);
-        __syncthreads();
-        lazy_dz_coefs<C>(p.lz, false, coef);
-        lazy_dz_load<C>(coef, ot * 16 + (tid & 1) * 8, lt);
-        __syncthreads();
-    }
     float xsc[8], xsh[8];                                     // input chunk q = tid + 256 i covers channels (q & 7) * 8 = (tid & 7) * 8
     if (p.x_coef != nullptr) {
 #pragma unroll
@@ -1771,7 +1761,12 @@ __device__ __forceinline__ void wgrad64_body(const Wgrad64Params& p, const int o
     // lane (fr, fg) of a transposing read: reduction element 8 fg + (fr >> 2) (+4 for the second read) = pixel (row h0 + fg, column (fr >> 2) [+ 4]),
     // 8-byte segment fr & 3 of the 16-channel tile
     const int prow = fg, pcol = fr >> 2, seg = (fr & 3) * 8;
-    if (n_beg < n_end) gload(n_beg);
+    if (n_beg < n_end) gload(n_beg);                          // in flight while the coefficient prologue runs (see wgrad32_body)
+    if constexpr (lzd) {                                      // gradient chunk q = tid covers channels ot * 16 + (tid & 1) * 8
+        float* coef = reinterpret_cast<float*>(zs);
+        lazy_dz_coefs<C>(p.lz, false, coef);
+        lazy_dz_load<C>(coef, ot * 16 + (tid & 1) * 8, lt);
+    }
     for (int n = n_beg; n < n_end; n += IPI) {
         __syncthreads();
         sstore(n);
@@ -2043,8 +2038,12 @@ thread_local bool g_defer_on = false;
 
 __global__ __launch_bounds__(256) void wgrad_multi_reduce_kernel(ReduceTable t) {
     __shared__ float4 part[4][64];
-    int u = 0;
-    while (u + 1 < t.n && blockIdx.x >= t.e[u + 1].first_block) ++u;
+    // the entry whose block range holds blockIdx.x: one 64-lane load + ballot (a walk over e[1..].first_block is one dependent scalar load per
+    // entry -- 33 of them on CifarResNet-32, most of this launch's 10.7 us at batch 32)
+    static_assert(kDeferMax <= 64, "one lane per entry");
+    const int l64 = threadIdx.x & 63;
+    const bool le = l64 < t.n && t.e[l64 < kDeferMax ? l64 : 0].first_block <= blockIdx.x;
+    const int u = __builtin_amdgcn_readfirstlane(__popcll(__ballot(le)) - 1);
     const ReduceEntry& d = t.e[u];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long i = (long long)(blockIdx.x - d.first_block) * 64 + lane;

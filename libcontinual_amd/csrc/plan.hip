@@ -510,7 +510,15 @@ __device__ __forceinline__ size_t packed_index(int c, int tap, int k, int K, int
     if (Cpad < 64) return ((size_t)c * 10 + tap) * K + k;
     return ((((size_t)(c >> 6) * (K >> 4) + (k >> 4)) * 64 + (c & 63)) * 21 + tap * 2 + ((k >> 3) & 1)) * 8 + (k & 7);
 }
-struct PrepTable { int n; PrepEntry e[kPrepMax]; };
+struct PrepTable { int n; unsigned first[kPrepMax]; PrepEntry e[kPrepMax]; };      // first[u] = e[u].first_block (a block finds its conv with ONE 64-lane load + ballot)
+// the entry whose block range holds blockIdx.x.  (The first version walked e[1..].first_block with one dependent scalar load per entry: up to 31 round
+// trips before a block's first real load -- 13.8 us for CifarResNet-32's 1.8 MB of weights, most of it this scan.)
+__device__ __forceinline__ int prep_entry_of_block(const PrepTable& t) {
+    static_assert(kPrepMax <= 64, "one lane per entry");
+    const int l = threadIdx.x & 63;
+    const bool le = l < t.n && t.first[l < kPrepMax ? l : 0] <= blockIdx.x;
+    return __popcll(__ballot(le)) - 1;
+}
 
 // block = one (tap, 32 out-channels x 32 in-channels) tile: coalesced fp32 reads along C, coalesced writes of the forward copy
 // along C and -- through a 32 x 33 LDS transpose -- of the dgrad copy along K (the first version wrote the dgrad copy with a
@@ -518,8 +526,7 @@ struct PrepTable { int n; PrepEntry e[kPrepMax]; };
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* __restrict__ params, char* __restrict__ shadow, PrepTable t) {
     __shared__ float tile[32][33];
-    int u = 0;
-    while (u + 1 < t.n && blockIdx.x >= t.e[u + 1].first_block) ++u;
+    const int u = __builtin_amdgcn_readfirstlane(prep_entry_of_block(t));
     const PrepEntry& d = t.e[u];
     const int kb = (d.K + 31) / 32, cb = (d.Cpad + 31) / 32;
     int r = blockIdx.x - d.first_block;
@@ -554,8 +561,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* __r
 // 11.2 M weights in 37 us = 2.4 TB/s per training step; this one: profiles/r02_conv4_notes.md)
 __global__ __launch_bounds__(256) void weight_prep_multi64_kernel(const float* __restrict__ params, char* __restrict__ shadow, PrepTable t) {
     __shared__ float tile[64][65];
-    int u = 0;
-    while (u + 1 < t.n && blockIdx.x >= t.e[u + 1].first_block) ++u;
+    const int u = __builtin_amdgcn_readfirstlane(prep_entry_of_block(t));
     const PrepEntry& d = t.e[u];
     const int kb = (d.K + 63) / 64, cb = (d.Cpad + 63) / 64;
     int r = blockIdx.x - d.first_block;
@@ -616,7 +622,7 @@ extern "C" int clhip_plan_prep_weights(clhip_plan* p, const float* params, void*
                 e.wp_tap0 = owner ? 0 : 9;
             }
             e.K = u.d.cout; e.taps = u.d.ksize * u.d.ksize; e.Creal = u.d.cin; e.Cpad = u.cin_pad;
-            e.first_block = blocks;
+            e.first_block = blocks; t.first[t.n - 1] = blocks;
             blocks += (unsigned)(e.taps * ((e.K + tb - 1) / tb) * ((e.Cpad + tb - 1) / tb));
         }
         if (wide) hipLaunchKernelGGL(weight_prep_multi64_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, sh, t);

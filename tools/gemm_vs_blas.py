@@ -44,3 +44,53 @@ for name, M, N, K in SHAPES:
     blas = timeit(lambda i: torch.mm(A[i % nset], B[i % nset].t(), out=C[i % nset]), reps)
     fl = 2.0 * M * N * K
     print(f"{name:22s} M{M:6d} N{N:5d} K{K:6d}  ours {ours*1e3:7.1f} us {fl/ours/1e9:6.0f} TF/s | vendor {blas*1e3:7.1f} us {fl/blas/1e9:6.0f} TF/s | ours/vendor time {ours/blas:5.2f}  maxrel {err:.1e}", flush=True)
+
+
+# ---- the step's FUSED forms against the vendor path for the same operation (what torch runs: addmm / linear through hipBLASLt, then the
+#      elementwise kernels of the epilogue).  Same operands, same outputs; the vendor side is given every fusion torch offers (bias inside
+#      addmm's epilogue, in-place residual add, one fused-GELU kernel for the activation and one for its derivative).
+print("\nfused epilogues (ours: one launch) vs vendor GEMM + torch elementwise", flush=True)
+SQRT1_2, INV_SQRT_2PI = 0.7071067811865476, 0.3989422804014327
+EPI = {"plain": 0, "bias": 1, "bias+res": 2, "bias+GELU+GELU'": 3, "x H": 4}
+FUSED = []
+for tag, M in (("inflora b128", 128 * 197), ("l2p b16", 16 * 222)):
+    FUSED += [(f"{tag} qkv (+bias)", M, 2304, 768, "bias"), (f"{tag} proj (+bias+res)", M, 768, 768, "bias+res"),
+              (f"{tag} fc1 (+bias,GELU,GELU')", M, 3072, 768, "bias+GELU+GELU'"), (f"{tag} fc2 (+bias+res)", M, 768, 3072, "bias+res"),
+              (f"{tag} d fc2 (x GELU')", M, 3072, 768, "x H"), (f"{tag} d fc1", M, 768, 3072, "plain"),
+              (f"{tag} d proj", M, 768, 768, "plain"), (f"{tag} d qkv", M, 768, 2304, "plain")]
+for name, M, N, K, kind in FUSED:
+    nset = max(2, min(6, int(300e6 / ((M * K + N * K + 3 * M * N) * 2)) + 1))
+    A = [torch.randn(M, K, device=dev).bfloat16() for _ in range(nset)]
+    B = [(torch.randn(N, K, device=dev) * 0.03).bfloat16() for _ in range(nset)]
+    C = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(nset)]
+    bias = torch.randn(N, device=dev) * 0.1
+    bias_bf = bias.bfloat16()
+    R = [torch.randn(M, N, device=dev).bfloat16() for _ in range(nset)] if kind == "bias+res" else None
+    Hb = [torch.rand(M, N, device=dev).bfloat16() for _ in range(nset)] if kind in ("x H", "bias+GELU+GELU'") else None
+    ones = torch.ones(M, N, device=dev, dtype=torch.bfloat16) if kind == "bias+GELU+GELU'" else None
+
+    def ours_fn(i):
+        j = i % nset
+        _lib.call("clhip_gemm_nt", A[j].data_ptr(), B[j].data_ptr(), C[j].data_ptr(), bias.data_ptr() if "bias" in kind else None,
+                  R[j].data_ptr() if R else None, Hb[j].data_ptr() if Hb else None, M, N, K, K, K, N, N, N, EPI[kind], _lib.BF16, st)
+
+    def vendor_fn(i):
+        j = i % nset
+        if kind == "plain":
+            torch.mm(A[j], B[j].t(), out=C[j])
+        elif kind == "bias":
+            torch.addmm(bias_bf, A[j], B[j].t(), out=C[j])
+        elif kind == "bias+res":
+            torch.addmm(bias_bf, A[j], B[j].t(), out=C[j]); C[j].add_(R[j])
+        elif kind == "x H":
+            torch.mm(A[j], B[j].t(), out=C[j]); C[j].mul_(Hb[j])
+        else:   # pre-activation -> GELU (saved for fc2 and its backward) and GELU' (saved for the backward)
+            pre = torch.addmm(bias_bf, A[j], B[j].t())
+            torch.ops.aten.gelu.out(pre, approximate="none", out=C[j])
+            # d/dx gelu = Phi(x) + x phi(x): torch has no forward kernel for it; autograd's gelu_backward with grad 1 is the one fused kernel that computes it
+            torch.ops.aten.gelu_backward.grad_input(ones, pre, approximate="none", grad_input=Hb[j])
+
+    ours = timeit(ours_fn, reps)
+    vend = timeit(vendor_fn, reps)
+    fl = 2.0 * M * N * K
+    print(f"{name:34s} M{M:6d} N{N:5d} K{K:5d}  ours {ours*1e3:7.1f} us {fl/ours/1e9:6.0f} TF/s | vendor path {vend*1e3:7.1f} us {fl/vend/1e9:6.0f} TF/s | ours/vendor time {ours/vend:5.2f}", flush=True)
