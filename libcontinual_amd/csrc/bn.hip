@@ -132,27 +132,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float a1[8], a2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
-    // first trip's operands before the constants' round trip and barrier (see bn_apply_train_kernel)
-    constexpr int UN = 2;                                      // rows per trip, every load issued before the first use
-    const int64_t rstep = (int64_t)gridDim.x * rpi;
-    const int64_t r_first = (int64_t)blockIdx.x * rpi + ro;
-    float g[UN][8], yy[UN][8], zz[UN][8];
-    unsigned mk[UN];
-    auto load_trip = [&](int64_t r) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            mk[u] = 0;
-            const int64_t ru = r + u * rstep;
-            if (ru < M) {
-                const int64_t off = ru * C + cc * 8;
-                load8<T>(dy + off, g[u]);
-                load8<T>(z + off, zz[u]);
-                if (RELU == 1) load8<T>(y + off, yy[u]);
-                if (RELU == 3) mk[u] = reinterpret_cast<const unsigned char*>(y)[off >> 3];
-            }
-        }
-    };
-    if (ro < rpi) load_trip(r_first);
     // per-channel constants through LDS once per workgroup (behind the reduction scratch): [4][C] mean, invstd, scale, shift
     float* coef = red + 256 * 16;
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -169,8 +148,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             mu[e] = coef[cc * 8 + e]; is[e] = coef[C + cc * 8 + e];
             if (RELU == 2) { sc[e] = coef[2 * C + cc * 8 + e]; sh[e] = coef[3 * C + cc * 8 + e]; }
         }
-        for (int64_t r = r_first; r < M; r += rstep * UN) {
-            if (r != r_first) load_trip(r);
+        constexpr int UN = 2;                                  // rows per trip, every load issued before the first use
+        const int64_t rstep = (int64_t)gridDim.x * rpi;
+        for (int64_t r = (int64_t)blockIdx.x * rpi + ro; r < M; r += rstep * UN) {
+            float g[UN][8], yy[UN][8], zz[UN][8];
+            unsigned mk[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                mk[u] = 0;
+                const int64_t ru = r + u * rstep;
+                if (ru < M) {
+                    const int64_t off = ru * C + cc * 8;
+                    load8<T>(dy + off, g[u]);
+                    load8<T>(z + off, zz[u]);
+                    if (RELU == 1) load8<T>(y + off, yy[u]);
+                    if (RELU == 3) mk[u] = reinterpret_cast<const unsigned char*>(y)[off >> 3];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 if (r + u * rstep >= M) break;
@@ -289,20 +283,6 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
                                                              const T* __restrict__ res, T* __restrict__ y, int64_t nchunks, int C,
                                                              unsigned char* __restrict__ relu_mask = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float coefs[];       // [2][C]: scale, shift
-    // The first trip's operands are fetched BEFORE the finalize prologue: the prologue is a memory round trip of its own (the fp64 replicas)
-    // behind a barrier, and most launches are a single trip long -- launch -> replicas -> data -> store in series was 1-2 us of a ~10 us launch.
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int UN = 4;                                              // chunks per trip, every load issued before the first use
-    float v[UN][8], r[UN][8];
-    auto load_trip = [&](int64_t i) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t iu = i + u * stride;
-            if (iu < nchunks) { load8<T>(z + iu * 8, v[u]); if (RES) load8<T>(res + iu * 8, r[u]); }
-        }
-    };
-    load_trip(i0);
     // block-cooperative finalize: sum the accumulator replicas, derive scale / shift once per workgroup
     __shared__ double sred[256];
     const bool narrow = 2 * C <= 128;
@@ -334,12 +314,21 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T* __restrict
         }
     }
     __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c0 = ((int)i0 & ((C >> 3) - 1)) * 8;                     // fixed per thread: C is a power of two and the grid stride a multiple of C/8
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = coefs[c0 + e]; sh[e] = coefs[C + c0 + e]; }
+    // UN chunks per trip, every load issued before the first use: the kernels are a few dependent round trips long on the small layers
+    constexpr int UN = 4;
     for (int64_t i = i0; i < nchunks; i += stride * UN) {
-        if (i != i0) load_trip(i);
+        float v[UN][8], r[UN][8];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t iu = i + u * stride;
+            if (iu < nchunks) { load8<T>(z + iu * 8, v[u]); if (RES) load8<T>(res + iu * 8, r[u]); }
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int64_t iu = i + u * stride;
@@ -372,27 +361,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
     // [6][C]: mean(g), mean(g * xhat), mean, invstd, scale, shift -- every per-channel constant goes through LDS once per workgroup (32
     // four-byte gathers per thread from the four parameter arrays were most of this kernel's fixed cost on the small layers)
     extern __shared__ __attribute__((aligned(16))) float coefs[];
-    // first trip's operands before the prologue (see bn_apply_train_kernel)
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int UN = sizeof(T) == 2 ? 4 : 2;
-    float g[UN][8], yy[UN][8], zz[UN][8], rr[UN][8];
-    unsigned mk[UN];
-    auto load_trip = [&](int64_t i) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            mk[u] = 0;
-            const int64_t iu = i + u * stride;
-            if (iu < nchunks) {
-                load8<T>(dy + iu * 8, g[u]);
-                load8<T>(z + iu * 8, zz[u]);
-                if (RELU == 1) load8<T>(y + iu * 8, yy[u]);
-                if (RELU == 3) mk[u] = reinterpret_cast<const unsigned char*>(y)[iu];
-                if (DRES == 2) load8<T>(dres + iu * 8, rr[u]);
-            }
-        }
-    };
-    load_trip(i0);
     __shared__ double sred[256];
     const bool narrow = 2 * C <= 128;
     if (narrow) replica_parts(acc, rep, C, sred);
@@ -412,6 +380,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
         if (blockIdx.x == 0) { dbeta[c] = db_old + (float)s1; dgamma[c] = dg_old + (float)s2; }
     }
     __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c0 = ((int)i0 & ((C >> 3) - 1)) * 8;
     float k0[8], k1[8], gi[8], mu[8], is[8], sh[8];
 #pragma unroll
@@ -423,8 +393,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
         gi[e] = coefs[4 * C + c0 + e];
         if (RELU == 2) sh[e] = coefs[5 * C + c0 + e];
     }
+    constexpr int UN = sizeof(T) == 2 ? 4 : 2;
     for (int64_t i = i0; i < nchunks; i += stride * UN) {
-        if (i != i0) load_trip(i);
+        float g[UN][8], yy[UN][8], zz[UN][8], rr[UN][8];
+        unsigned mk[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            mk[u] = 0;
+            const int64_t iu = i + u * stride;
+            if (iu < nchunks) {
+                load8<T>(dy + iu * 8, g[u]);
+                load8<T>(z + iu * 8, zz[u]);
+                if (RELU == 1) load8<T>(y + iu * 8, yy[u]);
+                if (RELU == 3) mk[u] = reinterpret_cast<const unsigned char*>(y)[iu];
+                if (DRES == 2) load8<T>(dres + iu * 8, rr[u]);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int64_t iu = i + u * stride;

@@ -191,8 +191,35 @@ __device__ __forceinline__ void lazy_input_coefs(const Conv3Params& p, int bx, f
 // of pixel m0 + wave*64 + i*16 + fr, channel c0 + e (c0 = this lane's first channel of the 4-channel group).  Per-channel sums over the
 // workgroup's 256 pixels: 16-lane DPP sums, the four waves through LDS, then one fp64 atomic per channel and sum into the producer's
 // accumulator replica; the centred form  sum g * xhat = invstd * (sum g z' - mean * sum g)  is taken once per channel.
+// the epilogue's operands, fetched before the MFMA loop (fetched in the epilogue they were a memory round trip at the end of a launch a handful long)
+template <int NJ> struct BwdPre { uint2 zz[4][NJ], yy[4][NJ]; float4 sc[NJ], sh[NJ]; float istd, mu; };
 template <int C, int NJ>
-__device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const float (&v)[4][NJ][4], int m0, int wave, int fr, int fg, int tid, char* smem, int bx) {
+__device__ __forceinline__ void bn_bwd_prefetch(const Conv3Params& p, int m0, int wave, int fr, int fg, int tid, BwdPre<NJ>& q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = m0 + wave * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            q.zz[i][j] = make_uint2(0u, 0u); q.yy[i][j] = make_uint2(0x3f803f80u, 0x3f803f80u);
+            if (pix < p.M) {
+                const size_t at = (size_t)pix * C + j * 16 + fg * 4;
+                q.zz[i][j] = *reinterpret_cast<const uint2*>(p.bn_z + at);
+                if (p.bn_y != nullptr) q.yy[i][j] = *reinterpret_cast<const uint2*>(p.bn_y + at);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        q.sc[j] = make_float4(0.f, 0.f, 0.f, 0.f); q.sh[j] = q.sc[j];
+        if (p.bn_y == nullptr && p.bn_coef != nullptr) {
+            q.sc[j] = *reinterpret_cast<const float4*>(p.bn_coef + j * 16 + fg * 4); q.sh[j] = *reinterpret_cast<const float4*>(p.bn_coef + C + j * 16 + fg * 4);
+        }
+    }
+    q.istd = 0.f; q.mu = 0.f;
+    if (tid < 2 * C) { const int cc = tid < C ? tid : tid - C; q.istd = p.bn_invstd[cc]; q.mu = p.bn_mean[cc]; }
+}
+template <int C, int NJ>
+__device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const float (&v)[4][NJ][4], const BwdPre<NJ>& q, int m0, int wave, int fr, int fg, int tid, char* smem, int bx) {
     float sv[NJ * 8];
 #pragma unroll
     for (int q = 0; q < NJ * 8; ++q) sv[q] = 0.f;
@@ -202,14 +229,12 @@ __device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const
         if (pix < p.M) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const size_t at = (size_t)pix * C + j * 16 + fg * 4;
-                const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + at);
-                uint2 yy = make_uint2(0x3f803f80u, 0x3f803f80u);
-                if (p.bn_y != nullptr) yy = *reinterpret_cast<const uint2*>(p.bn_y + at);
+                const uint2 zz = q.zz[i][j];
+                const uint2 yy = q.yy[i][j];
                 const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
                 float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
                 if (p.bn_y == nullptr && p.bn_coef != nullptr) {           // the producer's activation was never written: its sign from z (as bn.hip's z-mask kernels)
-                    const float4 sc = *reinterpret_cast<const float4*>(p.bn_coef + j * 16 + fg * 4), sh = *reinterpret_cast<const float4*>(p.bn_coef + C + j * 16 + fg * 4);
+                    const float4 sc = q.sc[j], sh = q.sh[j];
                     y4[0] = fmaf(z4[0], sc.x, sh.x); y4[1] = fmaf(z4[1], sc.y, sh.y); y4[2] = fmaf(z4[2], sc.z, sh.z); y4[3] = fmaf(z4[3], sc.w, sh.w);
                 }
 #pragma unroll
@@ -237,7 +262,7 @@ __device__ __forceinline__ void bn_bwd_sums_epilogue(const Conv3Params& p, const
         float t = 0.f, sg = 0.f;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) { t += red[(w2 * 2 + which) * C + cc]; sg += red[(w2 * 2 + 0) * C + cc]; }
-        if (which == 1) t = p.bn_invstd[cc] * (t - p.bn_mean[cc] * sg);
+        if (which == 1) t = q.istd * (t - q.mu * sg);
         atomicAdd(p.bn_acc + ((size_t)(bx & (p.bn_rep - 1)) * 2 + which) * C + cc, (double)t);
     }
 }
@@ -810,6 +835,8 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
     stage_patch<MODE, LZ, LI, 16, PP, BM, 3>(p, bx, m0, halo, smem);
 
     const int zaddr = p.np * PP + half * 16;
+    BwdPre<1> bpre;
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_prefetch<16, 1>(p, m0, wave, fr, fg, tid, bpre);
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -841,7 +868,7 @@ __device__ __forceinline__ void conv16_body(const Conv3Params& p, const int bx, 
         }
         fin[i][0][0] = v0; fin[i][0][1] = v1; fin[i][0][2] = v2; fin[i][0][3] = v3;
     }
-    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<16, 1>(p, fin, m0, wave, fr, fg, tid, smem, bx);
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<16, 1>(p, fin, bpre, m0, wave, fr, fg, tid, smem, bx);
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float sv[8];
 #pragma unroll
@@ -896,6 +923,8 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
     stage_patch<MODE, LZ, LI, 32, PP, BM, 5>(p, bx, m0, halo, smem);
 
     const int zaddr = p.np * PP + fg * 16;
+    BwdPre<2> bpre;
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_prefetch<32, 2>(p, m0, wave, fr, fg, tid, bpre);
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -933,7 +962,7 @@ __device__ __forceinline__ void conv32_body(const Conv3Params& p, const int bx, 
             fin[i][j][0] = v0; fin[i][j][1] = v1; fin[i][j][2] = v2; fin[i][j][3] = v3;
         }
     }
-    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<32, 2>(p, fin, m0, wave, fr, fg, tid, smem, bx);
+    if (MODE == 1 && p.bn_z != nullptr) bn_bwd_sums_epilogue<32, 2>(p, fin, bpre, m0, wave, fr, fg, tid, smem, bx);
     if (MODE == 0 && (p.stats != nullptr || p.stat_acc != nullptr)) {
         float sv[16];                                        // [j][e] sums, then [j][e] sums of squares
 #pragma unroll
@@ -998,6 +1027,27 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
     stage_patch<MODE, LZ, LI, C, PP, BM, (BM == 64 ? 3 : 6)>(p, bx, m0, halo, smem);
 
     const int zaddr = p.np * PP + fg * 16;
+    // dgrad + BatchNorm-backward sums of the producer: its z' (and y, or the z-mask coefficients) and the two statistics the final atomics need are
+    // fetched HERE, under the MFMA loop -- fetched in the epilogue they were one more memory round trip at the end of a launch that is a handful long
+    const int c4 = wave * 16 + fg * 4;                       // D[row = channel wave*16 + fg*4 + e][col = pixel fr]
+    const bool bwd_sums = MODE == 1 && p.bn_z != nullptr;
+    const bool zmask = bwd_sums && p.bn_y == nullptr && p.bn_coef != nullptr;
+    uint2 pzz[NT], pyy[NT];
+    float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc, pis = msc, pmu = msc;
+    if (bwd_sums) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int pix = m0 + i * 16 + fr;
+            pzz[i] = make_uint2(0u, 0u); pyy[i] = make_uint2(0u, 0u);
+            if (pix < p.M) {
+                const size_t at = (size_t)pix * C + c4;
+                pzz[i] = *reinterpret_cast<const uint2*>(p.bn_z + at);
+                if (p.bn_y != nullptr) pyy[i] = *reinterpret_cast<const uint2*>(p.bn_y + at);
+            }
+        }
+        if (zmask) { msc = *reinterpret_cast<const float4*>(p.bn_coef + c4); msh = *reinterpret_cast<const float4*>(p.bn_coef + C + c4); }
+        if (fr == 0) { pis = *reinterpret_cast<const float4*>(p.bn_invstd + c4); pmu = *reinterpret_cast<const float4*>(p.bn_mean + c4); }
+    }
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -1018,12 +1068,7 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
             }
         }
     }
-    // D[row = channel wave*16 + fg*4 + e][col = pixel fr]
-    const int c4 = wave * 16 + fg * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};      // forward: sum z, sum z^2; dgrad + bn_z: sum g, sum g z'
-    float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
-    const bool zmask = MODE == 1 && p.bn_z != nullptr && p.bn_y == nullptr && p.bn_coef != nullptr;
-    if (zmask) { msc = *reinterpret_cast<const float4*>(p.bn_coef + c4); msh = *reinterpret_cast<const float4*>(p.bn_coef + C + c4); }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int pix = m0 + i * 16 + fr;
@@ -1039,13 +1084,12 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s1[e] += acc[i][e]; s2[e] = fmaf(acc[i][e], acc[i][e], s2[e]); }
-            } else if (p.bn_z != nullptr) {
-                const size_t at = (size_t)pix * C + c4;
-                const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + at);
+            } else if (bwd_sums) {
+                const uint2 zz = pzz[i];
                 const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
                 float y4[4] = {1.f, 1.f, 1.f, 1.f};
                 if (p.bn_y != nullptr) {
-                    const uint2 yy = *reinterpret_cast<const uint2*>(p.bn_y + at);
+                    const uint2 yy = pyy[i];
                     y4[0] = __uint_as_float(yy.x << 16); y4[1] = __uint_as_float(yy.x & 0xffff0000u); y4[2] = __uint_as_float(yy.y << 16); y4[3] = __uint_as_float(yy.y & 0xffff0000u);
                 } else if (zmask) {
                     y4[0] = fmaf(z4[0], msc.x, msh.x); y4[1] = fmaf(z4[1], msc.y, msh.y); y4[2] = fmaf(z4[2], msc.z, msh.z); y4[3] = fmaf(z4[3], msc.w, msh.w);
@@ -1059,11 +1103,11 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
         }
     }
     const bool fwd_stats = MODE == 0 && p.stat_acc != nullptr;
-    const bool bwd_sums = MODE == 1 && p.bn_z != nullptr;
     if (fwd_stats || bwd_sums) {
         float sv[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
         row16_sum_n(sv);                                     // over the 16 pixels of a lane group: this wave saw all 64 pixels of its channels
         if (fr == 0) {
+            const float is4[4] = {pis.x, pis.y, pis.z, pis.w}, mu4[4] = {pmu.x, pmu.y, pmu.z, pmu.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (fwd_stats) {
@@ -1073,7 +1117,7 @@ __device__ __forceinline__ void conv64_body(const Conv3Params& p, const int bx, 
                 } else {
                     double* a = p.bn_acc + (size_t)(bx & (p.bn_rep - 1)) * 2 * C;
                     atomicAdd(a + c4 + e, (double)sv[e]);
-                    atomicAdd(a + C + c4 + e, (double)(p.bn_invstd[c4 + e] * (sv[4 + e] - p.bn_mean[c4 + e] * sv[e])));
+                    atomicAdd(a + C + c4 + e, (double)(is4[e] * (sv[4 + e] - mu4[e] * sv[e])));
                 }
             }
         }

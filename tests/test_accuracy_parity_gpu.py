@@ -37,6 +37,10 @@ N_RUNS = 10
 # points -- ten runs could not tell a -4-point bf16 bias from nothing), and an UNSATURATED rehearsal scenario (acc_icarl11_hard: the reference's own
 # runs sit at 99.3 +- 0.6, not at 99.9) with 24 runs per side.  A scenario runs as many product runs as its fixture holds reference runs, up to this cap.
 RUN_CAP = {"acc_lwf": 40, "acc_icarl11": 10, "acc_icarl11_hard": 24}
+# ... with CLHIP_ACC_RUNS=full (the evidence run behind profiles/r04_accuracy_parity.json: 16 minutes of GPU time for the three scenarios).  The default
+# suite keeps the same gates (bands are 0.3 + 2 SE of the runs actually made) on fewer product runs so that `pytest -m gpu` stays a quarter of an hour.
+if os.environ.get("CLHIP_ACC_RUNS", "") != "full":
+    RUN_CAP = {"acc_lwf": 10, "acc_icarl11": 10, "acc_icarl11_hard": 6}
 # first optimisation steps of the unperturbed run: these scenarios step at lr 0.05 (the short ones at 0.02), so the chaotic amplification
 # sets in one step earlier -- f32 mode observed 1.5e-7, 1.8e-5, then 9e-4 at the third step
 FIRST_STEPS_ACC = {"f32": (2, 2e-4), "bf16": (2, 3e-2)}
@@ -78,7 +82,7 @@ def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
                            product_mean=float(pr.mean()), product_std=float(pr.std(ddof=1)))
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    jp = os.path.join(out, "accuracy_parity_r04.json")
+    jp = os.path.join(out, "accuracy_parity_r04.json" if os.environ.get("CLHIP_ACC_RUNS", "") == "full" else "accuracy_parity_r04_quick.json")
     prev = json.load(open(jp)) if os.path.exists(jp) else {}
     prev[f"{name}/{dtype}"] = report
     json.dump(prev, open(jp, "w"), indent=1)

@@ -18,4 +18,11 @@ python tools/inflora_task_boundary.py 2400 128 > gpurun_out/inflora_task_boundar
 CLHIP_BN_INPUT_WT=1 python tools/wt_micro.py 256 > gpurun_out/wt_micro.md 2>&1
 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_default_with_cpu.json
 python tools/small_kernels.py > gpurun_out/small_kernels.txt 2>&1
+# the ViT-B/16 block GEMMs against the vendor library on this box: plain C = A B^T, and the step's fused forms against vendor GEMM + torch's elementwise kernels
+python tools/gemm_vs_blas.py 30 > gpurun_out/gemm_vs_blas.txt 2>&1
+# the 32-image CifarResNet-32 step (graph replay) with the launch classes removed one by one: timing only, results invalid (CLHIP_PLAN_SKIP: 1 forward BatchNorm
+# apply, 2 BatchNorm backward, 4 weight gradients)
+for sk in 0 1 2 4 7; do
+  echo "PLAN_SKIP=$sk $(CLHIP_PLAN_SKIP=$sk python bench.py --workload ewc_resnet32_b50_task1 --batch 32 --no-cpu-baseline 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*')"
+done > gpurun_out/b32_ablation.txt
 ls -la gpurun_out | tail -30
