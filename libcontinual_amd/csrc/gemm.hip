@@ -14,6 +14,8 @@
 // Block ids are remapped so each XCD (own L2) walks a contiguous range of row panels over all column panels.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -25,6 +27,10 @@ struct GemmParams {
     const float* bias; const void* R; void* H;
     int M, N, K, lda, ldb, ldc, ldr, ldh;
     int group_m;      // row panels per rasterisation group (gemm_nt_kernel), 1 = plain row-major
+    // split-K (small M, long K: too few output tiles to fill the chip): blockIdx.y owns K range [y, y + 1) * K / ksplit and leaves its raw fp32 accumulators
+    // in part[y][M][N]; splitk_epilogue_kernel sums the slices in index order and applies the epilogue -- bitwise reproducible
+    int ksplit = 1;
+    float* part = nullptr;
 };
 
 template <typename T> struct Chunk;
@@ -203,8 +209,9 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const T* A = static_cast<const T*>(p.A);
-    const T* B = static_cast<const T*>(p.B);
+    const int KT = p.K / BK / p.ksplit;                              // K steps of this workgroup (split-K: its slice)
+    const T* A = static_cast<const T*>(p.A) + (size_t)blockIdx.y * KT * BK;
+    const T* B = static_cast<const T*>(p.B) + (size_t)blockIdx.y * KT * BK;
 
     // global -> register staging: thread owns chunk c of rows r0 + RPP i.  Rows beyond M / N are clamped to the last valid row:
     // their products land in accumulators that are never stored
@@ -235,7 +242,6 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     Chunk<T> ra[AL], rb[BL];
-    const int KT = p.K / BK;
 #pragma unroll
     for (int i = 0; i < AL; ++i) ra[i] = cload<T>(ag[i]);
 #pragma unroll
@@ -279,6 +285,20 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
         __syncthreads();
     }
 
+    if (p.ksplit > 1) {                                              // split-K slice: raw accumulators, the epilogue runs in splitk_epilogue_kernel
+        float* out = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * 16 * MT + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 16 * NT + j * 16 + g * 4;
+                if (n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     // 256 x 256 bf16 tile: the results leave through LDS.  A lane's accumulators are 4 columns of 16 different rows, so direct
     // stores (and the H loads of the x H epilogue) touch 16 cache lines per instruction with 32 bytes each -- the GELU epilogue
     // (two outputs) cost +78 us and the x H epilogue (one extra input) +55 us on top of a 179 us product.  Staged through the
@@ -368,6 +388,22 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
     }
 }
 
+// second pass of a split-K product: C[m][n .. n+3] = epilogue(sum over slices, in index order)
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
+    const int n4 = p.N >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long long)m * n4) * 4;
+    const float* src = p.part + (size_t)m * p.N + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < p.ksplit; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)k * p.M * p.N);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    epi_store<T, EPI>(p, a, m, n);
+}
+
 // The round-1 LDS-DMA experiments (128 x 128 two-stage, 256 x 128 three-stage ring, barrier-staggered ping-pong; none faster than the
 // register-staged kernel above: profiles/r01_gemm_ablation.txt) are gone; their successor is gemm5.hip.
 
@@ -381,9 +417,38 @@ template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launc
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), dim3(tiles), dim3(64 * WM * WN), smem, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), dim3(tiles, p.ksplit), dim3(64 * WM * WN), smem, s, p);
     CLHIP_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const long long n = (long long)p.M * (p.N >> 2);
+        hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+        CLHIP_LAUNCH_CHECK();
+    }
     return CLHIP_OK;
+}
+
+// fp32 scratch of the split-K products: one buffer per stream that ever needed one (two streams never share a buffer), grown on demand outside stream
+// capture; nullptr = not available right now (the caller runs the unsplit kernel)
+float* splitk_scratch(hipStream_t s, size_t bytes) {
+    struct Slot { hipStream_t s; int dev; float* p; size_t n; };
+    static Slot slots[16];
+    static int nslots = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Slot* sl = nullptr;
+    for (int i = 0; i < nslots; ++i) if (slots[i].s == s && slots[i].dev == dev) sl = &slots[i];
+    if (sl != nullptr && sl->n >= bytes) return sl->p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    if (sl == nullptr) { if (nslots == 16) return nullptr; sl = &slots[nslots++]; *sl = Slot{s, dev, nullptr, 0}; }
+    // an outgrown buffer is NOT freed: a captured graph of this stream may hold its address (tens of MB at most; sizes are the ViT's few GEMM shapes)
+    sl->p = nullptr; sl->n = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&sl->p), want) != hipSuccess) { (void)hipGetLastError(); sl->p = nullptr; return nullptr; }
+    sl->n = want;
+    return sl->p;
 }
 
 // block tile: 64 x 64 when 128-wide tiles cannot fill half of the 512 resident workgroups (2 per CU); otherwise 128 columns and
@@ -419,6 +484,26 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
         // tile (891 vs 647 TFLOP/s at K = 3072) but 297 of them on 256 CUs take two rounds.  Run exactly one round of 256 x 256
         // tiles on the leading rows and hand the remaining rows to the small-tile kernels (a second, short launch).
         static const bool no_split = clhip_cfg("GEMM_NO_SPLIT") != nullptr || clhip_cfg("GEMM_MT") != nullptr;
+        // Few output tiles, long K (L2P at batch 16: [3552 x 3072] . [768 x 3072]^T is 168 tiles of 128 x 128 -- the 64 x 64 tiles that filled the chip instead ran
+        // at 422 TFLOP/s against the vendor's 693): 128 x 128 tiles over 2-4 K slices, then one reduce + epilogue pass (profiles/r04_gemm_vs_blas.txt).
+        static const bool no_splitk = clhip_cfg("GEMM_SPLITK") != nullptr && atoi(clhip_cfg("GEMM_SPLITK")) == 0;
+        if (allow_split && !no_split && !no_splitk && p.ksplit == 1 && p.K >= 1536 && (p.N & 3) == 0) {
+            const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+            if (t128 < 256) {
+                const int ksteps = p.K / BK;
+                int ks = (int)(512 / t128);
+                if (ks > 4) ks = 4;
+                while (ks > 1 && (ksteps % ks != 0 || ksteps / ks < 8)) --ks;
+                if (ks > 1) {
+                    float* ws = splitk_scratch(s, (size_t)ks * p.M * p.N * sizeof(float));
+                    if (ws != nullptr) {
+                        GemmParams q = p;
+                        q.ksplit = ks; q.part = ws; q.group_m = 1;
+                        return launch<T, EPI, 4, 4>(q, s);
+                    }
+                }
+            }
+        }
         if (allow_split && !no_split && p.N % 256 == 0 && p.K >= 2304) {
             const int tn = p.N / 256;
             const long t256 = (long)((p.M + 255) / 256) * tn;

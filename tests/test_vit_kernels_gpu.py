@@ -108,6 +108,43 @@ def test_gemm5_every_epilogue(M, N, K, epi):
         _lib.lib().clhip_gemm5_config(-1)
 
 
+@pytest.mark.parametrize("M,N,K", [(3552, 768, 3072), (3552, 768, 2304), (777, 768, 1536), (130, 256, 4096)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_nt_split_k(M, N, K, epi):
+    """few output tiles and a long K (the L2P batch-16 shapes first): 128 x 128 tiles over 2-4 K slices + one reduce / epilogue pass -- ragged last row tile,
+    every epilogue through the second pass, a guard row behind the outputs, and the same bits from a second call (fixed slice order)"""
+    A = rnd(M, K, seed=1).to(torch.bfloat16)
+    B = rnd(N, K, scale=1 / math.sqrt(K), seed=2).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    R = rnd(M, N, seed=4).to(torch.bfloat16)
+    Hin = rnd(M, N, seed=5).to(torch.bfloat16)
+    ref = A.double() @ B.double().T
+    if epi in (1, 2, 3):
+        ref = ref + bias.double()
+    if epi == 2:
+        ref = ref + R.double()
+    pre = ref.clone()
+    if epi == 3:
+        ref = F.gelu(ref)
+        pre = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    if epi == 4:
+        ref = ref * Hin.double()
+    outs = []
+    for _ in range(2):
+        Cc = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        Hout = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        Hp = Hout if epi == 3 else (Hin if epi == 4 else None)
+        call("clhip_gemm_nt", p(A), p(B), p(Cc), p(bias) if epi in (1, 2, 3) else None, p(R) if epi == 2 else None, p(Hp), M, N, K, K, K, N, N, N, epi, CODE["bf16"], st())
+        torch.cuda.synchronize()
+        assert relerr(Cc[:M], ref) < TOL["bf16"]
+        assert float((Cc[M].float() - 7.0).abs().max()) == 0.0
+        if epi == 3:
+            assert relerr(Hout[:M], pre) < TOL["bf16"]
+            assert float((Hout[M].float() - 7.0).abs().max()) == 0.0
+        outs.append((Cc.clone(), Hout.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("M,N,K", [(25216, 2304, 64), (25216, 768, 2304), (8192, 4096, 64), (25216, 3072, 768), (25216, 2304, 768)])
 @pytest.mark.parametrize("epi", [0, 2, 3, 4])
 def test_gemm_nt_full_size_tilings(M, N, K, epi):
