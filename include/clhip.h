@@ -336,7 +336,9 @@ int clhip_herding_select_batched(const float* feats, const int32_t* offsets, int
  *   255,1267-1271) and, with the [in,out] copy of a frozen weight as B, its input gradient.  Epilogues:
  *   0 none | 1 +bias | 2 +bias +R (residual add, :1333-1334) | 3 +bias, then C <- GELU(.) (:1268) and H <- GELU'(.)
  *   (nullable; saved for the backward) | 4 C <- (.) * H (backward of 3).  bias fp32; R, H in the compute dtype.
- *   K % 64 == 0, N % 4 == 0.                                                                                    */
+ *   K % 64 == 0, N % 4 == 0.  Products with fewer than 256 tiles of 128 x 128 and K >= 3072 (bf16) run as 2-4 K slices + one fixed-order
+ *   reduce / epilogue pass through a library-owned fp32 scratch (per stream, allocated at the first such call outside stream capture, never
+ *   freed while a graph may hold it); results are bitwise reproducible either way.                                                          */
 int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                   int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream);
 /* The input gradient AND the weight gradient of one layer in ONE launch (both consume dz and nothing of each other): the layers whose two
@@ -457,7 +459,7 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  *   dispatch (0 / 1 unless noted):
  *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV64 (0: 64 -> 64 channels on small maps stay on conv4 / wgrad4; CONV64_FWD 0: only their backward; CONV64_BM 64 | 128), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV7 (0: no small-channel entry kernels; FWD7 0 / WGRAD7 0: not their forward / weight-gradient pairs; CONV7_TPW n: tiles per wave), BN_INPUT (0: no lazy BatchNorm inputs), BN_INPUT_WT (0: not on the LDS-DMA kernels of the wide layers), BN_RES_INPUT (0: block outputs keep their own apply launch), BN_GRAD (0: no BatchNorm backward on the operand loads; BN_GRAD_MINC n: only for layers of >= n channels, BN_GRAD_RES 0: not for the +res layers), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
- *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, ATTN_GENERIC, CE_ROWS,
+ *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, GEMM_SPLITK (0: no split-K for the few-tile / long-K products; n > 1: the minimum K that splits, default 3072), ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
  *     activations), BN_FUSE_MAX_M, BN_MASK_BITS, BN_MASK_FROM_Y, BN_ONEPASS, PREP_NARROW,
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), BRANCH_STREAM (shortcut branches on a third stream: 0 never, 1 forward and backward, 2 forward only = default, 3 backward only), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD

@@ -486,8 +486,11 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
         static const bool no_split = clhip_cfg("GEMM_NO_SPLIT") != nullptr || clhip_cfg("GEMM_MT") != nullptr;
         // Few output tiles, long K (L2P at batch 16: [3552 x 3072] . [768 x 3072]^T is 168 tiles of 128 x 128 -- the 64 x 64 tiles that filled the chip instead ran
         // at 422 TFLOP/s against the vendor's 693): 128 x 128 tiles over 2-4 K slices, then one reduce + epilogue pass (profiles/r04_gemm_vs_blas.txt).
+        // Measured (r04_gemm_vs_blas.txt, M = 3552, N = 768): K = 3072 39.7 -> 35.4 us (vendor 24.9), K = 2304 25.4 -> 29.4 us -- the slices' 128 x 128 tiles run at the same
+        // ~600 TFLOP/s as the rest of this kernel and the second pass costs ~7 us, so only the longest K gains; CLHIP_GEMM_SPLITK = 0 disables, any other value = the minimum K.
         static const bool no_splitk = clhip_cfg("GEMM_SPLITK") != nullptr && atoi(clhip_cfg("GEMM_SPLITK")) == 0;
-        if (allow_split && !no_split && !no_splitk && p.ksplit == 1 && p.K >= 1536 && (p.N & 3) == 0) {
+        static const int splitk_min_k = (clhip_cfg("GEMM_SPLITK") != nullptr && atoi(clhip_cfg("GEMM_SPLITK")) > 1) ? atoi(clhip_cfg("GEMM_SPLITK")) : 3072;
+        if (allow_split && !no_split && !no_splitk && p.ksplit == 1 && p.K >= splitk_min_k && (p.N & 3) == 0) {
             const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
             if (t128 < 256) {
                 const int ksteps = p.K / BK;

@@ -116,20 +116,24 @@ class SGD(_FusedBase):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # Groups with the same (lr, momentum, weight decay) share a launch: the reference's `get_parameters` hands the backbone and the classifier over as two
+        # groups with identical hyper-parameters (core/model/finetune.py:59-64) -- two launches per step for one update rule.
+        batches = {}                                      # (lr, momentum, wd) -> [items, after, zero_mask]
         for group in self.param_groups:
             lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
             whole, rest = self._split(group)
             self._check_unconsumed_shards(rest)
             # every tensor of the group goes into ONE launch (clhip_sgd_step_multi, up to eight per launch): a backbone's flat buffer + the head's
             # weight and bias were three launches per step
-            items, after, zero_mask = [], [], 0
+            entry = batches.setdefault((lr, mom, wd), [[], [], 0])
+            items, after = entry[0], entry[1]
             for o in whole:
                 require_gpu(o._flat)
                 st = self.state[o._params[0]]
                 parts, shard = _dp_plan(o)
                 if self.zero_grads_in_step and shard is None and len(parts) == 1 and len(items) < 8:
                     # the whole flat gradient buffer is consumed by this launch: it leaves zeroed, and the backbone skips its fill at the next backward
-                    zero_mask |= 1 << len(items)
+                    entry[2] |= 1 << len(items)
                     o._gflat_zeroed = True
                 for flat, gflat, sfx in parts:
                     buf = None
@@ -155,6 +159,7 @@ class SGD(_FusedBase):
                 o = _owner_of(p)
                 if o is not None:
                     after.append((o, None))
+        for (lr, mom, wd), (items, after, zero_mask) in batches.items():
             same_dev = len({it[0].device for it in items}) <= 1
             if (len(items) >= 2 or zero_mask) and same_dev:
                 for k in range(0, len(items), 8):

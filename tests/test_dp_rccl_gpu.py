@@ -30,9 +30,16 @@ def _launch(script_args, timeout=900, **extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **extra)
     env.pop("CLHIP_DIST_BACKEND", None)
     env.pop("CLHIP_SHARED_GPU", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port())] + script_args
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    def cmd_with(port):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    # the port is free when it is picked, not necessarily when torchrun's store binds it a second later (an ephemeral port can be handed to another
+    # connection in between: one EADDRINUSE in ~800 launches on the GPU boxes) -- retry with a fresh one
+    for attempt in range(4):
+        r = subprocess.run(cmd_with(_free_port()), cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r
 
 
 @pytest.mark.parametrize("exchange", ["all_reduce", "reduce_scatter"])
