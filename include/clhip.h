@@ -361,7 +361,9 @@ int clhip_conv_dgrad_wgrad(const void* x, const void* dz, const void* w_dg, void
  * with x = relu(coef[0] * x_z + coef[1]) and, when acc != NULL, the producer's BatchNorm-backward sums reduced in the dgrad epilogue
  * with its ReLU mask taken from x_z (z_prod == x_z). */
 typedef struct clhip_bn_input {
-    const double* stat_acc; int replicas;     /* the producer's [replicas][2][C] fp64 sums (clhip_conv_fwd_acc) */
+    const double* stat_acc; int replicas;     /* the producer's [replicas][2][C] fp64 sums (clhip_conv_fwd_acc); NULL = the producer's BatchNorm is in EVAL mode:
+                                                 scale / shift come from running_mean / running_var (required, read only), mean / invstd / coef are not written
+                                                 (nullable), and the launch takes stat_acc == NULL for its own output too (no statistics in eval mode) */
     const float* gamma; const float* beta;
     float* running_mean; float* running_var;  /* nullable pair */
     float momentum, eps;
@@ -395,7 +397,7 @@ int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn /*hos
 typedef struct clhip_bn_res_input {
     const void* res;                          /* [N,H,W,C] the residual */
     void* y;                                  /* out [N,H,W,C] relu(bn(z_in) + res) */
-    void* relu_mask;                          /* out [N*H*W*C/8] bytes, bit e = (stored element e > 0) */
+    void* relu_mask;                          /* out [N*H*W*C/8] bytes, bit e = (stored element e > 0); nullable when the producer is in eval mode (bn->stat_acc == NULL) */
 } clhip_bn_res_input;
 int clhip_conv_fwd_acc_bn_res_input(const void* z_in, const clhip_bn_input* bn /*host*/, const clhip_bn_res_input* rs /*host*/, const void* w_fwd, void* z,
                                     double* stat_acc, int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype,
@@ -457,7 +459,7 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  * consults them: configure before that.  The product never needs a call: the defaults ARE the product; tests use the switches to
  * pin a code path, tools/ to sweep.
  *   dispatch (0 / 1 unless noted):
- *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV64 (0: 64 -> 64 channels on small maps stay on conv4 / wgrad4; CONV64_FWD 0: only their backward; CONV64_BM 64 | 128), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV7 (0: no small-channel entry kernels; FWD7 0 / WGRAD7 0: not their forward / weight-gradient pairs; CONV7_TPW n: tiles per wave), BN_INPUT (0: no lazy BatchNorm inputs), BN_INPUT_WT (0: not on the LDS-DMA kernels of the wide layers), BN_RES_INPUT (0: block outputs keep their own apply launch), BN_GRAD (0: no BatchNorm backward on the operand loads; BN_GRAD_MINC n: only for layers of >= n channels, BN_GRAD_RES 0: not for the +res layers), CONV_V1,
+ *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV64 (0: 64 -> 64 channels on small maps stay on conv4 / wgrad4; CONV64_FWD 0: only their backward; CONV64_BM 64 | 128), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV7 (0: no small-channel entry kernels; FWD7 0 / WGRAD7 0: not their forward / weight-gradient pairs; CONV7_TPW n: tiles per wave), BN_INPUT (0: no lazy BatchNorm inputs), BN_INPUT_WT (0: not on the LDS-DMA kernels of the wide layers), BN_RES_INPUT (0: block outputs keep their own apply launch), EVAL_LAZY (0: eval-mode forwards keep one BatchNorm apply launch per unit instead of the consumer-side forms), BN_GRAD (0: no BatchNorm backward on the operand loads; BN_GRAD_MINC n: only for layers of >= n channels, BN_GRAD_RES 0: not for the +res layers), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
  *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never, 1 where it wins, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, GEMM_SPLITK (0: no split-K for the few-tile / long-K products; n > 1: the minimum K that splits, default 3072), ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small

@@ -679,15 +679,22 @@ extern "C" int clhip_conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_inpu
 extern "C" int clhip_conv_fwd_acc_bn_res_input(const void* z_in, const clhip_bn_input* bn, const clhip_bn_res_input* rs, const void* w_fwd, void* z,
                                                double* stat_acc, int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype,
                                                void* stream) {
-    CLHIP_CHECK_ARG(rs && rs->res && rs->y && rs->relu_mask);
+    CLHIP_CHECK_ARG(rs && rs->res && rs->y && (rs->relu_mask || (bn && bn->stat_acc == nullptr)));      // (eval-mode producers keep no mask)
     return conv_fwd_acc_bn_input(z_in, bn, rs, w_fwd, z, stat_acc, replicas, N, H, W, C, K, ksize, stride, pad, dtype, stream);
 }
 static int conv_fwd_acc_bn_input(const void* z_in, const clhip_bn_input* bn, const clhip_bn_res_input* rs, const void* w_fwd, void* z, double* stat_acc,
                                  int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream) {
     if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
-    CLHIP_CHECK_ARG(z_in && bn && w_fwd && z && stat_acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
-    CLHIP_CHECK_ARG(bn->stat_acc && bn->gamma && bn->beta && bn->mean && bn->invstd && bn->coef && bn->replicas >= 1 && bn->replicas <= 64);
-    CLHIP_CHECK_ARG((bn->running_mean == nullptr) == (bn->running_var == nullptr));
+    CLHIP_CHECK_ARG(z_in && bn && w_fwd && z);
+    if (bn->stat_acc == nullptr) {
+        // eval-mode producer: scale / shift of its RUNNING statistics (read only), no by-products; the launch keeps no statistics of its own output either
+        CLHIP_CHECK_ARG(bn->gamma && bn->beta && bn->running_mean && bn->running_var && stat_acc == nullptr);
+        replicas = 1;
+    } else {
+        CLHIP_CHECK_ARG(stat_acc && replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
+        CLHIP_CHECK_ARG(bn->gamma && bn->beta && bn->mean && bn->invstd && bn->coef && bn->replicas >= 1 && bn->replicas <= 64);
+        CLHIP_CHECK_ARG((bn->running_mean == nullptr) == (bn->running_var == nullptr));
+    }
     CLHIP_CHECK_ARG(clhip_conv_bn_input_supported(N, H, W, C, K, ksize, stride, pad, dtype));
     if (C == 64)
         return clhip_conv64_launch_ex(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, bn,

@@ -129,7 +129,8 @@ struct Conv3Params {
     // relu(scale * z' + shift), applied while the patch is staged -- the producer's BatchNorm-apply launch and its activation tensor do
     // not exist.  Every workgroup derives scale / shift from the producer's fp64 statistics accumulators exactly as bn_apply_train_kernel
     // does; workgroup 0 also leaves mean / invstd / scale / shift for the backward and updates the running statistics.
-    const double* in_acc = nullptr;  // [in_rep][2][Cs], or nullptr: src is an ordinary activation
+    const double* in_acc = nullptr;  // [in_rep][2][Cs], or nullptr: src is an ordinary activation (or in_eval)
+    int in_eval = 0;                 // 1: the producer's BatchNorm is in eval mode -- scale / shift from in_rm / in_rv (read only), nothing is written back
     int in_rep = 1;
     const float* in_gamma = nullptr; const float* in_beta = nullptr;
     float* in_rm = nullptr; float* in_rv = nullptr;
@@ -154,6 +155,16 @@ template <int C>
 __device__ __forceinline__ void lazy_input_coefs(const Conv3Params& p, int bx, float* coef) {
     __shared__ double sred[256];
     const int c = threadIdx.x;
+    if (p.in_eval) {                                       // eval mode: bn_apply_eval_kernel's expressions (bn.hip), so the operand equals the tensor that launch would have written
+        if (c < C) {
+            const float istd = 1.f / sqrtf(p.in_rv[c] + p.in_eps);
+            const float sc = p.in_gamma[c] * istd;
+            coef[c] = sc;
+            coef[C + c] = p.in_beta[c] - p.in_rm[c] * sc;
+        }
+        __syncthreads();
+        return;
+    }
     const bool first = bx == 0;
     const bool upd = first && p.in_rm != nullptr;
     float rm_old = 0.f, rv_old = 0.f, ga_c = 0.f, be_c = 0.f;       // fetched before the replica sum (see lazy_dz_coefs)
@@ -777,7 +788,7 @@ __device__ __forceinline__ void stage_patch(const Conv3Params& p, const int bx, 
             } else if constexpr (lres) {
                 unsigned mb;
                 v = bn_res_relu8_bf16(rc.a, rc.b, isc, ish, mb);
-                if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + at) = v; p.in_mask[(size_t)g * CPP + ch] = (unsigned char)mb; }
+                if (q >= halo && q < halo + BM) { *reinterpret_cast<uint4*>(p.in_y + at) = v; if (p.in_mask != nullptr) p.in_mask[(size_t)g * CPP + ch] = (unsigned char)mb; }
             } else if constexpr (lazy) {
                 v = bn_relu8_bf16(rc.a, isc, ish);
             } else {
@@ -1206,7 +1217,7 @@ int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* st
     p.bn_coef = bn_coef;
     if (rs != nullptr) { p.in_res = static_cast<const bf16_t*>(rs->res); p.in_y = static_cast<bf16_t*>(rs->y); p.in_mask = static_cast<unsigned char*>(rs->relu_mask); }
     if (in != nullptr) {
-        p.in_acc = in->stat_acc; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
+        p.in_acc = in->stat_acc; p.in_eval = in->stat_acc == nullptr ? 1 : 0; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
         p.in_momentum = in->momentum; p.in_eps = in->eps; p.in_mean_o = in->mean; p.in_invstd_o = in->invstd; p.in_coef_o = in->coef;
         const double M = (double)N * H * W;
         p.in_invM = 1.0 / M; p.in_unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
@@ -1247,7 +1258,7 @@ int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* s
     p.bn_coef = bn_coef;
     if (rs != nullptr) { p.in_res = static_cast<const bf16_t*>(rs->res); p.in_y = static_cast<bf16_t*>(rs->y); p.in_mask = static_cast<unsigned char*>(rs->relu_mask); }
     if (in != nullptr) {
-        p.in_acc = in->stat_acc; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
+        p.in_acc = in->stat_acc; p.in_eval = in->stat_acc == nullptr ? 1 : 0; p.in_rep = in->replicas; p.in_gamma = in->gamma; p.in_beta = in->beta; p.in_rm = in->running_mean; p.in_rv = in->running_var;
         p.in_momentum = in->momentum; p.in_eps = in->eps; p.in_mean_o = in->mean; p.in_invstd_o = in->invstd; p.in_coef_o = in->coef;
         const double M = (double)N * H * W;
         p.in_invM = 1.0 / M; p.in_unbias = M > 1.0 ? M / (M - 1.0) : 1.0;

@@ -191,6 +191,40 @@ def test_lazy_batchnorm_inputs_do_not_change_a_resnet32_run():
     assert d <= 1e-5 and dg <= 1e-4
 
 
+@pytest.mark.parametrize("batch", [32, 256, 100])
+def test_eval_forward_with_consumer_side_batchnorm_is_bit_identical(batch):
+    """the eval-mode forward (frozen teachers, validation, herding / NCM features) applies relu(bn(z)) [+ res] of the RUNNING statistics on the next
+    convolution's operand load as well (EVAL_LAZY, default on): features and logits equal the apply-launch form (EVAL_LAZY=0) bit for bit, after a few
+    training steps have moved the running statistics away from (0, 1); the training forward that follows is unaffected"""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    m = _make("ewc", 11)
+    o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+    T.train_steps(m, o, _batches(4, 64), None, "EWC", None, "cuda")
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(batch, 3, 32, 32, generator=g).cuda()
+    out = []
+    try:
+        for lazy in (b"1", b"0", b"1"):
+            assert L.clhip_config(b"EVAL_LAZY", lazy) == 0
+            with torch.no_grad():
+                f = m.network.backbone(x)["features"].clone()
+                lg = m.network(x)
+                lg = (lg[0] if isinstance(lg, (tuple, list)) else lg).clone()
+            torch.cuda.synchronize()
+            out.append((f, lg))
+    finally:
+        L.clhip_config(b"EVAL_LAZY", None)
+    assert torch.isfinite(out[0][0]).all() and float(out[0][0].abs().max()) > 0
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[2][0])
+    m.train()
+    T.train_steps(m, o, _batches(2, 64), None, "EWC", None, "cuda")          # (the plan's lazy bookkeeping is reset by every forward)
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.network.backbone.flat_parameters()[0]).all()
+
+
 def test_lazy_residual_batchnorm_inputs_do_not_change_a_resnet32_run():
     """... and with the LAST BatchNorm + residual add + ReLU of a basic block applied by the next block's first convolution
     (clhip_conv_fwd_acc_bn_res_input, which also writes the block output and its packed mask): a run with BN_RES_INPUT=0 ends where the
