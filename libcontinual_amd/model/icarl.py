@@ -34,6 +34,8 @@ class Model(nn.Module):
 
 
 class ICarl(nn.Module):
+    cuda_graph_safe = True      # observe(): student forward, frozen teacher on its side stream (ops.TeacherPass), one fused CE + KD loss -- no host reads, fixed shapes per batch size
+
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__()
         self.device = kwargs["device"]
