@@ -317,7 +317,7 @@ def conv_rooflines(dev, dtype, B, workload):
                 ms_full = _time_launches(full_chip_run(), 50)
             finally:
                 L.clhip_wgrad4_config(0)
-            e.update(grid_workgroups_in_step=128, full_chip=dict(grid_workgroups=256, launch_ms=ms_full, frac=e["frac"] * ms / ms_full))
+            e.update(grid_workgroups_in_step=160, full_chip=dict(grid_workgroups=256, launch_ms=ms_full, frac=e["frac"] * ms / ms_full))
         ins = [_profile_lookup(workload, sy) for sy in (symbol if isinstance(symbol, (list, tuple)) else [symbol])]
         if all(i is not None for i in ins):      # the same symbol(s) inside the step (two streams share the chip): the conservative figure
             t_in = sum(i["avg_us"] for i in ins) * 1e-3

@@ -309,11 +309,13 @@ bool geometry_sk(int N, int H, int W, int C, int K, Wgrad4Params& p) {
     if ((SP + p.npatch) * 9 > G::NINST * 64) return false;
     p.tiles_c = C / 64; p.tiles = (C / 64) * (K / 64);
     p.total_steps = (p.M + SP - 1) / SP;
-    // 128 workgroups, not 256: inside a training step this kernel runs on the weight-gradient stream beside the dgrad / BatchNorm chain
+    // ~160 workgroups (128 until round 4), not 256: inside a training step this kernel runs on the weight-gradient stream beside the dgrad / BatchNorm chain
     // of the caller's stream, which is the critical path -- a launch that fills every CU (one workgroup each: 96 KB of LDS, 196 VGPRs)
     // costs the step more than its own 2 us (ResNet-18, batch 256: 2.66 ms per step at 256, 2.55 at 128-160; re-swept after the BatchNorm
     // kernels got shorter: 2.39 at 256, 2.28 at 160, 2.23 at 128-136, 2.26 at 104-112; profiles/r02_wgrad4_notes.md)
-    static const int target_env = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 128;
+    // (round 4, with the normal-priority weight-gradient stream and the queue cap: 128: 2.005 / 2.049, 160: 1.996 / 2.037, 192: 1.998 / 2.048, 224: - / 2.114 on two boxes, two or three
+    //  alternating runs each -> 160)
+    static const int target_env = clhip_cfg("WGRAD_TARGET") ? atoi(clhip_cfg("WGRAD_TARGET")) : 160;
     const int target = g_target_w4 > 0 ? g_target_w4 : target_env;
     static const int min_steps = clhip_cfg("WGRAD4_MIN_STEPS") ? atoi(clhip_cfg("WGRAD4_MIN_STEPS")) : 2;
     int splits = (target + p.tiles - 1) / p.tiles;
