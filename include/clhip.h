@@ -479,7 +479,7 @@ const char* clhip_config_get(const char* key);
 /* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never, 1 where it wins (default: N >= 2048,
  * >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
 void clhip_gemm5_config(int mode);
-/* workgroups the LDS-DMA weight-gradient kernel (wgrad4.hip) aims for: 0 = the default (128, chosen for the training step, where the
+/* workgroups the LDS-DMA weight-gradient kernel (wgrad4.hip) aims for: 0 = the default (160 -- 128 until round 4 --, chosen for the training step, where the
  * launch shares the chip with the dgrad / BatchNorm chain of the caller's stream; $CLHIP_WGRAD_TARGET), 256 = one per CU (the kernel
  * alone: bench.py's `full_chip` figures).  The scratch size (clhip_conv_wgrad_ws_bytes) follows the setting. */
 void clhip_wgrad4_config(int target_workgroups);
