@@ -320,13 +320,16 @@ int launch5(const Gemm5Params& p, hipStream_t st) {
 
 }  // namespace
 
-// bf16, N % 256 == 0, K % 32 == 0, operands below 2 GB.  Mode 1 (default) picks the shapes where the kernel beats gemm_nt_kernel
-// (profiles/r02_gemm5_notes.md): wide outputs (N >= 2048: the ViT's qkv / fc1 / fc2-backward GEMMs) with at least 3/4 of a round of
-// tiles and few enough column tiles for an XCD's workgroups to share row panels in L2; mode 2 forces it (tests, micro-benchmarks),
-// mode 0 disables it.  CLHIP_GEMM5 / clhip_gemm5_config.
+// bf16, N % 256 == 0, K % 32 == 0, operands below 2 GB.  Mode 1 picks the shapes where the kernel beats gemm_nt_kernel STAND-ALONE
+// (profiles/r02_gemm5_notes.md: rotating operand sets): wide outputs (N >= 2048: the ViT's qkv / fc1 / fc2-backward GEMMs) with at least 3/4 of a
+// round of tiles and few enough column tiles for an XCD's workgroups to share row panels in L2; mode 2 forces it (tests, micro-benchmarks), mode 0
+// disables it.  CLHIP_GEMM5 / clhip_gemm5_config.
+// DEFAULT since the end of round 4: mode 0.  Inside the ViT steps (operands hot from the previous launch, the step's epilogues) the register-staged
+// kernel with its whole-round / tail split wins on every workload measured -- InfLoRA_OPT batch 128 16.5 -> 16.1 ms, batch 256 31.95 -> 31.05, L2P batch
+// 256 50.5 -> 49.1, batch 16 unchanged (two alternating same-box runs each) -- one 8-wave workgroup per CU leaves nothing to cover its epilogue.
 static int g_mode5 = -1;
 bool clhip_gemm5_supported(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype) {
-    if (g_mode5 < 0) g_mode5 = clhip_cfg("GEMM5") ? atoi(clhip_cfg("GEMM5")) : 1;
+    if (g_mode5 < 0) g_mode5 = clhip_cfg("GEMM5") ? atoi(clhip_cfg("GEMM5")) : 0;
     if (g_mode5 == 0 || dtype != CLHIP_BF16) return false;
     if (N % 256 != 0 || K % 32 != 0 || K < 128 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldr % 4 != 0 || ldh % 8 != 0) return false;
     if ((long long)M * lda * 2 >= (1ll << 31) || (long long)N * ldb * 2 >= (1ll << 31)) return false;
