@@ -486,6 +486,9 @@ size_t clhip_wgrad4_ws_bytes(int N, int H, int W, int C, int K, int ksize, int s
 int clhip_wgrad4_launch(const void* x, const void* dz, float* dw, float* ws, int N, int H, int W, int C, int K, int ksize, int stride, hipStream_t st);
 bool clhip_conv5_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv5.hip
 int clhip_conv5_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, hipStream_t st);
+bool clhip_conv8_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv8.hip
+int clhip_conv8_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, const LazyIn* in,
+                       const void* bn_z, const void* bn_y, const void* bn_mask, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
 static bool use_v3() {
     static const bool v = clhip_cfg("NO_CONV3") == nullptr;    // A/B switch: halo kernel for 3x3 stride-1 layers
     return v;
@@ -558,7 +561,10 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
             hipMemsetAsync(stat_partials + (size_t)tiles_used * 2 * K, 0, (size_t)(tiles_alloc - tiles_used) * 2 * K * sizeof(float), st);
         return clhip_conv16_launch(x, w_fwd, z, stat_partials, stat_acc, stat_rep, N, H, W, C, 0, 0, st);
     }
-    // 64 -> 64 channels on large activations: the weight-stationary kernel (statistics through the accumulators only)
+    // 64 -> 64 channels on large activations: two four-wave workgroups per CU, the filters of 32 output channels resident in each wave (conv8.hip) ...
+    if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv8_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_conv8_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+    // ... or the weight-stationary kernel with one 512-register wave per SIMD (statistics through the accumulators only)
     if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype))
         return clhip_conv5_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype)) {
@@ -610,6 +616,8 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
         return clhip_conv16_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv64_launch_ex(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, st);
+    if (!use_v1() && use_v3() && clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv8_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     if (!use_v1() && use_v3() && clhip_conv5_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv5_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype))

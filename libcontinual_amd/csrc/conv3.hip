@@ -1248,7 +1248,9 @@ int clhip_conv16_launch_ex(const void* src, const void* wt, void* dst, float* st
 bool clhip_conv64_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype) {
     static const bool off = clhip_cfg("CONV64") != nullptr && atoi(clhip_cfg("CONV64")) == 0;
     // small maps only: from ~64 k pixels up conv4 / conv5 (LDS-DMA rings, persistent tiles) win; below, the launch is at its latency floor
-    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == 64 && Cd == 64 && W <= 16 && W >= 2 && H >= 1 && (int64_t)N * H * W <= 32768;
+    static const int max_w = clhip_cfg("CONV64_MAX_W") ? atoi(clhip_cfg("CONV64_MAX_W")) : 16;                 // (experiments: the high-occupancy kernel on the large maps)
+    static const long long max_m = clhip_cfg("CONV64_MAX_M") ? atoll(clhip_cfg("CONV64_MAX_M")) : 32768;
+    return !off && dtype == CLHIP_BF16 && ksize == 3 && stride == 1 && pad == 1 && Cs == 64 && Cd == 64 && W <= max_w && W >= 2 && H >= 1 && (int64_t)N * H * W <= max_m;
 }
 
 int clhip_conv64_launch_ex(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode,

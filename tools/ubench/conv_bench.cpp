@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
     // ablation mode: conv_bench <filter> <reps> abl wm,wn,kg,ck  -> one configuration under every debug mask of interest (no checks)
     const bool abl = argc > 4 && !strcmp(argv[3], "abl");
     const bool trace = argc > 5 && !strcmp(argv[5], "trace");   // ... one wm,wn,kg,ck trace : phase stamps of workgroup 0 (ablation build only)
+    const bool one8 = argc > 4 && !strcmp(argv[3], "one8");    // conv_bench <filter> <reps> one8 - [trace] : conv8.hip only
     const bool one = argc > 4 && !strcmp(argv[3], "one");      // conv_bench <filter> <reps> one wm,wn,kg,ck : only that configuration (PMC passes)
     int acfg[4] = {0, 0, 0, 0};
     if (abl || one) sscanf(argv[4], "%d,%d,%d,%d", &acfg[0], &acfg[1], &acfg[2], &acfg[3]);
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
         {"L1f32 32x32x32 64->64", 32, 32, 32, 64, 64, 0},   {"odd 3x12x20 64->128", 3, 12, 20, 64, 128, 0},
     };
     std::vector<Cfg> cfgs = {
-        {0, 0, 0, 0, 0}, {1, 0, 0, 0, 0}, {2, 0, 0, 0, 0},       // on = 2: the weight-stationary kernel (conv5.hip) where it applies
+        {0, 0, 0, 0, 0}, {1, 0, 0, 0, 0}, {2, 0, 0, 0, 0}, {3, 0, 0, 0, 0},      // on = 2: the weight-stationary kernel (conv5.hip) where it applies; 3: conv8.hip
         {1, 4, 1, 1, 32}, {1, 4, 1, 1, 64}, {1, 2, 1, 1, 32}, {1, 2, 1, 1, 64}, {1, 2, 2, 1, 32}, {1, 2, 2, 1, 64}, {1, 4, 2, 1, 32}, {1, 4, 2, 1, 64},
         {1, 2, 1, 2, 32}, {1, 2, 1, 2, 64}, {1, 1, 2, 2, 32}, {1, 2, 2, 2, 32}, {1, 1, 1, 4, 32}, {1, 1, 1, 4, 64}, {1, 2, 1, 4, 32}, {1, 2, 1, 4, 64}, {1, 1, 2, 4, 32},
     };
@@ -97,11 +98,15 @@ int main(int argc, char** argv) {
             continue;
         }
         if (one) { cfgs.clear(); cfgs.push_back(Cfg{acfg[0] > 0 ? 1 : 0, acfg[0], acfg[1], acfg[2], acfg[3]}); }
+        if (one8) { cfgs.clear(); cfgs.push_back(Cfg{3, 0, 0, 0, 0}); }
         for (const Cfg& cf : cfgs) {
             clhip_conv4_enable(cf.on ? 1 : 0);
             clhip_config("CONV5", cf.on == 2 ? "1" : "0");
             clhip_config("CONV5_MIN_TILES", "1");
-            if (cf.on == 2 && !(Cs == 64 && Cd == 64)) continue;
+            clhip_config("CONV8", cf.on == 3 ? "1" : "0");
+            clhip_config("CONV8_MIN_TILES", "1");
+            if (cf.on >= 2 && !(Cs == 64 && Cd == 64)) continue;
+            if (cf.on == 3 && !(128 % cs.W == 0 && cs.W >= 8 && cs.H % (128 / cs.W) == 0)) continue;
             clhip_conv4_set_cfg(cf.wm, cf.wn, cf.kg, cf.ck);
             if (cf.wm > 0) {
                 if (Cd % (cf.wn * 64) || Cs % cf.ck || (Cs / cf.ck) % cf.kg) continue;
@@ -158,8 +163,18 @@ int main(int argc, char** argv) {
             if (trace) {
                 unsigned long long* dt; CK(hipMalloc(&dt, 512 * 8)); CK(hipMemset(dt, 0, 512 * 8));
                 clhip_conv4_set_trace(dt);
+                cfg_ptr("CONV8_TRACE", dt);
                 run(0, 0); CK(hipStreamSynchronize(st));
                 clhip_conv4_set_trace(nullptr);
+                cfg_ptr("CONV8_TRACE", nullptr);
+                if (cf.on == 3) {
+                    std::vector<unsigned long long> h8(512); CK(hipMemcpy(h8.data(), dt, 512 * 8, hipMemcpyDeviceToHost));
+                    for (int w8 = 0; w8 < 8; ++w8) {
+                        printf("conv8 wg %d wave %d hwid %08llx xcc %llx t0 %+lld:", w8 >> 2, w8 & 3, h8[w8 * 64 + 63] & 0xffffffffull, h8[w8 * 64 + 63] >> 32, (long long)(h8[w8 * 64] - h8[0]));
+                        for (int i = 1; i < 62 && h8[w8 * 64 + i]; ++i) printf(" %llu", h8[w8 * 64 + i] - h8[w8 * 64 + i - 1]);
+                        printf("\n");
+                    }
+                }
                 std::vector<unsigned long long> ht(512); CK(hipMemcpy(ht.data(), dt, 512 * 8, hipMemcpyDeviceToHost));
                 for (int h = 0; h < 2; ++h) {
                     printf("wave %d stamps (deltas, cycles of the 100 MHz-free s_memtime counter):", h * 4);
