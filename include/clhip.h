@@ -85,6 +85,9 @@ int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int accumulate,
  * zeroed by the caller.  3x3 / stride 1 / pad 1 bf16 layers the fourth-generation kernel covers:
  * clhip_conv_dgrad_bn_reduce_supported() != 0. */
 int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
+/* != 0: the layer runs on a kernel that hides this epilogue (conv8.hip: two workgroups per CU, one multiplies while the other reduces), so the
+ * fused form pays on large maps as well -- the plan fuses such layers whatever their pixel count */
+int clhip_conv_dgrad_bn_reduce_overlapped(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype);
 int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod /*nullable*/,
                                const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C, int K,
                                int ksize, int stride, int pad, int dtype, void* stream);

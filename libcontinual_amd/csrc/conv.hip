@@ -638,7 +638,18 @@ extern "C" int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, 
     if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK) return 0;
     if (use_v1() || !use_v3()) return 0;
     return (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype) ||
-            clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
+            clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype) || clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype)) ? 1 : 0;
+}
+
+// ... and where that epilogue is hidden (conv8.hip: the other workgroup of the CU multiplies meanwhile), so that the plan fuses it on large maps too
+extern "C" int clhip_conv_dgrad_bn_reduce_overlapped(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
+    if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK || use_v1() || !use_v3()) return 0;
+    if (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype)) return 0;
+    // OFF by default (CONV8_BNR=1 enables it): the epilogue gathers z' / y' in 8-byte pieces of 128-byte lines (32 lines per load instruction) and
+    // the texture path, not HBM, becomes the limit -- ResNet-18 step 2.02 -> 2.19 ms with the four layer-1 reductions fused (r05 A/B)
+    const char* cfg = clhip_cfg("CONV8_BNR");
+    if (cfg == nullptr || atoi(cfg) == 0) return 0;
+    return clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype) ? 1 : 0;
 }
 
 extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod,
@@ -654,6 +665,8 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
     if (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype))      // 16 -> 16 / 32 -> 32 channels: the register-resident kernels' epilogue
         return clhip_conv16_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
                                       static_cast<hipStream_t>(stream));
+    if (clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv8_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, z_prod, y_prod, nullptr, mean, invstd, acc, replicas, static_cast<hipStream_t>(stream));
     return clhip_conv4_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
                                  static_cast<hipStream_t>(stream));
 }
@@ -724,9 +737,12 @@ extern "C" int clhip_conv_bn_input_wt_supported(int N, int H, int W, int C, int 
     // OFF by default (BN_INPUT_WT=1 enables it): measured on ResNet-18 layer1 at batch 256 the fused launch is 41.5 us against 47.2 us for the two it
     // replaces stand-alone, but inside the step the apply launches run at 10-11 us out of the Infinity Cache and the step got SLOWER (2.095 ->
     // 2.14 ms with the four layer-1 units fused; the +res form loses stand-alone as well: 59 vs 55 us) -- profiles/r04_wt_notes.md
+    // (round 5: conv8.hip hides the transform under the other workgroup's MFMAs, and the step is still neutral -- 2.00-2.06 vs 2.00-2.03 ms: the layer is
+    //  HBM-bound, the fused launch re-reads the halo rows of z' AND r (1.55 x each at 128-pixel tiles) and saves one read of the activation)
     const char* cfg = clhip_cfg("BN_INPUT_WT");
     if (cfg == nullptr || atoi(cfg) == 0) return 0;
     if (conv64_fwd_on() && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 0;      // (that layer runs on the register-staged kernel)
+    if (clhip_conv8_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 1;
     if (clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 1;
     if (clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype) && clhip_conv4_in_supported(N, H, W, C, K)) return 1;
     return 0;
@@ -747,6 +763,8 @@ extern "C" int clhip_conv_fwd_acc_bn_input_wt(const void* z_in, const clhip_bn_i
     in.invM = 1.0 / M; in.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
     in.res = static_cast<const bf16_t*>(rs->res); in.y = static_cast<bf16_t*>(rs->y); in.mask = static_cast<unsigned char*>(rs->relu_mask);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (clhip_conv8_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_conv8_launch(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, &in, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     if (clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return clhip_conv5_launch_in(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, &in, st);
     return clhip_conv4_launch_in(z_in, w_fwd, z, stat_acc, replicas, N, H, W, C, K, &in, st);
 }

@@ -326,7 +326,8 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     for (int i = 0; i < n_units; ++i) {
         Unit& u = p->units[i];
         u.fuse_src_bn = false;
-        if (!fuse_on || u.d.src < 1 || u.raw_src || u.pre_res || u.no_bn || (long long)u.M > fuse_max_m) continue;
+        if (!fuse_on || u.d.src < 1 || u.raw_src || u.pre_res || u.no_bn) continue;
+        if ((long long)u.M > fuse_max_m && !clhip_conv_dgrad_bn_reduce_overlapped(N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, dtype)) continue;
         const int a = u.d.src;                      // the activation; produced by unit a - 1
         const Unit& prod = p->units[a - 1];
         if (prod.no_bn || prod.pre_res || prod.raw_src || prod.has_dzr || prod.rep_bwd <= 0) continue;

@@ -13,8 +13,8 @@ for fn in glob.glob('/tmp/tl_o/**/*kernel_trace.csv', recursive=True):
     rows = list(csv.DictReader(open(fn)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     name = lambda r: re.sub(r'\(anonymous namespace\)::|void |\(.*$', '', r['Kernel_Name'])
-    sg = [i for i, r in enumerate(rows) if name(r).startswith('sgd_kernel')]
-    far = [i for i in range(len(sg) - 1) if sg[i + 1] - sg[i] > 10]      # (two optimizer launches per step: backbone, head)
+    sg = [i for i, r in enumerate(rows) if name(r).startswith('sgd_')]
+    far = [i for i in range(len(sg) - 1) if sg[i + 1] - sg[i] > 10]      # (one or two optimizer launches per step)
     a, b = sg[far[len(far) // 2]], sg[far[len(far) // 2] + 1]
     t0 = int(rows[a]['End_Timestamp'])
     qs = {}
