@@ -91,6 +91,12 @@ int clhip_conv_dgrad_bn_reduce_overlapped(int N, int H, int W, int C, int K, int
 int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod /*nullable*/,
                                const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C, int K,
                                int ksize, int stride, int pad, int dtype, void* stream);
+/* ... with cheaper sources for the producer's ReLU mask (both nullable; kernels that cannot use them fall back to y_prod): mask_prod = its packed mask
+ * [N*H*W][C/8] (bit e of byte c/8 = element c%8 > 0, what clhip_bn_apply_train_mask writes), gamma_prod / beta_prod = its weight / bias for a ReLU straight
+ * behind the BatchNorm (mask = scale z + shift > 0, scale = gamma * invstd, shift = beta - mean * scale as in the forward) */
+int clhip_conv_dgrad_bn_reduce_ex(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod /*nullable*/,
+                                  const void* mask_prod /*nullable*/, const float* gamma_prod /*nullable*/, const float* beta_prod, const float* mean, const float* invstd, double* acc,
+                                  int replicas, int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype, void* stream);
 size_t clhip_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Creal, int K, int ksize, int stride, int pad, int dtype);
 int clhip_conv_wgrad(const void* x, const void* dz, float* dw, void* ws, int N, int H, int W, int C, int Creal, int K, int ksize,
                      int stride, int pad, int dtype, void* stream);

@@ -68,6 +68,8 @@ _PROTOS = {
     "clhip_conv_dgrad": (_i, [_p, _p, _p, _i] + [_i] * 9 + [_p]),
     "clhip_conv_dgrad_bn_reduce_supported": (_i, [_i] * 9),
     "clhip_conv_dgrad_bn_reduce": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
+    "clhip_conv_dgrad_bn_reduce_overlapped": (_i, [_i] * 9),
+    "clhip_conv_dgrad_bn_reduce_ex": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
     "clhip_bn_bwd_apply_acc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _i, _p]),
     "clhip_conv_wgrad_ws_bytes": (_sz, [_i] * 10),
     "clhip_conv_dgrad_wgrad_supported": (_i, [_i] * 10),

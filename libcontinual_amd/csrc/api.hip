@@ -32,9 +32,9 @@ const char* const kKeys[] = {
     // tuning values
     "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
-    "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK",
+    "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "CONV9", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
-    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE", "CONV6_TRACE", "CONV8_TRACE",
+    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE", "CONV6_TRACE", "CONV8_TRACE", "CONV9_TRACE",
 };
 std::mutex g_cfg_mu;
 // values are strdup'ed and never freed: look-up sites cache the pointer (a few bytes per clhip_config call, by design)
@@ -57,6 +57,8 @@ void clhip_conv5_enable(int on);
 void clhip_conv5_min_tiles(int n);
 void clhip_conv6_enable(int on);
 void clhip_conv8_enable(int on);
+void clhip_conv9_enable(int on);
+void clhip_conv9_set_trace(unsigned long long* dev_buf);
 void clhip_conv8_min_tiles(int n);
 void clhip_conv8_set_trace(unsigned long long* dev_buf);
 void clhip_conv6_set_trace(unsigned long long* buf, int wg);
@@ -102,11 +104,13 @@ extern "C" int clhip_config(const char* key, const char* value) {
         clhip_conv6_set_trace(reinterpret_cast<unsigned long long*>(ptr), (end && *end == ',') ? atoi(end + 1) : 0);
         return CLHIP_OK;
     }
+    if (strcmp(key, "CONV9_TRACE") == 0) { clhip_conv9_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "CONV8_TRACE") == 0) { clhip_conv8_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "WGRAD4_TRACE") == 0) { clhip_wgrad4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "CONV5") == 0) clhip_conv5_enable(value ? atoi(v) : -1);                   // immediate AND recorded below
     if (strcmp(key, "CONV6") == 0) clhip_conv6_enable(value ? atoi(v) : -1);
     if (strcmp(key, "CONV8") == 0) clhip_conv8_enable(value ? atoi(v) : -1);
+    if (strcmp(key, "CONV9") == 0) clhip_conv9_enable(value ? atoi(v) : -1);
     if (strcmp(key, "CONV8_MIN_TILES") == 0) clhip_conv8_min_tiles(value ? atoi(v) : -1);
     if (strcmp(key, "CONV5_MIN_TILES") == 0) clhip_conv5_min_tiles(value ? atoi(v) : -1);
     std::lock_guard<std::mutex> lk(g_cfg_mu);

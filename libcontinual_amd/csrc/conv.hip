@@ -488,7 +488,11 @@ bool clhip_conv5_supported(int N, int H, int W, int Cs, int Cd, int ksize, int s
 int clhip_conv5_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, hipStream_t st);
 bool clhip_conv8_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv8.hip
 int clhip_conv8_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, const LazyIn* in,
-                       const void* bn_z, const void* bn_y, const void* bn_mask, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
+                       const void* bn_z, const void* bn_y, const void* bn_mask, const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_invstd,
+                       double* bn_acc, int bn_rep, hipStream_t st);
+bool clhip_conv9_supported(int N, int H, int W, int Cs, int Cd, int ksize, int stride, int pad, int dtype);      // conv9.hip
+int clhip_conv9_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int C, int accumulate, int mode, const LazyIn* in,
+                       const void* bn_z, const void* bn_y, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st);
 static bool use_v3() {
     static const bool v = clhip_cfg("NO_CONV3") == nullptr;    // A/B switch: halo kernel for 3x3 stride-1 layers
     return v;
@@ -563,10 +567,13 @@ static int conv_fwd_impl(const void* x, const void* w_fwd, void* z, float* stat_
     }
     // 64 -> 64 channels on large activations: two four-wave workgroups per CU, the filters of 32 output channels resident in each wave (conv8.hip) ...
     if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv8_supported(N, H, W, C, K, ksize, stride, pad, dtype))
-        return clhip_conv8_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+        return clhip_conv8_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     // ... or the weight-stationary kernel with one 512-register wave per SIMD (statistics through the accumulators only)
     if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype))
         return clhip_conv5_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, 0, 0, st);
+    // 128 -> 128 / 256 -> 256 channels: resident patch, one barrier per 32-KB filter slab (conv9.hip; statistics through the accumulators only)
+    if (!use_v1() && use_v3() && stat_partials == nullptr && clhip_conv9_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_conv9_launch(x, w_fwd, z, stat_acc, stat_rep, N, H, W, C, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype)) {
         int tiles_alloc = clhip_conv_fwd_tiles(N, H, W, C, K, ksize, stride, pad);
         int tiles_used = clhip_conv4_tiles_m(p.M, C, K, W);
@@ -617,9 +624,11 @@ extern "C" int clhip_conv_dgrad(const void* dz, const void* w_dg, void* dx, int 
     if (!use_v1() && use_v3() && clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv64_launch_ex(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, st);
     if (!use_v1() && use_v3() && clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype))
-        return clhip_conv8_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+        return clhip_conv8_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     if (!use_v1() && use_v3() && clhip_conv5_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv5_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, st);
+    if (!use_v1() && use_v3() && clhip_conv9_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv9_launch(dz, w_dg, dx, nullptr, 1, N, H, W, C, accumulate, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     if (!use_v1() && use_v3() && clhip_conv4_supported(N, H, W, K, C, ksize, stride, pad, dtype))
         return clhip_conv4_launch(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, st);
     if (!use_v1() && use_v3() && clhip_conv3_supported(H, W, K, C, ksize, stride, pad, dtype))
@@ -645,16 +654,20 @@ extern "C" int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, 
 extern "C" int clhip_conv_dgrad_bn_reduce_overlapped(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
     if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK || use_v1() || !use_v3()) return 0;
     if (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype)) return 0;
-    // OFF by default (CONV8_BNR=1 enables it): the epilogue gathers z' / y' in 8-byte pieces of 128-byte lines (32 lines per load instruction) and
-    // the texture path, not HBM, becomes the limit -- ResNet-18 step 2.02 -> 2.19 ms with the four layer-1 reductions fused (r05 A/B)
-    const char* cfg = clhip_cfg("CONV8_BNR");
-    if (cfg == nullptr || atoi(cfg) == 0) return 0;
+    const char* cfg = clhip_cfg("CONV8_BNR");                  // 0: keep the separate reduce launches on the large maps (A/B switch)
+    if (cfg != nullptr && atoi(cfg) == 0) return 0;
     return clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype) ? 1 : 0;
 }
 
 extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod,
                                           const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C, int K,
                                           int ksize, int stride, int pad, int dtype, void* stream) {
+    return clhip_conv_dgrad_bn_reduce_ex(dz, w_dg, dx, accumulate, z_prod, y_prod, nullptr, nullptr, nullptr, mean, invstd, acc, replicas, N, H, W, C, K, ksize, stride, pad, dtype, stream);
+}
+
+extern "C" int clhip_conv_dgrad_bn_reduce_ex(const void* dz, const void* w_dg, void* dx, int accumulate, const void* z_prod, const void* y_prod, const void* mask_prod,
+                                             const float* gamma_prod, const float* beta_prod, const float* mean, const float* invstd, double* acc, int replicas, int N, int H, int W, int C,
+                                             int K, int ksize, int stride, int pad, int dtype, void* stream) {
     if (int e = check_conv(N, H, W, C, K, ksize, stride, pad)) return e;
     CLHIP_CHECK_ARG(dz && w_dg && dx && z_prod && mean && invstd && acc);
     CLHIP_CHECK_ARG(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0);
@@ -666,7 +679,10 @@ extern "C" int clhip_conv_dgrad_bn_reduce(const void* dz, const void* w_dg, void
         return clhip_conv16_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
                                       static_cast<hipStream_t>(stream));
     if (clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype))
-        return clhip_conv8_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, z_prod, y_prod, nullptr, mean, invstd, acc, replicas, static_cast<hipStream_t>(stream));
+        return clhip_conv8_launch(dz, w_dg, dx, nullptr, 1, N, H, W, accumulate, 1, nullptr, z_prod, y_prod, mask_prod, gamma_prod, beta_prod, mean, invstd, acc, replicas,
+                                  static_cast<hipStream_t>(stream));
+    if (clhip_conv9_supported(N, H, W, K, C, ksize, stride, pad, dtype))
+        return clhip_conv9_launch(dz, w_dg, dx, nullptr, 1, N, H, W, C, accumulate, 1, nullptr, z_prod, y_prod, mean, invstd, acc, replicas, static_cast<hipStream_t>(stream));
     return clhip_conv4_launch_bn(dz, w_dg, dx, nullptr, nullptr, 1, N, H, W, K, C, accumulate, 1, z_prod, y_prod, mean, invstd, acc, replicas,
                                  static_cast<hipStream_t>(stream));
 }
@@ -743,6 +759,7 @@ extern "C" int clhip_conv_bn_input_wt_supported(int N, int H, int W, int C, int 
     if (cfg == nullptr || atoi(cfg) == 0) return 0;
     if (conv64_fwd_on() && clhip_conv64_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 0;      // (that layer runs on the register-staged kernel)
     if (clhip_conv8_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 1;
+    if (clhip_conv9_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 1;
     if (clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return 1;
     if (clhip_conv4_supported(N, H, W, C, K, ksize, stride, pad, dtype) && clhip_conv4_in_supported(N, H, W, C, K)) return 1;
     return 0;
@@ -764,7 +781,9 @@ extern "C" int clhip_conv_fwd_acc_bn_input_wt(const void* z_in, const clhip_bn_i
     in.res = static_cast<const bf16_t*>(rs->res); in.y = static_cast<bf16_t*>(rs->y); in.mask = static_cast<unsigned char*>(rs->relu_mask);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (clhip_conv8_supported(N, H, W, C, K, ksize, stride, pad, dtype))
-        return clhip_conv8_launch(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, &in, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+        return clhip_conv8_launch(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, &in, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
+    if (clhip_conv9_supported(N, H, W, C, K, ksize, stride, pad, dtype))
+        return clhip_conv9_launch(z_in, w_fwd, z, stat_acc, replicas, N, H, W, C, 0, 0, &in, nullptr, nullptr, nullptr, nullptr, nullptr, 1, st);
     if (clhip_conv5_supported(N, H, W, C, K, ksize, stride, pad, dtype)) return clhip_conv5_launch_in(z_in, w_fwd, z, stat_acc, replicas, N, H, W, 0, 0, &in, st);
     return clhip_conv4_launch_in(z_in, w_fwd, z, stat_acc, replicas, N, H, W, C, K, &in, st);
 }

@@ -46,7 +46,9 @@ struct Conv8Params {
     // dgrad: BatchNorm-backward sums of the layer that PRODUCED the tensor whose gradient this launch completes (see conv4.hip)
     const bf16_t* bn_z;
     const bf16_t* bn_y;          // its activation (ReLU mask y > 0), or nullptr
-    const unsigned char* bn_mask; // ... or its packed mask [M][8], or nullptr (neither: no ReLU)
+    const unsigned char* bn_mask; // ... or its packed mask [M][8]
+    const float* bn_gamma;       // ... or its BatchNorm weight / bias (ReLU straight behind the BatchNorm: mask = scale z' + shift > 0 with the forward's
+    const float* bn_beta;        //     scale = gamma * invstd, shift = beta - mean * scale); none of the three: no ReLU
     const float* bn_mean;
     const float* bn_invstd;
     double* bn_acc;
@@ -89,10 +91,10 @@ __device__ __forceinline__ unsigned or8(unsigned v) {
     return v;
 }
 
-template <int MODE, int XF, bool BNR>
+template <int MODE, int XF, int BNR>      // BNR (dgrad): 0 no sums; the producer's ReLU mask comes 1 from its packed bits, 2 from z' (scale / shift), 3 from its activation, 4 there is no ReLU
 __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
     static_assert(XF == 0 || MODE == 0, "lazy inputs exist in the forward only");
-    static_assert(!BNR || MODE == 1, "BatchNorm-backward sums belong to the dgrad");
+    static_assert(BNR == 0 || MODE == 1, "BatchNorm-backward sums belong to the dgrad");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,6 +191,28 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
 #endif
     };
     auto pdma = [&](int tile, char* b) { dma_from(srs, tile, b); };
+    // dgrad with the producer's BatchNorm-backward sums: z' of THIS wave's 64 pixels x 32 channels (64 bytes per pixel) -> buffer 0, four pieces per
+    // wave, slot n = 64 i + lane = (pixel n / 4, swizzled 16-byte slot n % 4 = chunk ^ ((pixel >> 2) & 3)).  Nobody else reads them: the wave's own
+    // vmcnt wait is all the synchronisation they need.  (The first version gathered z' / y' from global memory in 8-byte pieces, 32 cache lines per
+    // load instruction: the texture path became the limit and the ResNet-18 step went from 2.02 to 2.19 ms.)
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(BNR != 0 ? p.bn_z : p.src), 0, p.M * C8 * 2, 0x00020000);
+    int zrel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = i * 64 + lane, pl = n >> 2, sl = n & 3;
+        zrel[i] = (ph * 64 + pl) * (C8 * 2) + (jj * 4 + (sl ^ ((pl >> 2) & 3))) * 16;
+    }
+    auto zdma = [&](int tile) {
+        if constexpr (BNR != 0) {
+            const int base = tile * BM8 * (C8 * 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(zrs, (lvoid_t*)(smem + wv * 4096 + i * 1024), 16, zrel[i] + base, 0, 0, 0);
+#else
+            (void)base;
+#endif
+        }
+    };
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(XF == 2 ? p.in.res : p.src), 0, p.M * C8 * 2, 0x00020000);
     auto rdma = [&](int tile) { if constexpr (XF == 2) dma_from(rrs, tile, smem); };         // the residual's patch: always buffer 0
 
@@ -240,6 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
         // scale / shift of the producer's BatchNorm from its fp64 sums while the first DMAs fly (fp64 scratch: the statistics rows, idle until the first epilogue)
         lazy_in_coefs(p.in, C8, coefs, reinterpret_cast<double*>(red0), blockIdx.x == 0);
     }
+    if constexpr (BNR == 2) {
+        if (tid < C8) {              // the producer's scale / shift, as its forward formed them (published by the barriers below)
+            const float sc_c = p.bn_gamma[tid] * p.bn_invstd[tid];
+            coefs[tid] = sc_c;
+            coefs[C8 + tid] = p.bn_beta[tid] - p.bn_mean[tid] * sc_c;
+        }
+    }
     wait_vm0_8();
     STAMP8();
     wg_barrier8();
@@ -279,6 +310,8 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
         const char* pb = smem + ((k & 1) ? 1 : 2) * PB;                  // the first tile sits in buffer 2
         char* nb = smem + ((k & 1) ? 2 : 1) * PB;
         if (k + 1 < nmy) { pdma(tile + t_step, nb); rdma(tile + t_step); }       // lands under this tile's MFMAs
+        zdma(tile);
+
         STAMP8();
         f32x16 acc[2];
 #pragma unroll
@@ -325,11 +358,20 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
             const size_t pix = (size_t)tile * BM8 + ph * 64 + i * 32 + l31;
             bf16_t* drow = p.dst + pix * C8 + jj * 32;
             if (MODE == 1 && p.accumulate) {
+                // the old gradient in the STORE pattern (16 bytes = 8 consecutive channels per lane, 32 contiguous bytes per pixel and instruction; the
+                // 8-byte form touched 32 cache lines per instruction for 16 bytes each), the half-waves exchange the halves they hold for each other
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const uint2 old = *reinterpret_cast<const uint2*>(drow + g4 * 8 + kh * 4);
-                    acc[i][4 * g4 + 0] += __uint_as_float(old.x << 16); acc[i][4 * g4 + 1] += __uint_as_float(old.x & 0xffff0000u);
-                    acc[i][4 * g4 + 2] += __uint_as_float(old.y << 16); acc[i][4 * g4 + 3] += __uint_as_float(old.y & 0xffff0000u);
+                for (int pr = 0; pr < 2; ++pr) {
+                    const u32x4 old = *reinterpret_cast<const u32x4*>(drow + pr * 16 + kh * 8);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(old[0], old[2], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(old[1], old[3], false, false);
+                    // lanes 0-31: {own d0, partner's d0}, {own d1, partner's d1} = channels 16 pr + {0..3} and 16 pr + 8 + {0..3};
+                    // lanes 32-63: {partner's d2, own d2}, ... = channels 16 pr + 4 + {0..3} and 16 pr + 12 + {0..3}
+                    const unsigned a0 = s0[0], a1 = s1[0], b0 = s0[1], b1 = s1[1];
+                    acc[i][8 * pr + 0] += __uint_as_float(a0 << 16); acc[i][8 * pr + 1] += __uint_as_float(a0 & 0xffff0000u);
+                    acc[i][8 * pr + 2] += __uint_as_float(a1 << 16); acc[i][8 * pr + 3] += __uint_as_float(a1 & 0xffff0000u);
+                    acc[i][8 * pr + 4] += __uint_as_float(b0 << 16); acc[i][8 * pr + 5] += __uint_as_float(b0 & 0xffff0000u);
+                    acc[i][8 * pr + 6] += __uint_as_float(b1 << 16); acc[i][8 * pr + 7] += __uint_as_float(b1 & 0xffff0000u);
                 }
             }
 #pragma unroll
@@ -341,20 +383,30 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
                 *reinterpret_cast<u32x4*>(drow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
             }
             if constexpr (MODE == 1 && BNR) {
-                // sum g, sum g * z' of the producer with g = dy * (y' > 0), from the fp32 results (conv4.hip's epilogue)
-                const size_t row = pix * C8 + jj * 32 + kh * 4;
-                unsigned mbits = 0xffffffffu;
-                if (p.bn_mask != nullptr) mbits = *reinterpret_cast<const unsigned*>(p.bn_mask + pix * 8 + jj * 4) >> (4 * kh);
+                // sum g, sum g * z' of the producer with g = dy * (y' > 0), from the fp32 results; z' out of this wave's LDS tile
+                const int pl = i * 32 + l31;
+                const char* zl = smem + wv * 4096 + pl * 64 + kh * 8;
+                int cofs = 0;                                    // (opaque: the table reads below are tile-invariant, hoisted they cost 32 registers and spill)
+                asm volatile("" : "+v"(cofs));
+                unsigned mbits = 0xffffffffu;                    // packed ReLU mask of this lane's pixel: the four chunks of this wave's channels
+                if constexpr (BNR == 1) mbits = *reinterpret_cast<const unsigned*>(p.bn_mask + pix * 8 + jj * 4) >> (4 * kh);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const uint2 zz = *reinterpret_cast<const uint2*>(p.bn_z + row + g4 * 8);
-                    uint2 yy = make_uint2(0x3f803f80u, 0x3f803f80u);
-                    if (p.bn_mask == nullptr && p.bn_y != nullptr) yy = *reinterpret_cast<const uint2*>(p.bn_y + row + g4 * 8);
+                    const uint2 zz = *reinterpret_cast<const uint2*>(zl + ((g4 ^ ((pl >> 2) & 3)) << 4));
                     const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u), __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
-                    const float y4[4] = {__uint_as_float(yy.x << 16), __uint_as_float(yy.x & 0xffff0000u), __uint_as_float(yy.y << 16), __uint_as_float(yy.y & 0xffff0000u)};
+                    float y4[4] = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (BNR == 2) {
+                        const int cc = jj * 32 + g4 * 8 + kh * 4;
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(coefs + cofs + cc), sh = *reinterpret_cast<const f32x4*>(coefs + cofs + C8 + cc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y4[e] = fmaf(z4[e], sc[e], sh[e]);
+                    } else if constexpr (BNR == 3) {
+                        const uint2 yy = *reinterpret_cast<const uint2*>(p.bn_y + pix * C8 + jj * 32 + kh * 4 + g4 * 8);
+                        y4[0] = __uint_as_float(yy.x << 16); y4[1] = __uint_as_float(yy.x & 0xffff0000u); y4[2] = __uint_as_float(yy.y << 16); y4[3] = __uint_as_float(yy.y & 0xffff0000u);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const bool on = p.bn_mask != nullptr ? ((mbits >> (8 * g4 + e)) & 1u) != 0u : y4[e] > 0.f;
+                        const bool on = BNR == 1 ? ((mbits >> (8 * g4 + e)) & 1u) != 0u : y4[e] > 0.f;
                         const float g = on ? acc[i][4 * g4 + e] : 0.f;
                         sv[4 * g4 + e] += g;
                         sv[16 + 4 * g4 + e] = fmaf(g, z4[e], sv[16 + 4 * g4 + e]);
@@ -380,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
         STAMP8();
     }
     // ---- the sums: 16-lane reduction, the four half-wave rows through LDS, one fp64 atomic per (which, channel) and workgroup
-    const bool stats = (MODE == 0 && p.stat_acc != nullptr) || (MODE == 1 && BNR);
+    const bool stats = (MODE == 0 && p.stat_acc != nullptr) || (MODE == 1 && BNR != 0);
     double run = 0.0;
     if (stats) {
         row16_sum_n(sv);
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv8_kernel(const Conv8Params p) {
     if constexpr (MODE == 0) {
         if (p.stat_acc != nullptr && tid < 2 * C8)
             atomicAdd(p.stat_acc + ((size_t)(blockIdx.x & (p.stat_rep - 1)) * 2 + (tid >> 6)) * C8 + (tid & 63), run);
-    } else if constexpr (BNR) {
+    } else if constexpr (BNR != 0) {
         // sum g * xhat = invstd * (sum g z' - mean * sum g), in fp64
         double* ex = reinterpret_cast<double*>(red0 + 4 * 2 * C8);      // (the second half of the statistics area)
         if (tid < C8) ex[tid] = run;
@@ -438,7 +490,7 @@ bool geometry8(int N, int H, int W, Conv8Params& p) {
 
 size_t lds8(const Conv8Params& p) { return (size_t)3 * p.patch_bytes + 2 * 4 * 2 * C8 * sizeof(float) + 2 * C8 * sizeof(float); }
 
-template <int MODE, int XF, bool BNR>
+template <int MODE, int XF, int BNR>
 int launch8(Conv8Params& p, hipStream_t st) {
     const size_t lds = lds8(p);
     if (lds > 80 * 1024) { clhip_set_error("conv8: %zu bytes of LDS", lds); return CLHIP_EINVAL; }
@@ -484,8 +536,10 @@ int clhip_conv8_tiles_m(int M) { return (M + BM8 - 1) / BM8; }
 // mode 0: forward (stat_acc may be nullptr); mode 1: dgrad, with the producer's BatchNorm-backward sums when bn_z != nullptr.
 // in != nullptr (forward only): src is the producer's pre-BatchNorm output, the operand relu(bn(src) [+ in->res]) is formed in LDS and written to in->y
 int clhip_conv8_launch(const void* src, const void* wt, void* dst, double* stat_acc, int stat_rep, int N, int H, int W, int accumulate, int mode, const LazyIn* in,
-                       const void* bn_z, const void* bn_y, const void* bn_mask, const float* bn_mean, const float* bn_invstd, double* bn_acc, int bn_rep, hipStream_t st) {
+                       const void* bn_z, const void* bn_y, const void* bn_mask, const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_invstd,
+                       double* bn_acc, int bn_rep, hipStream_t st) {
     Conv8Params p;
+    p.bn_gamma = bn_gamma; p.bn_beta = bn_gamma != nullptr ? bn_beta : nullptr;
     if (!geometry8(N, H, W, p)) { clhip_set_error("conv8: unsupported geometry %d x %d x %d", N, H, W); return CLHIP_EINVAL; }
     if (in != nullptr) {
         if (mode != 0 || in->acc == nullptr || in->y == nullptr) { clhip_set_error("conv8: a lazy input needs the forward mode, the producer's sums and an output activation"); return CLHIP_EINVAL; }
@@ -497,8 +551,11 @@ int clhip_conv8_launch(const void* src, const void* wt, void* dst, double* stat_
     p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_acc = bn_acc; p.bn_rep = bn_rep > 0 ? bn_rep : 1;
     p.trace = g_trace8;
     if (mode == 0) {
-        if (in == nullptr) return launch8<0, 0, false>(p, st);
-        return in->res != nullptr ? launch8<0, 2, false>(p, st) : launch8<0, 1, false>(p, st);
+        if (in == nullptr) return launch8<0, 0, 0>(p, st);
+        return in->res != nullptr ? launch8<0, 2, 0>(p, st) : launch8<0, 1, 0>(p, st);
     }
-    return bn_z != nullptr ? launch8<1, 0, true>(p, st) : launch8<1, 0, false>(p, st);
+    if (bn_z == nullptr) return launch8<1, 0, 0>(p, st);
+    if (bn_mask != nullptr) return launch8<1, 0, 1>(p, st);
+    if (bn_gamma != nullptr) return launch8<1, 0, 2>(p, st);
+    return bn_y != nullptr ? launch8<1, 0, 3>(p, st) : launch8<1, 0, 4>(p, st);
 }

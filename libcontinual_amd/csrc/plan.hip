@@ -1153,9 +1153,12 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                                  u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
         } else if (u.d.src != 0 && u.fuse_src_bn) {
             const Unit& prod = p->units[u.d.src - 1];
-            TRY(clhip_conv_dgrad_bn_reduce(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, ws + prod.z_off, prod.relu ? ws + src.y_off : nullptr,
-                                           fr + prod.f_mean, fr + prod.f_invstd, reinterpret_cast<double*>(ws + p->acc_off) + prod.a_bwd, prod.rep_bwd,
-                                           p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
+            // (the producer's ReLU mask: its packed bits if it keeps them, its scale / shift if the ReLU follows the BatchNorm directly, else its activation)
+            const bool pz = prod.relu && prod.d.res < 0 && !mask_from_y, pb = prod.relu && prod.mask_off != 0 && !mask_from_y;
+            TRY(clhip_conv_dgrad_bn_reduce_ex(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, ws + prod.z_off, prod.relu ? ws + src.y_off : nullptr,
+                                              pb ? ws + prod.mask_off : nullptr, pz ? params + prod.d.gamma_off : nullptr, pz ? params + prod.d.beta_off : nullptr,
+                                              fr + prod.f_mean, fr + prod.f_invstd, reinterpret_cast<double*>(ws + p->acc_off) + prod.a_bwd, prod.rep_bwd,
+                                              p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
             p->bwd_sums_ready[u.d.src - 1] = 1;
         } else if (pair_b) {
             pair_dz = dz;                                      // its partner is the next unit of this sweep

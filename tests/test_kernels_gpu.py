@@ -234,6 +234,126 @@ def test_weight_stationary_conv5(shape):
         assert (a.float() - b.float()).abs().max() <= 2 ** -7 * float(r.abs().max())
 
 
+CONV8_CASES = [(8, 32, 32), (3, 16, 16), (5, 32, 64), (260, 32, 32), (1, 32, 32)]
+
+
+@pytest.mark.parametrize("shape", CONV8_CASES)
+def test_two_workgroups_per_cu_conv8(shape):
+    """conv8.hip (64 -> 64 channels, 3x3 / s1: two four-wave workgroups per CU, the filters of 32 output channels resident per wave, zero-padded
+    XOR-swizzled patch of whole image rows) forced onto small problems (CONV8_MIN_TILES = 1) against the fp64 convolution and against conv4.hip
+    on the same operands: forward + the fp64 BatchNorm accumulators, dgrad, dgrad with accumulation; tiles at the top / bottom of an image and in
+    its middle, 16-wide images (8 rows per tile), more tiles than workgroups (260 images: 2080 tiles, four or five per workgroup), a single tile
+    range per XCD shorter than the grid."""
+    N, H, W = shape
+    case = (N, H, W, 64, 64, 3, 1, 1)
+    L = _lib.lib()
+    code, tdt = DT["bf16"]
+    x, w, xd, wfd, _, _, cpad = conv_setup(case, "bf16", seed=21)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    rep = 4
+    outs = {}
+    try:
+        for which in ("conv8", "conv4"):
+            assert L.clhip_config(b"CONV8", b"1" if which == "conv8" else b"0") == 0
+            assert L.clhip_config(b"CONV8_MIN_TILES", b"1") == 0
+            assert L.clhip_config(b"CONV5", b"0") == 0
+            z = torch.full((N, H, W, 64), float("nan"), dtype=tdt, device=DEV)
+            acc = torch.zeros(rep, 2, 64, dtype=torch.float64, device=DEV)
+            call("clhip_conv_fwd_acc", xd.data_ptr(), wfd.data_ptr(), z.data_ptr(), acc.data_ptr(), rep, N, H, W, 64, 64, 3, 1, 1, code, st())
+            wq = quant(rnd((64, 64, 3, 3), 5, 1.0 / 24.0), tdt)
+            dz = quant(rnd((N, 64, H, W), 6), tdt)
+            wdg = wq.permute(1, 2, 3, 0).contiguous().to(tdt).to(DEV)
+            dzd = to_nhwc(dz, tdt)
+            dx = torch.full((N, H, W, 64), float("nan"), dtype=tdt, device=DEV)
+            call("clhip_conv_dgrad", dzd.data_ptr(), wdg.data_ptr(), dx.data_ptr(), 0, N, H, W, 64, 64, 3, 1, 1, code, st())
+            base = quant(rnd((N, 64, H, W), 7), tdt)
+            dx2 = to_nhwc(base, tdt)
+            call("clhip_conv_dgrad", dzd.data_ptr(), wdg.data_ptr(), dx2.data_ptr(), 1, N, H, W, 64, 64, 3, 1, 1, code, st())
+            torch.cuda.synchronize()
+            outs[which] = (z.clone(), acc.sum(0).cpu(), dx.clone(), dx2.clone())
+    finally:
+        L.clhip_config(b"CONV8", None)
+        L.clhip_config(b"CONV8_MIN_TILES", None)
+        L.clhip_config(b"CONV5", None)
+    z8, s8, dx8, dxa8 = outs["conv8"]
+    z4, s4, dx4, dxa4 = outs["conv4"]
+    assert (from_nhwc(z8).double() - ref).abs().max() <= tol("bf16", ref)
+    r1, r2 = ref.sum(dim=(0, 2, 3)), (ref * ref).sum(dim=(0, 2, 3))
+    assert (s8[0] - r1).abs().max() <= 1e-4 * (ref.abs().sum(dim=(0, 2, 3)).max() + 1e-30)
+    assert (s8[1] - r2).abs().max() <= 1e-4 * (r2.max() + 1e-30)
+    xr = torch.zeros(N, 64, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wq.double(), None, 1, 1).backward(dz.double())
+    assert (from_nhwc(dx8).double() - xr.grad).abs().max() <= tol("bf16", xr.grad)
+    ref2 = xr.grad + base.double()
+    assert (from_nhwc(dxa8).double() - ref2).abs().max() <= tol("bf16", ref2) * 1.5
+    for a, b, r in ((z8, z4, ref), (dx8, dx4, xr.grad), (dxa8, dxa4, ref2)):      # different summation orders: equal to the final bf16 rounding
+        assert (a.float() - b.float()).abs().max() <= 2 ** -7 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("mask_from", ["bits", "z", "y", "none"])
+@pytest.mark.parametrize("accumulate", [0, 1])
+@pytest.mark.parametrize("shape", [(6, 32, 32), (3, 16, 16), (70, 32, 32)])
+def test_conv8_dgrad_with_batchnorm_backward_sums(shape, accumulate, mask_from):
+    """conv8.hip's dgrad epilogue: sum g and sum g * xhat of the PRODUCING layer's BatchNorm backward from the fp32 results, z' staged through LDS by
+    the wave that needs it, the producer's ReLU mask from its packed bits / from z' (scale z' + shift > 0) / from its activation / absent
+    (clhip_conv_dgrad_bn_reduce_ex) -- against the unfused clhip_conv_dgrad on the same kernel (dx bit-identical) and fp64 sums."""
+    N, H, W = shape
+    C = 64
+    L = _lib.lib()
+    code, tdt = DT["bf16"]
+    dzn = quant(rnd((N, C, H, W), 31, 0.5), tdt)
+    wd = quant(rnd((C, 9, C), 32, 0.05), tdt)
+    zp = quant(rnd((N, C, H, W), 33, 1.5) + 0.2, tdt)
+    gamma, beta = rnd((C,), 38) * 0.5 + 1.0, rnd((C,), 39) * 0.2
+    mean, invstd = rnd((C,), 36) * 0.3, rnd((C,), 37).abs() + 0.5
+    sc = gamma * invstd
+    sh = beta - mean * sc
+    if mask_from == "z":
+        yact = torch.relu(zp.float() * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1))          # ReLU straight behind the BatchNorm
+    else:
+        yact = torch.relu(rnd((N, C, H, W), 34))
+    yp = quant(yact, tdt)
+    on = (yp.float() > 0) if mask_from != "none" else torch.ones_like(yp, dtype=torch.bool)
+    old = quant(rnd((N, C, H, W), 35, 0.3), tdt)
+    dzd, wdd, zpd, ypd = to_nhwc(dzn, tdt), wd.to(tdt).to(DEV).contiguous(), to_nhwc(zp, tdt), to_nhwc(yp, tdt)
+    bits = on.permute(0, 2, 3, 1).reshape(-1, C // 8, 8).to(torch.uint8)
+    packed = (bits << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8).to(DEV).contiguous()
+    d = lambda t: t.to(DEV)
+    md, isd, gd, bd = d(mean), d(invstd), d(gamma), d(beta)
+    rep = 4
+    res = {}
+    try:
+        assert L.clhip_config(b"CONV8_MIN_TILES", b"1") == 0
+        assert L.clhip_config(b"CONV8_BNR", b"1") == 0
+        assert L.clhip_conv_dgrad_bn_reduce_overlapped(N, H, W, C, C, 3, 1, 1, code) == 1
+        for fused in (1, 0):
+            dx = to_nhwc(old, tdt).clone() if accumulate else torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
+            acc = torch.zeros(rep, 2, C, dtype=torch.float64, device=DEV)
+            if fused:
+                call("clhip_conv_dgrad_bn_reduce_ex", dzd.data_ptr(), wdd.data_ptr(), dx.data_ptr(), accumulate, zpd.data_ptr(),
+                     ypd.data_ptr() if mask_from != "none" else None, packed.data_ptr() if mask_from == "bits" else None,
+                     gd.data_ptr() if mask_from == "z" else None, bd.data_ptr() if mask_from == "z" else None,
+                     md.data_ptr(), isd.data_ptr(), acc.data_ptr(), rep, N, H, W, C, C, 3, 1, 1, code, st())
+            else:
+                call("clhip_conv_dgrad", dzd.data_ptr(), wdd.data_ptr(), dx.data_ptr(), accumulate, N, H, W, C, C, 3, 1, 1, code, st())
+            torch.cuda.synchronize()
+            res[fused] = (dx.clone(), acc.sum(0).cpu())
+    finally:
+        L.clhip_config(b"CONV8_MIN_TILES", None)
+        L.clhip_config(b"CONV8_BNR", None)
+    assert torch.equal(res[1][0], res[0][0])
+    w4 = wd.double().reshape(C, 3, 3, C).permute(3, 0, 1, 2).contiguous()
+    dx_ref = F.conv_transpose2d(dzn.double(), w4, padding=1)
+    if accumulate:
+        dx_ref = dx_ref + old.double()
+    assert (from_nhwc(res[1][0]).double() - dx_ref).abs().max() <= tol("bf16", dx_ref) * 1.5
+    g = dx_ref * on.double()
+    xhat = (zp.double() - mean.double().view(1, C, 1, 1)) * invstd.double().view(1, C, 1, 1)
+    s_ref = torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))])
+    scale = torch.stack([g.abs().sum((0, 2, 3)), (g * xhat).abs().sum((0, 2, 3))]) + 1e-9
+    assert ((res[1][1] - s_ref).abs() / scale).max() < 4e-3
+
+
 @pytest.mark.parametrize("shape", [(9, 32, 32, 16), (140, 32, 32, 16), (33, 16, 16, 32), (140, 16, 16, 32), (3, 8, 16, 32), (9, 8, 8, 64), (140, 8, 8, 64),
                                    (3, 16, 8, 64), (256, 8, 8, 64), (33, 4, 8, 64)])
 @pytest.mark.parametrize("with_bn,accumulate", [(0, 0), (1, 1), (1, 0)])

@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
     // ablation mode: conv_bench <filter> <reps> abl wm,wn,kg,ck  -> one configuration under every debug mask of interest (no checks)
     const bool abl = argc > 4 && !strcmp(argv[3], "abl");
     const bool trace = argc > 5 && !strcmp(argv[5], "trace");   // ... one wm,wn,kg,ck trace : phase stamps of workgroup 0 (ablation build only)
+    const bool one9 = argc > 4 && !strcmp(argv[3], "one9");    // ... conv9.hip only
     const bool one8 = argc > 4 && !strcmp(argv[3], "one8");    // conv_bench <filter> <reps> one8 - [trace] : conv8.hip only
     const bool one = argc > 4 && !strcmp(argv[3], "one");      // conv_bench <filter> <reps> one wm,wn,kg,ck : only that configuration (PMC passes)
     int acfg[4] = {0, 0, 0, 0};
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
         {"L1f32 32x32x32 64->64", 32, 32, 32, 64, 64, 0},   {"odd 3x12x20 64->128", 3, 12, 20, 64, 128, 0},
     };
     std::vector<Cfg> cfgs = {
-        {0, 0, 0, 0, 0}, {1, 0, 0, 0, 0}, {2, 0, 0, 0, 0}, {3, 0, 0, 0, 0},      // on = 2: the weight-stationary kernel (conv5.hip) where it applies; 3: conv8.hip
+        {0, 0, 0, 0, 0}, {1, 0, 0, 0, 0}, {2, 0, 0, 0, 0}, {3, 0, 0, 0, 0}, {4, 0, 0, 0, 0},      // 4: conv9.hip; on = 2: the weight-stationary kernel (conv5.hip) where it applies; 3: conv8.hip
         {1, 4, 1, 1, 32}, {1, 4, 1, 1, 64}, {1, 2, 1, 1, 32}, {1, 2, 1, 1, 64}, {1, 2, 2, 1, 32}, {1, 2, 2, 1, 64}, {1, 4, 2, 1, 32}, {1, 4, 2, 1, 64},
         {1, 2, 1, 2, 32}, {1, 2, 1, 2, 64}, {1, 1, 2, 2, 32}, {1, 2, 2, 2, 32}, {1, 1, 1, 4, 32}, {1, 1, 1, 4, 64}, {1, 2, 1, 4, 32}, {1, 2, 1, 4, 64}, {1, 1, 2, 4, 32},
     };
@@ -99,13 +100,16 @@ int main(int argc, char** argv) {
         }
         if (one) { cfgs.clear(); cfgs.push_back(Cfg{acfg[0] > 0 ? 1 : 0, acfg[0], acfg[1], acfg[2], acfg[3]}); }
         if (one8) { cfgs.clear(); cfgs.push_back(Cfg{3, 0, 0, 0, 0}); }
+        if (one9) { cfgs.clear(); cfgs.push_back(Cfg{4, 0, 0, 0, 0}); }
         for (const Cfg& cf : cfgs) {
             clhip_conv4_enable(cf.on ? 1 : 0);
             clhip_config("CONV5", cf.on == 2 ? "1" : "0");
             clhip_config("CONV5_MIN_TILES", "1");
             clhip_config("CONV8", cf.on == 3 ? "1" : "0");
             clhip_config("CONV8_MIN_TILES", "1");
-            if (cf.on >= 2 && !(Cs == 64 && Cd == 64)) continue;
+            clhip_config("CONV9", cf.on == 4 ? "1" : "0");
+            if (cf.on == 4 && !((Cs == 128 || Cs == 256) && Cs == Cd)) continue;
+            if ((cf.on == 2 || cf.on == 3) && !(Cs == 64 && Cd == 64)) continue;
             if (cf.on == 3 && !(128 % cs.W == 0 && cs.W >= 8 && cs.H % (128 / cs.W) == 0)) continue;
             clhip_conv4_set_cfg(cf.wm, cf.wn, cf.kg, cf.ck);
             if (cf.wm > 0) {
@@ -164,7 +168,17 @@ int main(int argc, char** argv) {
                 unsigned long long* dt; CK(hipMalloc(&dt, 512 * 8)); CK(hipMemset(dt, 0, 512 * 8));
                 clhip_conv4_set_trace(dt);
                 cfg_ptr("CONV8_TRACE", dt);
+                cfg_ptr("CONV9_TRACE", dt);
                 run(0, 0); CK(hipStreamSynchronize(st));
+                cfg_ptr("CONV9_TRACE", nullptr);
+                if (cf.on == 4) {
+                    std::vector<unsigned long long> h9(512); CK(hipMemcpy(h9.data(), dt, 512 * 8, hipMemcpyDeviceToHost));
+                    for (int w9 = 0; w9 < 8; ++w9) {
+                        printf("conv9 wave %d t0 %+lld:", w9, (long long)(h9[w9 * 64] - h9[0]));
+                        for (int i = 1; i < 64 && h9[w9 * 64 + i]; ++i) printf(" %llu", h9[w9 * 64 + i] - h9[w9 * 64 + i - 1]);
+                        printf("\n");
+                    }
+                }
                 clhip_conv4_set_trace(nullptr);
                 cfg_ptr("CONV8_TRACE", nullptr);
                 if (cf.on == 3) {
