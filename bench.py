@@ -178,13 +178,14 @@ def cpu_baseline(workload, steps, batch):
     def step():
         _, _, loss = m.observe(x, y, True)
         opt.zero_grad(); loss.backward(); opt.step()
-    step()
+    for _ in range(3):
+        step()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
     return dict(value=batch * steps / dt, unit="images/sec", cores=cores, kind="port",
-                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle on {cores} physical cores), 1 warm-up")
+                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle on {cores} physical cores), 3 warm-ups")
 
 
 def _cpu_baseline_vit(workload, steps, batch, cores):
@@ -254,7 +255,7 @@ def _time_launches(run, reps, warm=5):
 def _profile_lookup(workload, symbol):
     """in-step average duration of a kernel symbol from the committed rocprofv3 --kernel-trace --stats summary of THIS command
     (profiles/r02_bench_kernel_stats.json, written by tools/bench_profile.sh); None if absent"""
-    for name in ("r04_bench_kernel_stats.json", "r03_bench_kernel_stats.json", "r02_bench_kernel_stats.json"):
+    for name in ("r05_bench_kernel_stats.json", "r04_bench_kernel_stats.json", "r03_bench_kernel_stats.json", "r02_bench_kernel_stats.json"):
         pj = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pj):
             break
@@ -272,7 +273,7 @@ def _profile_lookup(workload, symbol):
 
 
 def _pmc_lookup(key):
-    for name in ("r04_roofline_pmc.json", "r03_roofline_pmc.json", "r02_roofline_pmc.json"):
+    for name in ("r05_roofline_pmc.json", "r04_roofline_pmc.json", "r03_roofline_pmc.json", "r02_roofline_pmc.json"):
         pj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pj):
             continue
@@ -324,7 +325,11 @@ def conv_rooflines(dev, dtype, B, workload):
             # a helper symbol shared with other kernels (the partial-block reduce runs once behind EVERY weight-gradient launch of the step)
             # counts with the launches it has behind THIS entry's first symbol only
             share = ins[0]["share_of_kernel_time"] + sum(i["share_of_kernel_time"] * min(1.0, ins[0]["calls"] / i["calls"]) for i in ins[1:])
-            e.update(in_step_launch_ms=t_in, in_step_frac=e["frac"] * ms / t_in, in_step_share_of_kernel_time=share, in_step_source=ins[0]["source"])
+            # `frac` / `achieved` = the IN-STEP figure (what follows from profiles/: the launch shares the chip with the other stream), the
+            # live stand-alone measurement of this run is kept beside it
+            e.update(standalone_frac=e["frac"], standalone_achieved=e["achieved"], standalone_launch_ms=ms)
+            e.update(in_step_launch_ms=t_in, frac=e["standalone_frac"] * ms / t_in, achieved=e["standalone_achieved"] * ms / t_in, in_step_frac=e["standalone_frac"] * ms / t_in,
+                     in_step_share_of_kernel_time=share, in_step_source=ins[0]["source"])
         out.append(e)
 
     def wgrad_full(x, dz, dw, N, H, W, C, K, stride):

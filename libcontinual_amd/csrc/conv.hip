@@ -654,8 +654,12 @@ extern "C" int clhip_conv_dgrad_bn_reduce_supported(int N, int H, int W, int C, 
 extern "C" int clhip_conv_dgrad_bn_reduce_overlapped(int N, int H, int W, int C, int K, int ksize, int stride, int pad, int dtype) {
     if (check_conv(N, H, W, C, K, ksize, stride, pad) != CLHIP_OK || use_v1() || !use_v3()) return 0;
     if (clhip_conv16_supported(H, W, K, C, ksize, stride, pad, dtype) || clhip_conv64_supported(N, H, W, K, C, ksize, stride, pad, dtype)) return 0;
-    const char* cfg = clhip_cfg("CONV8_BNR");                  // 0: keep the separate reduce launches on the large maps (A/B switch)
-    if (cfg != nullptr && atoi(cfg) == 0) return 0;
+    // OFF by default (CONV8_BNR=1 enables it).  Correct with every mask source (tests/test_kernels_gpu.py), z' staged through LDS by the wave that needs
+    // it -- and the ResNet-18 step is 5 % SLOWER with the four layer-1 reductions fused (2.14 vs 2.02 ms, r05 A/B): the layer's backward is HBM-bound,
+    // the fused launch takes 47-60 us instead of 22-32 (it reads z' on top of its 67 MB beside the weight-gradient stream), the apply pass that follows
+    // loses the cache hits the reduce pass used to leave it (35-41 vs 19-24 us), and what disappears is a 26-us launch -- profiles/r05_conv_notes.md
+    const char* cfg = clhip_cfg("CONV8_BNR");
+    if (cfg == nullptr || atoi(cfg) == 0) return 0;
     return clhip_conv8_supported(N, H, W, K, C, ksize, stride, pad, dtype) ? 1 : 0;
 }
 

@@ -130,6 +130,8 @@ def main(out_dir=None):
     jobs["l2p"] = vit_job(vit_scenarios.scenario_l2p)
     jobs["inflora"] = vit_job(vit_scenarios.scenario_inflora)
     jobs["inflora_orig"] = vit_job(vit_scenarios.scenario_inflora_orig)
+    # ViT-B/16 at its full geometry through the reference's own classes (batch 2, one forward + backward of the LoRA branch, one L2P step): summaries only
+    jobs["vit_b16_full"] = vit_job(vit_scenarios.scenario_vit_full)
     def schedulers():
         """learning-rate sequences of the reference's own scheduler classes (core/scheduler.py:47-124): value at construction,
         then after every `step()`"""

@@ -367,3 +367,125 @@ def scenario_inflora_orig(adapter):
     res["losses"] = np.asarray(losses, np.float64)
     res["preds"] = np.stack(preds)
     return res
+
+
+# ---------------------------------------------------------------- full geometry: ViT-B/16, 224 x 224
+# The small fixtures above cannot reach the 12-head packing of the attention kernels, the ragged 197- / 222-token key loops or the 768 /
+# 3072-wide GEMM tilings.  This scenario runs the same plugin classes ONCE at the geometry of BASELINE.json's ViT configurations -- batch 2,
+# deterministic weights -- and keeps only small summaries (the cls features, per-tensor norms and corner blocks of the gradients), so that the
+# reference-generated fixture stays well below 1 MB.
+FULL_L2P = dict(pool=10, length=5, top_k=5, total=100, init=10, inc=10, task_num=10, coeff=1.0)
+
+
+def _summ(res, name, g):
+    """norm + an 8 x 8 corner (of the last two dimensions' leading block) of one gradient tensor"""
+    g = np.asarray(g, np.float64)
+    res[name + "/norm"] = np.asarray([np.linalg.norm(g)], np.float64)
+    g2 = g.reshape(-1, g.shape[-1])
+    res[name + "/corner"] = g2[:8, :8].copy()
+    res[name + "/rownorm"] = np.linalg.norm(g2, axis=1)[:64].copy()          # (row SUMS of the prompt gradient vanish: it leaves a LayerNorm)
+
+
+def full_lora_inputs():
+    cfg = ov.VIT_B16
+    P = {k: v.to(torch.float64) for k, v in ov.det_params(cfg, "full/lora", 10, torch.float64).items()}
+    x = fx._t(detrand.uniform("full/lora/x", (2, 3, cfg["img"], cfg["img"]), -1.0, 1.0)).to(torch.float64)
+    cw = torch.from_numpy(np.asarray(detrand.uniform("full/lora/cw", (2, cfg["dim"]), -1.0, 1.0))).to(torch.float64)
+    for k in P:
+        if "lora_B" in k:
+            P[k] = torch.from_numpy(np.asarray(detrand.uniform("full/lora/B/" + k, tuple(P[k].shape), -0.1, 0.1))).to(torch.float64)
+    return cfg, P, x, cw
+
+
+def full_l2p_inputs():
+    """keys built so that every sample votes for the even pool entries by a wide margin (no tie at the vote's cut); the query feature that
+    places them comes from the oracle's fp64 forward (a deterministic function of the tagged weights)"""
+    cfg, c = ov.VIT_B16, FULL_L2P
+    D = cfg["dim"]
+    P = {k: v.to(torch.float64) for k, v in ov.det_params(cfg, "full/l2p", 0, torch.float64).items()}
+    x = fx._t(detrand.uniform("full/l2p/x", (2, 3, cfg["img"], cfg["img"]), -1.0, 1.0)).to(torch.float64)
+    y = torch.tensor([3, 7])
+    with torch.no_grad():
+        q = ov.cls_features(P, x, cfg)
+    qm = torch.nn.functional.normalize(q.mean(0), dim=0)
+    noise = torch.from_numpy(np.asarray(detrand.uniform("full/l2p/key", (c["pool"], D), -0.02, 0.02))).to(torch.float64)
+    sign = torch.tensor([1.0 if j % 2 == 0 else -1.0 for j in range(c["pool"])], dtype=torch.float64)
+    P["prompt.prompt_key"] = sign[:, None] * (1.0 + 0.05 * torch.arange(c["pool"], dtype=torch.float64)[:, None]) * qm[None, :] + noise
+    P["prompt.prompt"] = torch.from_numpy(np.asarray(detrand.uniform("full/l2p/prompt", (1, c["pool"], c["length"], D), 0.0, 1.0))).to(torch.float64)
+    b = 1.0 / np.sqrt(D)
+    P["classifier.weight"] = torch.from_numpy(np.asarray(detrand.uniform("full/l2p/cw", (c["total"], D), -b, b))).to(torch.float64)
+    P["classifier.bias"] = torch.from_numpy(np.asarray(detrand.uniform("full/l2p/cb", (c["total"],), -b, b))).to(torch.float64)
+    return cfg, P, x, y
+
+
+def scenario_vit_full(adapter, parts=("lora", "l2p")):
+    """the reference's classes -> the fixture; the product -> the GPU test; the oracle (fp64) -> tests/test_oracle_vit_golden.py"""
+    if adapter.kind == "oracle":
+        return _vit_full_oracle(parts)
+    ns, dev = adapter.ns, adapter.device
+    dt = fx._DTYPE[0]
+    res = {}
+    if "lora" in parts:
+        cfg, P, x, cw = full_lora_inputs()
+        bb = ns.make_vit(cfg, "MultiHeadAttention_LoRA", 10)
+        bb.load_state_dict({k: v.to(dt) for k, v in P.items()}, strict=True)
+        bb = bb.to(dev)
+        _set_lora(bb, True)
+        names = [k for k in P if "lora_B" in k]
+        for n_, p_ in bb.named_parameters():
+            p_.requires_grad_(n_ in names)
+        f = bb(x.to(dt).to(dev))
+        (f * cw.to(dt).to(dev)).sum().backward()
+        res["lora/feat"] = _np(f)
+        got = dict(bb.named_parameters())
+        for k in names:
+            _summ(res, "lora/grad/" + k, _np(got[k].grad))
+    if "l2p" in parts:
+        cfg, P, x, y = full_l2p_inputs()
+        c = FULL_L2P
+        bb = ns.make_vit(cfg, "MultiHeadAttention", 0)
+        m = ns.L2P(bb, dev, init_cls_num=c["init"], inc_cls_num=c["inc"], num_class=c["total"], task_num=c["task_num"], feat_dim=cfg["dim"],
+                   prompt_length=c["length"], pool_size=c["pool"], top_k=c["top_k"], pull_constraint_coeff=c["coeff"])
+        sd = {("backbone." + k if not k.startswith("classifier") else k): v.to(dt) for k, v in P.items()}
+        m.network.load_state_dict(sd, strict=True)
+        m.network.to(dev)
+        m.before_task(0, None, None, None)
+        m.train()
+        pred, acc, loss = m.observe(adapter.batch(x.to(dt).to(dev), y.to(dev)))
+        named = dict(m.network.named_parameters())
+        res["l2p/loss"] = np.asarray([float(loss.detach())], np.float64)
+        res["l2p/pred"] = pred.detach().cpu().numpy().astype(np.int64)
+        gp = _np(named["backbone.prompt.prompt"].grad)
+        res["l2p/touched"] = (np.abs(gp[0]).reshape(c["pool"], -1).max(1) > 0).astype(np.int64)
+        for n_ in ("backbone.prompt.prompt", "backbone.prompt.prompt_key", "classifier.weight"):
+            _summ(res, "l2p/grad/" + n_, _np(named[n_].grad))
+    return res
+
+
+def _vit_full_oracle(parts):
+    res = {}
+    if "lora" in parts:
+        cfg, P, x, cw = full_lora_inputs()
+        names = [k for k in P if "lora_B" in k]
+        Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+        f = ov.cls_features(Pg, x, cfg, lora=True)
+        (f * cw).sum().backward()
+        res["lora/feat"] = _np(f)
+        for k in names:
+            _summ(res, "lora/grad/" + k, _np(Pg[k].grad))
+    if "l2p" in parts:
+        cfg, P, x, y = full_l2p_inputs()
+        c = FULL_L2P
+        ov.TIES_AT_CUT.clear()
+        Po = {k: v.clone() for k, v in P.items()}
+        m = ov.L2P(Po, cfg, c["init"], c["inc"], c["total"], c["top_k"], c["coeff"])
+        m.before_task(0)
+        pred, acc, loss, ids, norm = m.observe(x, y)
+        assert not ov.TIES_AT_CUT
+        res["l2p/loss"] = np.asarray([float(loss.detach())], np.float64)
+        res["l2p/pred"] = pred.numpy().astype(np.int64)
+        gp = _np(Po["prompt.prompt"].grad)
+        res["l2p/touched"] = (np.abs(gp[0]).reshape(c["pool"], -1).max(1) > 0).astype(np.int64)
+        for n_, k_ in (("backbone.prompt.prompt", "prompt.prompt"), ("backbone.prompt.prompt_key", "prompt.prompt_key"), ("classifier.weight", "classifier.weight")):
+            _summ(res, "l2p/grad/" + n_, _np(Po[k_].grad))
+    return res

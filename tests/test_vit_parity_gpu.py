@@ -246,3 +246,24 @@ def test_vit_b16_full_geometry_l2p_step_vs_oracle(dtype):
         d = float(np.linalg.norm(g - ref_) / (np.linalg.norm(ref_) + 1e-300))
         print(f"ViT-B/16 full geometry L2P step, {dtype}: {n} gradient relnorm {d:.2e}")
         assert d < gtol, (n, d)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vit_b16_full_geometry_reference_fixture(golden, dtype):
+    """The HIP path at the FULL ViT-B/16 geometry against tests/golden/vit_b16_full.npz -- an fp64 run of the REFERENCE's own VisionTransformer /
+    MultiHeadAttention_LoRA / L2P classes (oracle/gen_golden.py `vit_b16_full`), not the oracle: the cls features and every lora_B gradient of the
+    LoRA branch (norm, corner block, row norms), and one L2P step (loss, predictions, voted prompts, clipped gradients).  VERDICT r4 item 6a."""
+    want = golden("vit_b16_full")
+    got = vs.scenario_vit_full(adapter(dtype))
+    ftol, gtol, ltol = (2e-5, 1e-4, 2e-5) if dtype == "f32" else (3e-2, 0.12, 3e-2)
+    assert rel(got["lora/feat"], want["lora/feat"]) < ftol
+    np.testing.assert_array_equal(got["l2p/pred"], want["l2p/pred"])
+    np.testing.assert_array_equal(got["l2p/touched"], want["l2p/touched"])
+    assert abs(float(got["l2p/loss"][0]) - float(want["l2p/loss"][0])) < ltol * abs(float(want["l2p/loss"][0]))
+    worst = (0.0, "")
+    for k in got:
+        if "/grad/" in k:
+            d = rel(got[k], want[k])
+            worst = max(worst, (d, k))
+            assert d < gtol, (k, d)
+    print(f"ViT-B/16 full geometry vs the reference fixture, {dtype}: feature {rel(got['lora/feat'], want['lora/feat']):.2e}, worst gradient summary {worst[0]:.2e} ({worst[1]})")
