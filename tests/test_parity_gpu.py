@@ -11,6 +11,8 @@ shows the CPU fp32 oracle 3e-3 .. 5e-3 off at the fourth step of the EWC / WA sc
 mode -- losses 2e-4 (LwF, DER, LUCIR), 1e-3 (iCaRL), 7e-3 .. 9e-3 (EWC, WA at step 4); final parameters <= 8e-3 of their
 abs-sum; bounds below are ~3x the observed values.  The arithmetic itself is pinned kernel by kernel in test_kernels_gpu.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -59,7 +61,13 @@ def relnorm(a, b):
 
 def relmax(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+    v = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+    if os.environ.get("CLHIP_PRINT_DEVS"):          # bound-setting runs: every measured deviation with the line that asserts on it
+        import inspect
+        fr = inspect.stack()[1]
+        with open(os.environ["CLHIP_PRINT_DEVS"], "a") as f:
+            f.write(f"{fr.function}:{fr.lineno} {v:.3e}\n")
+    return v
 
 
 @pytest.mark.parametrize("arch", ["cifar_resnet32", "resnet18", "resnet32_V2"])
@@ -296,7 +304,7 @@ def test_backbone_golden(golden, arch):
     assert relmax(got["buf_rows"][:, :3], want["buf_rows"][:, :3]) < 1e-4
     got = sc.scenario_backbone(adapter("bf16"), arch)
     assert relmax(got["features_train"], want["features_train"]) < 5e-2
-    assert relmax(got["features_eval"], want["features_eval"]) < 5e-2
+    assert relmax(got["features_eval"], want["features_eval"]) < 2.5e-2      # r05: 6.4e-3 observed (features_train of the worst architecture sits at 2.9e-2: its bound stays)
 
 
 def _param_rel(got, want):
@@ -316,7 +324,7 @@ def test_ewc_golden(golden):
     assert _param_rel(got, want) < 2e-2
     assert relmax(got["rm_last"], want["rm_last"]) < 1e-2
     got = sc.scenario_ewc(adapter("bf16"))
-    assert relmax(got["losses"][:3], want["losses"][:3]) < 5e-2
+    assert relmax(got["losses"][:3], want["losses"][:3]) < 2e-2      # r05: 5.5e-3 observed
     assert relnorm(got["fisher_head_w"], want["fisher_head_w"]) < 0.2
 
 
@@ -365,7 +373,7 @@ def test_lwf_golden(golden, name, cfg):
     assert relmax(got["logits_eval"], want["logits_eval"]) < 3e-2    # eval-mode logits after the three updates (9e-3 observed)
     assert _param_rel(got, want) < 5e-3
     got = sc.scenario_lwf(adapter("bf16"), cfg)
-    assert relmax(got["losses"], want["losses"]) < 5e-2
+    assert relmax(got["losses"], want["losses"]) < 1.5e-2      # r05: 4.6e-3 observed
     assert relmax(got["teacher_rm"], want["teacher_rm"]) < 3e-2
 
 
@@ -418,7 +426,7 @@ def test_icarl_golden(golden, tmp_path):
     differ = got["ncm_pred0"] != want["ncm_pred0"]
     assert (got["ncm_margin0"][differ] < 1e-5).all() and (want["ncm_margin0"][differ] < 1e-5).all(), (got["ncm_margin0"], want["ncm_margin0"], differ)
     got = sc.scenario_icarl(adapter("bf16"), str(tmp_path / "b"))
-    assert relmax(got["losses"][:2], want["losses"][:2]) < 5e-2
+    assert relmax(got["losses"][:2], want["losses"][:2]) < 2.5e-2      # r05: 6.9e-3 observed
     np.testing.assert_array_equal(got["buffer_labels1"], want["buffer_labels1"])
 
 
@@ -432,7 +440,7 @@ def test_lucir_golden(golden):
     assert relmax(got["fc2_w"], want["fc2_w"]) < 2e-3
     assert _param_rel(got, want) < 2e-2
     got = sc.scenario_lucir(adapter("bf16"))
-    assert relmax(got["losses"], want["losses"]) < 5e-2
+    assert relmax(got["losses"], want["losses"]) < 2.5e-2      # r05: 7.1e-3 observed
 
 
 def test_wa_golden(golden):
@@ -452,7 +460,7 @@ def test_wa_golden(golden):
     assert relmax(got["logits_eval"], want["logits_eval"]) < 0.15
     assert _param_rel(got, want) < 2.5e-2
     got = sc.scenario_wa(adapter("bf16"))
-    assert relmax(got["losses"], want["losses"]) < 5e-2
+    assert relmax(got["losses"], want["losses"]) < 2e-2      # r05: 6.5e-3 observed
     assert relmax(got["teacher_rm"], want["teacher_rm"]) < 3e-2
 
 
@@ -470,7 +478,7 @@ def test_der_golden(golden, monkeypatch):
     assert _param_rel(got, want) < 2e-3
     monkeypatch.setenv("CLHIP_DTYPE", "bf16")
     got = sc.scenario_der(adapter("bf16"))
-    assert relmax(got["losses"], want["losses"]) < 5e-2
+    assert relmax(got["losses"], want["losses"]) < 6e-3      # r05: 1.6e-3 observed
     assert bool(got["frozen_same"])
     assert relmax(got["rm_frozen"], want["rm_frozen"]) < 3e-2
 
@@ -492,8 +500,8 @@ def test_bic_golden(golden):
         if k.startswith("split"):
             np.testing.assert_array_equal(got[k], want[k], err_msg=k)
     got = sc.scenario_bic(adapter("bf16"))
-    assert relmax(got["losses"], want["losses"]) < 5e-2
-    assert relmax(got["losses2"], want["losses2"]) < 5e-2
+    assert relmax(got["losses"], want["losses"]) < 1e-3      # r05: 1.3e-4 observed
+    assert relmax(got["losses2"], want["losses2"]) < 8e-3      # r05: 2.1e-3 observed
     assert np.abs(got["bias"] - want["bias"]).max() < 2e-3
 
 
