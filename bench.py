@@ -691,7 +691,9 @@ def main():
         mine.update(dp_breakdown(model, opt, reducer, batches, name, dev))
         every = [None] * world
         dist.all_gather_object(every, mine)
-        dp = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), exchange=reducer.exchange, ranks=every)
+        import libcontinual_amd
+        dp = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), exchange=reducer.exchange, ranks=every,
+                  hw_queue_cap=dict(zip(("state", "GPU_MAX_HW_QUEUES"), libcontinual_amd.hw_queue_cap_state())))
     if rank != 0:
         return
     ips = world * a.batch * a.steps / dt

@@ -17,7 +17,35 @@ import os as _os
 # only same-stream packets carry the barrier bit: ResNet-18 task-0 step 2.1135 / 2.1025 / 2.098 / 2.096 ms at 1 / 3 / 4 / 8 queues), so the cap is
 # set here for every process that imports the package before the HIP runtime starts; an explicit GPU_MAX_HW_QUEUES in the environment wins.
 # Measurements: profiles/r04_stream_stall.md.
+_QUEUE_CAP_PRESET = "GPU_MAX_HW_QUEUES" in _os.environ
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
+
+def hw_queue_cap_state():
+    """-> ("ok" | "late" | "user", detail).  The cap only takes effect if it is in the environment BEFORE the HIP runtime initialises (ADVICE r4 /
+    VERDICT r4 item 7a): "late" = this package was imported after torch had already started the runtime without the variable set -- the runtime
+    keeps its default of four queues, which the two-network steps still tolerate (2.90 vs 2.61 ms) but which is not what was measured; "user" =
+    the caller chose a value itself."""
+    if _QUEUE_CAP_PRESET:
+        return "user", _os.environ.get("GPU_MAX_HW_QUEUES")
+    return ("late" if _HIP_WAS_UP else "ok"), "3"
+
+
+def _hip_already_up():
+    import sys
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+_HIP_WAS_UP = _hip_already_up()
+if _HIP_WAS_UP and not _QUEUE_CAP_PRESET:
+    import warnings as _warnings
+    _warnings.warn("libcontinual_amd was imported after the HIP runtime had started: GPU_MAX_HW_QUEUES=3 cannot take effect any more (the runtime keeps its "
+                   "default of 4 hardware queues).  Steps that run a frozen teacher beside the student keep their branch streams off, so nothing stalls, "
+                   "but import libcontinual_amd (or set GPU_MAX_HW_QUEUES=3) before the first torch.cuda call to get the measured configuration.")
 
 from . import _lib  # noqa: E402,F401
 

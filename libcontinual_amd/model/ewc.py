@@ -208,6 +208,8 @@ class EWC(Finetune):
         # diagonals are a stated output of the reference (ewc.py:147-205) and squares of bf16-path gradients are 20-40 % off per
         # entry on the fixtures, while the fp32 pass holds all 101 tensors to 1.3e-3 (tests/test_parity_gpu.py).  It runs once per
         # task over the task's data; the training steps keep the plan of the backbone's own dtype.
+        # (round 5: replaying this loop as a HIP graph was built and measured -- 1.86 vs 1.84 ms per batch of 32: the pass is not host-bound, its fp32
+        #  plan runs the generic implicit-GEMM / weight-gradient kernels, 1.92 ms of kernel time per batch; profiles/r05_notes.md)
         with bb.compute_dtype(self.kwargs.get("fisher_dtype", "f32")):
             for data in train_loader:
                 x, y = self._xy(data)

@@ -202,6 +202,9 @@ def attach(model, optimizer, reducer):
     own = reducer is not None and bool(getattr(model, "reduces_own_gradients", False))
     if reducer is not None:
         reducer.optimizer = optimizer
+        # the hardware-queue cap the multi-stream steps were measured under: say so (once) if this process started the HIP runtime without it
+        from . import hw_queue_cap_state
+        reducer.hw_queue_cap = hw_queue_cap_state()
         if reducer.world > 1 and os.environ.get("CLHIP_BRANCH_STREAM") is None:
             # multi-rank steps already run main + weight-gradient + the collective's stream(s): the plans' shortcut-branch stream (+0.5 % on one GPU)
             # stays off -- a fifth stream in one step is what made the LwF teacher step 2.4x slower (profiles/r03_step_notes.md), and the multi-GPU
