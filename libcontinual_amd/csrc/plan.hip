@@ -87,11 +87,15 @@ struct clhip_plan {
     std::vector<Act> acts;
     size_t ws_bytes, shadow_bytes;
     size_t dz_off;           // scratch for the pre-BN gradient
+    static constexpr int kDz = 4;   // dz buffers of the two-stream backward (round 5: four instead of two -- the caller's chain may run up to three units ahead
+                             // of the weight-gradient stream, which is the longer of the two on the 8x8 / 4x4 stages; DZ_BUFFERS = 2 restores the twin)
+    size_t dz_offs[kDz];
+    int n_dz;
     size_t dz_off2;          // its twin: units alternate, so unit i's weight gradient (side stream) may still read one while unit i-1's
                              // BatchNorm backward (main stream) fills the other
     hipStream_t side;        // weight-gradient stream (created on first use), with the events that order it against the caller's stream
-    hipEvent_t ev_dz[2], ev_wg[2], ev_end;
-    bool wg_pending[2];
+    hipEvent_t ev_dz[kDz], ev_wg[kDz], ev_end;
+    bool wg_pending[kDz];
     // branch stream: the 1x1 shortcut convolution + BatchNorm of a down-sampling block is independent of the block's first 3x3 unit in
     // the forward, and its BatchNorm backward / input gradient / weight gradient are independent of that unit's in the backward: small
     // launches that do not fill the chip, run beside the main path instead of in front of it
@@ -266,6 +270,15 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     }
     p->dz_off = off; off = align_up(off + max_z);
     p->dz_off2 = off; off = align_up(off + max_z);
+    {
+        static const int ndz_cfg = clhip_cfg("DZ_BUFFERS") ? atoi(clhip_cfg("DZ_BUFFERS")) : clhip_plan::kDz;
+        p->n_dz = (p->side_ok && ndz_cfg >= 2 && ndz_cfg <= clhip_plan::kDz) ? ndz_cfg : 2;
+        p->dz_offs[0] = p->dz_off; p->dz_offs[1] = p->dz_off2;
+        for (int q = 2; q < clhip_plan::kDz; ++q) {
+            p->dz_offs[q] = p->dz_off;
+            if (q < p->n_dz) { p->dz_offs[q] = off; off = align_up(off + max_z); }
+        }
+    }
     p->wg_off = off; off = align_up(off + max_wg);
     // networks whose weight gradients stay on the caller's stream (no layer big enough for the side stream: the CIFAR ResNet-32s): one
     // scratch region PER UNIT, so that the partial-block reduces can wait for the end of the backward and run as one launch
@@ -451,7 +464,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
 extern "C" void clhip_plan_destroy(clhip_plan* p) {
     if (p && p->side) {
         (void)hipStreamSynchronize(p->side);
-        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(p->ev_dz[k]); (void)hipEventDestroy(p->ev_wg[k]); }
+        for (int k = 0; k < clhip_plan::kDz; ++k) { (void)hipEventDestroy(p->ev_dz[k]); (void)hipEventDestroy(p->ev_wg[k]); }
         (void)hipEventDestroy(p->ev_end);
         (void)hipStreamDestroy(p->side);
     }
@@ -933,7 +946,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         // write-back + invalidate in the middle of the caller's stream; CLHIP_EVENT_FLAGS overrides the flag word)
         static const unsigned ev_flags = clhip_cfg("EVENT_FLAGS") ? (unsigned)strtoul(clhip_cfg("EVENT_FLAGS"), nullptr, 0)
                                                                       : (hipEventDisableTiming | hipEventDisableSystemFence);
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < clhip_plan::kDz; ++k) {
             (void)hipEventCreateWithFlags(&p->ev_dz[k], ev_flags);
             (void)hipEventCreateWithFlags(&p->ev_wg[k], ev_flags);
             p->wg_pending[k] = false;
@@ -975,13 +988,16 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         return clhip_bn_apply(ws + ua.z_off, fr + ua.f_scale, fr + ua.f_shift, nullptr, ws + p->acts[a + 1].y_off, ua.M, ua.d.cout, 1, p->dtype, stream);
     };
     int k = 0;
-    for (int i = unit_hi - 1; i >= unit_lo; --i, k ^= 1) {
+    const int n_dz = two_streams ? p->n_dz : 2;
+    auto any_pending = [&]() { for (int q = 0; q < clhip_plan::kDz; ++q) if (p->wg_pending[q]) return true; return false; };
+    auto clear_pending = [&]() { for (int q = 0; q < clhip_plan::kDz; ++q) p->wg_pending[q] = false; };
+    for (int i = unit_hi - 1; i >= unit_lo; --i, k = (k + 1) % n_dz) {
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
         void* dres = (u.d.res >= 0 && !u.pre_res) ? ws + p->acts[u.d.res].dy_off : nullptr;
         const bool pair_b = pair_on && u.pair >= 0 && u.d.ksize == 1 && u.pair == i - 1 && u.pair >= unit_lo;
-        char* dz = ws + ((two_streams ? k != 0 : pair_b) ? p->dz_off2 : p->dz_off);
+        char* dz = ws + (two_streams ? p->dz_offs[k] : (pair_b ? p->dz_off2 : p->dz_off));
         if (br_on && u.branch >= 0 && p->bfork_ev[u.branch] != nullptr) {
             // ---- shortcut branch (1x1 conv -> BN, its activation consumed as a residual only): BatchNorm backward, input gradient and weight
             //      gradient on the branch stream, beside the main path's next unit (which shares nothing with it but the gradient of their
@@ -1085,14 +1101,14 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             }
             (void)hipStreamWaitEvent(p->side, p->ev_dz[k], 0);
             wg_stream = p->side;
-        } else if (two_streams && (p->wg_pending[0] || p->wg_pending[1]) &&
+        } else if (two_streams && any_pending() &&
                    (clhip_cfg("WGRAD_ALWAYS_QUEUE") != nullptr ||
                     clhip_conv_wgrad_ws_bytes(p->N, u.H, u.W, u.cin_pad, u.d.cin, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype) > 0)) {
             // this unit's weight gradient shares the partial-sum scratch with the ones in flight on the side stream: queue behind them
             // (the atomic kernels -- the stem -- use no scratch and run beside the side stream's tail instead of behind it)
             (void)hipEventRecord(p->ev_end, p->side);
             (void)hipStreamWaitEvent(main_s, p->ev_end, 0);
-            p->wg_pending[0] = p->wg_pending[1] = false;
+            clear_pending();
         }
         if (defer_side) clhip_wgrad_defer_pause(!on_side);             // only the side stream's launches are collected
         // layers whose dgrad and weight gradient are both launches at their latency floor on this one stream: ONE launch for the two
@@ -1186,10 +1202,10 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         p->br_act = -1;
     }
     for (int q = 0; q < clhip_plan::kMaxBranch && br_on; ++q) p->bfork_ev[q] = nullptr;      // (a consumer whose branch unit lies outside this range)
-    if (two_streams && (p->wg_pending[0] || p->wg_pending[1])) {      // the caller's stream owns the gradients again when this call returns
+    if (two_streams && any_pending()) {      // the caller's stream owns the gradients again when this call returns
         (void)hipEventRecord(p->ev_end, p->side);
         (void)hipStreamWaitEvent(main_s, p->ev_end, 0);
-        p->wg_pending[0] = p->wg_pending[1] = false;
+        clear_pending();
     }
     return CLHIP_OK;
 }
