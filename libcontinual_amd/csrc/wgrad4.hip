@@ -232,6 +232,13 @@ __global__ __launch_bounds__(512) void conv_wgrad4_kernel(const Wgrad4Params p) 
         wg_barrier4();                                               // ... everybody's; and the other stage is no longer read
         STAMP4();
         if (i + 1 < nst) dma(s_beg + i + 1, stage ^ 1);              // one step (1-1.5 us of MFMAs) ahead
+        // Round-5 measurements of this loop (profiles/r05_conv_notes.md section 5; 160 workgroups, cycles per 128-pixel step of workgroup 0):
+        // as it stands 4 450 (2 304 of matrix pipe); DMA alone 2 100 (= 7.7 TB/s over the 160 CUs: the memory side is at its roofline);
+        // MFMAs + fragment reads alone 3 100; conflict-free fragment addresses: no change; fragment reads two slots ahead of their
+        // MFMAs (hipcc keeps ONE input fragment: read -> wait -> 4 MFMAs): 3 900 per step and the SAME 42 us per launch, 0.3 % slower
+        // inside the step; the six DMA instructions spread over the step's MFMAs instead of behind the barrier: 52 us (they land late).
+        // With no MFMAs at all the launch + its reduce still take 31-35 of the 42 us: prologue 3.3, 13 DMA steps 13, exchange +
+        // partial block 5.4, reduce launch 7.4.
         const char* sb = smem + stage * STAGE;
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
