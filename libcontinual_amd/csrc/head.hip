@@ -839,10 +839,12 @@ extern "C" int clhip_herding_select(const float* feats, int n, int D, int m, int
     const size_t lds = (size_t)n * (D + 1) * sizeof(float);
     const bool in_lds = lds <= 150 * 1024;
     if (in_lds) {
-        static size_t attr = 0;
-        if (lds > attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(herding_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { clhip_set_error("clhip_herding_select: cannot reserve LDS"); return CLHIP_EHIP; }
-            attr = 150 * 1024;
+        int dev = 0;                                     // function attributes are per device (a process may drive several)
+        (void)hipGetDevice(&dev);
+        static size_t attr[16] = {0};
+        if (dev < 0 || dev >= 16 || lds > attr[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(herding_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { clhip_set_error("clhip_herding_select: cannot reserve 150 KB of LDS on device %d", dev); return CLHIP_EHIP; }
+            if (dev >= 0 && dev < 16) attr[dev] = 150 * 1024;
         }
     }
     hipLaunchKernelGGL(herding_kernel, dim3(1), dim3(256), in_lds ? lds : 0, ST, feats, n, D, m, chosen, ws, in_lds ? 1 : 0);
@@ -856,10 +858,12 @@ extern "C" int clhip_herding_select_batched(const float* feats, const int32_t* o
     int lds_rows = (int)((150 * 1024) / ((size_t)(D + 1) * sizeof(float)));
     if (lds_rows > max_rows) lds_rows = max_rows;
     const size_t lds = (size_t)lds_rows * (D + 1) * sizeof(float);
-    static size_t attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(herding_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { clhip_set_error("clhip_herding_select_batched: cannot reserve LDS"); return CLHIP_EHIP; }
-        attr = 150 * 1024;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static size_t attr[16] = {0};
+    if (dev < 0 || dev >= 16 || lds > attr[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(herding_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { clhip_set_error("clhip_herding_select_batched: cannot reserve 150 KB of LDS on device %d", dev); return CLHIP_EHIP; }
+        if (dev >= 0 && dev < 16) attr[dev] = 150 * 1024;
     }
     hipLaunchKernelGGL(herding_batched_kernel, dim3(n_classes), dim3(256), lds, ST, feats, offsets, D, m, chosen, ws, lds_rows);
     CLHIP_LAUNCH_CHECK();

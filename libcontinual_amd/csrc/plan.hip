@@ -117,6 +117,9 @@ struct clhip_plan {
     bool use_acc;            // some unit takes its BN statistics through the fp64 accumulators (see Unit::acc_fwd)
     std::vector<char> res_pending;      // per unit: its forward skipped the (+res) apply launch and its consumer has not run yet
     std::vector<char> wt_pending;       // ... likewise for the write-through form of the wide layers
+    const float* params_dev = nullptr;  // the parameter / running-statistics pointers of the last forward (clhip_plan_read_act rebuilds an eval-lazy activation from them)
+    const float* bn_stats_dev = nullptr;
+    std::vector<char> eval_unwritten;   // per unit: the last EVAL forward consumed its BatchNorm on the next convolution's operand load and never wrote the activation
     std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
     int feat_dim;
@@ -393,6 +396,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     // on its operand load (forward) and in its fused dgrad + weight-gradient launch (backward)
     for (auto& u : p->units) { u.lazy_to = u.lazy_from = -1; }
     p->lazy_live.assign(p->units.size(), 0);
+    p->eval_unwritten.assign(p->units.size(), 0);
     static const bool mask_y = clhip_cfg("BN_MASK_FROM_Y") != nullptr;
     for (int a = 0; a + 1 < n_units && want_acc && !mask_y; ++a) {
         Unit& ua = p->units[a];
@@ -731,7 +735,8 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const char* elazy_cfg = clhip_cfg("EVAL_LAZY");
     const bool eval_lazy = !training && p->use_acc && p->dtype == CLHIP_BF16 && lazy_env && !(rlazy_cfg != nullptr && atoi(rlazy_cfg) == 0) &&
                            !(elazy_cfg != nullptr && atoi(elazy_cfg) == 0);
-    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = 0;
+    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = 0;
+    p->params_dev = params; p->bn_stats_dev = bn_stats;
     int fwd_pair_done = -1;                                  // the 3x3/s2 unit whose launch also ran its shortcut partner's convolution
     for (size_t i = 0; i < p->units.size(); ++i) {
         const Unit& u = p->units[i];
@@ -854,6 +859,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 TRY(clhip_conv_fwd_acc_bn_input(ws + a.z_off, &bi, sh + u.sh_fwd, ws + u.z_off, nullptr, 1, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride,
                                                 u.d.pad, p->dtype, stream));
                 p->lazy_live[u.lazy_from] = 0;
+                p->eval_unwritten[u.lazy_from] = 1;       // clhip_plan_read_act materialises it on demand
             } else {
                 TRY(clhip_conv_fwd(in, sh + u.sh_fwd, ws + u.z_off, nullptr, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
             }
@@ -1223,6 +1229,18 @@ extern "C" int clhip_plan_read_act(clhip_plan* p, const void* workspace, int idx
         float* fr = reinterpret_cast<float*>(wsm + p->f_base);
         if (int e = clhip_bn_apply(wsm + ua.z_off, fr + ua.f_scale, fr + ua.f_shift, nullptr, wsm + a.y_off, ua.M, ua.d.cout, 1, p->dtype, stream)) return e;
         p->lazy_live[idx - 1] = 0;
+    }
+    if (which == 0 && idx >= 1 && p->eval_unwritten[idx - 1]) {
+        // the eval forward applied this unit's BatchNorm (running statistics) on its consumer's operand load: the buffer holds whatever an
+        // earlier pass left there.  Its z is intact, so the apply launch the eager eval path would have made produces the same values now.
+        const Unit& ua = p->units[idx - 1];
+        if (p->params_dev == nullptr || p->bn_stats_dev == nullptr) { clhip_set_error("clhip_plan_read_act: activation %d was not written by the eval forward (EVAL_LAZY) and the plan has no parameter pointers to rebuild it from", idx); return CLHIP_EINVAL; }
+        char* wsm = static_cast<char*>(const_cast<void*>(workspace));
+        const float* params = p->params_dev; const float* bn_stats = p->bn_stats_dev;
+        const void* res_e = ua.d.res >= 0 ? wsm + p->acts[ua.d.res].y_off : nullptr;
+        if (int e = clhip_bn_apply_eval(wsm + ua.z_off, params + ua.d.gamma_off, params + ua.d.beta_off, bn_stats + ua.d.rm_off, bn_stats + ua.d.rv_off, kBnEps, res_e,
+                                        wsm + a.y_off, ua.M, ua.d.cout, ua.relu, p->dtype, stream)) return e;
+        p->eval_unwritten[idx - 1] = 0;
     }
     const char* src = which == 0 ? ws + a.y_off : (which == 1 ? ws + p->units[idx - 1].z_off : ws + a.dy_off);
     return clhip_nhwc_to_nchw(src, out_nchw, p->N, a.C, a.H, a.W, p->dtype, stream);

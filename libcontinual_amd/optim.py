@@ -118,14 +118,14 @@ class SGD(_FusedBase):
     def step(self, closure=None):
         # Groups with the same (lr, momentum, weight decay) share a launch: the reference's `get_parameters` hands the backbone and the classifier over as two
         # groups with identical hyper-parameters (core/model/finetune.py:59-64) -- two launches per step for one update rule.
-        batches = {}                                      # (lr, momentum, wd) -> [items, after, zero_mask]
+        batches = {}                                      # (lr, momentum, wd) -> [items, after, zero_mask, owners whose gradient buffer the launch zeroes]
         for group in self.param_groups:
             lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
             whole, rest = self._split(group)
             self._check_unconsumed_shards(rest)
             # every tensor of the group goes into ONE launch (clhip_sgd_step_multi, up to eight per launch): a backbone's flat buffer + the head's
             # weight and bias were three launches per step
-            entry = batches.setdefault((lr, mom, wd), [[], [], 0])
+            entry = batches.setdefault((lr, mom, wd), [[], [], 0, []])
             items, after = entry[0], entry[1]
             for o in whole:
                 require_gpu(o._flat)
@@ -134,7 +134,7 @@ class SGD(_FusedBase):
                 if self.zero_grads_in_step and shard is None and len(parts) == 1 and len(items) < 8:
                     # the whole flat gradient buffer is consumed by this launch: it leaves zeroed, and the backbone skips its fill at the next backward
                     entry[2] |= 1 << len(items)
-                    o._gflat_zeroed = True
+                    entry[3].append(o)                # flagged AFTER the launch that really zeroes it (the per-tensor fallback below does not)
                 for flat, gflat, sfx in parts:
                     buf = None
                     if mom != 0:
@@ -159,11 +159,13 @@ class SGD(_FusedBase):
                 o = _owner_of(p)
                 if o is not None:
                     after.append((o, None))
-        for (lr, mom, wd), (items, after, zero_mask) in batches.items():
+        for (lr, mom, wd), (items, after, zero_mask, zeroed) in batches.items():
             same_dev = len({it[0].device for it in items}) <= 1
             if (len(items) >= 2 or zero_mask) and same_dev:
                 for k in range(0, len(items), 8):
                     ops.sgd_step_multi(items[k:k + 8], lr, mom, wd, self.grad_scale, zero_mask if k == 0 else 0)
+                for o in zeroed:
+                    o._gflat_zeroed = True
             else:
                 for pd, gd, buf in items:
                     ops.sgd_step(pd, gd, buf, lr, mom, wd, self.grad_scale)

@@ -191,6 +191,40 @@ def test_lazy_batchnorm_inputs_do_not_change_a_resnet32_run():
     assert d <= 1e-5 and dg <= 1e-4
 
 
+@pytest.mark.parametrize("kind", ["ewc", "lwf"])
+def test_activations_read_after_a_lazy_eval_forward_are_the_eager_ones(kind):
+    """after an EVAL_LAZY forward the activations whose BatchNorm ran on the consumer's operand load were never written; reading one
+    (clhip_plan_read_act / HipResNet.debug_read) must rebuild it from its z and the running statistics, not hand back stale workspace contents"""
+    from libcontinual_amd import _lib
+    L = _lib.lib()
+    m = _make(kind, 11)
+    o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+    T.train_steps(m, o, _batches(3, 64), None, "EWC" if kind == "ewc" else "LWF", None, "cuda")
+    bb = m.network.backbone if kind == "ewc" else m.backbone
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(64, 3, 32, 32, generator=g).cuda()
+    n_act = len(bb._units)
+    other = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(7)).cuda()
+    reads = {}
+    m.eval()
+    try:
+        with torch.no_grad():
+            assert L.clhip_config(b"EVAL_LAZY", b"0") == 0
+            bb(other)                                   # every buffer now holds OTHER data's activations: what must not come back
+            assert L.clhip_config(b"EVAL_LAZY", b"1") == 0
+            bb(x)
+            reads[1] = [bb.debug_read(a).clone() for a in range(1, n_act + 1)]
+            assert L.clhip_config(b"EVAL_LAZY", b"0") == 0
+            bb(x)
+            reads[0] = [bb.debug_read(a).clone() for a in range(1, n_act + 1)]
+        torch.cuda.synchronize()
+    finally:
+        L.clhip_config(b"EVAL_LAZY", None)
+        m.train()
+    differing = [a + 1 for a in range(n_act) if not torch.equal(reads[0][a], reads[1][a])]
+    assert not differing, f"activations {differing} read after the lazy eval forward differ from the eager eval forward's"
+
+
 @pytest.mark.parametrize("batch", [32, 256, 100])
 def test_eval_forward_with_consumer_side_batchnorm_is_bit_identical(batch):
     """the eval-mode forward (frozen teachers, validation, herding / NCM features) applies relu(bn(z)) [+ res] of the RUNNING statistics on the next
