@@ -21,12 +21,12 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (must be set before the HIP runtime starts)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")               # see libcontinual_amd/__init__.py: more than four busy hardware queues are time-sliced
 
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import libcontinual_amd  # noqa: E402,F401   (sets the hardware-queue cap -- 3 on one GPU, 4 for a rank of a multi-process job -- before the first HIP call)
 
 FLOP_FWD_PER_IMG = {"resnet18": 1.1108e9, "cifar_resnet32": 0.13825e9}     # 2*MAC, SURVEY.md section 8(d)
 # whole-step algorithmic FLOP per image of the ViT-B/16 methods: L2P = query fwd (N=197) + prompted
@@ -375,8 +375,8 @@ def conv_rooflines(dev, dtype, B, workload):
                                     None, None, None, 1, N, H, W, C, C, C, 3, 1, 1, code, st),
                   2 * 2.0 * M * 9 * C * C, 4 * M * C * es + C * 9 * C * 4, f"bwd16/{N}x{H}x{W}x{C}")
             del keep
-    # the 64 -> 64-channel forward runs on the weight-stationary kernel (conv5.hip) from 512 tiles of 256 pixels up (batch >= 128 at 32 x 32)
-    l1_sym = "conv5_kernel<0, 12, 0>" if B * 32 * 32 >= 512 * 256 else "conv4_kernel<4, 1, 1, 32, 32, 0>"
+    # the 64 -> 64-channel forward runs on conv8.hip (round 5: two four-wave workgroups per CU) from 1024 tiles of 128 pixels up (batch >= 128 at 32 x 32)
+    l1_sym = "conv8_kernel<0, 0, 0>" if B * 32 * 32 >= 1024 * 128 else "conv4_kernel<4, 1, 1, 32, 32, 0>"
     shapes = ((32, 64, l1_sym), (16, 128, "conv4_kernel<4, 2, 1, 64, 32, 0>")) if r18 else ((8, 64, "conv4_kernel<2, 1, 2, 64, 8, 0>"),)
     for i, (H, C, sym) in enumerate(shapes):
         N, W, K = B, H, C

@@ -474,12 +474,16 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
  *     activations), BN_FUSE_MAX_M, BN_MASK_BITS, BN_MASK_FROM_Y, BN_ONEPASS, PREP_NARROW,
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), BRANCH_STREAM (shortcut branches on a third stream: 0 never, 1 forward and backward, 2 forward only = default, 3 backward only), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD
+ *     round 5: CONV8 (0: the 64 -> 64-channel 3x3/s1 layers with >= CONV8_MIN_TILES [1024] tiles of 128 pixels stay on conv5.hip), CONV8_BNR (1: conv8's dgrad epilogue
+ *     reduces the producer's BatchNorm backward -- measured slower, off), CONV9 (1: 128 / 256-channel 3x3/s1 layers on conv9.hip -- equal in the step, off),
+ *     STREAM_PROBE (0: the executors' extra stream is the first one created, not the first one MEASURED to run beside the caller's stream)
  *   tuning values:
+ *     DZ_BUFFERS (2..4 rotating gradient buffers of the two-stream backward, default 4), CONV8_GRID, CONV8_OPT, CONV64_MAX_W, CONV64_MAX_M,
  *     WGRAD_TARGET (workgroups of the weight-gradient kernels), WGRAD_NET_GFLOP, WGRAD4_MIN_STEPS, WGRAD4_MIN_TOTAL, CONV3_CFG "wm,wn",
  *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, PLAN_SKIP (timing ablations: 1 no forward BatchNorm apply, 2 no BatchNorm backward, 4 no weight gradients -- results invalid), IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
  *     STEM_WGRAD_GRID, SHORTCUT_MIN_PIXELS, BN_ACC_CPT, BN_BWD_ITERS
  *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG, CONV6_DEBUG (read once),
- *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE (device address of
+ *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE, CONV8_TRACE, CONV9_TRACE (device address of
  *     a stamp buffer as a number; ablation builds only) */
 int clhip_config(const char* key, const char* value);
 /* the value clhip_config() last set for `key` (NULL: never set or erased -- the environment's value applies).  For callers that flip a

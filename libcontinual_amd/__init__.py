@@ -17,8 +17,22 @@ import os as _os
 # only same-stream packets carry the barrier bit: ResNet-18 task-0 step 2.1135 / 2.1025 / 2.098 / 2.096 ms at 1 / 3 / 4 / 8 queues), so the cap is
 # set here for every process that imports the package before the HIP runtime starts; an explicit GPU_MAX_HW_QUEUES in the environment wins.
 # Measurements: profiles/r04_stream_stall.md.
+# Round 5: THREE queues for a single-GPU process, FOUR for a rank of a multi-process job (WORLD_SIZE > 1 in the environment, as torch.distributed.run sets it).
+# RCCL brings streams of its own; with three queues the step's weight-gradient stream then shares a hardware queue with one of them (which one depends on
+# the order the streams were created in) and a queue whose head packet waits for an event holds back the other stream's packets behind it: the batch-256
+# ResNet-18 step on a 1-rank RCCL group ran 2.19 OR 2.61 ms at a cap of 2 or 3 -- plain steps without a reducer included, 2.10 vs 2.56-2.60 -- and
+# 2.15-2.19 / 2.10 ms every time at 4; 4.2-4.3 ms at 6 (tools/dp_step_micro.py, profiles/r05_notes.md).  Without RCCL in the process three queues are the
+# faster setting by 1.5 % (2.053 vs 2.087 ms, two alternating runs) and the other workloads do not care (iCaRL, LwF with the teacher, InfLoRA: within 1 %).
+def _default_queue_cap():
+    try:
+        return "4" if int(_os.environ.get("WORLD_SIZE", "1")) > 1 else "3"
+    except ValueError:
+        return "3"
+
+
 _QUEUE_CAP_PRESET = "GPU_MAX_HW_QUEUES" in _os.environ
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+_QUEUE_CAP_DEFAULT = _default_queue_cap()
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", _QUEUE_CAP_DEFAULT)
 
 
 def hw_queue_cap_state():
@@ -28,7 +42,7 @@ def hw_queue_cap_state():
     the caller chose a value itself."""
     if _QUEUE_CAP_PRESET:
         return "user", _os.environ.get("GPU_MAX_HW_QUEUES")
-    return ("late" if _HIP_WAS_UP else "ok"), "3"
+    return ("late" if _HIP_WAS_UP else "ok"), _QUEUE_CAP_DEFAULT
 
 
 def _hip_already_up():
@@ -43,9 +57,9 @@ def _hip_already_up():
 _HIP_WAS_UP = _hip_already_up()
 if _HIP_WAS_UP and not _QUEUE_CAP_PRESET:
     import warnings as _warnings
-    _warnings.warn("libcontinual_amd was imported after the HIP runtime had started: GPU_MAX_HW_QUEUES=3 cannot take effect any more (the runtime keeps its "
+    _warnings.warn("libcontinual_amd was imported after the HIP runtime had started: its GPU_MAX_HW_QUEUES setting cannot take effect any more (the runtime keeps its "
                    "default of 4 hardware queues).  Steps that run a frozen teacher beside the student keep their branch streams off, so nothing stalls, "
-                   "but import libcontinual_amd (or set GPU_MAX_HW_QUEUES=3) before the first torch.cuda call to get the measured configuration.")
+                   "but import libcontinual_amd (or set GPU_MAX_HW_QUEUES yourself: 3 on one GPU, 4 for a rank of a multi-GPU job) before the first torch.cuda call to get the measured configuration.")
 
 from . import _lib  # noqa: E402,F401
 

@@ -1,8 +1,11 @@
 // api.hip -- error reporting, version and the run-time configuration of the C ABI (include/clhip.h).
 #include <map>
+#include <utility>
+#include <vector>
 #include <mutex>
 #include <string>
 #include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -32,10 +35,11 @@ const char* const kKeys[] = {
     // tuning values
     "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
-    "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "DZ_BUFFERS", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "CONV9", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK",
+    "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "DZ_BUFFERS", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "CONV9", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK", "STREAM_PROBE",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
     "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE", "CONV6_TRACE", "CONV8_TRACE", "CONV9_TRACE",
 };
+std::mutex g_stream_mu;
 std::mutex g_cfg_mu;
 // values are strdup'ed and never freed: look-up sites cache the pointer (a few bytes per clhip_config call, by design)
 std::map<std::string, const char*>& cfg_map() { static std::map<std::string, const char*> m; return m; }
@@ -44,6 +48,72 @@ bool known_key(const char* k) {
     return false;
 }
 }  // namespace
+
+namespace {
+__global__ void stream_probe_spin_kernel(unsigned long long* out, long long ticks) {       // wall_clock64: the constant 100-MHz counter
+    const unsigned long long t0 = wall_clock64();
+    while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(64);
+    out[0] = wall_clock64();
+}
+__global__ void stream_probe_stamp_kernel(unsigned long long* out) { out[1] = wall_clock64(); }
+
+struct SharedStreams {
+    std::vector<hipStream_t> pool;                                   // candidates in creation order
+    std::map<std::pair<hipStream_t, int>, hipStream_t> chosen;       // (main stream, role) -> stream
+    hipStream_t low_prio = nullptr;                                   // SIDE_PRIO=1: a lowest-priority stream (a queue class of its own: no probing needed)
+    unsigned long long* probe_buf = nullptr;
+};
+SharedStreams g_shared[16];
+
+// can a kernel on `b` start while a kernel on `a` is running?  (false also when the probe itself fails: the caller then tries the next candidate)
+bool runs_beside(SharedStreams& S, hipStream_t a, hipStream_t b) {
+    if (S.probe_buf == nullptr && hipMalloc(reinterpret_cast<void**>(&S.probe_buf), 2 * sizeof(unsigned long long)) != hipSuccess) return false;
+    hipLaunchKernelGGL(stream_probe_spin_kernel, dim3(1), dim3(1), 0, a, S.probe_buf, 30000ll);
+    hipLaunchKernelGGL(stream_probe_stamp_kernel, dim3(1), dim3(1), 0, b, S.probe_buf);
+    if (hipStreamSynchronize(b) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, S.probe_buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return h[1] < h[0];
+}
+}  // namespace
+
+hipStream_t clhip_shared_stream(int role, hipStream_t main_s, bool low_priority) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || role < 0 || role > 1) return nullptr;
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    SharedStreams& S = g_shared[dev];
+    if (low_priority) {
+        if (S.low_prio == nullptr) {
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (hipStreamCreateWithPriority(&S.low_prio, hipStreamNonBlocking, prio_lo) != hipSuccess) S.low_prio = nullptr;
+        }
+        return S.low_prio;
+    }
+    // ONE extra stream serves both roles: the branch launches belong to the forward, the weight gradients to the backward, and the step measured 1.3-2 % FASTER
+    // with the two on one hardware queue than with a queue each (1.957-1.962 vs 1.976-1.991 ms alternating on one box; 2.014 vs 2.058 on another;
+    // profiles/r05_notes.md) -- what used to happen by accident at GPU_MAX_HW_QUEUES=3 and not at 4.
+    (void)role;
+    const auto key = std::make_pair(main_s, 0);
+    auto it = S.chosen.find(key);
+    if (it != S.chosen.end()) return it->second;
+    const int probe_cfg = clhip_cfg("STREAM_PROBE") != nullptr ? atoi(clhip_cfg("STREAM_PROBE")) : 1;      // 0: the first candidate, unmeasured
+    hipStream_t pick = nullptr, fallback = nullptr;
+    for (size_t k = 0; k < 8 && pick == nullptr; ++k) {
+        if (k == S.pool.size()) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+            S.pool.push_back(s);
+        }
+        hipStream_t c = S.pool[k];
+        if (c == main_s) continue;
+        if (fallback == nullptr) fallback = c;
+        if (probe_cfg == 0 || runs_beside(S, main_s, c)) pick = c;
+    }
+    if (pick == nullptr) pick = fallback;              // every candidate shares the caller's hardware queue (GPU_MAX_HW_QUEUES=1): correct, only slower
+    if (pick != nullptr) S.chosen[key] = pick;
+    return pick;
+}
 
 // hooks that take effect at once (defined next to the kernels they steer)
 void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck);

@@ -13,6 +13,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 void clhip_set_error(const char* fmt, ...);
+// api.hip: the extra streams of the executors (role 0 = weight-gradient / LoRA side stream, 1 = shortcut-branch stream): process-wide, per device, never destroyed,
+// BORROWED by the plans, and chosen so that a kernel on the returned stream really can start while one on `main_s` is running.  The HIP runtime maps streams to
+// hardware queues round-robin in creation order (GPU_MAX_HW_QUEUES of them) and packets of one hardware queue execute in order, whichever stream they came from:
+// a weight-gradient stream that lands on the caller's hardware queue turns the two-stream backward into one stream (batch-256 ResNet-18 step 2.55 instead of
+// 2.0 ms -- every third / fourth model of a process, depending on the cap: round 5, tools/dp_step_micro.py, profiles/r05_notes.md).  No API tells a stream's
+// queue, so the first request for a (main stream, role) pair MEASURES: a 300-us spin kernel on `main_s`, a stamp kernel on the candidate, and the candidate is taken if
+// the stamp precedes the spin's end (two stream synchronisations, once per caller's stream; candidates are created until one passes, at most eight per device).
+// Both roles get the SAME stream (they are busy in different halves of a step, and one shared hardware queue measured faster than two: api.hip).
+hipStream_t clhip_shared_stream(int role, hipStream_t main_s, bool low_priority);
 const char* clhip_cfg(const char* name);      // api.hip: value of a configuration switch (clhip_config(), else $CLHIP_<name>), nullptr if unset
 
 #define CLHIP_CHECK_ARG(cond)                                                          \

@@ -469,14 +469,12 @@ extern "C" void clhip_plan_destroy(clhip_plan* p) {
     if (p && p->side) {
         (void)hipStreamSynchronize(p->side);
         for (int k = 0; k < clhip_plan::kDz; ++k) { (void)hipEventDestroy(p->ev_dz[k]); (void)hipEventDestroy(p->ev_wg[k]); }
-        (void)hipEventDestroy(p->ev_end);
-        (void)hipStreamDestroy(p->side);
+        (void)hipEventDestroy(p->ev_end);              // (the stream itself is the process-wide one: clhip_shared_stream)
     }
     if (p && p->br) {
         (void)hipStreamSynchronize(p->br);
         for (int k = 0; k < clhip_plan::kMaxBranch; ++k) { (void)hipEventDestroy(p->ev_fork[k]); (void)hipEventDestroy(p->ev_join[k]); (void)hipEventDestroy(p->ev_bfork[k]); (void)hipEventDestroy(p->ev_bjoin[k]); }
         (void)hipEventDestroy(p->ev_br_end);
-        (void)hipStreamDestroy(p->br);
     }
     delete p;
 }
@@ -502,8 +500,11 @@ static bool branch_stream_on(clhip_plan* p, hipStream_t main_s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(main_s, &cap);
     if (cap != hipStreamCaptureStatusNone) return false;
-    if (!p->br) {
-        if (hipStreamCreateWithFlags(&p->br, hipStreamNonBlocking) != hipSuccess) { p->br = nullptr; p->n_branch = 0; return false; }
+    hipStream_t shared_br = clhip_shared_stream(1, main_s, false);        // (looked up per call: the caller's stream may change between calls)
+    if (shared_br == nullptr) { p->n_branch = 0; return false; }
+    const bool first_br = p->br == nullptr;
+    p->br = shared_br;
+    if (first_br) {
         static const unsigned ev_flags = clhip_cfg("EVENT_FLAGS") ? (unsigned)strtoul(clhip_cfg("EVENT_FLAGS"), nullptr, 0)
                                                                   : (hipEventDisableTiming | hipEventDisableSystemFence);
         for (int k = 0; k < clhip_plan::kMaxBranch; ++k) {
@@ -937,17 +938,20 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(main_s, &cap);
     const bool two_streams = two_streams_env && cap == hipStreamCaptureStatusNone;
-    if (two_streams && !p->side) {
+    hipStream_t shared_side = nullptr;
+    if (two_streams) {
+        static const bool flat_prio = !(clhip_cfg("SIDE_PRIO") != nullptr && atoi(clhip_cfg("SIDE_PRIO")) != 0);
+        shared_side = clhip_shared_stream(0, main_s, !flat_prio);          // (looked up per call: the caller's stream may change between calls)
+        if (shared_side == nullptr) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
+    }
+    const bool first_side = two_streams && !p->side;
+    if (two_streams) p->side = shared_side;
+    if (first_side) {
         // lowest priority: the weight gradients are off the critical path (nothing waits for them before the optimizer step); when both
         // queues have workgroups ready the dispatcher should serve the caller's stream (dgrad, BatchNorm backward) first
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         // round 4: a NORMAL-priority side stream is the default (SIDE_PRIO=1 restores the lowest priority).  A priority is a property of the hardware queue the
         // stream maps to; with the three-queue cap of the package (libcontinual_amd/__init__.py) the low-priority stream no longer gets a queue class of its own
         // and the step measured 1.2-1.7 % faster flat (2.0547 vs 2.0936 / 2.0834 on one box, 2.115 / 2.120 vs 2.149 / 2.141 on a slower one)
-        static const bool flat = !(clhip_cfg("SIDE_PRIO") != nullptr && atoi(clhip_cfg("SIDE_PRIO")) != 0);
-        const hipError_t e = flat ? hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_lo);
-        if (e != hipSuccess) { clhip_set_error("clhip_plan_backward: cannot create the weight-gradient stream"); return CLHIP_EHIP; }
         // the events order two streams of ONE device: no timing, and no system-scope fence (the default flags make every record a cache
         // write-back + invalidate in the middle of the caller's stream; CLHIP_EVENT_FLAGS overrides the flag word)
         static const unsigned ev_flags = clhip_cfg("EVENT_FLAGS") ? (unsigned)strtoul(clhip_cfg("EVENT_FLAGS"), nullptr, 0)

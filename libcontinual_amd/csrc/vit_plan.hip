@@ -129,8 +129,7 @@ extern "C" void clhip_vit_destroy(clhip_vit* v) {
     if (v && v->side) {
         (void)hipStreamSynchronize(v->side);
         (void)hipEventDestroy(v->ev_q);
-        (void)hipEventDestroy(v->ev_l);
-        (void)hipStreamDestroy(v->side);
+        (void)hipEventDestroy(v->ev_l);               // (the stream is the process-wide one: clhip_shared_stream)
     }
     delete v;
 }
@@ -235,8 +234,11 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
     static const bool two_streams = !(clhip_cfg("WGRAD_STREAM") && atoi(clhip_cfg("WGRAD_STREAM")) == 0);
     hipStream_t main_s = static_cast<hipStream_t>(stream);
     const bool side_on = two_streams && d_lora_b != nullptr;
-    if (side_on && !v->side) {
-        if (hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking) != hipSuccess) { clhip_set_error("clhip_vit_backward: cannot create the side stream"); return CLHIP_EHIP; }
+    hipStream_t shared_side = side_on ? clhip_shared_stream(0, main_s, false) : nullptr;
+    if (side_on && shared_side == nullptr) { clhip_set_error("clhip_vit_backward: cannot create the side stream"); return CLHIP_EHIP; }
+    const bool first_side = side_on && !v->side;
+    if (side_on) v->side = shared_side;
+    if (first_side) {
         (void)hipEventCreateWithFlags(&v->ev_q, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&v->ev_l, hipEventDisableTiming);
     }

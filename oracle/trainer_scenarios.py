@@ -66,6 +66,16 @@ ACC_SCENARIOS = {
     # step: no teacher, no forgetting) -- the gated quantity of this scenario; the two-task final figure is recorded and compared loosely.
     "acc_lwf": dict(method="LWF", arch="resnet18", feat_dim=512, kwargs=dict(), buffer=None,
                     common=dict(ACC_COMMON, init=20, inc=5, tasks=2, init_epoch=12, epoch=6, milestones=[6, 9, 11], gamma=0.1, signal=0.45, noise=1.0)),
+    # round 5: a scenario whose reference accuracy ends in the 70-90 % band.  Weaker class signal alone does not give one the gate can use
+    # (explored: signal 0.35 / noise 1.0 -> 96.1 +- 1.8, signal 0.28 -> 85.9 +- 1.9 over four reference runs: once the network stops separating the classes
+    # cleanly, forgetting under the 200-exemplar buffer makes the reference's own runs scatter).  Real class OVERLAP does (`mix`, _mixed() below): every sample is a
+    # blend of its class pattern and its partner class's, the blend weight uniform in [0, mix) -- the samples beyond 0.5 belong to the partner for any
+    # classifier, the ones near 0.5 are decided by the details of the trained network.
+    # (explored: mix 0.62 -> 79.2 +- 0.35 final / 80.0 +- 0.41 overall; mix 0.58 -> 84.1 +- 0.28 / 85.3 +- 0.18 over four reference runs each; the second is the scenario)
+    "acc_icarl11_overlap": dict(method="ICarl", arch="cifar_resnet32", feat_dim=64, kwargs=dict(), png=True,
+                                buffer=("LinearHerdingBuffer", dict(buffer_size=200, batch_size=32)),
+                                common=dict(ACC_COMMON, init=20, inc=2, tasks=11, train_per_class=50, init_epoch=12, epoch=8, milestones=[5, 7], gamma=0.1,
+                                            signal=0.8, noise=0.9, mix=0.58)),
 }
 SCENARIOS.update(ACC_SCENARIOS)
 
@@ -108,6 +118,27 @@ class TaskLoaders:
         return self.dataloaders[task_idx] if self.mode == "train" else self.dataloaders[:task_idx + 1]
 
 
+def _pattern(tag, cls, chw):
+    """the class pattern of make_store (CHW) / make_png_loaders (HWC)"""
+    yy, xx = np.meshgrid(np.linspace(0, 1, 32), np.linspace(0, 1, 32), indexing="ij")
+    coef = detrand.uniform(f"{tag}/coef{cls}", (3, 6), -1.0, 1.0)
+    return np.stack([coef[ch, 0] * np.sin(2 * np.pi * (coef[ch, 1] * 2 * xx + coef[ch, 2] * 2 * yy)) +
+                     coef[ch, 3] * np.cos(2 * np.pi * (coef[ch, 4] * 3 * xx - coef[ch, 5] * 3 * yy)) for ch in range(3)], 0 if chw else -1)
+
+
+def _mixed(tag, c, cls, pat, n, pattern, chw):
+    """per-sample class pattern [n, ...].  Without `mix` in the scenario: the class's own pattern for every sample (the data of every earlier fixture,
+    unchanged).  With mix = a_max: sample k of class c shows (1 - a_k) * pattern(c) + a_k * pattern(c ^ 1), a_k ~ U[0, a_max) -- REAL class overlap:
+    for a_max > 0.5 the samples with a_k > 0.5 look more like the partner class (which shares the task: init and inc are even), the Bayes accuracy is
+    about 0.5 / a_max, and the samples near a_k = 0.5 are decided by the details of the trained network."""
+    a_max = c.get("mix", 0.0)
+    if a_max <= 0.0:
+        return np.broadcast_to(pat[None], (n,) + pat.shape)
+    other = pattern(tag, cls ^ 1, chw)
+    a = detrand.uniform(f"{tag}/mix{cls}", (n,), 0.0, a_max).reshape((n,) + (1,) * pat.ndim)
+    return (1.0 - a) * pat[None] + a * other[None]
+
+
 def make_store(tag, c=COMMON):
     """class-structured 32 x 32 images, already normalised: a smooth class pattern (low-frequency, shared by the class) plus
     per-sample noise, mixed so that a small ResNet separates the classes well but not perfectly after a few epochs"""
@@ -120,7 +151,7 @@ def make_store(tag, c=COMMON):
         pat = np.stack([coef[ch, 0] * np.sin(2 * np.pi * (coef[ch, 1] * 2 * xx + coef[ch, 2] * 2 * yy)) +
                         coef[ch, 3] * np.cos(2 * np.pi * (coef[ch, 4] * 3 * xx - coef[ch, 5] * 3 * yy)) for ch in range(3)])
         noise = detrand.uniform(f"{tag}/noise{cls}", (n_tr + n_te, 3, 32, 32), -1.0, 1.0)
-        x = c.get("signal", 0.55) * pat[None] + c.get("noise", 1.1) * noise
+        x = c.get("signal", 0.55) * _mixed(tag, c, cls, pat, n_tr + n_te, _pattern, chw=True) + c.get("noise", 1.1) * noise
         base = sum(r.shape[0] for r in rows)
         rows.append(x.astype(np.float32))
         idx_tr += list(range(base, base + n_tr)); labels_tr += [cls] * n_tr
@@ -154,12 +185,13 @@ def make_png_loaders(root, tag, c=COMMON):
                         coef[ch, 3] * np.cos(2 * np.pi * (coef[ch, 4] * 3 * xx - coef[ch, 5] * 3 * yy)) for ch in range(3)], -1)      # HWC
         n = c["train_per_class"] + c["test_per_class"]
         noise = detrand.uniform(f"{tag}/noise{cls}", (n, 32, 32, 3), -1.0, 1.0)
+        pats = _mixed(tag, c, cls, pat, n, _pattern, chw=False)
         for k in range(n):
             mode = "train" if k < c["train_per_class"] else "test"
             d = os.path.join(root, mode, f"{cls:03d}")
             os.makedirs(d, exist_ok=True)
             ks, kn = (0.2 * c["signal"], 0.2 * c["noise"]) if "signal" in c else (0.11, 0.22)
-            a = np.clip((0.5 + ks * pat + kn * noise[k]) * 255.0, 0, 255).astype(np.uint8)
+            a = np.clip((0.5 + ks * pats[k] + kn * noise[k]) * 255.0, 0, 255).astype(np.uint8)
             rel = os.path.join(f"{cls:03d}", f"{k}.png")
             Image.fromarray(a).save(os.path.join(root, mode, rel))
             lists[mode][0].append(rel); lists[mode][1].append(cls)

@@ -7,7 +7,7 @@
   in-step average durations bench.py reports next to its stand-alone measurements;
 * `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains) over `bench.py --roofline-only` ->
   gpurun_out/roofline_pmc.json {key: {traffic_bytes_per_launch, ...}} for the roofline kernels of the default workload.
-Copy both into profiles/ (r02_bench_kernel_stats.json, r02_roofline_pmc.json, r02_bench_kernel_stats_<W>.txt)."""
+Copy both into profiles/ (rNN_bench_kernel_stats.json, rNN_roofline_pmc.json, rNN_bench_kernel_stats_<W>.txt; bench.py reads the newest round's)."""
 import csv
 import glob
 import json
@@ -94,8 +94,8 @@ if __name__ == "__main__":
     wl = sys.argv[1:] or ["lwf_resnet18_b50_task0"]
     pj = os.path.join(OUT, "bench_kernel_stats.json")
     # (the GPU box starts with an empty gpurun_out/: begin from the committed table so that a partial re-run keeps the other workloads)
-    committed = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.json")
-    stats = json.load(open(pj)) if os.path.exists(pj) else (json.load(open(committed)) if os.path.exists(committed) else {})
+    committed = next((c for c in (os.path.join(ROOT, "profiles", f"r0{r}_bench_kernel_stats.json") for r in (5, 4)) if os.path.exists(c)), "")
+    stats = json.load(open(pj)) if os.path.exists(pj) else (json.load(open(committed)) if committed else {})
     for w in wl:
         stats[w] = kernel_stats(w)
         json.dump(stats, open(pj, "w"), indent=1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box (gpurun -- bash tools/collect_evidence.sh): every figure profiles/r04_* and the READMEs quote -- in-step kernel tables + PMC traffic
+# On the GPU box (gpurun -- bash tools/collect_evidence.sh): every figure profiles/rNN_* (the current round's) and the READMEs quote -- in-step kernel tables + PMC traffic
 # (tools/bench_profile.py), the per-shape roofline table (tools/layer_roofline.py), the bench lines of all workloads, the small-kernel timings.
 # Outputs land in gpurun_out/; copy the ones to keep into profiles/.
 export TMPDIR=/tmp

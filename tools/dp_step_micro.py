@@ -8,6 +8,8 @@ from libcontinual_amd import optim, parallel
 from libcontinual_amd.trainer import train_steps
 
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+import libcontinual_amd
+print("hw_queue_cap", libcontinual_amd.hw_queue_cap_state())        # read at import: WORLD_SIZE > 1 in the caller's environment gives the cap of a rank (4)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1)
@@ -45,9 +47,18 @@ def run(kind, steps=60):
     e0.record()
     train_steps(m, o, (bs[i % 4] for i in range(steps)), red, "LWF", None, "cuda")
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / steps
+    if os.environ.get("DP_MICRO_PTR"):
+        bb = m.backbone
+        print("   ws %x  shadow %x  flat %x  gflat %x" % (bb._ws.data_ptr(), bb._shadow.data_ptr(), bb._flat.data_ptr(), bb._gflat.data_ptr()),
+              " reserved %.2f GB" % (torch.cuda.memory_reserved() / 2**30))
+    ms = e0.elapsed_time(e1) / steps
+    if os.environ.get("DP_MICRO_FREE"):                     # hand the memory back, so that the next model lands on the same addresses
+        import gc
+        del m, o, red, bs
+        gc.collect(); torch.cuda.empty_cache()
+    return ms
 
 
-for kind in ("plain", "no_tail", "tail", "plain", "no_tail", "tail"):
+for kind in os.environ.get("DP_MICRO_KINDS", "plain,no_tail,tail,plain,no_tail,tail").split(","):
     print(kind, f"{run(kind):.3f} ms")
 dist.destroy_process_group()
