@@ -356,7 +356,12 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
                     gelu_both2((f2){v[0], v[1]}, y0, d0);
                     gelu_both2((f2){v[2], v[3]}, y1, d1);
                     v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
-                    if (p.H) {                                            // GELU' leaves directly (a second staged pass would have to keep or recompute it)
+                    // GELU' leaves directly (a second staged pass would have to keep or recompute it).  Round 5 measured the alternatives on fc1 of ViT-B/16 at
+                    // M = 25216 (this form: 239 us, the plain product 155-158): both outputs through LDS in two half-tile passes with coalesced 16-byte stores,
+                    // no extra registers: 246 us; GELU' kept packed for a second staged pass: 303 spilled registers on the 256 x 256 tile, 517 us.  The 85 us
+                    // are the erf arithmetic (one v_exp_f32 + one v_rcp_f32 + ~12 packed FMAs per element, 77 M elements) and the second tensor's bytes, not
+                    // the shape of the stores; hiding them needs a second accumulator set under the next tile's K loop (not built).
+                    if (p.H) {
                         const int m = m0 + wm * 16 * MT + i * 16 + l15;
                         if (m < p.M && n0 + wn * 16 * NT + j * 16 + g * 4 < p.N) {
                             const float d[4] = {d0.x, d0.y, d1.x, d1.y};

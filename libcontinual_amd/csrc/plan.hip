@@ -37,6 +37,11 @@ struct Act {
     size_t bytes;
 };
 
+}  // namespace
+bool clhip_stage_eval_supported(int H, int W, int C, int nconv, int dtype);                                                   // stage.hip
+int clhip_stage_eval_launch(const void* x, void* y, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
+                            const float* const* mean, const float* const* var, float eps, int dtype, hipStream_t st);
+namespace {
 struct Unit {
     clhip_unit_desc d;
     int cin_pad;
@@ -76,6 +81,8 @@ struct Unit {
     int forks;                                   // >= 0: this unit's forward BatchNorm launch completes ev_fork[forks] (its activation feeds a branch unit)
     int joins;                                   // >= 0: this unit adds the output of branch unit slot `joins` as its residual
     size_t wg_own;                               // this unit's own weight-gradient scratch (plans that defer the reduces), else the shared one
+    int stage_len;                               // > 0 (round 5): this unit opens a run of `stage_len` units = stage_len / 2 BasicBlocks of C -> C 3x3 / stride-1 convolutions that
+                                                 // the EVAL forward runs as ONE launch with the image resident in LDS (stage.hip); the activations inside the run are not written
     bool fuse_src_bn;                            // this unit's dgrad completes the gradient of its input activation AND can reduce the
                                                  // BatchNorm backward of the unit that produced it in its epilogue (clhip_conv_dgrad_bn_reduce)
 };
@@ -119,6 +126,7 @@ struct clhip_plan {
     std::vector<char> wt_pending;       // ... likewise for the write-through form of the wide layers
     const float* params_dev = nullptr;  // the parameter / running-statistics pointers of the last forward (clhip_plan_read_act rebuilds an eval-lazy activation from them)
     const float* bn_stats_dev = nullptr;
+    std::vector<char> stage_skipped;    // per unit: the last EVAL forward ran it inside a fused stage launch: its activation does not exist (clhip_plan_read_act refuses)
     std::vector<char> eval_unwritten;   // per unit: the last EVAL forward consumed its BatchNorm on the next convolution's operand load and never wrote the activation
     std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
@@ -397,6 +405,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     for (auto& u : p->units) { u.lazy_to = u.lazy_from = -1; }
     p->lazy_live.assign(p->units.size(), 0);
     p->eval_unwritten.assign(p->units.size(), 0);
+    p->stage_skipped.assign(p->units.size(), 0);
     static const bool mask_y = clhip_cfg("BN_MASK_FROM_Y") != nullptr;
     for (int a = 0; a + 1 < n_units && want_acc && !mask_y; ++a) {
         Unit& ua = p->units[a];
@@ -461,6 +470,27 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (ub.no_bn || ub.pre_res || ub.rep_fwd <= 0 || ub.cin_pad != ub.d.cin || ub.branch >= 0 || ub.pair >= 0 || ub.lazy_from >= 0 || ub.res_lazy_from >= 0) continue;
         if (!clhip_conv_bn_input_wt_supported(N, ub.H, ub.W, ub.cin_pad, ub.d.cout, ub.d.ksize, ub.d.stride, ub.d.pad, dtype)) continue;
         ua.wt_to = b; ub.wt_from = a;
+    }
+    // runs of BasicBlocks the eval forward can take as one launch (stage.hip): pairs (a, b) of 3x3 / stride-1 C -> C units, a: conv -> BN -> ReLU on the block input,
+    // b: conv -> BN -> + block input -> ReLU on a's output, the next pair on b's output
+    for (Unit& u : p->units) u.stage_len = 0;
+    for (int i = 0; i + 1 < n_units;) {
+        int len = 0;
+        const int C = p->units[i].d.cout, Hs = p->units[i].H, Ws = p->units[i].W;
+        int s_in = p->units[i].d.src;
+        while (i + len + 1 < n_units && len + 2 <= 16) {
+            const Unit& a = p->units[i + len];
+            const Unit& b = p->units[i + len + 1];
+            auto plain3 = [&](const Unit& q) {
+                return q.d.ksize == 3 && q.d.stride == 1 && q.d.pad == 1 && q.d.cin == C && q.d.cout == C && q.cin_pad == C && q.H == Hs && q.W == Ws && q.relu && !q.pre_res &&
+                       !q.raw_src && !q.no_bn && q.branch < 0;
+            };
+            if (!(plain3(a) && plain3(b) && a.d.res < 0 && a.d.src == s_in && b.d.src == i + len + 1 && b.d.res == s_in)) break;
+            len += 2;
+            s_in = i + len;                                   // b's output activation
+        }
+        if (len >= 2 && clhip_stage_eval_supported(Hs, Ws, C, len, dtype)) { p->units[i].stage_len = len; i += len; }
+        else ++i;
     }
     return p;
 }
@@ -736,7 +766,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const char* elazy_cfg = clhip_cfg("EVAL_LAZY");
     const bool eval_lazy = !training && p->use_acc && p->dtype == CLHIP_BF16 && lazy_env && !(rlazy_cfg != nullptr && atoi(rlazy_cfg) == 0) &&
                            !(elazy_cfg != nullptr && atoi(elazy_cfg) == 0);
-    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = 0;
+    const char* stage_cfg = clhip_cfg("STAGE_EVAL");                 // (looked up per call, like EVAL_LAZY: the tests compare the two forms in one process)
+    const bool stage_on = eval_lazy && !(stage_cfg != nullptr && atoi(stage_cfg) == 0);
+    for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = p->stage_skipped[i] = 0;
     p->params_dev = params; p->bn_stats_dev = bn_stats;
     int fwd_pair_done = -1;                                  // the 3x3/s2 unit whose launch also ran its shortcut partner's convolution
     for (size_t i = 0; i < p->units.size(); ++i) {
@@ -846,6 +878,20 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 bi.mean = nullptr; bi.invstd = nullptr; bi.coef = nullptr;
                 return bi;
             };
+            if (stage_on && u.stage_len > 0) {
+                // a run of BasicBlocks as ONE launch, the image resident in LDS (stage.hip); its input activation was written (the producers' lazy forms are
+                // switched off below for units that open a run), its inner activations are not
+                const void* wv[16]; const float *gv[16], *bv[16], *mv[16], *vv[16];
+                for (int k = 0; k < u.stage_len; ++k) {
+                    const Unit& q = p->units[i + k];
+                    wv[k] = sh + q.sh_fwd; gv[k] = params + q.d.gamma_off; bv[k] = params + q.d.beta_off; mv[k] = bn_stats + q.d.rm_off; vv[k] = bn_stats + q.d.rv_off;
+                    if (k + 1 < u.stage_len) p->stage_skipped[i + k] = 1;
+                }
+                TRY(clhip_stage_eval_launch(ws + src.y_off, ws + p->acts[i + u.stage_len].y_off, p->N, u.H, u.W, u.d.cout, u.stage_len, wv, gv, bv, mv, vv, kBnEps, p->dtype,
+                                            (hipStream_t)stream));
+                i += u.stage_len - 1;
+                continue;
+            }
             if (u.res_lazy_from >= 0 && p->res_pending[u.res_lazy_from]) {
                 const Unit& a = p->units[u.res_lazy_from];
                 const clhip_bn_input bi = eval_bi(a);
@@ -864,8 +910,8 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
             } else {
                 TRY(clhip_conv_fwd(in, sh + u.sh_fwd, ws + u.z_off, nullptr, p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype, stream));
             }
-            if (u.lazy_to >= 0) { p->lazy_live[i] = 1; continue; }
-            if (u.res_lazy_to >= 0) { p->res_pending[i] = 1; continue; }
+            if (u.lazy_to >= 0 && !(stage_on && p->units[u.lazy_to].stage_len > 0)) { p->lazy_live[i] = 1; continue; }          // (a fused run reads a WRITTEN activation)
+            if (u.res_lazy_to >= 0 && !(stage_on && p->units[u.res_lazy_to].stage_len > 0)) { p->res_pending[i] = 1; continue; }
             const void* res_e = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
             TRY(clhip_bn_apply_eval(ws + u.z_off, params + u.d.gamma_off, params + u.d.beta_off, bn_stats + u.d.rm_off, bn_stats + u.d.rv_off, kBnEps, res_e, ws + dst.y_off,
                                     u.M, u.d.cout, u.relu, p->dtype, stream));
@@ -1233,6 +1279,11 @@ extern "C" int clhip_plan_read_act(clhip_plan* p, const void* workspace, int idx
         float* fr = reinterpret_cast<float*>(wsm + p->f_base);
         if (int e = clhip_bn_apply(wsm + ua.z_off, fr + ua.f_scale, fr + ua.f_shift, nullptr, wsm + a.y_off, ua.M, ua.d.cout, 1, p->dtype, stream)) return e;
         p->lazy_live[idx - 1] = 0;
+    }
+    if (which <= 1 && idx >= 1 && p->stage_skipped[idx - 1]) {
+        clhip_set_error("clhip_plan_read_act: activation %d lies inside a run of blocks the eval forward executed as one launch (stage.hip) and was never written; "
+                        "clhip_config(\"STAGE_EVAL\", \"0\") keeps one launch per unit", idx);
+        return CLHIP_EINVAL;
     }
     if (which == 0 && idx >= 1 && p->eval_unwritten[idx - 1]) {
         // the eval forward applied this unit's BatchNorm (running statistics) on its consumer's operand load: the buffer holds whatever an

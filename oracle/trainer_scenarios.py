@@ -71,7 +71,7 @@ ACC_SCENARIOS = {
     # cleanly, forgetting under the 200-exemplar buffer makes the reference's own runs scatter).  Real class OVERLAP does (`mix`, _mixed() below): every sample is a
     # blend of its class pattern and its partner class's, the blend weight uniform in [0, mix) -- the samples beyond 0.5 belong to the partner for any
     # classifier, the ones near 0.5 are decided by the details of the trained network.
-    # (explored: mix 0.62 -> 79.2 +- 0.35 final / 80.0 +- 0.41 overall; mix 0.58 -> 84.1 +- 0.28 / 85.3 +- 0.18 over four reference runs each; the second is the scenario)
+    # (explored: mix 0.62 -> 79.2 +- 0.35 final / 80.0 +- 0.41 overall; mix 0.58 -> 84.1 +- 0.28 / 85.3 +- 0.18 over four reference runs each; the second is the scenario -- its fixture's 24 runs: 85.4 +- 0.56 / 85.3 +- 0.28)
     "acc_icarl11_overlap": dict(method="ICarl", arch="cifar_resnet32", feat_dim=64, kwargs=dict(), png=True,
                                 buffer=("LinearHerdingBuffer", dict(buffer_size=200, batch_size=32)),
                                 common=dict(ACC_COMMON, init=20, inc=2, tasks=11, train_per_class=50, init_epoch=12, epoch=8, milestones=[5, 7], gamma=0.1,
