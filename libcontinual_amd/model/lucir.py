@@ -43,6 +43,14 @@ class LUCIR(Finetune):
     # device), the frozen model's pass forks / joins a side stream inside the capture like iCaRL's; eight replayed steps equal eight eager ones bit for
     # bit (tests/test_graph_step_gpu.py::test_lucir_replays_like_eager).  At 32 images per GPU: 1.33 -> 0.91 ms per step.
     cuda_graph_safe = True
+
+    @property
+    def cuda_graph_auto_max_batch(self):
+        """round 5: LUCIR's step (cosine heads, three loss terms, the frozen model's pass) is host-enqueue-bound up to batch 256 on the CIFAR ResNet-32 backbones
+        the reference configures it with (1.47-1.54 ms eager, 1.41-1.43 replayed); their plans have no weight-gradient stream, so a capture loses nothing.  Wider
+        backbones (feat_dim > 64: ResNet-18's two-stream backward) keep the default cap."""
+        return 256 if self.feat_dim <= 64 else 64
+
     def __init__(self, backbone, feat_dim, num_class, **kwargs):
         super().__init__(backbone, feat_dim, num_class, **kwargs)
         self.kwargs = kwargs

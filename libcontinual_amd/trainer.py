@@ -180,7 +180,7 @@ def _graph_mode(model, reducer, device, optimizer=None):
     return "always" if env == "1" else "auto"
 
 
-GRAPH_AUTO_MAX_BATCH = 64
+GRAPH_AUTO_MAX_BATCH = 64          # (a plugin may raise it for itself: `cuda_graph_auto_max_batch`, e.g. LUCIR, whose batch-256 step is still host-enqueue-bound)
 
 
 def _batch_rows(batch):
@@ -228,7 +228,7 @@ def _train_loop(model, optimizer, batches, reducer, method_name, meter, on_gpu, 
     with ops.deferred_metrics(on_gpu), overlap, (torch.cuda.stream(gs.stream) if gs is not None else contextlib.nullcontext()):
         for b, batch in enumerate(batches):
             batch["batch_id"] = b
-            if gs is not None and (mode == "always" or _batch_rows(batch) <= GRAPH_AUTO_MAX_BATCH):
+            if gs is not None and (mode == "always" or _batch_rows(batch) <= getattr(model, "cuda_graph_auto_max_batch", GRAPH_AUTO_MAX_BATCH)):
                 gs.stream.wait_stream(caller)                  # loaders that produce their batches on the caller's stream
                 output, acc, loss = gs({k: v for k, v in batch.items() if k != "batch_id"})
             else:
