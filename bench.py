@@ -692,7 +692,9 @@ def main():
         every = [None] * world
         dist.all_gather_object(every, mine)
         import libcontinual_amd
+        gs = getattr(model, "_graphed_step", None)
         dp = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), exchange=reducer.exchange, ranks=every,
+                  graph_replay=bool(gs is not None and gs.graphs and not gs.disabled),       # the timed steps replayed backward + all-reduce + optimizer from one HIP graph
                   hw_queue_cap=dict(zip(("state", "GPU_MAX_HW_QUEUES"), libcontinual_amd.hw_queue_cap_state())))
     if rank != 0:
         return

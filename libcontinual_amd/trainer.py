@@ -69,8 +69,13 @@ class GraphedStep:
     WARM, KEEP = 2, 4
     _PLAN_SWITCHES = (b"BN_INPUT", b"BN_INPUT_WT", b"BN_RES_INPUT", b"BN_GRAD", b"BN_GRAD_RES", b"BN_FUSE", b"BRANCH_STREAM", b"WGRAD_STREAM", b"CONV6_PAIR")
 
-    def __init__(self, model, optimizer, method_name):
+    def __init__(self, model, optimizer, method_name, reducer=None):
         self.model, self.optimizer, self.method_name = model, optimizer, method_name
+        # data parallel (round 5): the gradient exchange is PART of the captured step -- backward, the RCCL all-reduce(s)
+        # of the flat gradient buffers (the early tail fired from inside the backward included) and the fused optimizer replay as one graph.
+        # RCCL collectives are capturable; torch's ProcessGroupNCCL records the fork / join between the step's stream and the collective's
+        # as captured event dependencies, and Work.wait() is a stream wait, not a host wait.  See _graph_mode for when this is legal.
+        self.reducer = reducer
         # the backbones whose flat parameter buffers the captured optimizer launches rewrite: a replay runs those launches on the
         # device only, so the host-side "weights changed" mark (HipResNet.mark_params_modified, normally set by optimizer.step())
         # has to be set here after every replay -- otherwise the next eager forward (validation, after_task) would skip the
@@ -97,7 +102,9 @@ class GraphedStep:
         from . import _lib
         L = _lib.lib()
         cfg = tuple(L.clhip_config_get(k) for k in self._PLAN_SWITCHES)
-        return shapes, lrs, self.model.training, cfg
+        red = self.reducer
+        dp = None if red is None else (red.world, red.exchange, getattr(self.optimizer, "grad_scale", None))
+        return shapes, lrs, self.model.training, cfg, dp
 
     def _step(self, batch):
         if self.method_name in _OBSERVE_DOES_BACKWARD:
@@ -107,6 +114,8 @@ class GraphedStep:
             out = self.model.observe(batch)
             self.optimizer.zero_grad()
             _backward(out[2])
+        if self.reducer is not None:
+            self.reducer.reduce(self.model)
         self.optimizer.step()
         return out
 
@@ -169,7 +178,7 @@ def _graph_mode(model, reducer, device, optimizer=None):
     eager 1.33 ms, replayed 1.41 ms in bench.py), while a loop that shares its process with a busy loader went 1.76 -> 1.34 ms
     (tools/graph_step.py; profiles/r02_small_batch_notes.md)"""
     env = os.environ.get("CLHIP_CUDA_GRAPH")
-    legal = (device is not None and torch.device(device).type == "cuda" and reducer is None and getattr(model, "grad_reducer", None) is None
+    legal = (device is not None and torch.device(device).type == "cuda" and _reducer_capturable(reducer) and getattr(model, "grad_reducer", None) is None
              and getattr(model, "cuda_graph_safe", False) and getattr(optimizer, "capture_safe", False))
     if not legal or env == "0":
         return None
@@ -178,6 +187,22 @@ def _graph_mode(model, reducer, device, optimizer=None):
     # out of the picture (eager 0.985 ... 1.106 ms box to box and run to run, replayed 0.846-0.849 ms: profiles/r03_step_notes.md); the large
     # batches keep the eager path -- their steps are GPU-bound and use side streams a capture keeps on one stream.
     return "always" if env == "1" else "auto"
+
+
+def _reducer_capturable(reducer):
+    """A data-parallel step replays from a graph when its exchange is made of capturable launches only: the RCCL backend (gloo stages through
+    the host), the in-place all-reduce exchange (the sharded one publishes parameters with a second collective behind the optimizer and keeps
+    per-shard state the replay cannot re-point), and CLHIP_DP_GRAPH != 0.  Every rank takes the same decision (same env, same backend), so
+    either all ranks replay or none does -- a mixture would still match collectives one to one, replayed or not."""
+    if reducer is None:
+        return True
+    if os.environ.get("CLHIP_DP_GRAPH", "1") == "0" or getattr(reducer, "exchange", None) != "all_reduce":
+        return False
+    import torch.distributed as dist
+    try:
+        return dist.is_initialized() and dist.get_backend(getattr(reducer, "group", None)) == "nccl"
+    except Exception:
+        return False
 
 
 GRAPH_AUTO_MAX_BATCH = 64          # (a plugin may raise it for itself: `cuda_graph_auto_max_batch`, e.g. LUCIR, whose batch-256 step is still host-enqueue-bound)
@@ -203,8 +228,8 @@ def train_steps(model, optimizer, batches, reducer=None, method_name="", meter=N
     gs = None
     if mode is not None:
         gs = getattr(model, "_graphed_step", None)
-        if gs is None or gs.optimizer is not optimizer:
-            gs = model._graphed_step = GraphedStep(model, optimizer, method_name)
+        if gs is None or gs.optimizer is not optimizer or gs.reducer is not reducer:
+            gs = model._graphed_step = GraphedStep(model, optimizer, method_name, reducer)
         gs.fallback_ok = mode == "auto"
     caller = torch.cuda.current_stream() if gs is not None else None
     if gs is not None:

@@ -116,3 +116,40 @@ def test_reduced_step_does_not_stall_under_the_queue_cap():
     assert len(plain) == 3 and len(tail) == 4
     assert max(plain) < 1.05 * min(plain), plain
     assert max(tail) < 1.12 * min(plain), (plain, tail)
+
+
+def _make_r32(seed):
+    torch.manual_seed(seed)
+    bb = M.cifar_resnet32(dtype="bf16")
+    m = M.EWC(bb, 64, 100, device="cuda", init_cls_num=50, inc_cls_num=5, lamda=100.0).to("cuda")
+    m.before_task(0, None, None, None)
+    m.train()
+    return m
+
+
+def test_reduced_step_replays_from_a_graph_bit_for_bit(rccl_group, monkeypatch):
+    """the data-parallel step -- backward, the RCCL all-reduce of the flat gradient buffer and of the head's bucket, the fused
+    optimizer -- is captured into ONE HIP graph and replayed (trainer.GraphedStep with a reducer); on a 1-rank RCCL group (the reducer told the
+    world is 2, so every collective is really enqueued) ten steps of which eight are replays end bit-identical to ten eager steps of the same
+    reduced loop (CifarResNet-32 at 32 images: every kernel of the step is deterministic, tests/test_graph_step_gpu.py), and CLHIP_DP_GRAPH=0 keeps
+    a reduced loop eager."""
+    monkeypatch.setenv("CLHIP_SGD_ZERO", "0")
+    res = []
+    for mode, dpg in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("CLHIP_CUDA_GRAPH", mode)
+        monkeypatch.setenv("CLHIP_DP_GRAPH", dpg)
+        m = _make_r32(11)
+        o = optim.SGD(m.get_parameters({}), lr=0.05, momentum=0.9, weight_decay=5e-4)
+        red = parallel.GradientReducer()
+        red.world = 2
+        parallel.attach(m, o, red)
+        assert o.grad_scale == 0.5                                  # kept: both runs scale the ("summed") gradient the same way
+        batches = [_batch(40 + i) for i in range(10)]
+        train_steps(m, o, batches, red, "EWC", None, "cuda")
+        torch.cuda.synchronize()
+        res.append((m.network.backbone.flat_parameters()[0].clone(), m.network.classifier.weight.detach().clone(), getattr(m, "_graphed_step", None)))
+    (p0, h0, g0), (p1, h1, g1), (p2, h2, g2) = res
+    assert g0 is None and g2 is None
+    assert g1 is not None and g1.reducer is not None and len(g1.graphs) == 1 and not g1.disabled
+    assert torch.equal(p0, p1) and torch.equal(h0, h1)
+    assert torch.equal(p0, p2)
