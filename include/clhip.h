@@ -492,6 +492,11 @@ const char* clhip_config_get(const char* key);
 /* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never (the default since round 4: inside the ViT steps the
  * register-staged kernel wins), 1 where it wins stand-alone (N >= 2048, >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
 void clhip_gemm5_config(int mode);
+/* the 256 x 256 eight-phase kernel with 64-deep K tiles (gemm8.hip, round 5; bf16, N % 256 == 0, K % 128 == 0, K >= 256): 0 never, 1 (the default) the
+ * row panels that fill whole rounds of its 256 persistent workgroups -- the remaining rows go to the register-staged kernel --, 2 wherever it is
+ * supported (tests); -1 = from $CLHIP_GEMM8.  Same epilogues as clhip_gemm_nt's other kernels
+ * (core/model/backbone/transformer.py:172, 194, 1259-1271). */
+void clhip_gemm8_config(int mode);
 /* workgroups the LDS-DMA weight-gradient kernel (wgrad4.hip) aims for: 0 = the default (160 -- 128 until round 4 --, chosen for the training step, where the
  * launch shares the chip with the dgrad / BatchNorm chain of the caller's stream; $CLHIP_WGRAD_TARGET), 256 = one per CU (the kernel
  * alone: bench.py's `full_chip` figures).  The scratch size (clhip_conv_wgrad_ws_bytes) follows the setting. */

@@ -580,6 +580,10 @@ int clhip_gemm5_launch(const void* A, const void* B, void* C, const float* bias,
                        int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st);
 
 
+int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype);
+int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
+                       int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st);
+
 extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                              int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, int dtype, void* stream) {
     CLHIP_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
@@ -593,6 +597,19 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
     static const int gm_env = clhip_cfg("GEMM_GROUP_M") ? atoi(clhip_cfg("GEMM_GROUP_M")) : 0;
     GemmParams p{A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, gm_env > 0 ? gm_env : (N >= 4096 ? 4 : 1)};     // wide outputs: 8192^3 991 -> 1046 TFLOP/s; the ViT shapes (N <= 3072) are indifferent
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (const int m8 = clhip_gemm8_rows(M, N, K, lda, ldb, ldc, ldr, ldh, dtype)) {
+        // gemm8.hip takes the leading m8 rows (whole rounds of its 256 persistent workgroups), the register-staged kernel the rest
+        if (int rc = clhip_gemm8_launch(A, B, C, bias, R, H, m8, N, K, lda, ldb, ldc, ldr, ldh, epilogue, s)) return rc;
+        if (m8 >= M) return CLHIP_OK;
+        const size_t e = 2;                                    // bf16
+        A = static_cast<const char*>(A) + (size_t)m8 * lda * e;
+        C = static_cast<char*>(C) + (size_t)m8 * ldc * e;
+        if (R) R = static_cast<const char*>(R) + (size_t)m8 * ldr * e;
+        if (H) H = static_cast<char*>(H) + (size_t)m8 * ldh * e;
+        M -= m8;
+        p.A = A; p.C = C; p.R = R; p.H = H; p.M = M;
+        return dispatch<bf16_t>(epilogue, p, s);
+    }
     if (clhip_gemm5_supported(M, N, K, lda, ldb, ldc, ldr, ldh, dtype))
         return clhip_gemm5_launch(A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, epilogue, s);
     return dtype == CLHIP_BF16 ? dispatch<bf16_t>(epilogue, p, s) : dispatch<float>(epilogue, p, s);

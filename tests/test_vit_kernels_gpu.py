@@ -108,6 +108,85 @@ def test_gemm5_every_epilogue(M, N, K, epi):
         _lib.lib().clhip_gemm5_config(-1)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 512, 384), (513, 768, 768), (256 * 9 + 7, 2304, 768), (77, 256, 3072), (256 * 33, 768, 256), (256 * 70 + 131, 1024, 512)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm8_every_epilogue(M, N, K, epi):
+    """the 256 x 256 eight-phase kernel (gemm8.hip, 64-deep K tiles in quadrant half tiles, DMA seven phases ahead) forced onto shapes it would not
+    pick: ragged last row tile, one to nine column tiles, 4 to 48 K tiles, fewer tiles than workgroups, several tiles per persistent workgroup
+    (the DMA queue runs across tile boundaries) and more tiles than 256 workgroups"""
+    _lib.lib().clhip_gemm8_config(2)
+    try:
+        A = rnd(M, K, seed=1).to(torch.bfloat16)
+        B = rnd(N, K, scale=1 / math.sqrt(K), seed=2).to(torch.bfloat16)
+        bias = rnd(N, seed=3)
+        R = rnd(M, N, seed=4).to(torch.bfloat16)
+        Hin = rnd(M, N, seed=5).to(torch.bfloat16)
+        Cc = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)          # one guard row behind the output
+        Hout = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        ref = A.double() @ B.double().T
+        if epi in (1, 2, 3):
+            ref = ref + bias.double()
+        if epi == 2:
+            ref = ref + R.double()
+        pre = ref.clone()
+        if epi == 3:
+            ref = F.gelu(ref)
+            pre = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+        if epi == 4:
+            ref = ref * Hin.double()
+        Hp = Hout if epi == 3 else (Hin if epi == 4 else None)
+        call("clhip_gemm_nt", p(A), p(B), p(Cc), p(bias) if epi in (1, 2, 3) else None, p(R) if epi == 2 else None, p(Hp), M, N, K, K, K, N, N, N, epi, CODE["bf16"], st())
+        torch.cuda.synchronize()
+        assert relerr(Cc[:M], ref) < TOL["bf16"]
+        assert float((Cc[M].float() - 7.0).abs().max()) == 0.0
+        if epi == 3:
+            assert relerr(Hout[:M], pre) < TOL["bf16"]
+            assert float((Hout[M].float() - 7.0).abs().max()) == 0.0
+    finally:
+        _lib.lib().clhip_gemm8_config(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 86 + 100, 768, 256), (256 * 40, 2304, 256), (256 * 64, 1024, 384), (300, 256, 256)])
+@pytest.mark.parametrize("epi", [0, 2, 3, 4])
+def test_gemm8_whole_rounds_and_a_register_staged_tail(M, N, K, epi):
+    """mode 1 (what CLHIP_GEMM8=1 runs): gemm8.hip computes the row panels that fill whole rounds of its 256 workgroups, the register-staged
+    kernel the remaining rows (261 tiles -> 85 panels + 356 rows; 360 tiles -> 28 panels + 12 panels; 256 tiles -> all; 2 tiles -> none): one
+    result, every row written once, the guard row behind the output untouched"""
+    _lib.lib().clhip_gemm8_config(1)
+    try:
+        A = rnd(M, K, seed=11).to(torch.bfloat16)
+        B = rnd(N, K, scale=1 / math.sqrt(K), seed=12).to(torch.bfloat16)
+        bias = rnd(N, seed=13)
+        R = rnd(M, N, seed=14).to(torch.bfloat16)
+        Hin = rnd(M, N, seed=15).to(torch.bfloat16)
+        Cc = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        Hout = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        ref = A.double() @ B.double().T
+        if epi in (1, 2, 3):
+            ref = ref + bias.double()
+        if epi == 2:
+            ref = ref + R.double()
+        pre = ref.clone()
+        if epi == 3:
+            ref = F.gelu(ref)
+            pre = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+        if epi == 4:
+            ref = ref * Hin.double()
+        Hp = Hout if epi == 3 else (Hin if epi == 4 else None)
+        call("clhip_gemm_nt", p(A), p(B), p(Cc), p(bias) if epi in (1, 2, 3) else None, p(R) if epi == 2 else None, p(Hp), M, N, K, K, K, N, N, N, epi, CODE["bf16"], st())
+        torch.cuda.synchronize()
+        assert relerr(Cc[:M], ref) < TOL["bf16"]
+        # row blocks: both kernels' parts separately (a missing part would hide in the norm of the whole)
+        for lo in range(0, M, 4096):
+            assert relerr(Cc[lo:min(M, lo + 4096)], ref[lo:min(M, lo + 4096)]) < TOL["bf16"]
+        assert float((Cc[M].float() - 7.0).abs().max()) == 0.0
+        if epi == 3:
+            assert relerr(Hout[:M], pre) < TOL["bf16"]
+            assert float((Hout[M].float() - 7.0).abs().max()) == 0.0
+    finally:
+        _lib.lib().clhip_gemm8_config(-1)
+
+
 @pytest.mark.parametrize("M,N,K", [(3552, 768, 3072), (3552, 768, 2304), (777, 768, 1536), (130, 256, 4096)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
 def test_gemm_nt_split_k(M, N, K, epi):
