@@ -467,7 +467,12 @@ def gemm_roofline(dev, dtype, M):
             for m in json.load(f):
                 if m.get("shape") == [M, N, K] and m.get("dtype") == dtype:
                     traffic, src = m["traffic_bytes_per_launch"], "profiles/r01_roofline_pmc_gemm.json (rocprofv3 --pmc, separate passes)"
-    return dict(bound="mfma", kernel=f"gemm_nt_kernel<{dtype}, bias+GELU> fc1 @ [{M},768]x[3072,768]^T", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+    # which kernel clhip_gemm_nt picks for this shape: gemm8.hip (round 5) takes the row panels that fill whole rounds of its 256 workgroups (all rows when
+    # the last round is >= 90 % full), the register-staged gemm_nt_kernel the rest -- and everything for fp32, for fewer than 256 tiles, or with CLHIP_GEMM8=0
+    tiles = ((M + 255) // 256) * (N // 256)
+    g8 = dtype == "bf16" and os.environ.get("CLHIP_GEMM8", "1") != "0" and tiles >= 256
+    sym = "gemm8_kernel<bias+GELU> (+ gemm_nt_kernel for the rows behind the last whole round)" if g8 else f"gemm_nt_kernel<{dtype}, bias+GELU>"
+    return dict(bound="mfma", kernel=f"{sym} fc1 @ [{M},768]x[3072,768]^T", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                 frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, traffic_source=src, launch_ms=ms, algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=alg_bytes,
                 hbm_gbs_algorithmic=alg_bytes / (ms * 1e-3) / 1e9)
 

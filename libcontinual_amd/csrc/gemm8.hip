@@ -275,6 +275,19 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
             for (int j = 0; j < 2; ++j) {
                 const int nb = n0 + wn * 64 + j * 32;        // this lane's groups: nb + 8 g4 + 4 kh
                 if (mv && EPI != EPI_NONE) {
+                    // residual / multiplier operands: ONE 16-byte load per 8 outputs at the address the lane will store to (crow + pr * 16 + kh * 8), brought into
+                    // the accumulator layout by the inverse of the store's half-wave exchange (v_permlane32_swap is its own inverse)
+                    unsigned ex[2][4];                       // [pr][ax ay bx by] packed bf16 pairs of the lane's groups g4 = 2 pr (a) and 2 pr + 1 (b)
+                    if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_MUL) {
+                        const bf16_t* erow = (EPI == EPI_BIAS_RES ? p.R + (size_t)m * p.ldr : p.H + (size_t)m * p.ldh) + nb;
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const u32x4 q = *reinterpret_cast<const u32x4*>(erow + pr * 16 + kh * 8);
+                            auto sx = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+                            auto sy = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+                            ex[pr][0] = sx[0]; ex[pr][1] = sy[0]; ex[pr][2] = sx[1]; ex[pr][3] = sy[1];
+                        }
+                    }
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int n = nb + 8 * g4 + 4 * kh;
@@ -283,15 +296,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
                             const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
                             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                         }
-                        if constexpr (EPI == EPI_BIAS_RES) {
-                            float r4[4];
-                            unpack4_8(*reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n), r4);
-                            v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-                        }
-                        if constexpr (EPI == EPI_MUL) {
-                            float h4[4];
-                            unpack4_8(*reinterpret_cast<const uint2*>(p.H + (size_t)m * p.ldh + n), h4);
-                            v[0] *= h4[0]; v[1] *= h4[1]; v[2] *= h4[2]; v[3] *= h4[3];
+                        if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_MUL) {
+                            float e4[4];
+                            unpack4_8(make_uint2(ex[g4 >> 1][2 * (g4 & 1)], ex[g4 >> 1][2 * (g4 & 1) + 1]), e4);
+                            if constexpr (EPI == EPI_BIAS_RES) { v[0] += e4[0]; v[1] += e4[1]; v[2] += e4[2]; v[3] += e4[3]; }
+                            else { v[0] *= e4[0]; v[1] *= e4[1]; v[2] *= e4[2]; v[3] *= e4[3]; }
                         }
                         acc[j][i][4 * g4] = v[0]; acc[j][i][4 * g4 + 1] = v[1]; acc[j][i][4 * g4 + 2] = v[2]; acc[j][i][4 * g4 + 3] = v[3];
                     }
@@ -367,7 +376,7 @@ static int g_mode8 = -1;
 int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype) {
     if (g_mode8 < 0) g_mode8 = clhip_cfg("GEMM8") ? atoi(clhip_cfg("GEMM8")) : 1;
     if (g_mode8 == 0 || dtype != CLHIP_BF16) return 0;
-    if (N % 256 != 0 || K % 128 != 0 || K < 256 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldr % 4 != 0 || ldh % 8 != 0) return 0;
+    if (N % 256 != 0 || K % 128 != 0 || K < 256 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldr % 8 != 0 || ldh % 8 != 0) return 0;
     if ((long long)M * lda * 2 >= (1ll << 31) - (1 << 20) || (long long)N * ldb * 2 >= (1ll << 31) - (1 << 20)) return 0;
     if (g_mode8 == 2) return M;
     static const int split = clhip_cfg("GEMM8_SPLIT") ? atoi(clhip_cfg("GEMM8_SPLIT")) : 1;
@@ -375,8 +384,11 @@ int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, in
     const int nt = N / 256, panels = (M + 255) / 256;
     const long tiles = (long)panels * nt;
     const long rounds = (tiles + 255) / 256;
-    if (tiles * 100 >= rounds * 256 * min_fill) return M;                  // the last round is (nearly) full
+    // a single round of 12 K tiles (proj at batch 128: 24 us of tile latency + the tail's launch) does not beat the register-staged kernel's 47 us
+    static const int min_work = clhip_cfg("GEMM8_MINWORK") ? atoi(clhip_cfg("GEMM8_MINWORK")) : 24;      // whole rounds x K tiles
+    if (tiles * 100 >= rounds * 256 * min_fill) return rounds * (K / 64) >= min_work ? M : 0;           // the last round is (nearly) full
     if (!split || tiles < 256) return 0;
+    if ((tiles / 256) * (K / 64) < min_work) return 0;
     const int full_panels = (int)((tiles / 256) * 256 / nt);               // whole rounds (the last panel of a round may leave a few tiles unused)
     return full_panels * 256;
 }
