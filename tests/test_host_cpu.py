@@ -354,3 +354,30 @@ def test_hw_queue_cap_state_is_reported():
     env["GPU_MAX_HW_QUEUES"] = "2"
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout
     assert "('user', '2') 2" in out
+
+
+def test_data_parallel_graph_replay_is_only_legal_on_rccl(monkeypatch):
+    """trainer._graph_mode: a reduced step may be captured only when its exchange is made of capturable launches -- the RCCL backend with the in-place
+    all-reduce; gloo (host staging), the sharded exchange and CLHIP_DP_GRAPH=0 keep the loop eager (round 5)"""
+    from libcontinual_amd import trainer as T
+
+    class Red:
+        def __init__(self, exchange):
+            self.exchange, self.group, self.world = exchange, None, 2
+
+    monkeypatch.delenv("CLHIP_DP_GRAPH", raising=False)
+    assert T._reducer_capturable(None)
+    assert not T._reducer_capturable(Red("all_reduce"))            # no process group in this process: not the RCCL backend
+    assert not T._reducer_capturable(Red("reduce_scatter"))
+    monkeypatch.setenv("CLHIP_DP_GRAPH", "0")
+    assert not T._reducer_capturable(Red("all_reduce"))
+
+    class M:
+        cuda_graph_safe, grad_reducer = True, None
+
+    class O:
+        capture_safe = True
+    assert T._graph_mode(M(), Red("all_reduce"), "cuda", O()) is None
+    monkeypatch.delenv("CLHIP_DP_GRAPH", raising=False)
+    assert T._graph_mode(M(), None, "cuda", O()) == "auto"
+    assert T._graph_mode(M(), None, "cpu", O()) is None
