@@ -47,6 +47,7 @@ struct Gemm8Params {
     const float* bias; const bf16_t* R; bf16_t* H;
     int M, N, K, lda, ldb, ldc, ldr, ldh;
     int nt, items, ipx;          // n tiles, tiles, tiles per XCD
+    int max_nmy, shift;          // tiles of the busiest workgroup; start delay (shader cycles) of the workgroups that walk fewer tiles (see the kernel)
     int opt;                     // experiments (CLHIP_GEMM8_OPT): bit 0 = the two wave halves realign at a tile's end and store at the same time (measured: no gain, qkv 101 -> 107 us)
 };
 
@@ -130,6 +131,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
     const int t_lo = xcd * p.ipx, t_hi = min(p.items, t_lo + p.ipx);
     const int nmy = t_lo + slot0 < t_hi ? (t_hi - t_lo - slot0 + per_xcd - 1) / per_xcd : 0;
     if (nmy == 0) return;
+    // All workgroups start together and stay in lockstep from tile to tile: the chip alternates between "every CU multiplies" and "every CU stores its tile"
+    // (fc1 + GELU + GELU': 62 MB per round, the HBM write rate fully exposed).  A workgroup that walks FEWER tiles than the busiest one has the time of a tile to
+    // spare: it starts half a tile late, so that its epilogues fall into the others' K loops -- free, whenever the last round is not full.
+    if (p.shift > 0 && (nmy < p.max_nmy || ((p.opt & 2) && (slot0 & 1)))) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.shift) __builtin_amdgcn_s_sleep(16);
+    }
     auto tile_of = [&](int k, int& m0, int& n0) {
         const int t = t_lo + slot0 + k * per_xcd;
         const int mt = t / p.nt;
@@ -397,12 +405,20 @@ extern "C" void clhip_gemm8_config(int mode) { g_mode8 = mode; }
 int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                        int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st) {
     Gemm8Params p{static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), static_cast<bf16_t*>(C), bias, static_cast<const bf16_t*>(R),
-                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 0};
+                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 0, 0, 0};
     static const int opt = clhip_cfg("GEMM8_OPT") ? atoi(clhip_cfg("GEMM8_OPT")) : 0;
     p.opt = opt;
     p.nt = N / 256;
     p.items = ((M + 255) / 256) * p.nt;
     p.ipx = (p.items + 7) / 8;
+    {
+        int grid = 256;
+        if (grid > (p.items + 7) / 8 * 8) grid = (p.items + 7) / 8 * 8;
+        const int per_xcd = grid / 8;
+        p.max_nmy = (p.ipx + per_xcd - 1) / per_xcd;
+        static const int shift_kt = clhip_cfg("GEMM8_SHIFT") ? atoi(clhip_cfg("GEMM8_SHIFT")) : 2000;      // shader cycles per K tile: about half of what a K tile takes
+        p.shift = p.max_nmy > 1 ? (K / 64) * shift_kt : 0;
+    }
     switch (epilogue) {
         case EPI_NONE: return launch8<EPI_NONE>(p, st);
         case EPI_BIAS: return launch8<EPI_BIAS>(p, st);
