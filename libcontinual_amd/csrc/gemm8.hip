@@ -387,6 +387,8 @@ int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, in
     if (N % 256 != 0 || K % 128 != 0 || K < 256 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldr % 8 != 0 || ldh % 8 != 0) return 0;
     if ((long long)M * lda * 2 >= (1ll << 31) - (1 << 20) || (long long)N * ldb * 2 >= (1ll << 31) - (1 << 20)) return 0;
     if (g_mode8 == 2) return M;
+    static const int min_n = clhip_cfg("GEMM8_MINN") ? atoi(clhip_cfg("GEMM8_MINN")) : 0;
+    if (N < min_n) return 0;
     static const int split = clhip_cfg("GEMM8_SPLIT") ? atoi(clhip_cfg("GEMM8_SPLIT")) : 1;
     static const int min_fill = clhip_cfg("GEMM8_FILL") ? atoi(clhip_cfg("GEMM8_FILL")) : 90;      // per cent of the last round
     const int nt = N / 256, panels = (M + 255) / 256;
