@@ -461,12 +461,13 @@ def gemm_roofline(dev, dtype, M):
     # HBM traffic per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/roofline_pmc_gemm.sh) of this kernel at this shape, committed
     # under profiles/; null if no matching measurement is on disk
     traffic, src = None, None
-    pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_roofline_pmc_gemm.json")
-    if os.path.exists(pj):
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    pj = next((os.path.join(pdir, f) for f in ("r05_roofline_pmc_gemm.json", "r01_roofline_pmc_gemm.json") if os.path.exists(os.path.join(pdir, f))), "")
+    if pj:
         with open(pj) as f:
             for m in json.load(f):
                 if m.get("shape") == [M, N, K] and m.get("dtype") == dtype:
-                    traffic, src = m["traffic_bytes_per_launch"], "profiles/r01_roofline_pmc_gemm.json (rocprofv3 --pmc, separate passes)"
+                    traffic, src = m["traffic_bytes_per_launch"], f"profiles/{os.path.basename(pj)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)"
     # which kernel clhip_gemm_nt picks for this shape: gemm8.hip (round 5) takes the row panels that fill whole rounds of its 256 workgroups (all rows when
     # the last round is >= 90 % full), the register-staged gemm_nt_kernel the rest -- and everything for fp32, for fewer than 256 tiles, or with CLHIP_GEMM8=0
     tiles = ((M + 255) // 256) * (N // 256)
