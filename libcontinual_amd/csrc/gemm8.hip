@@ -47,6 +47,7 @@ struct Gemm8Params {
     const float* bias; const bf16_t* R; bf16_t* H;
     int M, N, K, lda, ldb, ldc, ldr, ldh;
     int nt, items, ipx;          // n tiles, tiles, tiles per XCD
+    int group_m, panels;         // rasterisation: tiles are numbered column-major inside groups of group_m row panels (1: row-major)
     int max_nmy, shift;          // tiles of the busiest workgroup; start delay (shader cycles) of the workgroups that walk fewer tiles (see the kernel)
     int opt;                     // experiments (CLHIP_GEMM8_OPT): bit 0 = the two wave halves realign at a tile's end and store at the same time (measured: no gain, qkv 101 -> 107 us)
 };
@@ -140,8 +141,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
     }
     auto tile_of = [&](int k, int& m0, int& n0) {
         const int t = t_lo + slot0 + k * per_xcd;
-        const int mt = t / p.nt;
-        m0 = mt * BM; n0 = (t - mt * p.nt) * BN;
+        if (p.group_m <= 1) {
+            const int mt = t / p.nt;
+            m0 = mt * BM; n0 = (t - mt * p.nt) * BN;
+        } else {
+            // groups of group_m row panels, column-major inside a group: the 32 tiles an XCD's workgroups hold at a time share
+            // group_m activation panels and 32 / group_m weight panels instead of ~3 and all of them
+            const int per_group = p.group_m * p.nt;
+            const int gi = t / per_group, r = t - gi * per_group;
+            const int gm = min(p.group_m, p.panels - gi * p.group_m);
+            const int col = r / gm, mt = gi * p.group_m + (r - col * gm);
+            m0 = mt * BM; n0 = col * BN;
+        }
     };
 
     // ---- DMA cursor: half tiles are issued in the order W0 X0 W1 X1 of K tile 0, 1, ... of tile 0, 1, ...; it advances behind every X1
@@ -407,12 +418,15 @@ extern "C" void clhip_gemm8_config(int mode) { g_mode8 = mode; }
 int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                        int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st) {
     Gemm8Params p{static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), static_cast<bf16_t*>(C), bias, static_cast<const bf16_t*>(R),
-                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 0, 0, 0};
+                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 1, 0, 0, 0, 0};
     static const int opt = clhip_cfg("GEMM8_OPT") ? atoi(clhip_cfg("GEMM8_OPT")) : 0;
     p.opt = opt;
     p.nt = N / 256;
     p.items = ((M + 255) / 256) * p.nt;
     p.ipx = (p.items + 7) / 8;
+    p.panels = (M + 255) / 256;
+    static const int group_m = clhip_cfg("GEMM8_GROUP") ? atoi(clhip_cfg("GEMM8_GROUP")) : 1;
+    p.group_m = group_m;
     {
         int grid = 256;
         if (grid > (p.items + 7) / 8 * 8) grid = (p.items + 7) / 8 * 8;
