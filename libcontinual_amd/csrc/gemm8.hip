@@ -49,6 +49,10 @@ struct Gemm8Params {
     int nt, items, ipx;          // n tiles, tiles, tiles per XCD
     int group_m, panels;         // rasterisation: tiles are numbered column-major inside groups of group_m row panels (1: row-major)
     int max_nmy, shift;          // tiles of the busiest workgroup; start delay (shader cycles) of the workgroups that walk fewer tiles (see the kernel)
+    // stream-K last round (sk_tiles > 0): the tiles behind the last whole round, ids [sk_first, sk_first + sk_tiles), are cut along K into spans of sk_L K tiles over
+    // all workgroups; partial accumulators go through sk_ws ([tile][contributor <= sk_cap][8 blocks][512 threads][16 floats]), sk_cnt[tile] counts the published ones
+    int sk_tiles, sk_first, sk_L, sk_cap;
+    float* sk_ws; int* sk_cnt; int* sk_err;
     int opt;                     // experiments (CLHIP_GEMM8_OPT): bit 0 = the two wave halves realign at a tile's end and store at the same time (measured: no gain, qkv 101 -> 107 us)
 };
 
@@ -130,7 +134,19 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
     // ---- this workgroup's tiles: XCD x = blockIdx % 8 owns tiles [x * ipx, (x + 1) * ipx), its workgroups take them round-robin
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int t_lo = xcd * p.ipx, t_hi = min(p.items, t_lo + p.ipx);
-    const int nmy = t_lo + slot0 < t_hi ? (t_hi - t_lo - slot0 + per_xcd - 1) / per_xcd : 0;
+    const int ndp = t_lo + slot0 < t_hi ? (t_hi - t_lo - slot0 + per_xcd - 1) / per_xcd : 0;      // whole tiles of the data-parallel rounds
+    // stream-K spans: workgroup wq (numbered so that an XCD's workgroups are neighbours) owns K-tile iterations [wq * L, (wq + 1) * L) of the left-over tiles: at most
+    // the end of one tile and the beginning of the next (L < K tiles per tile; L, the K tiles per tile and therefore every cut are even)
+    int sk_tile[2] = {0, 0}, sk_kb[2] = {0, 0}, sk_kc[2] = {0, 0}, nsk = 0;
+    const int wq = xcd * per_xcd + slot0;
+    if (p.sk_tiles > 0) {
+        const int q0 = wq * p.sk_L, q1 = min(q0 + p.sk_L, p.sk_tiles * nkt);
+        if (q0 < q1) {
+            sk_tile[0] = q0 / nkt; sk_kb[0] = q0 - sk_tile[0] * nkt; sk_kc[0] = min(nkt - sk_kb[0], q1 - q0); nsk = 1;
+            if (q0 + sk_kc[0] < q1) { sk_tile[1] = sk_tile[0] + 1; sk_kb[1] = 0; sk_kc[1] = q1 - q0 - sk_kc[0]; nsk = 2; }
+        }
+    }
+    const int nmy = ndp + nsk;
     if (nmy == 0) return;
     // All workgroups start together and stay in lockstep from tile to tile: the chip alternates between "every CU multiplies" and "every CU stores its tile"
     // (fc1 + GELU + GELU': 62 MB per round, the HBM write rate fully exposed).  A workgroup that walks FEWER tiles than the busiest one has the time of a tile to
@@ -155,20 +171,28 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
         }
     };
 
+    // segment k of this workgroup: a whole tile of the data-parallel rounds (k < ndp) or a stream-K span
+    auto seg_of = [&](int k, int& m0, int& n0, int& kb, int& kc) {
+        if (k < ndp) { tile_of(k, m0, n0); kb = 0; kc = nkt; return; }
+        const int t = p.sk_first + sk_tile[k - ndp];
+        const int mt = t / p.nt;
+        m0 = mt * BM; n0 = (t - mt * p.nt) * BN; kb = sk_kb[k - ndp]; kc = sk_kc[k - ndp];
+    };
+
     // ---- DMA cursor: half tiles are issued in the order W0 X0 W1 X1 of K tile 0, 1, ... of tile 0, 1, ...; it advances behind every X1
     // (at most two K tiles ahead of the multiplying phases and K >= 256, so it enters tile k + 1 while tile k is being multiplied: the bases of the
     // NEXT tile are computed once per tile, outside the phase code)
-    int d_s = 0, d_abase, d_bbase, n_abase = 0, n_bbase = 0;
+    int d_s = 0, d_kb, d_kc, d_abase, d_bbase, n_abase = 0, n_bbase = 0, n_kb = 0, n_kc = 2;
     bool d_live = true, n_live = false;
     {
         int m0, n0;
-        tile_of(0, m0, n0);
+        seg_of(0, m0, n0, d_kb, d_kc);
         d_abase = m0 * p.lda * 2; d_bbase = n0 * p.ldb * 2;
     }
     auto dma = [&](auto sub_c, auto par_c) {
         constexpr int SUB = decltype(sub_c)::value, PAR = decltype(par_c)::value;
         char* l = smem + PAR * KTILE + SUB * HALF + wave * 2048;
-        const int koff = d_s * (BK * 2);
+        const int koff = (d_kb + d_s) * (BK * 2);
         constexpr int h = SUB >> 1;
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (SUB == SUB_W0 || SUB == SUB_W1) {
@@ -185,14 +209,83 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
 #endif
         if constexpr (SUB == SUB_X1) {                      // branch-free: a branch here splits the K-tile body into basic blocks and hipcc sinks MFMAs across the barriers
             const int s1 = d_s + 1;
-            const bool wrap = s1 == nkt;
+            const bool wrap = s1 == d_kc;
             d_s = wrap ? 0 : s1;
             d_abase = wrap ? n_abase : d_abase;
             d_bbase = wrap ? n_bbase : d_bbase;
+            d_kb = wrap ? n_kb : d_kb;
+            d_kc = wrap ? n_kc : d_kc;
             d_live = wrap ? n_live : d_live;
         }
     };
 #define IC(v) std::integral_constant<int, (v)>{}
+
+    // ---- epilogue of ONE 32 x 32 accumulator block (m fragment i, n half j) of a tile at (m0, n0).  D[row = n: (r & 3) + 8 (r >> 2) + 4 kh][col = m: l31]: a lane
+    //      holds 4 groups of 4 consecutive n
+    auto epi_block = [&](f32x16& a, int m0, int n0, int i, int j) {
+        const int m = m0 + wm * 128 + i * 32 + l31;
+        const bool mv = m < p.M;
+        const int nb = n0 + wn * 64 + j * 32;                // this lane's groups: nb + 8 g4 + 4 kh
+        if (mv && EPI != EPI_NONE) {
+            // residual / multiplier operands: ONE 16-byte load per 8 outputs at the address the lane will store to (crow + pr * 16 + kh * 8), brought into
+            // the accumulator layout by the inverse of the store's half-wave exchange (v_permlane32_swap is its own inverse)
+            unsigned ex[2][4];                               // [pr][ax ay bx by] packed bf16 pairs of the lane's groups g4 = 2 pr (a) and 2 pr + 1 (b)
+            if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_MUL) {
+                const bf16_t* erow = (EPI == EPI_BIAS_RES ? p.R + (size_t)m * p.ldr : p.H + (size_t)m * p.ldh) + nb;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const u32x4 q = *reinterpret_cast<const u32x4*>(erow + pr * 16 + kh * 8);
+                    auto sx = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+                    auto sy = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+                    ex[pr][0] = sx[0]; ex[pr][1] = sy[0]; ex[pr][2] = sx[1]; ex[pr][3] = sy[1];
+                }
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = nb + 8 * g4 + 4 * kh;
+                float v[4] = {a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]};
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_MUL) {
+                    float e4[4];
+                    unpack4_8(make_uint2(ex[g4 >> 1][2 * (g4 & 1)], ex[g4 >> 1][2 * (g4 & 1) + 1]), e4);
+                    if constexpr (EPI == EPI_BIAS_RES) { v[0] += e4[0]; v[1] += e4[1]; v[2] += e4[2]; v[3] += e4[3]; }
+                    else { v[0] *= e4[0]; v[1] *= e4[1]; v[2] *= e4[2]; v[3] *= e4[3]; }
+                }
+                a[4 * g4] = v[0]; a[4 * g4 + 1] = v[1]; a[4 * g4 + 2] = v[2]; a[4 * g4 + 3] = v[3];
+            }
+        }
+        float dv[16];
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f2 y, d;
+                gelu_both8((f2){a[r], a[r + 1]}, y, d);
+                a[r] = y.x; a[r + 1] = y.y; dv[r] = d.x; dv[r + 1] = d.y;
+            }
+        }
+        bf16_t* crow = p.C + (size_t)m * p.ldc + nb;
+        bf16_t* hrow = p.H + (size_t)m * p.ldh + nb;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            {
+                unsigned ax = pack_bf16x2(a[8 * pr + 0], a[8 * pr + 1]), ay = pack_bf16x2(a[8 * pr + 2], a[8 * pr + 3]);
+                unsigned bx = pack_bf16x2(a[8 * pr + 4], a[8 * pr + 5]), by = pack_bf16x2(a[8 * pr + 6], a[8 * pr + 7]);
+                auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (mv) *reinterpret_cast<u32x4*>(crow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+            }
+            if constexpr (EPI == EPI_BIAS_GELU) {
+                unsigned ax = pack_bf16x2(dv[8 * pr + 0], dv[8 * pr + 1]), ay = pack_bf16x2(dv[8 * pr + 2], dv[8 * pr + 3]);
+                unsigned bx = pack_bf16x2(dv[8 * pr + 4], dv[8 * pr + 5]), by = pack_bf16x2(dv[8 * pr + 6], dv[8 * pr + 7]);
+                auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (mv && p.H != nullptr) *reinterpret_cast<u32x4*>(hrow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+            }
+        }
+    };
 
     // ---- prologue: seven half tiles in flight, K tile 0 landed and published
     dma(IC(SUB_W0), IC(0)); dma(IC(SUB_X0), IC(0)); dma(IC(SUB_W1), IC(0)); dma(IC(SUB_X1), IC(0));
@@ -201,13 +294,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    bool aligned = true;                                     // both wave halves at the same barrier count (false while waves 4-7 run one behind)
     for (int k = 0; k < nmy; ++k) {
-        int m0, n0;
-        tile_of(k, m0, n0);
+        int m0, n0, kb, kc;
+        seg_of(k, m0, n0, kb, kc);
+        (void)kb;
         n_live = k + 1 < nmy;
         if (n_live) {
             int m1, n1;
-            tile_of(k + 1, m1, n1);
+            seg_of(k + 1, m1, n1, n_kb, n_kc);
             n_abase = m1 * p.lda * 2; n_bbase = n1 * p.ldb * 2;
         }
         f32x16 acc[2][4];                                    // [n half j][m fragment 2 i + i2]
@@ -219,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
         bf16x8_t xf[2][4], wf0[4], wf1[4];
-        if (lag && (k == 0 || (p.opt & 1))) __builtin_amdgcn_s_barrier();                // waves 4-7 run one barrier behind from here on
+        if (aligned) { if (lag) __builtin_amdgcn_s_barrier(); aligned = false; }         // waves 4-7 run one barrier behind from here on
         // one K tile out of buffer PAR: four phases
 #define MFMA8(J, IB, WF)                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
@@ -277,82 +372,81 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
             MFMA8(0, 2, wf0)                                                                                                    \
         }
 
-        for (int s = 0; s < nkt; s += 2) {
+        for (int s = 0; s < kc; s += 2) {
             KTILE8(0)
             KTILE8(1)
         }
 #undef KTILE8
 #undef MFMA8
-        if (!lag && (k == nmy - 1 || (p.opt & 1))) __builtin_amdgcn_s_barrier();               // the barrier waves 4-7 still owe
+        if (k == nmy - 1 || k >= ndp || (p.opt & 1)) { if (!lag) __builtin_amdgcn_s_barrier(); aligned = true; }      // the barrier waves 4-7 still owe
 
-        // ---- epilogue.  D[row = n: (r & 3) + 8 (r >> 2) + 4 kh][col = m: l31]; per (j, i) a lane holds 4 groups of 4 consecutive n
+        if (k >= ndp) {
+            // ---- stream-K span: the raw accumulators of this span go to the workspace (every thread its 8 blocks of 16 floats, 64 contiguous bytes each) and are
+            //      published; NOTHING is waited for here (a wait between a workgroup's two spans would chain the tiles one behind the other) -- see "phase 2" below
+            const int sk = sk_tile[k - ndp];
+            const int wf = (sk * nkt) / p.sk_L;              // first contributor of the tile
+            float* slab = p.sk_ws + ((size_t)(sk * p.sk_cap + (wq - wf)) * 8) * (512 * 16) + (size_t)tid * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 128 + i * 32 + l31;
-            const bool mv = m < p.M;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int nb = n0 + wn * 64 + j * 32;        // this lane's groups: nb + 8 g4 + 4 kh
-                if (mv && EPI != EPI_NONE) {
-                    // residual / multiplier operands: ONE 16-byte load per 8 outputs at the address the lane will store to (crow + pr * 16 + kh * 8), brought into
-                    // the accumulator layout by the inverse of the store's half-wave exchange (v_permlane32_swap is its own inverse)
-                    unsigned ex[2][4];                       // [pr][ax ay bx by] packed bf16 pairs of the lane's groups g4 = 2 pr (a) and 2 pr + 1 (b)
-                    if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_MUL) {
-                        const bf16_t* erow = (EPI == EPI_BIAS_RES ? p.R + (size_t)m * p.ldr : p.H + (size_t)m * p.ldh) + nb;
+                for (int i = 0; i < 4; ++i) {
+                    float* d = slab + (size_t)(i * 2 + j) * (512 * 16);
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const u32x4 q = *reinterpret_cast<const u32x4*>(erow + pr * 16 + kh * 8);
-                            auto sx = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
-                            auto sy = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
-                            ex[pr][0] = sx[0]; ex[pr][1] = sy[0]; ex[pr][2] = sx[1]; ex[pr][3] = sy[1];
-                        }
-                    }
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int n = nb + 8 * g4 + 4 * kh;
-                        float v[4] = {acc[j][i][4 * g4], acc[j][i][4 * g4 + 1], acc[j][i][4 * g4 + 2], acc[j][i][4 * g4 + 3]};
-                        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) {
-                            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                        }
-                        if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_MUL) {
-                            float e4[4];
-                            unpack4_8(make_uint2(ex[g4 >> 1][2 * (g4 & 1)], ex[g4 >> 1][2 * (g4 & 1) + 1]), e4);
-                            if constexpr (EPI == EPI_BIAS_RES) { v[0] += e4[0]; v[1] += e4[1]; v[2] += e4[2]; v[3] += e4[3]; }
-                            else { v[0] *= e4[0]; v[1] *= e4[1]; v[2] *= e4[2]; v[3] *= e4[3]; }
-                        }
-                        acc[j][i][4 * g4] = v[0]; acc[j][i][4 * g4 + 1] = v[1]; acc[j][i][4 * g4 + 2] = v[2]; acc[j][i][4 * g4 + 3] = v[3];
-                    }
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        *reinterpret_cast<f32x4*>(d + 4 * q4) = (f32x4){acc[j][i][4 * q4], acc[j][i][4 * q4 + 1], acc[j][i][4 * q4 + 2], acc[j][i][4 * q4 + 3]};
                 }
-                float dv[16];
-                if constexpr (EPI == EPI_BIAS_GELU) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(p.sk_cnt + sk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+
+        // ---- epilogue of a whole tile
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        f2 y, d;
-                        gelu_both8((f2){acc[j][i][r], acc[j][i][r + 1]}, y, d);
-                        acc[j][i][r] = y.x; acc[j][i][r + 1] = y.y; dv[r] = d.x; dv[r + 1] = d.y;
-                    }
-                }
-                bf16_t* crow = p.C + (size_t)m * p.ldc + nb;
-                bf16_t* hrow = p.H + (size_t)m * p.ldh + nb;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    {
-                        unsigned ax = pack_bf16x2(acc[j][i][8 * pr + 0], acc[j][i][8 * pr + 1]), ay = pack_bf16x2(acc[j][i][8 * pr + 2], acc[j][i][8 * pr + 3]);
-                        unsigned bx = pack_bf16x2(acc[j][i][8 * pr + 4], acc[j][i][8 * pr + 5]), by = pack_bf16x2(acc[j][i][8 * pr + 6], acc[j][i][8 * pr + 7]);
-                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                        if (mv) *reinterpret_cast<u32x4*>(crow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
-                    }
-                    if constexpr (EPI == EPI_BIAS_GELU) {
-                        unsigned ax = pack_bf16x2(dv[8 * pr + 0], dv[8 * pr + 1]), ay = pack_bf16x2(dv[8 * pr + 2], dv[8 * pr + 3]);
-                        unsigned bx = pack_bf16x2(dv[8 * pr + 4], dv[8 * pr + 5]), by = pack_bf16x2(dv[8 * pr + 6], dv[8 * pr + 7]);
-                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                        if (mv && p.H != nullptr) *reinterpret_cast<u32x4*>(hrow + pr * 16 + kh * 8) = u32x4{rx[0], ry[0], rx[1], ry[1]};
-                    }
+            for (int j = 0; j < 2; ++j) epi_block(acc[j][i], m0, n0, i, j);
+    }
+
+    // ---- stream-K, phase 2: every span of the launch has been published or will be without waiting for anything (above), so waiting here cannot deadlock while
+    //      all workgroups are resident (one per CU, grid <= 256).  A tile's contributors are the workgroups whose spans meet it, numbered in K order; contributor jc
+    //      reduces the blocks b with b % c == jc: it sums the c partial blocks in contributor order (a fixed order: the result does not depend on who arrives when)
+    //      and runs the block's epilogue.
+    for (int e = 0; e < nsk; ++e) {
+        const int sk = sk_tile[e];
+        const int wf = (sk * nkt) / p.sk_L;
+        const int wl = min((sk * nkt + nkt - 1) / p.sk_L, (p.sk_tiles * nkt - 1) / p.sk_L);
+        const int c = wl - wf + 1, jc = wq - wf;
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(p.sk_cnt + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) { __hip_atomic_store(p.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // never in a correct launch: no hang
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const int t = p.sk_first + sk, mt = t / p.nt;
+        const int m0 = mt * BM, n0 = (t - mt * p.nt) * BN;
+        const float* tile_ws = p.sk_ws + (size_t)sk * p.sk_cap * 8 * (512 * 16) + (size_t)tid * 16;
+#pragma unroll 1
+        for (int b = jc; b < 8; b += c) {
+            f32x16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+            for (int jj = 0; jj < c; ++jj) {
+                const float* src = tile_ws + (size_t)(jj * 8 + b) * (512 * 16);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * q4);
+                    v[4 * q4] += x[0]; v[4 * q4 + 1] += x[1]; v[4 * q4 + 2] += x[2]; v[4 * q4 + 3] += x[3];
                 }
             }
+            epi_block(v, m0, n0, b >> 1, b & 1);
         }
     }
     wait_vm8<0>();                                           // the zero-fill requests behind the last tile write LDS too: nothing may be in flight when the wave ends
@@ -410,15 +504,66 @@ int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, in
     if (tiles * 100 >= rounds * 256 * min_fill) return rounds * (K / 64) >= min_work ? M : 0;           // the last round is (nearly) full
     if (!split || tiles < 256) return 0;
     if ((tiles / 256) * (K / 64) < min_work) return 0;
+    const int sk = clhip_cfg("GEMM8_SK") ? atoi(clhip_cfg("GEMM8_SK")) : 0;
+    if (sk) return M;                                                      // the left-over tiles run as a stream-K round inside the launch (sk_setup)
     const int full_panels = (int)((tiles / 256) * 256 / nt);               // whole rounds (the last panel of a round may leave a few tiles unused)
     return full_panels * 256;
 }
 extern "C" void clhip_gemm8_config(int mode) { g_mode8 = mode; }
 
+// ---- stream-K last round (CLHIP_GEMM8_SK=1).  With T tiles and 256 workgroups the first 256 * (T / 256) tiles run as whole rounds; the R left-over tiles are cut
+// along K into spans of L K tiles (even; at least R * nkt / 256 so that 256 spans cover them, at least nkt / 7 so that a tile has at most 8 contributors), one span
+// per workgroup.  Workspace and counters are per device, allocated on first use (never inside a stream capture: such a launch runs without the stream-K round).
+namespace {
+struct SkState { float* ws = nullptr; size_t ws_bytes = 0; int* cnt = nullptr; };       // cnt[0 .. 255] published spans per tile, cnt[256] the time-out flag
+SkState g_sk[16];
+
+int sk_setup(Gemm8Params& p, hipStream_t st) {
+    const int sk_mode = clhip_cfg("GEMM8_SK") ? atoi(clhip_cfg("GEMM8_SK")) : 0;         // (looked up per launch: tests flip it with clhip_config)
+    const int T = p.items, F = T / 256, R = T - 256 * F;
+    if (sk_mode == 0 || F < 1 || R == 0) return CLHIP_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return CLHIP_OK;
+    const int nkt = p.K / 64;
+    int L = 2 * ((R * nkt + 511) / 512);
+    if (L < 2 * ((nkt + 13) / 14)) L = 2 * ((nkt + 13) / 14);
+    const int cap = (nkt + L - 1) / L + 1 < 8 ? (nkt + L - 1) / L + 1 : 8;
+    const size_t need = (size_t)R * cap * 8 * 512 * 16 * sizeof(float);
+    SkState& S = g_sk[dev];
+    if (S.cnt == nullptr || S.ws_bytes < need) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return CLHIP_OK;      // no allocation inside a capture
+        (void)hipDeviceSynchronize();                        // an older launch may still use the smaller workspace
+        if (S.ws) (void)hipFree(S.ws);
+        S.ws = nullptr; S.ws_bytes = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&S.ws), need) != hipSuccess) { (void)hipGetLastError(); return CLHIP_OK; }      // no memory: the plain rounds
+        S.ws_bytes = need;
+        if (S.cnt == nullptr) {
+            if (hipMalloc(reinterpret_cast<void**>(&S.cnt), 257 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); S.cnt = nullptr; return CLHIP_OK; }
+            (void)hipMemset(S.cnt, 0, 257 * sizeof(int));
+        }
+    }
+    if (hipMemsetAsync(S.cnt, 0, 256 * sizeof(int), st) != hipSuccess) { clhip_set_error("gemm8: cannot reset the stream-K counters"); return CLHIP_EHIP; }
+    p.sk_tiles = R; p.sk_first = 256 * F; p.sk_L = L; p.sk_cap = cap;
+    p.sk_ws = S.ws; p.sk_cnt = S.cnt; p.sk_err = S.cnt + 256;
+    p.items = 256 * F; p.ipx = 32 * F; p.max_nmy = F; p.shift = 0; p.group_m = 1;
+    return CLHIP_OK;
+}
+}  // namespace
+
+// 1 if a stream-K launch on the current device ever gave up waiting for a span (it then stored a wrong tile instead of hanging); tests assert 0.  Synchronises.
+extern "C" int clhip_gemm8_sk_status(void) {
+    int dev = 0, flag = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || g_sk[dev].cnt == nullptr) return 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(&flag, g_sk[dev].cnt + 256, sizeof(int), hipMemcpyDeviceToHost);
+    return flag;
+}
+
 int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                        int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st) {
     Gemm8Params p{static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), static_cast<bf16_t*>(C), bias, static_cast<const bf16_t*>(R),
-                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 1, 0, 0, 0, 0};
+                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
     static const int opt = clhip_cfg("GEMM8_OPT") ? atoi(clhip_cfg("GEMM8_OPT")) : 0;
     p.opt = opt;
     p.nt = N / 256;
@@ -435,6 +580,7 @@ int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias,
         static const int shift_kt = clhip_cfg("GEMM8_SHIFT") ? atoi(clhip_cfg("GEMM8_SHIFT")) : 2000;      // shader cycles per K tile: about half of what a K tile takes
         p.shift = p.max_nmy > 1 ? (K / 64) * shift_kt : 0;
     }
+    if (int rc = sk_setup(p, st)) return rc;
     switch (epilogue) {
         case EPI_NONE: return launch8<EPI_NONE>(p, st);
         case EPI_BIAS: return launch8<EPI_BIAS>(p, st);
