@@ -497,7 +497,7 @@ void clhip_gemm5_config(int mode);
  * supported (tests); -1 = from $CLHIP_GEMM8.  Same epilogues as clhip_gemm_nt's other kernels
  * (core/model/backbone/transformer.py:172, 194, 1259-1271). */
 void clhip_gemm8_config(int mode);
-/* stream-K last round of gemm8.hip ($CLHIP_GEMM8_SK=1): 1 if a launch on the current device ever gave up waiting for another workgroup's span (a bounded wait: a wrong
+/* stream-K last round of gemm8.hip ($CLHIP_GEMM8_SK=1; off by default: measured slower than the whole-rounds + tail split, profiles/r05_gemm8_notes.md section 7): 1 if a launch on the current device ever gave up waiting for another workgroup's span (a bounded wait: a wrong
  * tile instead of a hang; never observed), else 0.  Synchronises the device.  Test / diagnostics hook. */
 int clhip_gemm8_sk_status(void);
 /* workgroups the LDS-DMA weight-gradient kernel (wgrad4.hip) aims for: 0 = the default (160 -- 128 until round 4 --, chosen for the training step, where the
