@@ -67,6 +67,7 @@ class GraphedStep:
         (clhip_plan_read_act: debugging hooks) materialises it with a launch of its own and does not disturb the next replay: the replayed
         forward rewrites every buffer it reads."""
     WARM, KEEP = 2, 4
+    PROBE = 12                      # auto mode: steps of each kind timed per key before the faster one is kept (see _pick)
     _PLAN_SWITCHES = (b"BN_INPUT", b"BN_INPUT_WT", b"BN_RES_INPUT", b"BN_GRAD", b"BN_GRAD_RES", b"BN_FUSE", b"BRANCH_STREAM", b"WGRAD_STREAM", b"CONV6_PAIR")
 
     def __init__(self, model, optimizer, method_name, reducer=None):
@@ -93,6 +94,8 @@ class GraphedStep:
         # every step of a graphed loop -- warm-up, capture, replay -- runs on this stream: autograd binds a parameter's gradient
         # accumulation to the stream of its first backward, and a capture cannot depend on the legacy default stream
         self.stream = torch.cuda.Stream()
+        self.choice = {}            # key -> "replay" | "eager": what the probe of this key measured to be faster (auto mode only)
+        self._probe = {}            # key -> probe state while it is being measured
         self.disabled = False       # a capture failed under the auto mode: this loop stays eager
         self.fallback_ok = True     # ... which only the auto mode allows (train_steps sets it)
 
@@ -118,6 +121,35 @@ class GraphedStep:
             self.reducer.reduce(self.model)
         self.optimizer.step()
         return out
+
+    def _pick(self, key):
+        """Auto mode only (CLHIP_CUDA_GRAPH unset): replay or eager for THIS step of a captured key?  A replay takes the host out of the step, but HIP's graph launch has a
+        per-node cost of its own: the 32-image CifarResNet-32 step replays at 0.74 ms on every box, while the eager enqueue runs 0.67 ms on a box with a fast, idle host and
+        0.87-1.03 ms on others (profiles/r05_dp_graph_micro.txt, r05_notes.md).  So the first PROBE steps of a key are replayed and the next PROBE enqueued eagerly, each
+        block timed with a pair of events (two stream synchronisations per key, every probe step a real training step: both paths give the same bits), and the faster kind
+        is kept -- replay unless eager wins by more than 3 %."""
+        c = self.choice.get(key)
+        if c is not None:
+            return c == "replay"
+        st = self._probe.get(key)
+        if st is None:
+            st = self._probe[key] = dict(kind="replay", n=0, ev=torch.cuda.Event(enable_timing=True), ms={})
+            st["ev"].record()
+        if st["n"] == self.PROBE:                            # a block is complete: read its time, start the next one or decide
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            end.synchronize()
+            st["ms"][st["kind"]] = st["ev"].elapsed_time(end) / self.PROBE
+            if st["kind"] == "replay":
+                st.update(kind="eager", n=0, ev=torch.cuda.Event(enable_timing=True))
+                st["ev"].record()
+            else:
+                self.choice[key] = "eager" if st["ms"]["eager"] < 0.97 * st["ms"]["replay"] else "replay"
+                self.probe_ms = dict(st["ms"])                # (last probe's figures: diagnostics, tests)
+                del self._probe[key]
+                return self.choice[key] == "replay"
+        st["n"] += 1
+        return st["kind"] == "replay"
 
     def __call__(self, batch):
         if self.disabled:
@@ -157,6 +189,8 @@ class GraphedStep:
                 self.graphs.pop(next(iter(self.graphs)))
             ent = self.graphs[key] = (g, static, out)
         g, static, out = ent
+        if self.fallback_ok and not self._pick(key):
+            return self._step(batch)
         for k, v in batch.items():
             if torch.is_tensor(v):
                 static[k].copy_(v, non_blocking=True)

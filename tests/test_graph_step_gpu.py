@@ -538,3 +538,25 @@ def test_stage_level_eval_forward(batch):
     T.train_steps(m, o, _batches(2, 64), None, "EWC", None, "cuda")
     torch.cuda.synchronize()
     assert torch.isfinite(bb.flat_parameters()[0]).all()
+
+
+def test_auto_mode_keeps_the_faster_of_replay_and_eager(monkeypatch):
+    """round 5: without CLHIP_CUDA_GRAPH a captured key is PROBED -- GraphedStep.PROBE steps replayed, as many enqueued eagerly, each block timed with events -- and the
+    faster kind is kept (replay unless eager wins by 3 %: HIP's graph launch has a per-node cost, an idle fast host can beat it).  Every probe step is a real step and both
+    kinds give the same bits, so 40 steps end exactly where 40 eager steps end, whatever the probe decided."""
+    res = []
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("CLHIP_CUDA_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("CLHIP_CUDA_GRAPH", mode)
+        m = _make("ewc", 31)
+        o = optim.SGD(m.get_parameters({}), lr=0.02, momentum=0.9, weight_decay=5e-4)
+        T.train_steps(m, o, _batches(40, 32), None, "EWC", None, "cuda")
+        torch.cuda.synchronize()
+        res.append((m.network.backbone.flat_parameters()[0].clone(), getattr(m, "_graphed_step", None)))
+    (p0, g0), (p1, g1) = res
+    assert g0 is None and g1 is not None and len(g1.graphs) == 1
+    assert list(g1.choice.values())[0] in ("replay", "eager") and set(g1.probe_ms) == {"replay", "eager"}
+    print("probe (ms per 32-image EWC step): ", g1.probe_ms, "->", list(g1.choice.values())[0])
+    assert torch.equal(p0, p1)
