@@ -29,6 +29,7 @@
 //
 // Epilogues as gemm.hip / gemm5.hip.  Replaces F.linear on the ViT path (core/model/backbone/transformer.py:172, 194, 1259-1271).
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -529,6 +530,8 @@ int sk_setup(Gemm8Params& p, hipStream_t st) {
     if (L < 2 * ((nkt + 13) / 14)) L = 2 * ((nkt + 13) / 14);
     const int cap = (nkt + L - 1) / L + 1 < 8 ? (nkt + L - 1) / L + 1 : 8;
     const size_t need = (size_t)R * cap * 8 * 512 * 16 * sizeof(float);
+    static std::mutex mu;                                    // (launches of several host threads on one device: one of them allocates)
+    std::lock_guard<std::mutex> lk(mu);
     SkState& S = g_sk[dev];
     if (S.cnt == nullptr || S.ws_bytes < need) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
