@@ -217,6 +217,17 @@ void clhip_plan_destroy(clhip_plan*);
 size_t clhip_plan_workspace_bytes(const clhip_plan*);      /* activations + saved tensors + grads + scratch */
 size_t clhip_plan_shadow_bytes(const clhip_plan*);         /* `dtype` copies of the conv weights */
 int clhip_plan_feat_dim(const clhip_plan*);
+/* (round 6) Runs of BasicBlocks of the CIFAR ResNet-32s (core/model/backbone/resnet.py:289-316, 381-392) execute as ONE launch per direction in training mode
+ * when the batch fits the device one image per compute unit (bf16 plans, N <= number of CUs; clhip_config("STAGE_TRAIN", "0") keeps one launch per unit).
+ * Those launches need every workgroup resident at once, so: (1) a plan's training passes must not run on two streams concurrently, nor beside the training
+ * passes of another plan of the same device on another stream (the library serialises stream switches outside a capture; inside a capture the caller must);
+ * (2) several PROCESSES sharing one GPU must switch STAGE_TRAIN off.  Every in-launch wait is bounded: a violation ends in wrong results plus a sticky error
+ * word, not a hung device.  clhip_plan_stage_status returns that word (0 = clean; synchronises the device -- call it at epoch / task boundaries). */
+int clhip_plan_stage_status(clhip_plan*);
+/* what: 0 = units of the plan that run inside stage-level training launches, 1 / 2 = such forward / backward launches made so far (tests, diagnostics) */
+long long clhip_plan_stage_info(const clhip_plan*, int what);
+/* diagnostic (clhip_config("STAGE_TRACE", "<channels>:<convolution>")): 24 phase stamps (100-MHz ticks) of workgroup 0's last traced forward [0..7] / backward [8..23] unit */
+int clhip_plan_stage_trace(clhip_plan*, unsigned long long* out24);
 /* refresh the `dtype` weight shadows from the fp32 masters (call after every optimizer step) */
 int clhip_plan_prep_weights(clhip_plan*, const float* params, void* shadow, void* stream);
 /* x: fp32 NCHW input; feat: fp32 [N, feat_dim].  training!=0: batch statistics, running stats updated,

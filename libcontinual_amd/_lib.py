@@ -112,6 +112,9 @@ _PROTOS = {
     "clhip_plan_workspace_bytes": (_sz, [_p]),
     "clhip_plan_shadow_bytes": (_sz, [_p]),
     "clhip_plan_feat_dim": (_i, [_p]),
+    "clhip_plan_stage_status": (_i, [_p]),
+    "clhip_plan_stage_info": (C.c_longlong, [_p, _i]),
+    "clhip_plan_stage_trace": (_i, [_p, _p]),
     "clhip_plan_prep_weights": (_i, [_p, _p, _p, _p]),
     "clhip_plan_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "clhip_plan_forward_ex": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),

@@ -41,6 +41,17 @@ struct Act {
 bool clhip_stage_eval_supported(int H, int W, int C, int nconv, int dtype);                                                   // stage.hip
 int clhip_stage_eval_launch(const void* x, void* y, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
                             const float* const* mean, const float* const* var, float eps, int dtype, hipStream_t st);
+bool clhip_stage_train_supported(int N, int H, int W, int C, int nconv, int dtype);                                            // stage_train.hip
+size_t clhip_stage_train_xch_bytes(int N);
+int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
+                                 float* const* rm, float* const* rv, float* const* mean, float* const* invstd, float* const* coef, void* const* z, void* const* y,
+                                 void* const* mask, float momentum, float eps, void* xch, int trace, int dtype, hipStream_t st);
+int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
+                                 const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* xch, int trace, int dtype, hipStream_t st);
+int clhip_stage_train_trace(void* xch, unsigned long long* out24);
+int clhip_stage_train_status(void* xch);
+int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);                                // conv3.hip
 namespace {
 struct Unit {
     clhip_unit_desc d;
@@ -83,6 +94,10 @@ struct Unit {
     size_t wg_own;                               // this unit's own weight-gradient scratch (plans that defer the reduces), else the shared one
     int stage_len;                               // > 0 (round 5): this unit opens a run of `stage_len` units = stage_len / 2 BasicBlocks of C -> C 3x3 / stride-1 convolutions that
                                                  // the EVAL forward runs as ONE launch with the image resident in LDS (stage.hip); the activations inside the run are not written
+    int run_first;                               // >= 0: this unit lies inside the training run that unit `run_first` opens (stage_train)
+    size_t st_slab;                              // ... its weight-gradient slab of that launch: N blocks of cout * 9 * cin floats (bytes into the workspace)
+    bool stage_train;                            // (round 6) ... and the TRAINING forward / backward can run it as one launch per direction (stage_train.hip): every
+                                                 // first convolution of a block hands its activation to the second one lazily, every block output keeps a packed mask
     bool fuse_src_bn;                            // this unit's dgrad completes the gradient of its input activation AND can reduce the
                                                  // BatchNorm backward of the unit that produced it in its epilogue (clhip_conv_dgrad_bn_reduce)
 };
@@ -130,6 +145,10 @@ struct clhip_plan {
     std::vector<char> eval_unwritten;   // per unit: the last EVAL forward consumed its BatchNorm on the next convolution's operand load and never wrote the activation
     std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
+    void* xch = nullptr;     // exchange buffer of the stage-level training launches (xch.h): owned by the plan, zeroed at creation
+    hipStream_t xch_stream = nullptr;   // the stream of the last such launch (two of them must never be in flight on two streams: see stage_train_serialize)
+    bool xch_used = false;
+    long long st_fwd_launches = 0, st_bwd_launches = 0;      // stage-level training launches so far (clhip_plan_stage_info)
     int feat_dim;
     bool side_ok;            // some unit's weight gradient is big enough for the side stream to pay (see clhip_plan_backward_range)
     int pool_win;            // 0: global average pool, else nn.AvgPool2d(pool_win) + NCHW flatten
@@ -492,6 +511,57 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         if (len >= 2 && clhip_stage_eval_supported(Hs, Ws, C, len, dtype)) { p->units[i].stage_len = len; i += len; }
         else ++i;
     }
+    // ... and the runs the TRAINING passes can take as one launch per direction (stage_train.hip): every workgroup (= image) resident at once, the lazy hand-over
+    // inside each block and the packed mask of each block output in place (what that forward leaves is what the per-unit backward expects, and vice versa)
+    bool any_train = false;
+    for (int i = 0; i < n_units; ++i) {
+        Unit& u = p->units[i];
+        u.stage_train = false;
+        if (u.stage_len <= 0 || !clhip_stage_train_supported(N, u.H, u.W, u.d.cout, u.stage_len, dtype)) continue;
+        bool ok = want_acc;
+        for (int k = 0; k < u.stage_len && ok; ++k) {
+            const Unit& q = p->units[i + k];
+            // (a unit whose apply launch would start a shortcut-branch stream keeps it: only plans with layers big enough for extra streams have one -- branch_stream_on)
+            if (q.rep_fwd <= 0 || q.rep_bwd <= 0 || q.has_dzr || (q.forks >= 0 && p->side_ok) || q.joins >= 0 || q.pair >= 0) ok = false;
+            if ((k & 1) == 0 && q.lazy_to != i + k + 1) ok = false;
+            if ((k & 1) == 1 && q.mask_off == 0) ok = false;
+        }
+        u.stage_train = ok;
+        any_train = any_train || ok;
+        if (getenv("CLHIP_PLAN_DEBUG")) {
+            fprintf(stderr, "plan: run at unit %d len %d C %d H %d: stage_train %d\n", i, u.stage_len, u.d.cout, u.H, (int)ok);
+            for (int k = 0; k < u.stage_len; ++k) {
+                const Unit& q = p->units[i + k];
+                fprintf(stderr, "   unit %d: rep %d/%d dzr %d forks %d joins %d pair %d lazy_to %d res_lazy_to %d mask %d\n", i + k, q.rep_fwd, q.rep_bwd, (int)q.has_dzr, q.forks, q.joins,
+                        q.pair, q.lazy_to, q.res_lazy_to, (int)(q.mask_off != 0));
+            }
+        }
+    }
+    if (getenv("CLHIP_PLAN_DEBUG"))
+        for (int i = 0; i < n_units; ++i) fprintf(stderr, "plan: unit %d stage_len %d src %d res %d k %d s %d C %d->%d H %d\n", i, p->units[i].stage_len, p->units[i].d.src, p->units[i].d.res,
+                                                  p->units[i].d.ksize, p->units[i].d.stride, p->units[i].d.cin, p->units[i].d.cout, p->units[i].H);
+    for (Unit& u : p->units) { u.run_first = -1; u.st_slab = 0; }
+    if (any_train) {
+        size_t off2 = p->ws_bytes;
+        for (int i = 0; i < n_units; ++i) {
+            if (!p->units[i].stage_train) continue;
+            for (int k = 0; k < p->units[i].stage_len; ++k) {
+                Unit& q = p->units[i + k];
+                q.run_first = i;
+                q.st_slab = off2;
+                off2 = align_up(off2 + (size_t)N * q.d.cout * 9 * q.cin_pad * sizeof(float));
+            }
+        }
+        p->ws_bytes = off2;
+    }
+    if (any_train) {
+        const size_t xb = clhip_stage_train_xch_bytes(N);
+        if (hipMalloc(&p->xch, xb) != hipSuccess || hipMemset(p->xch, 0, xb) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p->xch) { (void)hipFree(p->xch); p->xch = nullptr; }
+            for (Unit& u : p->units) { u.stage_train = false; u.run_first = -1; }          // (no exchange buffer: the per-unit launches)
+        }
+    }
     return p;
 }
 
@@ -506,8 +576,23 @@ extern "C" void clhip_plan_destroy(clhip_plan* p) {
         for (int k = 0; k < clhip_plan::kMaxBranch; ++k) { (void)hipEventDestroy(p->ev_fork[k]); (void)hipEventDestroy(p->ev_join[k]); (void)hipEventDestroy(p->ev_bfork[k]); (void)hipEventDestroy(p->ev_bjoin[k]); }
         (void)hipEventDestroy(p->ev_br_end);
     }
+    if (p && p->xch) {
+        if (p->xch_used) (void)hipDeviceSynchronize();
+        (void)hipFree(p->xch);
+    }
     delete p;
 }
+// 0: no stage-level training launch of this plan has run out of its bounded waits (or the plan has none); synchronises the device
+// what: 0 = units the plan can run inside stage-level training launches, 1 / 2 = such forward / backward launches so far
+extern "C" long long clhip_plan_stage_info(const clhip_plan* p, int what) {
+    if (!p) return 0;
+    if (what == 1) return p->st_fwd_launches;
+    if (what == 2) return p->st_bwd_launches;
+    long long n = 0;
+    for (const Unit& u : p->units) if (u.stage_train) n += u.stage_len;
+    return n;
+}
+extern "C" int clhip_plan_stage_status(clhip_plan* p) { return (p && p->xch && p->xch_used) ? clhip_stage_train_status(p->xch) : 0; }
 extern "C" size_t clhip_plan_workspace_bytes(const clhip_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" size_t clhip_plan_shadow_bytes(const clhip_plan* p) { return p ? p->shadow_bytes : 0; }
 extern "C" int clhip_plan_feat_dim(const clhip_plan* p) { return p ? p->feat_dim : 0; }
@@ -545,6 +630,37 @@ static bool branch_stream_on(clhip_plan* p, hipStream_t main_s) {
         (void)hipEventCreateWithFlags(&p->ev_br_end, ev_flags);
     }
     return true;
+}
+
+// the STAGE_TRAIN switch: "0" / "1", unset = the built-in default
+static bool stage_train_default(const char* cfg) { return cfg != nullptr ? atoi(cfg) != 0 : false; }
+// STAGE_TRACE = "<channels>:<convolution>" (diagnostic): workgroup 0 of the runs with that channel count stamps the phases of that convolution
+static int stage_trace_cfg(int C) {
+    const char* v = clhip_cfg("STAGE_TRACE");
+    if (v == nullptr) return 0;
+    int c = 0, cv = 0;
+    if (sscanf(v, "%d:%d", &c, &cv) != 2 || c != C) return 0;
+    return cv;
+}
+extern "C" int clhip_plan_stage_trace(clhip_plan* p, unsigned long long* out24) { return p && p->xch ? clhip_stage_train_trace(p->xch, out24) : CLHIP_EINVAL; }
+
+// Two stage-level training launches must never be in flight on two streams at once: each needs ALL its workgroups resident (they wait for one another), and two
+// half-resident grids would wait for each other's compute units until their bounded spins run out.  One plan's launches normally share one stream; when the
+// stream changes (outside a capture) the host waits for the previous one first.  (Callers that run a second network beside this one -- ops.TeacherPass --
+// switch STAGE_TRAIN off for the side pass; several PROCESSES sharing one GPU must switch it off too: parallel.attach does.)
+static int stage_train_serialize(clhip_plan* p, hipStream_t st) {
+    static hipStream_t g_last[16] = {};
+    static bool g_any[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (dev >= 0 && dev < 16 && cap == hipStreamCaptureStatusNone) {
+        if (g_any[dev] && g_last[dev] != st) (void)hipStreamSynchronize(g_last[dev]);
+        g_last[dev] = st; g_any[dev] = true;
+    }
+    p->xch_stream = st; p->xch_used = true;
+    return CLHIP_OK;
 }
 
 // All conv weights of the backbone in ONE launch (the per-conv launches were 20 x 6.7 us of a 3.5 ms ResNet-18 step):
@@ -768,6 +884,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                            !(elazy_cfg != nullptr && atoi(elazy_cfg) == 0);
     const char* stage_cfg = clhip_cfg("STAGE_EVAL");                 // (looked up per call, like EVAL_LAZY: the tests compare the two forms in one process)
     const bool stage_on = eval_lazy && !(stage_cfg != nullptr && atoi(stage_cfg) == 0);
+    // STAGE_TRAIN (default on; looked up per call): runs of BasicBlocks as ONE training launch (stage_train.hip) where the plan found them and the lazy forms are on
+    const char* strain_cfg = clhip_cfg("STAGE_TRAIN");
+    const bool strain_on = rlazy_on && p->xch != nullptr && stage_train_default(strain_cfg);
     for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = p->stage_skipped[i] = 0;
     p->params_dev = params; p->bn_stats_dev = bn_stats;
     int fwd_pair_done = -1;                                  // the 3x3/s2 unit whose launch also ran its shortcut partner's convolution
@@ -792,6 +911,25 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
         }
         if (use_acc && u.rep_fwd > 0) {
             // conv epilogue adds the per-channel sums into the fp64 accumulator; BN-apply derives scale / shift on the fly
+            if (strain_on && u.stage_train) {
+                // a run of BasicBlocks as ONE launch: one workgroup per image, the activation resident in LDS, the batch statistics of every convolution through the
+                // in-launch all-reduce (stage_train.hip).  Leaves what the per-unit launches leave: z, saved + running statistics, the block outputs with their masks;
+                // the activation between a block's two convolutions stays lazy (the backward recomputes it from z)
+                const void* wv[16]; const float *gv[16], *bv[16]; float *rmv[16], *rvv[16], *mev[16], *isv[16], *cov[16]; void *zv[16], *yv[16], *mkv[16];
+                for (int k = 0; k < u.stage_len; ++k) {
+                    const Unit& q = p->units[i + k];
+                    wv[k] = sh + q.sh_fwd; gv[k] = params + q.d.gamma_off; bv[k] = params + q.d.beta_off; rmv[k] = bn_stats + q.d.rm_off; rvv[k] = bn_stats + q.d.rv_off;
+                    mev[k] = fr + q.f_mean; isv[k] = fr + q.f_invstd; cov[k] = fr + q.f_scale; zv[k] = ws + q.z_off;
+                    yv[k] = (k & 1) ? ws + p->acts[i + k + 1].y_off : nullptr; mkv[k] = (k & 1) ? ws + q.mask_off : nullptr;
+                    p->lazy_live[i + k] = (k & 1) ? 0 : 1;
+                }
+                TRY(stage_train_serialize(p, (hipStream_t)stream));
+                TRY(clhip_stage_train_fwd_launch(ws + src.y_off, p->N, u.H, u.W, u.d.cout, u.stage_len, wv, gv, bv, rmv, rvv, mev, isv, cov, zv, yv, mkv, kBnMomentum, kBnEps,
+                                                 p->xch, stage_trace_cfg(u.d.cout), p->dtype, (hipStream_t)stream));
+                ++p->st_fwd_launches;
+                i += u.stage_len - 1;
+                continue;
+            }
             void* us = stream;                                   // the stream this unit's two launches go to
             const bool on_br = br_on && u.branch >= 0;
             if (on_br) {                                         // shortcut branch: starts when its input activation is complete (ev_fork)
@@ -848,9 +986,11 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                                        u.d.stride, u.d.pad, p->dtype, us));
             }
             p->lazy_live[i] = 0;
-            if (wt_on && u.wt_to >= 0) { p->wt_pending[i] = 1; continue; }              // its first reader applies it in LDS and writes the activation [+ mask]
-            if (lazy_on && u.lazy_to >= 0) { p->lazy_live[i] = 1; continue; }          // its one consumer applies the BatchNorm: no apply launch, no activation
-            if (rlazy_on && u.res_lazy_to >= 0) { p->res_pending[i] = 1; continue; }   // its first consumer applies it and writes the activation + mask
+            // (a fused training run reads a WRITTEN activation: its producer keeps the apply launch)
+            auto opens_run = [&](int k) { return strain_on && p->units[k].stage_train; };
+            if (wt_on && u.wt_to >= 0 && !opens_run(u.wt_to)) { p->wt_pending[i] = 1; continue; }              // its first reader applies it in LDS and writes the activation [+ mask]
+            if (lazy_on && u.lazy_to >= 0 && !opens_run(u.lazy_to)) { p->lazy_live[i] = 1; continue; }          // its one consumer applies the BatchNorm: no apply launch, no activation
+            if (rlazy_on && u.res_lazy_to >= 0 && !opens_run(u.res_lazy_to)) { p->res_pending[i] = 1; continue; }   // its first consumer applies it and writes the activation + mask
             const void* res_ = u.d.res >= 0 ? ws + p->acts[u.d.res].y_off : nullptr;
             if (plan_skip() & 1) continue;                       // timing ablation: no forward BatchNorm apply (results invalid)
             if (br_on && u.joins >= 0) (void)hipStreamWaitEvent((hipStream_t)stream, p->ev_join[u.joins], 0);      // the residual comes from the branch stream
@@ -1047,7 +1187,36 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     const int n_dz = two_streams ? p->n_dz : 2;
     auto any_pending = [&]() { for (int q = 0; q < clhip_plan::kDz; ++q) if (p->wg_pending[q]) return true; return false; };
     auto clear_pending = [&]() { for (int q = 0; q < clhip_plan::kDz; ++q) p->wg_pending[q] = false; };
+    // STAGE_TRAIN_BWD (default on; looked up per call): a run of BasicBlocks that lies inside this call's range goes as ONE launch (stage_train.hip), whichever forward ran
+    const char* stb_cfg = clhip_cfg("STAGE_TRAIN_BWD");
+    const char* stb_cfg2 = clhip_cfg("STAGE_TRAIN");
+    const bool stb_on = p->xch != nullptr && !(stb_cfg != nullptr && atoi(stb_cfg) == 0) && stage_train_default(stb_cfg2) && !br_on && !(plan_skip() & 6);
     for (int i = unit_hi - 1; i >= unit_lo; --i, k = (k + 1) % n_dz) {
+        if (stb_on && p->units[i].run_first >= 0) {
+            const int f = p->units[i].run_first;
+            const Unit& uf = p->units[f];
+            if (i == f + uf.stage_len - 1 && f >= unit_lo) {
+                const int len = uf.stage_len;
+                const void* wdv[16]; const float *gv[16], *bv[16], *mev[16], *isv[16]; const void *zv[16], *yv[16]; float *dgv[16], *dbv[16], *slv[16];
+                for (int q = 0; q < len; ++q) {
+                    const Unit& uq = p->units[f + q];
+                    wdv[q] = sh + uq.sh_dg; gv[q] = params + uq.d.gamma_off; bv[q] = params + uq.d.beta_off; mev[q] = fr + uq.f_mean; isv[q] = fr + uq.f_invstd;
+                    zv[q] = ws + uq.z_off; yv[q] = (q & 1) ? ws + p->acts[f + q + 1].y_off : nullptr;
+                    dgv[q] = grads + uq.d.gamma_off; dbv[q] = grads + uq.d.beta_off; slv[q] = reinterpret_cast<float*>(ws + uq.st_slab);
+                }
+                if (p->br_act >= 0) join_branch();
+                TRY(stage_train_serialize(p, main_s));
+                TRY(clhip_stage_train_bwd_launch(ws + p->acts[uf.d.src].y_off, ws + p->acts[f + len].dy_off, ws + p->acts[uf.d.src].dy_off, p->units[f + 1].dres_acc, p->N, uf.H,
+                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, p->xch, stage_trace_cfg(uf.d.cout), p->dtype, main_s));
+                ++p->st_bwd_launches;
+                for (int q = len - 1; q >= 0; --q) {
+                    const Unit& uq = p->units[f + q];
+                    TRY(clhip_wgrad_reduce_launch(reinterpret_cast<const float*>(ws + uq.st_slab), grads + uq.d.w_off, (int64_t)uq.d.cout * 9 * uq.cin_pad / 4, p->N, main_s));
+                }
+                i = f;                                               // (the loop's own decrement moves past the run)
+                continue;
+            }
+        }
         const Unit& u = p->units[i];
         const Act& src = p->acts[u.d.src];
         const Act& dst = p->acts[i + 1];
