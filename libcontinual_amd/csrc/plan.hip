@@ -48,7 +48,8 @@ int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int 
                                  void* const* mask, float momentum, float eps, void* xch, int trace, int dtype, hipStream_t st);
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
-                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* xch, int trace, int dtype, hipStream_t st);
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int dtype, hipStream_t st);
+int clhip_stage_train_slab_blocks(int N, int C);
 int clhip_stage_train_trace(void* xch, unsigned long long* out24);
 int clhip_stage_train_status(void* xch);
 int clhip_wgrad_reduce_launch(const float* slab, float* dw, int64_t n4, int splits, hipStream_t st);                                // conv3.hip
@@ -145,6 +146,8 @@ struct clhip_plan {
     std::vector<char> eval_unwritten;   // per unit: the last EVAL forward consumed its BatchNorm on the next convolution's operand load and never wrote the activation
     std::vector<char> lazy_live;        // per unit: the last training forward left its activation unwritten (its z, mean / invstd and coefficients are there)
     std::vector<char> bwd_sums_ready;   // per unit: its BatchNorm-backward sums were accumulated by a consumer's dgrad (since the last forward)
+    std::vector<char> mask_stale;       // per unit: the last training forward ran it inside a stage-level launch, which writes the block outputs but NOT their packed ReLU
+                                        // masks (byte stores from an MFMA-layout epilogue cost more than the rest of the epilogue): a per-unit backward reads the activation
     void* xch = nullptr;     // exchange buffer of the stage-level training launches (xch.h): owned by the plan, zeroed at creation
     hipStream_t xch_stream = nullptr;   // the stream of the last such launch (two of them must never be in flight on two streams: see stage_train_serialize)
     bool xch_used = false;
@@ -366,6 +369,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     //  kernel supports it: one launch less per unit, measured in profiles/r03_step_notes.md)
     const long long fuse_max_m = clhip_cfg("BN_FUSE_MAX_M") ? atoll(clhip_cfg("BN_FUSE_MAX_M")) : ((fe == nullptr && p->side_ok) ? 16384 : (1ll << 62));
     p->bwd_sums_ready.assign(p->units.size(), 0);
+    p->mask_stale.assign(p->units.size(), 0);
     for (int i = 0; i < n_units; ++i) {
         Unit& u = p->units[i];
         u.fuse_src_bn = false;
@@ -888,6 +892,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const char* strain_cfg = clhip_cfg("STAGE_TRAIN");
     const bool strain_on = rlazy_on && p->xch != nullptr && stage_train_default(strain_cfg);
     for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = p->stage_skipped[i] = 0;
+    if (training) std::fill(p->mask_stale.begin(), p->mask_stale.end(), 0);
     p->params_dev = params; p->bn_stats_dev = bn_stats;
     int fwd_pair_done = -1;                                  // the 3x3/s2 unit whose launch also ran its shortcut partner's convolution
     for (size_t i = 0; i < p->units.size(); ++i) {
@@ -920,8 +925,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                     const Unit& q = p->units[i + k];
                     wv[k] = sh + q.sh_fwd; gv[k] = params + q.d.gamma_off; bv[k] = params + q.d.beta_off; rmv[k] = bn_stats + q.d.rm_off; rvv[k] = bn_stats + q.d.rv_off;
                     mev[k] = fr + q.f_mean; isv[k] = fr + q.f_invstd; cov[k] = fr + q.f_scale; zv[k] = ws + q.z_off;
-                    yv[k] = (k & 1) ? ws + p->acts[i + k + 1].y_off : nullptr; mkv[k] = (k & 1) ? ws + q.mask_off : nullptr;
+                    yv[k] = (k & 1) ? ws + p->acts[i + k + 1].y_off : nullptr; mkv[k] = nullptr;
                     p->lazy_live[i + k] = (k & 1) ? 0 : 1;
+                    p->mask_stale[i + k] = (k & 1) ? 1 : 0;
                 }
                 TRY(stage_train_serialize(p, (hipStream_t)stream));
                 TRY(clhip_stage_train_fwd_launch(ws + src.y_off, p->N, u.H, u.W, u.d.cout, u.stage_len, wv, gv, bv, rmv, rvv, mev, isv, cov, zv, yv, mkv, kBnMomentum, kBnEps,
@@ -1197,21 +1203,22 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             const Unit& uf = p->units[f];
             if (i == f + uf.stage_len - 1 && f >= unit_lo) {
                 const int len = uf.stage_len;
-                const void* wdv[16]; const float *gv[16], *bv[16], *mev[16], *isv[16]; const void *zv[16], *yv[16]; float *dgv[16], *dbv[16], *slv[16];
+                const void* wdv[16]; const float *gv[16], *bv[16], *mev[16], *isv[16]; const void *zv[16], *yv[16]; float *dgv[16], *dbv[16], *slv[16]; void* dzv[16];
                 for (int q = 0; q < len; ++q) {
                     const Unit& uq = p->units[f + q];
                     wdv[q] = sh + uq.sh_dg; gv[q] = params + uq.d.gamma_off; bv[q] = params + uq.d.beta_off; mev[q] = fr + uq.f_mean; isv[q] = fr + uq.f_invstd;
                     zv[q] = ws + uq.z_off; yv[q] = (q & 1) ? ws + p->acts[f + q + 1].y_off : nullptr;
                     dgv[q] = grads + uq.d.gamma_off; dbv[q] = grads + uq.d.beta_off; slv[q] = reinterpret_cast<float*>(ws + uq.st_slab);
+                    dzv[q] = ws + p->acts[f + q + 1].dy_off;         // (the gradient buffer of the unit's output: the launch keeps that gradient in registers and parks its dz there)
                 }
                 if (p->br_act >= 0) join_branch();
                 TRY(stage_train_serialize(p, main_s));
                 TRY(clhip_stage_train_bwd_launch(ws + p->acts[uf.d.src].y_off, ws + p->acts[f + len].dy_off, ws + p->acts[uf.d.src].dy_off, p->units[f + 1].dres_acc, p->N, uf.H,
-                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, p->xch, stage_trace_cfg(uf.d.cout), p->dtype, main_s));
+                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), p->dtype, main_s));
                 ++p->st_bwd_launches;
                 for (int q = len - 1; q >= 0; --q) {
                     const Unit& uq = p->units[f + q];
-                    TRY(clhip_wgrad_reduce_launch(reinterpret_cast<const float*>(ws + uq.st_slab), grads + uq.d.w_off, (int64_t)uq.d.cout * 9 * uq.cin_pad / 4, p->N, main_s));
+                    TRY(clhip_wgrad_reduce_launch(reinterpret_cast<const float*>(ws + uq.st_slab), grads + uq.d.w_off, (int64_t)uq.d.cout * 9 * uq.cin_pad / 4, clhip_stage_train_slab_blocks(p->N, uq.d.cout), main_s));
                 }
                 i = f;                                               // (the loop's own decrement moves past the run)
                 continue;
@@ -1275,13 +1282,14 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         const bool lazy_in = u.lazy_from >= 0 && p->lazy_live[u.lazy_from];
         const bool bn_grad_ok = both && lazy_grad_on && u.d.cout >= lazy_grad_minc && !u.no_bn && !u.pre_res && !u.has_dzr && u.rep_bwd > 0 && p->bwd_sums_ready[i] &&
                                 u.relu && !mask_from_y && u.cin_pad == u.d.cin &&                                 clhip_conv_bn_input_supported(p->N, u.H, u.W, u.cin_pad, u.d.cout, u.d.ksize, u.d.stride, u.d.pad, p->dtype);
-        const bool bn_grad = bn_grad_ok && (dres == nullptr ? true : (u.mask_off != 0 && lazy_res_on));
+        const bool stale = p->mask_stale[i] != 0;                  // its packed mask was not written (stage-level forward): the activation instead
+        const bool bn_grad = bn_grad_ok && (dres == nullptr ? true : (u.mask_off != 0 && lazy_res_on && !stale));
         if (u.no_bn || bn_grad) {
         } else if (((plan_skip() & 2) || ((plan_skip() & 8) && u.d.ksize == 1 && !u.relu)) && u.rep_bwd > 0) {         // timing ablation: no BatchNorm backward [8: of the shortcut units] (results invalid)
         } else if (u.rep_bwd > 0 && p->bwd_sums_ready[i]) {
             // the two channel sums came out of the epilogue of the dgrad that completed dy (see fuse_src_bn): apply pass only
             const bool zmask = u.relu && dres == nullptr && !mask_from_y;
-            const bool bits = !zmask && u.relu && u.mask_off != 0 && !mask_from_y;
+            const bool bits = !zmask && u.relu && u.mask_off != 0 && !mask_from_y && !stale;
             TRY(clhip_bn_bwd_apply_acc(ws + dst.dy_off, zmask ? nullptr : (bits ? ws + u.mask_off : ws + dst.y_off), ws + u.z_off, fr + u.f_mean, fr + u.f_invstd,
                                        params + u.d.gamma_off, params + u.d.beta_off, grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M,
                                        u.d.cout, zmask ? 2 : (bits ? 3 : (u.relu ? 1 : 0)), reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd,
@@ -1292,7 +1300,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                                        grads + u.d.gamma_off, grads + u.d.beta_off, dz, u.M, u.d.cout,
                                        reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
         } else if (u.rep_bwd > 0) {
-            const bool bits = u.relu && u.mask_off != 0 && !mask_from_y;
+            const bool bits = u.relu && u.mask_off != 0 && !mask_from_y && !stale;
             TRY(clhip_bn_bwd_acc(ws + dst.dy_off, bits ? ws + u.mask_off : ws + dst.y_off, ws + u.z_off, fr + u.f_mean, fr + u.f_invstd, params + u.d.gamma_off,
                                  grads + u.d.gamma_off, grads + u.d.beta_off, dz, dres, u.dres_acc, u.M, u.d.cout, bits ? 3 : (int)u.relu,
                                  reinterpret_cast<double*>(ws + p->acc_off) + u.a_bwd, u.rep_bwd, p->dtype, stream));
@@ -1395,7 +1403,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
         } else if (u.d.src != 0 && u.fuse_src_bn) {
             const Unit& prod = p->units[u.d.src - 1];
             // (the producer's ReLU mask: its packed bits if it keeps them, its scale / shift if the ReLU follows the BatchNorm directly, else its activation)
-            const bool pz = prod.relu && prod.d.res < 0 && !mask_from_y, pb = prod.relu && prod.mask_off != 0 && !mask_from_y;
+            const bool pz = prod.relu && prod.d.res < 0 && !mask_from_y, pb = prod.relu && prod.mask_off != 0 && !mask_from_y && !p->mask_stale[u.d.src - 1];
             TRY(clhip_conv_dgrad_bn_reduce_ex(dz, sh + u.sh_dg, ws + src.dy_off, u.dx_acc, ws + prod.z_off, prod.relu ? ws + src.y_off : nullptr,
                                               pb ? ws + prod.mask_off : nullptr, pz ? params + prod.d.gamma_off : nullptr, pz ? params + prod.d.beta_off : nullptr,
                                               fr + prod.f_mean, fr + prod.f_invstd, reinterpret_cast<double*>(ws + p->acc_off) + prod.a_bwd, prod.rep_bwd,

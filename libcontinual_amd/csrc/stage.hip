@@ -4,7 +4,7 @@
 // Replaces, for blocks of conv3x3(C -> C, stride 1) -> BN -> ReLU -> conv3x3 -> BN -> (+ x) -> ReLU in eval mode
 // (core/model/backbone/resnet.py:289-316, the stages built at :381-392), 2 x blocks launches of 6-8 us on activations of at most 8 MB by one:
 //  * one workgroup (four waves) per IMAGE; the image's activation lives in LDS for the whole run -- two zero-haloed buffers X / Y of (HW + 2)^2 pixels,
-//    pixel pitch 2 C + 16 bytes (16 consecutive pixels of a fragment read fall into disjoint banks): 32 x 32 x 16: 2 x 55 KB, 16 x 16 x 32: 2 x 26 KB, 8 x 8 x 64: 2 x 14 KB;
+//    pixel pitch 2 C + 16 bytes (16 consecutive pixels of a fragment read fall into disjoint banks; 32 bytes for 16 channels): 32 x 32 x 16: 2 x 37 KB, 16 x 16 x 32: 2 x 26 KB, 8 x 8 x 64: 2 x 14 KB;
 //  * a convolution is an implicit GEMM on v_mfma_f32_16x16x32_bf16 with the FILTERS as the A operand (rows = output channels) and the pixels as B
 //    (columns), K = tap * C + c: a lane then holds four consecutive output channels of one pixel and writes them with one 8-byte LDS store.  The filter
 //    fragments of a convolution sit in registers (20 / 72 / 72 per wave; the next convolution's set is requested while this one multiplies), loaded from the
@@ -39,7 +39,7 @@ struct StageParams {
 template <int C, int HW>
 struct StageGeo {
     static constexpr int P = HW + 2;                       // padded width
-    static constexpr int PB = 2 * C + 16;                  // bytes per pixel in LDS
+    static constexpr int PB = C == 16 ? 32 : 2 * C + 16;   // bytes per pixel in LDS (16 channels: the bare 32 bytes are conflict-free already -- conv16 -- and leave room for a training launch beside this one, stage_train.hip)
     static constexpr int BUF = P * P * PB;                 // one activation buffer
     static constexpr int NPT = HW * HW / 16;               // pixel tiles of 16
     static constexpr int KT = C / 16;                      // output-channel tiles of 16

@@ -54,7 +54,9 @@ struct StFwdParams {
 template <int C, int HW>
 struct StGeo {
     static constexpr int P = HW + 2;                       // padded width
-    static constexpr int PB = 2 * C + 16;                  // bytes per pixel in LDS (16 consecutive pixels of a fragment read fall into disjoint banks)
+    static constexpr int PB = C == 16 ? 32 : 2 * C + 16;   // bytes per pixel in LDS: 16 consecutive pixels of a fragment read fall into disjoint banks (16 channels: the bare 32
+                                                           // bytes already do, and at 37 KB per image the forward of a run and a frozen teacher's eval launch -- stage.hip --
+                                                           // fit one compute unit together: 79 + 76 of 160 KB)
     static constexpr int BUF = P * P * PB;                 // one activation buffer
     static constexpr int NPT = HW * HW / 16;               // pixel tiles of 16
     static constexpr int KT = C / 16;                      // output-channel tiles of 16
@@ -156,15 +158,17 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
             const int a = koff[s_] >= 0 ? pbase[t_] + koff[s_] : 0;
             return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(S + a));
         };
-        bf16x8_t xr[3];
-        xr[0] = xread(0);
-        if (SLOTS > 1) xr[1] = xread(1);
+        // (pixel fragments RING - 1 slots ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency)
+        constexpr int RING = 8;
+        bf16x8_t xr[RING];
+#pragma unroll
+        for (int n = 0; n < RING - 1; ++n) if (n < SLOTS) xr[n] = xread(n);
 #pragma unroll
         for (int n = 0; n < SLOTS; ++n) {
             const int s_ = n / PTW, t_ = n - s_ * PTW;
-            if (n + 2 < SLOTS) xr[(n + 2) % 3] = xread(n + 2);
+            if (n + RING - 1 < SLOTS) xr[(n + RING - 1) % RING] = xread(n + RING - 1);
 #pragma unroll
-            for (int kt = 0; kt < KTW; ++kt) acc[t_][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt][s_], xr[n % 3], acc[t_][kt], 0, 0, 0);
+            for (int kt = 0; kt < KTW; ++kt) acc[t_][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt][s_], xr[n % RING], acc[t_][kt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         st_stamp(p.xb, tr, 1);
@@ -325,7 +329,8 @@ struct StConvB {
     const bf16_t* y;          // block outputs (odd positions of the run): the activation; nullptr at even positions
     float* dgamma;
     float* dbeta;
-    float* slab;              // [N][C * 9 * C] weight-gradient partial sums, one block per image
+    float* slab;              // weight-gradient partial sums: [N][C * 9 * C], one block per image (16 channels); [groups][C * 9 * C] (wider: StGrp)
+    bf16_t* dzg;              // (group weight gradient) [C / 16][N][HW][HW][16]: this unit's dz in global memory, channel-tile-major, for other workgroups' work items
 };
 
 struct StBwdParams {
@@ -340,12 +345,26 @@ struct StBwdParams {
     StConvB c[kMaxConvT];
 };
 
+// the GROUP weight gradient of the 32- / 64-channel stages: a per-image partial block would be 36 / 147 KB (more than the image's operands: 302 MB of partial sums per
+// stage-3 run at batch 256), so there a workgroup takes one (output-channel tile, input-channel tile) pair of a GROUP of IPG images -- 16 x 16 x 9 sums = 9 KB whatever
+// the stage -- and fetches the 16-channel slices of the group's dz and input images from global memory into LDS.
 template <int C, int HW>
+struct StGrp {
+    static constexpr int IPG = (C / 16) * (C / 16);                  // images per group = number of (out tile, in tile) pairs: 4 / 16
+    static constexpr int P2 = HW + 2;
+    static constexpr int XS = P2 * P2 * 32, ZS = HW * HW * 32;       // one image's padded input slice / gradient slice (16 channels = 32 bytes per pixel)
+    static constexpr int IMG = XS + ZS;
+    static constexpr int KPI = HW * HW / 32;                         // K steps (32 pixels) per image: 8 / 2
+    static constexpr int BYTES = IPG * IMG + 2 * 5 * 64 * 16;        // staging + the K halves' hand-over
+};
+
+template <int C, int HW, bool GRP>
 struct StGeoB {
     using G = StGeo<C, HW>;
-    static constexpr int RED = C == 16 ? 4 * 2304 * 4 : 0;          // cross-wave sum of the 16-channel weight gradient
     static constexpr int AUX = 8 * C * 4 + 8 * C * 4 + 2 * C * 4 + 2 * C * 8 + kXchScratchDoubles * 8;      // ctab, red, vals, tot, scratch
-    static constexpr int LDS = 2 * G::BUF + AUX + RED;
+    // own-image weight gradient: dz + the input image of the unit whose weight gradient is pending (+ the cross-wave sum of the 16-channel form); group form: dz +
+    // the staging area
+    static constexpr int LDS = GRP ? G::BUF + AUX + StGrp<C, HW>::BYTES : 2 * G::BUF + AUX + (C == 16 ? 4 * 2304 * 4 : 0);
 };
 
 __device__ __forceinline__ uint4 st_tr8(const char* base, int addr, int second) {
@@ -356,40 +375,63 @@ __device__ __forceinline__ uint4 st_tr8(const char* base, int addr, int second) 
     return make_uint4(l.x, l.y, h.x, h.y);
 }
 
-// dw[k][tap][c] of ONE image: A = dz^T (rows = output channels, reduction = 32 pixels), B = the input image shifted by the tap, both fetched from the pixel-major
-// padded LDS images with transposing reads (ds_read_b64_tr_b16: 16 lanes fetch a [4 pixels][16 channels] block, lane i keeps channel i).  `slab`: this image's block.
+// dw[k][tap][c] of ONE 16-channel image (stage 1): A = dz^T (rows = output channels, reduction = 32 pixels = one image row), B = the input image shifted by the tap,
+// both fetched from the pixel-major padded LDS images with transposing reads (ds_read_b64_tr_b16: 16 lanes fetch a [4 pixels][16 channels] block, lane i keeps
+// channel i).  The reduction index is a free permutation as long as both operands use the same one: lane group fg takes pixels 4 fg .. 4 fg + 3 and 16 + 4 fg .. of
+// the row, so the four groups of a read cover 512 contiguous bytes (32-byte pixels: every bank once).  Wave w takes HW / 4 consecutive
+// rows and the four partial tiles are summed through LDS.  `slab`: this image's block.
+template <int HW>
+__device__ __forceinline__ void st_wgrad16(const char* D, const char* XA, float* red, float* slab) {
+    using G = StGeo<16, HW>;
+    constexpr int P = G::P, PB = G::PB, RPW = HW / 4;               // rows per wave: CONSECUTIVE rows, so that an input row fetched for tap row r serves r - 1 and r - 2 too
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int seg = (fr & 3) * 8;
+    const int col = fg * 4 + (fr >> 2);
+    const int row0 = wave * RPW;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // input rows in a ring of four slots (local row j in slot (j + 1) & 3), fetched two rows ahead of their first MFMA; the gradient row one ahead
+    uint4 X[4][3], zf[2];
+    auto xrow = [&](int j, int slot) {                              // image row row0 + j = padded row row0 + j + 1 (rows -1 and HW are the zero halo)
+        const int pb = ((row0 + j + 1) * P + col + 1) * PB + seg;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) X[slot][sx] = st_tr8(XA, pb + (sx - 1) * PB, 16 * PB);
+    };
+    auto zrow = [&](int j, int b) { zf[b] = st_tr8(D, ((row0 + j + 1) * P + col + 1) * PB + seg, 16 * PB); };
+    xrow(-1, 0); xrow(0, 1); xrow(1, 2);
+    zrow(0, 0);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        if (i + 2 <= RPW) xrow(i + 2, (i + 3) & 3);
+        if (i + 1 < RPW) zrow(i + 1, (i + 1) & 1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx)
+                acc[r * 3 + sx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf[i & 1]), __builtin_bit_cast(bf16x8_t, X[(i + r) & 3][sx]), acc[r * 3 + sx], 0, 0, 0);
+    }
+    // D[row = out channel fg * 4 + e][col = in channel fr]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave * 2304 + ((fg * 4 + e) * 9 + t) * 16 + fr] = acc[t][e];
+    __syncthreads();
+    for (int i = tid; i < 2304; i += 256) slab[i] = ((red[i] + red[2304 + i]) + red[4608 + i]) + red[6912 + i];
+}
+
+// the same for the wider stages (one image, everything from this workgroup's LDS; the partial block is 36 / 147 KB per image -- fine for small batches, see StGrp):
+//   32 channels: a K step = two image rows of 16 pixels; wave = (input-channel tile, tap half) over all K steps and both output-channel tiles: no cross-wave sum
+//   64 channels: a K step = four image rows of 8 pixels; wave = input-channel tile, nine taps, the four output-channel tiles in two passes of two
 template <int C, int HW>
-__device__ __forceinline__ void st_wgrad(const char* D, const char* XA, float* red, float* slab) {
+__device__ __forceinline__ void st_wgrad_wide(const char* D, const char* XA, float* slab) {
     using G = StGeo<C, HW>;
     constexpr int P = G::P, PB = G::PB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int seg = (fr & 3) * 8;
-    if constexpr (C == 16) {
-        // a K step = one image row of 32 pixels; wave w takes rows w, w + 4, ...; the four partial tiles are summed through LDS
-        f32x4 acc[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int col = fg * 8 + (fr >> 2);
-        for (int h = wave; h < HW; h += 4) {
-            const int pb = ((h + 1) * P + col + 1) * PB + seg;
-            const uint4 zf = st_tr8(D, pb, 4 * PB);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, sx = t - 3 * r;
-                const uint4 xf = st_tr8(XA, pb + ((r - 1) * P + (sx - 1)) * PB, 4 * PB);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[t], 0, 0, 0);
-            }
-        }
-        // D[row = out channel fg * 4 + e][col = in channel fr]
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) red[wave * 2304 + ((fg * 4 + e) * 9 + t) * 16 + fr] = acc[t][e];
-        __syncthreads();
-        for (int i = tid; i < 2304; i += 256) slab[i] = ((red[i] + red[2304 + i]) + red[4608 + i]) + red[6912 + i];
-    } else if constexpr (C == 32) {
-        // a K step = two image rows of 16 pixels; wave = (input-channel tile, tap half) over all K steps and both output-channel tiles: no cross-wave sum
+    if constexpr (C == 32) {
         const int it = wave & 1, th = wave >> 1, t0 = th * 5, nt = th == 0 ? 5 : 4;
         const int prow = fg >> 1, pcol = (fg & 1) * 8 + (fr >> 2);
         f32x4 acc[2][5];
@@ -397,6 +439,7 @@ __device__ __forceinline__ void st_wgrad(const char* D, const char* XA, float* r
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int q = 0; q < 5; ++q) acc[o][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int h0 = 0; h0 < HW; h0 += 2) {
             const int pb = ((h0 + prow + 1) * P + pcol + 1) * PB + seg;
             uint4 zf[2];
@@ -421,8 +464,6 @@ __device__ __forceinline__ void st_wgrad(const char* D, const char* XA, float* r
 #pragma unroll
                     for (int e = 0; e < 4; ++e) slab[((o * 16 + fg * 4 + e) * 9 + t0 + q) * 32 + it * 16 + fr] = acc[o][q][e];
     } else {
-        // a K step = four image rows of 8 pixels; wave = input-channel tile, nine taps, the four output-channel tiles in two passes of two (72 accumulator
-        // registers instead of 144: the backward keeps its gradient tile, the residual gradient and the dgrad filters live across this call)
         const int it = wave, prow = fg, pcol = fr >> 2;
 #pragma unroll 1
         for (int op = 0; op < 2; ++op) {
@@ -456,23 +497,146 @@ __device__ __forceinline__ void st_wgrad(const char* D, const char* XA, float* r
     }
 }
 
+// the operands of one work item of the group weight gradient, requested into registers: chunk q = tid + 256 k of the item's 4096 16-byte chunks (per image: the
+// input slice, then the gradient slice).  `xsrc`: the input tensor (an activation, or the z of the block's first convolution whose relu(scale z + shift) is taken on
+// the way into LDS); `dzrs`: buffer descriptor of the unit's dz tensor, written by OTHER workgroups of this launch with write-through stores: sc1 loads.
 template <int C, int HW>
+struct StGrpRegs { uint4 v[16]; };
+
+template <int C, int HW>
+__device__ __forceinline__ void st_grp_fetch(StGrpRegs<C, HW>& r, const bf16_t* xsrc, __amdgpu_buffer_rsrc_t dzrs, int item, int N) {
+    using Q = StGrp<C, HW>;
+    constexpr int CPI = HW * HW * 4;                                 // chunks per image: 2 per pixel of either slice
+    const int combo = item % Q::IPG, grp = item / Q::IPG;
+    const int ot = combo / (C / 16), it = combo % (C / 16);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        const int j = q / CPI, w = q - j * CPI;                      // image of the group, chunk inside the image's pair of slices
+        const int n = grp * Q::IPG + j;
+        const bool isz = w >= HW * HW * 2;
+        const int pc = isz ? w - HW * HW * 2 : w;
+        const int pix = pc >> 1, half = pc & 1;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n < N) {
+            // (dz is kept channel-tile-major -- [out tile][image][pixel][16] -- so that a slice is contiguous; the input tensors are the forward's pixel-major ones)
+            if (isz) v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(dzrs, (int)((((size_t)ot * N + n) * HW * HW + pix) * 32 + half * 16), 0, 16));
+            else v = *reinterpret_cast<const uint4*>(xsrc + ((size_t)n * HW * HW + pix) * C + it * 16 + half * 8);
+        }
+        r.v[k] = v;
+    }
+}
+
+// ... and the item itself: registers -> LDS (x slices zero-haloed: the halo of the staging area is zeroed once per launch and never written), then 32 K steps of 32
+// pixels x nine taps, the K STEPS split over the four waves (splitting the taps instead makes every wave read every gradient fragment: the loop is LDS-bandwidth
+// bound and ran 4 x longer), the four partial tile sets summed through `red` (its own 36 KB, 16-byte writes: lane (fr, fg) holds four consecutive output channels).
+// lazy: x = relu(sc z + sh), coef[0..7] / coef[8..15] = scale / shift of this thread's eight channels (thread-constant: chunk parity and the item's input tile fix them).
+template <int C, int HW>
+__device__ __forceinline__ void st_grp_run(const StGrpRegs<C, HW>& r, char* stg, float* red, const float* coef, bool lazy, int item, float* slab_unit, const XchBuf& tb, bool tr) {
+    using Q = StGrp<C, HW>;
+    constexpr int CPI = HW * HW * 4, P2 = Q::P2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int combo = item % Q::IPG, grp = item / Q::IPG;
+    const int ot = combo / (C / 16), it = combo % (C / 16);
+    st_stamp(tb, tr, 17);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = tid + 256 * k;
+        const int j = q / CPI, w = q - j * CPI;
+        const bool isz = w >= HW * HW * 2;
+        const int pc = isz ? w - HW * HW * 2 : w;
+        const int pix = pc >> 1, half = pc & 1;
+        const int yy = pix / HW, xx = pix - yy * HW;
+        uint4 v = r.v[k];
+        if (!isz && lazy) v = bn_relu8_bf16(v, coef, coef + 8);
+        char* dst = stg + j * Q::IMG + (isz ? Q::XS + pix * 32 : ((yy + 1) * P2 + xx + 1) * 32) + half * 16;
+        *reinterpret_cast<uint4*>(dst) = v;
+    }
+    __syncthreads();
+    st_stamp(tb, tr, 18);
+    // wave = (K half kh, tap group tg): 16 K steps x 5 (taps 0..4) or 4 (taps 5..8) MFMAs; the two K halves of a tap group meet through LDS in the lane layout they
+    // already have (one 16-byte write / read per tile, no index arithmetic), and the kh = 0 wave stores the sums
+    const int kh = wave & 1, tg = wave >> 1, t0 = tg * 5, nt = tg == 0 ? 5 : 4;
+    f32x4 acc[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int seg = (fr & 3) * 8;
+    // reduction index of a K step (a free permutation, the same for both operands; chosen so that the four lane groups of a read touch disjoint banks):
+    //   16-pixel rows: rows 2 s, 2 s + 1; group fg = columns 4 fg .. 4 fg + 3 of the first (first read) and of the second row (second read)
+    //    8-pixel rows: rows 4 s .. 4 s + 3; group fg = columns 4 (fg & 1) .. of row (fg >> 1) (first read) and of row (fg >> 1) + 2 (second read)
+    const int row0 = HW == 16 ? 0 : (fg >> 1), col0 = HW == 16 ? 4 * fg + (fr >> 2) : 4 * (fg & 1) + (fr >> 2);
+    constexpr int RSTEP = HW == 16 ? 2 : 4, SECOND = HW == 16 ? 1 : 2;      // rows per K step; row distance of the second read
+    int toff[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = t0 + (q < nt ? q : 0), rr = t / 3, sx = t - 3 * rr;
+        toff[q] = ((rr - 1) * P2 + (sx - 1)) * 32;
+    }
+    uint4 zf[2], xf[2][5];
+    auto fetch = [&](int i, int b) {                                 // the wave's i-th K step = step kh * 16 + i of the item (consecutive steps: image by image)
+        const int ks = kh * 16 + i;
+        const int j = ks / Q::KPI, ls = ks - j * Q::KPI;
+        const char* xs = stg + j * Q::IMG;
+        const int row = ls * RSTEP + row0;
+        zf[b] = st_tr8(xs + Q::XS, (row * HW + col0) * 32 + seg, SECOND * HW * 32);
+        const int xb = ((row + 1) * P2 + col0 + 1) * 32 + seg;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) xf[b][q] = st_tr8(xs, xb + toff[q], SECOND * P2 * 32);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int b = i & 1;
+        if (i + 1 < 16) fetch(i + 1, b ^ 1);
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (q < nt) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf[b]), __builtin_bit_cast(bf16x8_t, xf[b][q]), acc[q], 0, 0, 0);
+    }
+    st_stamp(tb, tr, 19);
+    float4* rq = reinterpret_cast<float4*>(red) + (tg * 5) * 64 + lane;
+    if (kh == 1) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) rq[q * 64] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    }
+    __syncthreads();
+    if (kh == 0) {
+        // D[row = out channel fg * 4 + e][col = in channel fr] -> the group's block [K][9][C]
+        float* out = slab_unit + (size_t)grp * (9 * C * C);
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (q < nt) {
+                const float4 o = rq[q * 64];
+                const float v[4] = {acc[q][0] + o.x, acc[q][1] + o.y, acc[q][2] + o.z, acc[q][3] + o.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[((ot * 16 + fg * 4 + e) * 9 + t0 + q) * C + it * 16 + fr] = v[e];
+            }
+    }
+    st_stamp(tb, tr, 20);
+    // (the next item's staging stores come after its own barrier-free prologue: the barrier at the top of the next call's MFMA phase orders them -- but this call's
+    //  readers must be done before ANY restaging: one more barrier here)
+    __syncthreads();
+}
+
+template <int C, int HW, bool GRP>
 __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams p) {
     using G = StGeo<C, HW>;
-    using GB = StGeoB<C, HW>;
+    using GB = StGeoB<C, HW, GRP>;
     constexpr int P = G::P, PB = G::PB, BUF = G::BUF, PTW = G::PTW, KTW = G::KTW, KS = G::KS, WK = G::WK;
     constexpr int LOGC = C == 16 ? 4 : (C == 32 ? 5 : 6);
     constexpr int CPP = C / 8;
     constexpr int NCH = HW * HW * CPP / 256;                       // 16-byte chunks of an image per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NBUF = GRP ? 1 : 2;                               // (GRP: the group weight gradient -- StGrp -- instead of the own-image one)
     char* D = smem;                                                // dz of the unit in flight, zero-haloed
-    char* XA = smem + BUF;                                         // input image of the unit whose weight gradient is pending, zero-haloed
-    float* ctab = reinterpret_cast<float*>(smem + 2 * BUF);        // [5][C]: mean(g), mean(g xhat), -, -, gamma invstd
+    char* XA = smem + BUF;                                         // (16 channels) input image of the unit whose weight gradient is pending, zero-haloed
+    float* ctab = reinterpret_cast<float*>(smem + NBUF * BUF);     // [5][C]: mean(g), mean(g xhat), -, -, gamma invstd
     float* red = ctab + 8 * C;                                     // [4 waves][2][C]
     float* vals = red + 8 * C;                                     // [2][C]
     double* tot = reinterpret_cast<double*>(vals + 2 * C);
     double* scratch = tot + 2 * C;
-    float* wred = reinterpret_cast<float*>(smem + 2 * BUF + GB::AUX);      // (C == 16) cross-wave sum of the weight gradient
+    char* stg = smem + NBUF * BUF + GB::AUX;                       // 16 channels: the cross-wave sum of the weight gradient; wider: the group staging area
+    float* wred = reinterpret_cast<float*>(stg);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
     const int wp = wave / WK, wk = wave % WK;
@@ -480,8 +644,51 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     const unsigned base = xch_base(p.xb);
     const size_t ibase = (size_t)img * HW * HW;
 
-    for (int o = tid * 16; o < 2 * BUF; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
+    for (int o = tid * 16; o < GB::LDS; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
+
+    // the group weight gradient of unit u (32 / 64 channels): this workgroup's work items -- (out tile, in tile) pair x group of images -- from global memory.  The first
+    // item's operands are REQUESTED (grp_issue) a stage before they are used (grp_finish): a batch of sixteen 16-byte loads per thread, a quarter of them write-through
+    // data of other workgroups (sc1: served past the L2), is 2-3 us of latency with every workgroup asking at once
+    StGrpRegs<C, HW> grp_regs;
+    float4 grp_raw[8];                                              // gamma, invstd, beta, mean of this thread's eight input channels (lazy input), requested AHEAD of the big batch:
+                                                                    // waiting for them must not mean waiting for the sixteen 16-byte loads behind them
+    auto grp_issue = [&](int u, int item) __attribute__((always_inline)) {
+        if constexpr (GRP) {
+            using Q = StGrp<C, HW>;
+            const bool lazy = u & 1;
+            const bf16_t* xsrc = lazy ? p.c[u - 1].z : (u == 0 ? p.x : p.c[u - 1].y);
+            const __amdgpu_buffer_rsrc_t dzrs = __builtin_amdgcn_make_buffer_rsrc(p.c[u].dzg, 0, p.N * HW * HW * C * 2, 0x00020000);
+            if (lazy) {
+                const StConvB& a = p.c[u - 1];
+                const int c0 = ((item % Q::IPG) % (C / 16)) * 16 + (tid & 1) * 8;
+                grp_raw[0] = *reinterpret_cast<const float4*>(a.gamma + c0); grp_raw[1] = *reinterpret_cast<const float4*>(a.gamma + c0 + 4);
+                grp_raw[2] = *reinterpret_cast<const float4*>(a.invstd + c0); grp_raw[3] = *reinterpret_cast<const float4*>(a.invstd + c0 + 4);
+                grp_raw[4] = *reinterpret_cast<const float4*>(a.beta + c0); grp_raw[5] = *reinterpret_cast<const float4*>(a.beta + c0 + 4);
+                grp_raw[6] = *reinterpret_cast<const float4*>(a.mean + c0); grp_raw[7] = *reinterpret_cast<const float4*>(a.mean + c0 + 4);
+            }
+            st_grp_fetch<C, HW>(grp_regs, xsrc, dzrs, item, p.N);
+        }
+    };
+    auto grp_finish = [&](int u, bool tr) __attribute__((always_inline)) {
+        if constexpr (GRP) {
+            using Q = StGrp<C, HW>;
+            const int nitems = Q::IPG * ((p.N + Q::IPG - 1) / Q::IPG);
+            for (int item = img; item < nitems; item += p.N) {
+                if (item != img) grp_issue(u, item);                 // (a second item: only when the batch is not a multiple of the group size)
+                float coef[16];
+                {
+                    const float ga[8] = {grp_raw[0].x, grp_raw[0].y, grp_raw[0].z, grp_raw[0].w, grp_raw[1].x, grp_raw[1].y, grp_raw[1].z, grp_raw[1].w};
+                    const float is[8] = {grp_raw[2].x, grp_raw[2].y, grp_raw[2].z, grp_raw[2].w, grp_raw[3].x, grp_raw[3].y, grp_raw[3].z, grp_raw[3].w};
+                    const float be[8] = {grp_raw[4].x, grp_raw[4].y, grp_raw[4].z, grp_raw[4].w, grp_raw[5].x, grp_raw[5].y, grp_raw[5].z, grp_raw[5].w};
+                    const float mu[8] = {grp_raw[6].x, grp_raw[6].y, grp_raw[6].z, grp_raw[6].w, grp_raw[7].x, grp_raw[7].y, grp_raw[7].z, grp_raw[7].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { coef[e] = ga[e] * is[e]; coef[8 + e] = be[e] - mu[e] * coef[e]; }
+                }
+                st_grp_run<C, HW>(grp_regs, stg, reinterpret_cast<float*>(stg + Q::IPG * Q::IMG), coef, (u & 1) != 0, item, p.c[u].slab, p.xb, tr);
+            }
+        }
+    };
 
     // ---- state that lives across units.  Everything a unit needs from global memory is requested one stage ahead of its use:
     //   zq / yq / mu4 .. : z, the block output and the saved statistics of the NEXT unit to process at this lane's positions -- requested before the dgrad of the
@@ -492,7 +699,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     float4 mu4[KTW], is4[KTW], ga4[KTW], be4[KTW];
     float c_gamma = 0.f, c_invstd = 0.f, c_dg = 0.f, c_db = 0.f;    // thread c < C: its channel's parameters; workgroup 0: the old dgamma / dbeta
 
-    auto prefetch = [&](int cv, int l15) {
+    auto prefetch = [&](int cv, int l15) __attribute__((always_inline)) {
         const StConvB& cc = p.c[cv];
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) {
@@ -515,11 +722,14 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         }
     };
 
-    auto unit = [&](int cv) {
+    auto unit = [&](int cv) __attribute__((always_inline)) {
         const bool second = cv & 1;
         const StConvB& cc = p.c[cv];
         const bool tr = p.trace > 0 && cv == p.trace && img == 0;
         st_stamp(p.xb, tr, 8);
+        st_stamp(p.xb, tr, 21);
+        if (GRP && cv + 2 < p.nconv) grp_issue(cv + 2, img);        // (the weight gradient of the unit two above: its operands are complete in memory since the last exchange)
+        st_stamp(p.xb, tr, 22);
         // (an opaque copy of the lane index: everything derived from it -- LDS addresses, global offsets -- is recomputed per unit instead of being hoisted out of
         //  the unit loop into ~100 loop-invariant registers)
         int l15 = lane & 15;
@@ -590,6 +800,8 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             else v = red[((ch >> 4) * 2 + stat) * C + ch];
             vals[tid] = v;
         }
+        // (group weight gradient: what this workgroup publishes next tells the others that its dz of the unit above is in memory -- every wave drains its stores first)
+        if constexpr (GRP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         st_stamp(p.xb, tr, 10);
         // ---- B: the batch's sums are on their way ...
@@ -599,37 +811,44 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         // ---- C: ... while this unit's input image is requested (the block input -- a written activation -- for the first convolution of a block; z of the first
         //      convolution for the second one, turned into relu(scale z + shift) with the forward's expressions on its way into LDS) and the weight gradient of
         //      the unit above runs (its dz in D, its input image in XA)
-        uint4 xin[NCH];
-        float xsc[8], xsh[8];
-        {
-            const bf16_t* src = second ? p.c[cv - 1].z : (cv == 0 ? p.x : p.c[cv - 1].y);
-            const uint4* s4 = reinterpret_cast<const uint4*>(src + ibase * C);
+        if constexpr (!GRP) {
+            uint4 xin[NCH];
+            float xsc[8], xsh[8];
+            {
+                const bf16_t* src = second ? p.c[cv - 1].z : (cv == 0 ? p.x : p.c[cv - 1].y);
+                const uint4* s4 = reinterpret_cast<const uint4*>(src + ibase * C);
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) xin[k] = s4[tid + k * 256];
-            if (second) {
-                const StConvB& a = p.c[cv - 1];
-                const int c0 = (tid & (CPP - 1)) * 8;
-                const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gamma + c0 + 4);
-                const float4 i0 = *reinterpret_cast<const float4*>(a.invstd + c0), i1 = *reinterpret_cast<const float4*>(a.invstd + c0 + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(a.beta + c0), b1 = *reinterpret_cast<const float4*>(a.beta + c0 + 4);
-                const float4 m0 = *reinterpret_cast<const float4*>(a.mean + c0), m1 = *reinterpret_cast<const float4*>(a.mean + c0 + 4);
-                const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-                const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                for (int k = 0; k < NCH; ++k) xin[k] = s4[tid + k * 256];
+                if (second) {
+                    const StConvB& a = p.c[cv - 1];
+                    const int c0 = (tid & (CPP - 1)) * 8;
+                    const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gamma + c0 + 4);
+                    const float4 i0 = *reinterpret_cast<const float4*>(a.invstd + c0), i1 = *reinterpret_cast<const float4*>(a.invstd + c0 + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.beta + c0), b1 = *reinterpret_cast<const float4*>(a.beta + c0 + 4);
+                    const float4 m0 = *reinterpret_cast<const float4*>(a.mean + c0), m1 = *reinterpret_cast<const float4*>(a.mean + c0 + 4);
+                    const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+                    const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { xsc[e] = ga[e] * is[e]; xsh[e] = be[e] - mu[e] * xsc[e]; }
+                    for (int e = 0; e < 8; ++e) { xsc[e] = ga[e] * is[e]; xsh[e] = be[e] - mu[e] * xsc[e]; }
+                }
             }
-        }
-        if (cv + 1 < p.nconv) {
-            st_wgrad<C, HW>(D, XA, wred, p.c[cv + 1].slab + (size_t)img * (9 * C * C));
-            __syncthreads();
-        }
-        st_stamp(p.xb, tr, 12);
+            if (cv + 1 < p.nconv) {
+                if constexpr (C == 16) st_wgrad16<HW>(D, XA, wred, p.c[cv + 1].slab + (size_t)img * (9 * C * C));
+                else st_wgrad_wide<C, HW>(D, XA, p.c[cv + 1].slab + (size_t)img * (9 * C * C));
+                __syncthreads();
+            }
+            st_stamp(p.xb, tr, 12);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int i = tid + k * 256;
-            const int q = i / CPP, c8 = i - q * CPP;
-            const int yy = q / HW, xx = q - yy * HW;
-            *reinterpret_cast<uint4*>(XA + ((yy + 1) * P + xx + 1) * PB + c8 * 16) = second ? bn_relu8_bf16(xin[k], xsc, xsh) : xin[k];
+            for (int k = 0; k < NCH; ++k) {
+                const int i = tid + k * 256;
+                const int q = i / CPP, c8 = i - q * CPP;
+                const int yy = q / HW, xx = q - yy * HW;
+                *reinterpret_cast<uint4*>(XA + ((yy + 1) * P + xx + 1) * PB + c8 * 16) = second ? bn_relu8_bf16(xin[k], xsc, xsh) : xin[k];
+            }
+        } else {
+            // the group weight gradient of the unit TWO above: every workgroup's dz of that unit was in memory before it published the exchange that has since completed
+            if (cv + 2 < p.nconv) grp_finish(cv + 2, tr);
+            st_stamp(p.xb, tr, 12);
         }
         bf16x8_t wf[KTW][KS];
 #pragma unroll
@@ -645,6 +864,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         }
         st_stamp(p.xb, tr, 13);
         // ---- D: dz of this unit into D
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t dzrs_own = __builtin_amdgcn_make_buffer_rsrc(GRP ? cc.dzg : const_cast<bf16_t*>(cc.z), 0, p.N * HW * HW * C * 2, 0x00020000);
         xch_end(p.xb, p.N, 2 * C, tag, tot, scratch);
         st_stamp(p.xb, tr, 14);
         if (tid < C) {
@@ -674,7 +894,13 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
                     const float xh = (zf[e] - mu[e]) * is[e];
                     o[e] = gi[e] * (gg[e] - k0[e] - xh * k1[e]);          // (bn_bwd_apply_acc_kernel's expression, bn.hip / lazy_dz8, conv3.hip)
                 }
-                *reinterpret_cast<uint2*>(D + pbase[t] + (P + 1) * PB + ch * 2) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                const uint2 dzv = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                *reinterpret_cast<uint2*>(D + pbase[t] + (P + 1) * PB + ch * 2) = dzv;
+                if constexpr (GRP) {                                 // write-through (sc1): other workgroups read it inside this launch
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){dzv.x, dzv.y}, dzrs_own,
+                                                          (int)((((size_t)(ch >> 4) * p.N + img) * HW * HW + (wp * PTW + t) * 16 + l15) * 32 + (ch & 15) * 2), 0, 16);
+                }
             }
         }
         __syncthreads();
@@ -699,15 +925,17 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             const int a = koff[s_] >= 0 ? pbase[t_] + koff[s_] : 0;
             return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(D + a));
         };
-        bf16x8_t xr[3];
-        xr[0] = xread(0);
-        if (SLOTS > 1) xr[1] = xread(1);
+        // (pixel fragments RING - 1 slots ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency)
+        constexpr int RING = 8;
+        bf16x8_t xr[RING];
+#pragma unroll
+        for (int n = 0; n < RING - 1; ++n) if (n < SLOTS) xr[n] = xread(n);
 #pragma unroll
         for (int n = 0; n < SLOTS; ++n) {
             const int s_ = n / PTW, t_ = n - s_ * PTW;
-            if (n + 2 < SLOTS) xr[(n + 2) % 3] = xread(n + 2);
+            if (n + RING - 1 < SLOTS) xr[(n + RING - 1) % RING] = xread(n + RING - 1);
 #pragma unroll
-            for (int kt = 0; kt < KTW; ++kt) acc[t_][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt][s_], xr[n % 3], acc[t_][kt], 0, 0, 0);
+            for (int kt = 0; kt < KTW; ++kt) acc[t_][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt][s_], xr[n % RING], acc[t_][kt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         st_stamp(p.xb, tr, 16);
@@ -766,25 +994,40 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             }
         }
     }
-    // ---- the weight gradient of the first unit
-    st_wgrad<C, HW>(D, XA, wred, p.c[0].slab + (size_t)img * (9 * C * C));
-    if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
+    // ---- the weight gradients still owed
+    if constexpr (!GRP) {
+        if constexpr (C == 16) st_wgrad16<HW>(D, XA, wred, p.c[0].slab + (size_t)img * (9 * C * C));
+        else st_wgrad_wide<C, HW>(D, XA, p.c[0].slab + (size_t)img * (9 * C * C));
+        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
+    } else {
+        // unit 1's dz is in memory everywhere (the exchange of unit 0 has completed); unit 0's needs one more grid-wide hand-shake, taken around unit 1's work
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned tag = base + (unsigned)p.nconv + 1u;
+        if (p.nconv > 1) grp_issue(1, img);
+        xch_begin(p.xb, img, p.N, 2 * C, tag, vals, scratch);
+        if (p.nconv > 1) grp_finish(1, false);
+        xch_end(p.xb, p.N, 2 * C, tag, tot, scratch);
+        grp_issue(0, img);
+        grp_finish(0, false);
+        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv + 1u);
+    }
 }
 
-template <int C, int HW>
+template <int C, int HW, bool GRP>
 int launch_bwd(const StBwdParams& p, hipStream_t st) {
-    constexpr int lds = StGeoB<C, HW>::LDS;
+    constexpr int lds = StGeoB<C, HW, GRP>::LDS;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr[16] = {};
     if (dev < 0 || dev >= 16 || !attr[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stage_train_bwd_kernel<C, HW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stage_train_bwd_kernel<C, HW, GRP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             clhip_set_error("stage_train_bwd: cannot reserve %d bytes of LDS", lds);
             return CLHIP_EHIP;
         }
         if (dev >= 0 && dev < 16) attr[dev] = true;
     }
-    hipLaunchKernelGGL((stage_train_bwd_kernel<C, HW>), dim3(p.N), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((stage_train_bwd_kernel<C, HW, GRP>), dim3(p.N), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -810,6 +1053,13 @@ bool clhip_stage_train_supported(int N, int H, int W, int C, int nconv, int dtyp
 }
 
 size_t clhip_stage_train_xch_bytes(int N) { return xch_bytes(N, 128); }
+// The weight gradient of a run's backward: per image out of the workgroup's own LDS (partial blocks of 9 / 36 / 147 KB per image and convolution), or -- 64 channels at
+// 128 images or more, where those blocks would be 300 MB per run -- per (channel-tile pair, group of 16 images) from global memory (StGrp).  Measured at batch 256 /
+// 32 (profiles/r06_stage_train_notes.md): the gather of 16-channel slices out of 64- / 128-byte pixels costs 2.4 / 5.8 us of load issue per unit at 64 / 32 channels,
+// more than the larger slabs cost the 32-channel stage or any stage at a small batch.
+static bool stage_train_group(int N, int C) { return C == 64 && N >= 128; }
+// partial blocks (of C * 9 * C floats) per convolution that a backward launch leaves in its slab
+int clhip_stage_train_slab_blocks(int N, int C) { const int ipg = (C / 16) * (C / 16); return stage_train_group(N, C) ? (N + ipg - 1) / ipg : N; }
 
 // One entry per convolution of the run (C ABI of the plan: plain arrays of pointers).  x: the run's input activation [N][H][W][C] bf16.
 int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
@@ -836,7 +1086,7 @@ int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int 
 // N x (C * 9 * C) floats of scratch per convolution -- the caller adds the N blocks to the weight gradient in a fixed order (clhip_wgrad_reduce_launch).
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
-                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* xch, int trace, int dtype, hipStream_t st) {
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int dtype, hipStream_t st) {
     if (!clhip_stage_train_supported(N, H, W, C, nconv, dtype) || xch == nullptr) { clhip_set_error("stage_train_bwd: unsupported geometry"); return CLHIP_EINVAL; }
     StBwdParams p;
     p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.dx = static_cast<bf16_t*>(dx); p.dx_acc = dx_accumulate;
@@ -846,10 +1096,12 @@ int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx
         StConvB& c = p.c[i];
         c.wd = static_cast<const bf16_t*>(wd[i]); c.gamma = gamma[i]; c.beta = beta[i]; c.mean = mean[i]; c.invstd = invstd[i];
         c.z = static_cast<const bf16_t*>(z[i]); c.y = static_cast<const bf16_t*>(y[i]); c.dgamma = dgamma[i]; c.dbeta = dbeta[i]; c.slab = slab[i];
+        c.dzg = static_cast<bf16_t*>(dzg[i]);
     }
-    if (C == 16) return launch_bwd<16, 32>(p, st);
-    if (C == 32) return launch_bwd<32, 16>(p, st);
-    return launch_bwd<64, 8>(p, st);
+    if (C == 16) return launch_bwd<16, 32, false>(p, st);
+    if (C == 32) return launch_bwd<32, 16, false>(p, st);
+    if (stage_train_group(N, C)) return launch_bwd<64, 8, true>(p, st);
+    return launch_bwd<64, 8, false>(p, st);
 }
 
 // the sticky error word of an exchange buffer (non-zero: a bounded spin ran out -- the grid was not co-resident); synchronises the device

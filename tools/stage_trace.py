@@ -1,4 +1,5 @@
-"""phase times inside the stage-level training launches (stage_train.hip): workgroup 0's s_memtime stamps of one convolution per geometry.
+"""(numbers are hundreds of s_memtime ticks = shader-clock cycles / 100: divide by ~24 for microseconds)
+phase times inside the stage-level training launches (stage_train.hip): workgroup 0's s_memtime stamps of one convolution per geometry.
     python tools/stage_trace.py [batch]"""
 import ctypes
 import sys
@@ -32,4 +33,8 @@ for C, cv in ((16, 4), (16, 5), (32, 4), (32, 5), (64, 4), (64, 5)):
     print(f"C {C} convolution {cv} ({'second' if cv & 1 else 'first'} of its block), batch {batch}")
     print("   forward : " + ", ".join(f"{n} {(t[i + 1] - t[i]) / 100:.2f}" for i, n in enumerate(FWD)) + f"  = {(t[6] - t[0]) / 100:.2f} us")
     print("   backward: " + ", ".join(f"{n} {(t[9 + i] - t[8 + i]) / 100:.2f}" for i, n in enumerate(BWD)) + f"  = {(t[16] - t[8]) / 100:.2f} us")
+    if C != 16:
+        GRP = ["fetch wait + LDS store", "MFMA", "slab"]
+        print(f"   group fetch issue {(t[22] - t[21]) / 100:.2f}")
+        print("   group wgrad: publish->start " + f"{(t[17] - t[11]) / 100:.2f}, " + ", ".join(f"{n} {(t[18 + i] - t[17 + i]) / 100:.2f}" for i, n in enumerate(GRP)))
 L.clhip_config(b"STAGE_TRACE", None)
