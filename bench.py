@@ -54,6 +54,7 @@ def parse():
                              "ewc_fisher_pass", "herding_b50"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the live lines of the other BASELINE workloads behind the headline")
     ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' launches (what the PMC passes sample) and print their block")
     ap.add_argument("--cpu-steps", type=int, default=None, help="steps of the CPU baseline sample (default: 5 ResNet, 1-2 ViT)")
     return ap.parse_args()
@@ -154,8 +155,9 @@ def _physical_cores():
 
 
 def cpu_baseline(workload, steps, batch):
-    """the CPU oracle (torch CPU fp32 restatement of the reference's step, oracle/) on the host's PHYSICAL cores, the GPU line's
-    own batch size; a bounded sample (about 10-30 s of CPU work)"""
+    """the CPU oracle (torch CPU fp32 restatement of the reference's step, oracle/), the GPU line's own batch size; a bounded sample (about 10-30 s
+    of CPU work).  ResNet workloads: timed at 8, 32 and all physical cores (one warm-up + two steps each) and the BEST thread count is reported with `steps`
+    more steps at it -- every core of a 128-core host on one 32 x 32 convolution is an oversubscribed run (32-50 img/s on 128 threads, 205 on 8)."""
     cores = _physical_cores()
     torch.set_num_threads(cores)
     if "vitb16" in workload:
@@ -178,14 +180,23 @@ def cpu_baseline(workload, steps, batch):
     def step():
         _, _, loss = m.observe(x, y, True)
         opt.zero_grad(); loss.backward(); opt.step()
-    for _ in range(3):
+    sweep = {}
+    for nt in sorted({min(8, cores), min(32, cores), cores}):
+        torch.set_num_threads(nt)
         step()
+        t0 = time.perf_counter()
+        step(); step()
+        sweep[nt] = batch * 2 / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
-    return dict(value=batch * steps / dt, unit="images/sec", cores=cores, kind="port",
-                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle on {cores} physical cores), 3 warm-ups")
+    torch.set_num_threads(cores)
+    return dict(value=batch * steps / dt, unit="images/sec", cores=best, kind="port", threads_tried={str(k): round(v, 1) for k, v in sweep.items()},
+                sample=f"{steps} steps of batch {batch} (LwF task-0 step, {arch}, fp32 torch-CPU oracle) on {best} threads -- the best of {sorted(sweep)} on a host with "
+                       f"{cores} physical cores, each tried with one warm-up + two steps")
 
 
 def _cpu_baseline_vit(workload, steps, batch, cores):
@@ -252,10 +263,45 @@ def _time_launches(run, reps, warm=5):
     return e0.elapsed_time(e1) / reps
 
 
+def _src_hash():
+    """fingerprint of the kernel sources: a committed in-step profile is stale as soon as a kernel changes (the GPU box has no .git, so not a commit id)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "libcontinual_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "libcontinual_amd", "csrc", "*.h"))):
+        with open(fn, "rb") as f:
+            h.update(os.path.basename(fn).encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
+
+
+_PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02")
+
+
+def _profile_family_share(workload, prefixes):
+    """share of the in-step kernel time of EVERY symbol of a family (all shapes), from the same committed table"""
+    for r in _PROFILE_ROUNDS:
+        pj = os.path.join(ROOT, "profiles", f"{r}_bench_kernel_stats.json")
+        if os.path.exists(pj):
+            with open(pj) as f:
+                ent = json.load(f).get(workload, {}).get("kernels", {})
+            return sum(v["pct"] for k, v in ent.items() if any(k.startswith(px) for px in prefixes)) / 100.0 if ent else None
+    return None
+
+
+def _profile_meta(workload):
+    for r in _PROFILE_ROUNDS:
+        pj = os.path.join(ROOT, "profiles", f"{r}_bench_kernel_stats.json")
+        if os.path.exists(pj):
+            with open(pj) as f:
+                ent = json.load(f).get(workload, {})
+            return dict(file=f"profiles/{r}_bench_kernel_stats.json", src_hash=ent.get("src_hash"), head=ent.get("head"))
+    return None
+
+
 def _profile_lookup(workload, symbol):
     """in-step average duration of a kernel symbol from the committed rocprofv3 --kernel-trace --stats summary of THIS command
     (profiles/r02_bench_kernel_stats.json, written by tools/bench_profile.sh); None if absent"""
-    for name in ("r05_bench_kernel_stats.json", "r04_bench_kernel_stats.json", "r03_bench_kernel_stats.json", "r02_bench_kernel_stats.json"):
+    for name in tuple(f"{r}_bench_kernel_stats.json" for r in _PROFILE_ROUNDS):
         pj = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pj):
             break
@@ -273,7 +319,7 @@ def _profile_lookup(workload, symbol):
 
 
 def _pmc_lookup(key):
-    for name in ("r05_roofline_pmc.json", "r04_roofline_pmc.json", "r03_roofline_pmc.json", "r02_roofline_pmc.json"):
+    for name in tuple(f"{r}_roofline_pmc.json" for r in _PROFILE_ROUNDS):
         pj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pj):
             continue
@@ -330,6 +376,8 @@ def conv_rooflines(dev, dtype, B, workload):
             e.update(standalone_frac=e["frac"], standalone_achieved=e["achieved"], standalone_launch_ms=ms)
             e.update(in_step_launch_ms=t_in, frac=e["standalone_frac"] * ms / t_in, achieved=e["standalone_achieved"] * ms / t_in, in_step_frac=e["standalone_frac"] * ms / t_in,
                      in_step_share_of_kernel_time=share, in_step_source=ins[0]["source"])
+            if kind == "wgrad":      # every shape of the symbol family, not just this entry's (the family is the story, 34 % of the step)
+                e["family_share"] = _profile_family_share(workload, ("conv_wgrad4_kernel", "wgrad3_reduce_kernel", "wgrad_multi_reduce_kernel"))
         out.append(e)
 
     def wgrad_full(x, dz, dw, N, H, W, C, K, stride):
@@ -626,6 +674,42 @@ def task_work_main(a):
     print(json.dumps(out))
 
 
+# the other BASELINE workloads, timed live in the same process behind the headline (20 steps each) so that they are in the driver's record
+SECONDARY = (("ewc_resnet32_b50_task1", 256), ("icarl_resnet32_b50_task1", 32), ("inflora_vitb16_b20_task1", 128))
+
+
+def secondary_lines(dtype, dev, steps=20):
+    import gc
+    from libcontinual_amd import parallel
+    from libcontinual_amd.trainer import train_steps
+    res = {}
+    for workload, batch in SECONDARY:
+        try:
+            vit = "vitb16" in workload
+            torch.manual_seed(1993)
+            model, opt, arch, teacher, (lo, hi) = build_method(workload, dtype, dev)
+            parallel.attach(model, opt, None)
+            model.train()
+            batches = [synthetic_batch(batch, lo, hi, 100 + i, dev, 224 if vit else 32) for i in range(4)]
+            name = type(model).__name__
+
+            def run(n):
+                train_steps(model, opt, (batches[i % 4] for i in range(n)), None, name, None, dev)
+            run(5 if vit else 30)                                   # (warm-up: plans, workspaces, the graph capture of the small batches and its probe)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[f"{workload} --batch {batch}"] = dict(ms_per_step=dt / steps * 1e3, images_per_sec=batch * steps / dt, steps=steps)
+            del model, opt, batches
+        except Exception as e:                                      # (never at the price of the headline line)
+            res[f"{workload} --batch {batch}"] = dict(error=f"{type(e).__name__}: {e}")
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     if a.workload in ("ewc_fisher_pass", "herding_b50"):
@@ -741,9 +825,20 @@ def main():
         out["step_bound"] = "hbm" if arch == "cifar_resnet32" else "mfma"
     if dp is not None:
         out["dp"] = dp
+    meta = _profile_meta(a.workload)
+    if meta is not None and isinstance(roofline, dict):
+        cur = _src_hash()
+        roofline["profile_head"] = meta["head"]
+        roofline["profile_src_hash"], roofline["src_hash"] = meta["src_hash"], cur
+        roofline["profile_stale"] = meta["src_hash"] != cur
+        if roofline["profile_stale"]:
+            print(f"bench.py: the in-step figures of `roofline` come from {meta['file']} taken at kernel sources {meta['src_hash']} (commit {meta['head']}); "
+                  f"the sources here hash to {cur}: re-run tools/bench_profile.py", file=sys.stderr)
     out["roofline"] = roofline
     if more:
         out["roofline_more"] = more
+    if a.workload == "lwf_resnet18_b50_task0" and world == 1 and not a.no_secondary:
+        out["secondary"] = secondary_lines(a.dtype, dev)
     if not a.no_cpu_baseline and world == 1:
         # the GPU line's own batch for the ResNet workloads; the ViT steps cost 2-3 CPU-seconds per image, so their bounded sample is a
         # smaller batch (the per-image cost of the CPU path does not depend on it)

@@ -481,7 +481,7 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  *   dispatch (0 / 1 unless noted):
  *     CONV4 (0: 3x3/s1 layers stay on conv3.hip), CONV5 (0: the 64 -> 64-channel 3x3/s1 layers stay on conv4.hip), CONV64 (0: 64 -> 64 channels on small maps stay on conv4 / wgrad4; CONV64_FWD 0: only their backward; CONV64_BM 64 | 128), CONV6 (0: no fused stride-2 dgrad pair kernel), CONV6_PAIR (0: plans keep the two separate input-gradient launches), CONV7 (0: no small-channel entry kernels; FWD7 0 / WGRAD7 0: not their forward / weight-gradient pairs; CONV7_TPW n: tiles per wave), BN_INPUT (0: no lazy BatchNorm inputs), BN_INPUT_WT (0: not on the LDS-DMA kernels of the wide layers), BN_RES_INPUT (0: block outputs keep their own apply launch), EVAL_LAZY (0: eval-mode forwards keep one BatchNorm apply launch per unit instead of the consumer-side forms), BN_GRAD (0: no BatchNorm backward on the operand loads; BN_GRAD_MINC n: only for layers of >= n channels, BN_GRAD_RES 0: not for the +res layers), CONV_V1,
  *     NO_CONV3, NO_CONV16, NO_STEM, NO_SHORTCUT, NO_PARITY_DGRAD, CONV3G, WGRAD4 (0 off, 2 stride-1 layers only), WGRAD5, WGRAD32,
- *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM5 (0 never = the default since round 4, 1 where it wins stand-alone, 2 wherever supported), GEMM_NO_SPLIT, GEMM_TAIL, GEMM_SPLITK (0: no split-K for the few-tile / long-K products; n > 1: the minimum K that splits, default 3072), ATTN_GENERIC, CE_ROWS,
+ *     WGRAD_NO_TR, WGRAD2_ATOMIC (1: the generic weight-gradient kernel keeps fp32 atomics even when scratch is handed in), BWD_FUSED (0: dgrad and weight gradient of the 16 / 32-channel layers as two launches), WGRAD_DEFER_SIDE (n > 0: plans WITH a weight-gradient stream reduce in groups of n launches), WGRAD_DEFER (0: plans without a weight-gradient stream reduce their partial blocks per layer instead of once per backward), GEMM_NO_SPLIT, GEMM_TAIL, GEMM_SPLITK (0: no split-K for the few-tile / long-K products; n > 1: the minimum K that splits, default 3072), ATTN_GENERIC, CE_ROWS,
  *     BN_PARTIALS (partial rows + finalize launches instead of the fp64 accumulators), BN_FUSE (0 never, 1 everywhere; default: small
  *     activations), BN_FUSE_MAX_M, BN_MASK_BITS, BN_MASK_FROM_Y, BN_ONEPASS, PREP_NARROW,
  *     WGRAD_STREAM (0: weight gradients on the caller's stream), BRANCH_STREAM (shortcut branches on a third stream: 0 never, 1 forward and backward, 2 forward only = default, 3 backward only), WGRAD_ALWAYS_QUEUE, SIDE_PRIO, EVENT_FLAGS, EVENT_RECORD
@@ -491,18 +491,15 @@ int clhip_conv_wgrad_pair(const void* x, const void* dz, const void* dz_sc, floa
  *   tuning values:
  *     DZ_BUFFERS (2..4 rotating gradient buffers of the two-stream backward, default 4), CONV8_GRID, CONV8_OPT, CONV64_MAX_W, CONV64_MAX_M,
  *     WGRAD_TARGET (workgroups of the weight-gradient kernels), WGRAD_NET_GFLOP, WGRAD4_MIN_STEPS, WGRAD4_MIN_TOTAL, CONV3_CFG "wm,wn",
- *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, PLAN_SKIP (timing ablations: 1 no forward BatchNorm apply, 2 no BatchNorm backward, 4 no weight gradients -- results invalid), IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, GEMM5_GRID, STEM_GRID,
+ *     CONV4_CFG "wm,wn,kg,ck", CONV4_GRID, CONV5_MIN_TILES, CONV5_GRID, PLAN_SKIP (timing ablations: 1 no forward BatchNorm apply, 2 no BatchNorm backward, 4 no weight gradients -- results invalid), IGEMM_TILE "bm,bn", GEMM_MT, GEMM_GROUP_M, STEM_GRID,
  *     STEM_WGRAD_GRID, SHORTCUT_MIN_PIXELS, BN_ACC_CPT, BN_BWD_ITERS
  *   micro-benchmark / ablation hooks (tools/ubench; take effect at once): CONV4_FORCE_CFG "wm,wn,kg,ck", CONV4_ENABLE, CONV4_DEBUG, CONV6_DEBUG (read once),
- *     GEMM5_DEBUG, CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, GEMM5_TRACE, WGRAD4_TRACE, CONV8_TRACE, CONV9_TRACE (device address of
+ *     CONV3_DEBUG, WGRAD_DEBUG (bit masks of phases to skip), CONV4_TRACE, WGRAD4_TRACE, CONV8_TRACE, CONV9_TRACE (device address of
  *     a stamp buffer as a number; ablation builds only) */
 int clhip_config(const char* key, const char* value);
 /* the value clhip_config() last set for `key` (NULL: never set or erased -- the environment's value applies).  For callers that flip a
  * switch around a region and must put back what was there (ops.TeacherPass).  The pointer stays valid for the process' life. */
 const char* clhip_config_get(const char* key);
-/* the 256 x 256 LDS-DMA kernel (gemm5.hip, bf16, N % 256 == 0, K % 32 == 0, K >= 128): 0 never (the default since round 4: inside the ViT steps the
- * register-staged kernel wins), 1 where it wins stand-alone (N >= 2048, >= 192 tiles), 2 wherever it is supported (tests); -1 = from $CLHIP_GEMM5 */
-void clhip_gemm5_config(int mode);
 /* the 256 x 256 eight-phase kernel with 64-deep K tiles (gemm8.hip, round 5; bf16, N % 256 == 0, K % 128 == 0, K >= 256): 0 never, 1 (the default) the
  * row panels that fill whole rounds of its 256 persistent workgroups -- the remaining rows go to the register-staged kernel --, 2 wherever it is
  * supported (tests); -1 = from $CLHIP_GEMM8.  Same epilogues as clhip_gemm_nt's other kernels

@@ -30,14 +30,14 @@ namespace {
 const char* const kKeys[] = {
     // dispatch switches (A/B runs, tests that pin a code path)
     "ATTN_GENERIC", "BN_FUSE", "BN_FUSE_MAX_M", "BN_MASK_BITS", "BN_MASK_FROM_Y", "BN_PARTIALS", "CE_ROWS", "CE_ONE_WG", "LINEAR_BWD_SPLIT", "CONV3G", "CONV4", "CONV_V1",
-    "GEMM5", "GEMM_NO_SPLIT", "GEMM_TAIL", "NO_CONV16", "NO_CONV3", "NO_PARITY_DGRAD", "NO_SHORTCUT", "NO_STEM", "PREP_NARROW", "WGRAD4",
+    "GEMM_NO_SPLIT", "GEMM_TAIL", "NO_CONV16", "NO_CONV3", "NO_PARITY_DGRAD", "NO_SHORTCUT", "NO_STEM", "PREP_NARROW", "WGRAD4",
     "WGRAD_NO_TR", "WGRAD2_ATOMIC", "WGRAD_DEFER", "WGRAD_DEFER_SIDE", "BWD_FUSED", "WGRAD_STREAM", "BRANCH_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "CONV6", "WGRAD16_PARTS", "WGRAD32_IPG", "WGRAD64_IPG", "WGRAD64_IPI2", "CONV64", "CONV64_BM", "CONV64_FWD", "CONV6_PAIR", "CONV7", "CONV7_TPW", "WGRAD7", "FWD7", "PAIR_BN_FUSE", "POOL_BN_FUSE", "BN_INPUT", "BN_INPUT_WT", "BN_RES_INPUT", "BN_GRAD", "BN_GRAD_MINC", "BN_GRAD_RES", "CONV6_DEBUG", "BN_ONEPASS", "WGRAD5", "WGRAD32",
     // tuning values
-    "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM5_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
+    "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
     "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "DZ_BUFFERS", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "CONV9", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK", "STREAM_PROBE", "STAGE_EVAL", "STAGE_TRAIN", "STAGE_TRAIN_BWD", "STAGE_TRACE",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
-    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "GEMM5_DEBUG", "GEMM5_TRACE", "WGRAD4_TRACE", "CONV6_TRACE", "CONV8_TRACE", "CONV9_TRACE",
+    "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "WGRAD4_TRACE", "CONV6_TRACE", "CONV8_TRACE", "CONV9_TRACE",
 };
 std::mutex g_stream_mu;
 std::mutex g_cfg_mu;
@@ -97,6 +97,18 @@ hipStream_t clhip_shared_stream(int role, hipStream_t main_s, bool low_priority)
     const auto key = std::make_pair(main_s, 0);
     auto it = S.chosen.find(key);
     if (it != S.chosen.end()) return it->second;
+    {
+        // the first request for this caller's stream MEASURES (spin + stamp kernels, two stream synchronisations, a hipMalloc): none of that may happen inside a
+        // stream capture -- the probe's nodes would land in the caller's graph and the synchronisation would invalidate the capture.  A capturing caller gets an
+        // already chosen stream of another main stream or the first candidate, unprobed and NOT remembered: the next eager call measures.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(main_s, &cap);
+        if (cap != hipStreamCaptureStatusNone) {
+            for (const auto& kv : S.chosen) if (kv.second != main_s) return kv.second;
+            for (hipStream_t c : S.pool) if (c != main_s) return c;
+            return nullptr;                                          // (no stream yet and none may be created now: the caller keeps to its own stream)
+        }
+    }
     const int probe_cfg = clhip_cfg("STREAM_PROBE") != nullptr ? atoi(clhip_cfg("STREAM_PROBE")) : 1;      // 0: the first candidate, unmeasured
     hipStream_t pick = nullptr, fallback = nullptr;
     for (size_t k = 0; k < 8 && pick == nullptr; ++k) {
@@ -120,8 +132,6 @@ void clhip_conv4_set_cfg(int wm, int wn, int kg, int ck);
 void clhip_conv4_enable(int on);
 void clhip_conv4_set_debug(int bits);
 void clhip_conv4_set_trace(unsigned long long* dev_buf);
-void clhip_gemm5_set_debug(int bits);
-void clhip_gemm5_set_trace(unsigned long long* dev_buf);
 void clhip_wgrad4_set_trace(unsigned long long* dev_buf);
 void clhip_conv5_enable(int on);
 void clhip_conv5_min_tiles(int n);
@@ -165,9 +175,7 @@ extern "C" int clhip_config(const char* key, const char* value) {
     }
     if (strcmp(key, "CONV4_ENABLE") == 0) { clhip_conv4_enable(value ? atoi(v) : -1); return CLHIP_OK; }
     if (strcmp(key, "CONV4_DEBUG") == 0) { clhip_conv4_set_debug(atoi(v)); return CLHIP_OK; }
-    if (strcmp(key, "GEMM5_DEBUG") == 0) { clhip_gemm5_set_debug(atoi(v)); return CLHIP_OK; }
     if (strcmp(key, "CONV4_TRACE") == 0) { clhip_conv4_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
-    if (strcmp(key, "GEMM5_TRACE") == 0) { clhip_gemm5_set_trace(reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0))); return CLHIP_OK; }
     if (strcmp(key, "CONV6_TRACE") == 0) {                         // "pointer[,workgroup]"
         char* end = nullptr;
         unsigned long long ptr = strtoull(v, &end, 0);

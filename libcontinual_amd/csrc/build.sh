@@ -11,7 +11,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value $EXTRA"
 mkdir -p $OBJ
 pids=()
-for f in api conv conv2 conv3 conv4 conv5 conv6 conv7 conv8 conv9 stage stage_train wgrad4 stem shortcut bn elementwise head plan gemm gemm5 gemm8 attn vit_ops vit_plan augment; do
+for f in api conv conv2 conv3 conv4 conv5 conv6 conv7 conv8 conv9 stage stage_train wgrad4 stem shortcut bn elementwise head plan gemm gemm8 attn vit_ops vit_plan augment; do
   if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ common.h -nt $OBJ/$f.o ] || [ xch.h -nt $OBJ/$f.o ] || [ ../../include/clhip.h -nt $OBJ/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o $OBJ/$f.o &
     pids+=($!)

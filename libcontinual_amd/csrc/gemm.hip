@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
 }
 
 // The round-1 LDS-DMA experiments (128 x 128 two-stage, 256 x 128 three-stage ring, barrier-staggered ping-pong; none faster than the
-// register-staged kernel above: profiles/r01_gemm_ablation.txt) are gone; their successor is gemm5.hip.
+// register-staged kernel above: profiles/r01_gemm_ablation.txt) are gone; their successor was gemm5.hip (rounds 2-5; deleted in round 6: gemm8.hip superseded it).
 
 template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launch(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -621,10 +621,6 @@ template <typename T> int dispatch(int epi, const GemmParams& p, hipStream_t s) 
 
 }  // namespace
 
-bool clhip_gemm5_supported(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype);
-int clhip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
-                       int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st);
-
 
 int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int ldh, int dtype);
 int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
@@ -656,7 +652,5 @@ extern "C" int clhip_gemm_nt(const void* A, const void* B, void* C, const float*
         p.A = A; p.C = C; p.R = R; p.H = H; p.M = M;
         return dispatch<bf16_t>(epilogue, p, s);
     }
-    if (clhip_gemm5_supported(M, N, K, lda, ldb, ldc, ldr, ldh, dtype))
-        return clhip_gemm5_launch(A, B, C, bias, R, H, M, N, K, lda, ldb, ldc, ldr, ldh, epilogue, s);
     return dtype == CLHIP_BF16 ? dispatch<bf16_t>(epilogue, p, s) : dispatch<float>(epilogue, p, s);
 }

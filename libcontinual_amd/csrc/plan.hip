@@ -636,8 +636,11 @@ static bool branch_stream_on(clhip_plan* p, hipStream_t main_s) {
     return true;
 }
 
-// the STAGE_TRAIN switch: "0" / "1", unset = the built-in default
-static bool stage_train_default(const char* cfg) { return cfg != nullptr ? atoi(cfg) != 0 : false; }
+// the STAGE_TRAIN switch: "0" / "1"; unset = on for batches above 64.  Measured on the EWC CifarResNet-32 step (ms per step, stage-level / per-unit launches,
+// profiles/r06_stage_train_notes.md): batch 32 0.76 / 0.75, 64 0.81 / 0.81, 96 0.83 / 0.94, 128 0.85 / 0.91, 192 0.94 / 1.03, 256 0.99 / 1.19 -- a stage-level
+// launch costs the same whatever the batch (one image per compute unit: its time is the per-image work plus the in-launch exchanges), the per-unit launches of a
+// small batch sit at their latency floor and replay from a HIP graph.
+static bool stage_train_default(const char* cfg, int N) { return cfg != nullptr ? atoi(cfg) != 0 : N > 64; }
 // STAGE_TRACE = "<channels>:<convolution>" (diagnostic): workgroup 0 of the runs with that channel count stamps the phases of that convolution
 static int stage_trace_cfg(int C) {
     const char* v = clhip_cfg("STAGE_TRACE");
@@ -890,7 +893,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     const bool stage_on = eval_lazy && !(stage_cfg != nullptr && atoi(stage_cfg) == 0);
     // STAGE_TRAIN (default on; looked up per call): runs of BasicBlocks as ONE training launch (stage_train.hip) where the plan found them and the lazy forms are on
     const char* strain_cfg = clhip_cfg("STAGE_TRAIN");
-    const bool strain_on = rlazy_on && p->xch != nullptr && stage_train_default(strain_cfg);
+    const bool strain_on = rlazy_on && p->xch != nullptr && stage_train_default(strain_cfg, p->N);
     for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = p->stage_skipped[i] = 0;
     if (training) std::fill(p->mask_stale.begin(), p->mask_stale.end(), 0);
     p->params_dev = params; p->bn_stats_dev = bn_stats;
@@ -1196,7 +1199,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     // STAGE_TRAIN_BWD (default on; looked up per call): a run of BasicBlocks that lies inside this call's range goes as ONE launch (stage_train.hip), whichever forward ran
     const char* stb_cfg = clhip_cfg("STAGE_TRAIN_BWD");
     const char* stb_cfg2 = clhip_cfg("STAGE_TRAIN");
-    const bool stb_on = p->xch != nullptr && !(stb_cfg != nullptr && atoi(stb_cfg) == 0) && stage_train_default(stb_cfg2) && !br_on && !(plan_skip() & 6);
+    const bool stb_on = p->xch != nullptr && !(stb_cfg != nullptr && atoi(stb_cfg) == 0) && stage_train_default(stb_cfg2, p->N) && !br_on && !(plan_skip() & 6);
     for (int i = unit_hi - 1; i >= unit_lo; --i, k = (k + 1) % n_dz) {
         if (stb_on && p->units[i].run_first >= 0) {
             const int f = p->units[i].run_first;

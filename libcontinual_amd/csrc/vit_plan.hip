@@ -233,7 +233,10 @@ extern "C" int clhip_vit_backward(clhip_vit* v, const clhip_vit_params* P, const
     // the lora_B gradients are leaves of the chain: they run on a side stream (ordered by events against the single dqkv buffer)
     static const bool two_streams = !(clhip_cfg("WGRAD_STREAM") && atoi(clhip_cfg("WGRAD_STREAM")) == 0);
     hipStream_t main_s = static_cast<hipStream_t>(stream);
-    const bool side_on = two_streams && d_lora_b != nullptr;
+    // (inside a stream capture everything stays on the captured stream, as plan.hip does: no fork / join nodes, no stream probe)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(main_s, &cap);
+    const bool side_on = two_streams && d_lora_b != nullptr && cap == hipStreamCaptureStatusNone;
     hipStream_t shared_side = side_on ? clhip_shared_stream(0, main_s, false) : nullptr;
     if (side_on && shared_side == nullptr) { clhip_set_error("clhip_vit_backward: cannot create the side stream"); return CLHIP_EHIP; }
     const bool first_side = side_on && !v->side;

@@ -474,8 +474,16 @@ class TeacherPass:
             if self._branch_off:
                 self._branch_prev = _lib.lib().clhip_config_get(b"BRANCH_STREAM")
                 _lib.lib().clhip_config(b"BRANCH_STREAM", b"0")
-            with torch.cuda.stream(side), torch.no_grad():
-                self._out = fn()
+            # ... and the side pass keeps to one launch per unit: a stage-level TRAINING launch (stage_train.hip; teachers that `model.train()` returned to batch
+            # statistics would take it) needs every workgroup resident at once, and two such grids on two streams would wait for each other's compute units.
+            # Per-unit launches beside the student's stage-level ones are the better pairing anyway: they run in the waits of its in-launch all-reduces.
+            st_prev = _lib.lib().clhip_config_get(b"STAGE_TRAIN")
+            _lib.lib().clhip_config(b"STAGE_TRAIN", b"0")
+            try:
+                with torch.cuda.stream(side), torch.no_grad():
+                    self._out = fn()
+            finally:
+                _lib.lib().clhip_config(b"STAGE_TRAIN", st_prev)
             self._side = side
 
     def result(self):

@@ -68,7 +68,8 @@ class GraphedStep:
         forward rewrites every buffer it reads."""
     WARM, KEEP = 2, 4
     PROBE = 12                      # auto mode: steps of each kind timed per key before the faster one is kept (see _pick)
-    _PLAN_SWITCHES = (b"BN_INPUT", b"BN_INPUT_WT", b"BN_RES_INPUT", b"BN_GRAD", b"BN_GRAD_RES", b"BN_FUSE", b"BRANCH_STREAM", b"WGRAD_STREAM", b"CONV6_PAIR")
+    _PLAN_SWITCHES = (b"BN_INPUT", b"BN_INPUT_WT", b"BN_RES_INPUT", b"BN_GRAD", b"BN_GRAD_RES", b"BN_FUSE", b"BRANCH_STREAM", b"WGRAD_STREAM", b"CONV6_PAIR",
+                      b"STAGE_EVAL", b"EVAL_LAZY", b"STAGE_TRAIN", b"STAGE_TRAIN_BWD", b"GEMM8", b"GEMM_TAIL")
 
     def __init__(self, model, optimizer, method_name, reducer=None):
         self.model, self.optimizer, self.method_name = model, optimizer, method_name
@@ -144,10 +145,21 @@ class GraphedStep:
                 st.update(kind="eager", n=0, ev=torch.cuda.Event(enable_timing=True))
                 st["ev"].record()
             else:
-                self.choice[key] = "eager" if st["ms"]["eager"] < 0.97 * st["ms"]["replay"] else "replay"
+                choice = "eager" if st["ms"]["eager"] < 0.97 * st["ms"]["replay"] else "replay"
+                if self.reducer is not None and getattr(self.reducer, "world", 1) > 1:
+                    # data parallel: every rank times its own probe while its step time depends on the other ranks' -- they must not decide apart (a mixture
+                    # still matches collectives one to one, but half the ranks would pay the slower kind for nothing, and a test could not pin it down):
+                    # rank 0's measurement decides for all (ranks reach this point in the same step: the probe counts steps, not time)
+                    import torch.distributed as dist
+                    flag = torch.tensor([1 if choice == "replay" else 0], device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.int32)
+                    dist.broadcast(flag, src=0, group=getattr(self.reducer, "group", None))
+                    choice = "replay" if int(flag.item()) else "eager"
+                self.choice[key] = choice
                 self.probe_ms = dict(st["ms"])                # (last probe's figures: diagnostics, tests)
                 del self._probe[key]
-                return self.choice[key] == "replay"
+                if choice == "eager":                         # the graph of a key that stays eager is dead weight (its memory pool included)
+                    self.graphs[key] = None
+                return choice == "replay"
         st["n"] += 1
         return st["kind"] == "replay"
 
@@ -155,6 +167,8 @@ class GraphedStep:
         if self.disabled:
             return self._step(batch)
         key = self._key(batch)
+        if self.choice.get(key) == "eager":
+            return self._step(batch)
         ent = self.graphs.get(key)
         if ent is None:
             n = self.seen.get(key, 0)
@@ -179,6 +193,8 @@ class GraphedStep:
                     raise
                 torch.cuda.synchronize()
                 self.disabled = True
+                if self.reducer is not None and hasattr(self.reducer, "_early"):
+                    self.reducer._early.clear()   # (segment hooks that fired inside the dropped capture left offsets and Work objects of an invalidated capture)
                 for o in self.owners:             # launches "made" during the dropped capture never ran: the weight copies they were to refresh are stale
                     o.mark_params_modified()
                 import warnings
@@ -226,11 +242,13 @@ def _graph_mode(model, reducer, device, optimizer=None):
 def _reducer_capturable(reducer):
     """A data-parallel step replays from a graph when its exchange is made of capturable launches only: the RCCL backend (gloo stages through
     the host), the in-place all-reduce exchange (the sharded one publishes parameters with a second collective behind the optimizer and keeps
-    per-shard state the replay cannot re-point), and CLHIP_DP_GRAPH != 0.  Every rank takes the same decision (same env, same backend), so
+    per-shard state the replay cannot re-point), and CLHIP_DP_GRAPH = 1.  Every rank takes the same decision (same env, same backend), so
     either all ranks replay or none does -- a mixture would still match collectives one to one, replayed or not."""
     if reducer is None:
         return True
-    if os.environ.get("CLHIP_DP_GRAPH", "1") == "0" or getattr(reducer, "exchange", None) != "all_reduce":
+    # (opt-in, CLHIP_DP_GRAPH=1: the capture of a reduced step has only ever run on a ONE-rank RCCL group -- tests/test_dp_gpu.py -- no multi-GPU node was available to
+    #  the builder; until a >= 2-rank capture has been exercised the default data-parallel step is the eager one, ADVICE r5)
+    if os.environ.get("CLHIP_DP_GRAPH", "0") != "1" or getattr(reducer, "exchange", None) != "all_reduce":
         return False
     import torch.distributed as dist
     try:

@@ -52,7 +52,15 @@ def kernel_stats(workload):
             f"bench line under the profiler: {bench['value']:.0f} img/s, {bench['ms_per_step']:.3f} ms/step, {bench['steps']} timed + {bench['warmup']} warm-up steps\n"
             f"kernel time in the whole run {tot / 1e6:.1f} ms (includes the roofline block's stand-alone launches and start-up)\n")
     open(os.path.join(OUT, f"bench_kernel_stats_{workload}.txt"), "w").write(head + "\n".join(lines) + "\n")
-    return dict(steps=bench["steps"], warmup=bench["warmup"], ms_per_step_under_profiler=bench["ms_per_step"], kernels=ks)
+    sys.path.insert(0, ROOT)
+    import bench as B
+    head = None
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        pass
+    head = head or os.environ.get("CLHIP_HEAD")                   # (the GPU box has no .git: pass the commit in the environment)
+    return dict(steps=bench["steps"], warmup=bench["warmup"], ms_per_step_under_profiler=bench["ms_per_step"], kernels=ks, src_hash=B._src_hash(), head=head)
 
 
 def pmc(workload):
