@@ -45,7 +45,7 @@ bool clhip_stage_train_supported(int N, int H, int W, int C, int nconv, int dtyp
 size_t clhip_stage_train_xch_bytes(int N);
 int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
                                  float* const* rm, float* const* rv, float* const* mean, float* const* invstd, float* const* coef, void* const* z, void* const* y,
-                                 void* const* mask, float momentum, float eps, void* xch, int trace, int dtype, hipStream_t st);
+                                 void* const* mask, float momentum, float eps, void* xch, int trace, int entry, int dtype, hipStream_t st);
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
                                  const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int dtype, hipStream_t st);
@@ -95,6 +95,8 @@ struct Unit {
     size_t wg_own;                               // this unit's own weight-gradient scratch (plans that defer the reduces), else the shared one
     int stage_len;                               // > 0 (round 5): this unit opens a run of `stage_len` units = stage_len / 2 BasicBlocks of C -> C 3x3 / stride-1 convolutions that
                                                  // the EVAL forward runs as ONE launch with the image resident in LDS (stage.hip); the activations inside the run are not written
+    int entry_first;                             // >= 0 (on the unit that opens a training run): the run's launch can start three units earlier, with the stage's down-sampling
+                                                 // block -- units entry_first (3x3 / s2), + 1 (1x1 / s2 shortcut), + 2 (second convolution) -- in front of it (STAGE_ENTRY)
     int run_first;                               // >= 0: this unit lies inside the training run that unit `run_first` opens (stage_train)
     size_t st_slab;                              // ... its weight-gradient slab of that launch: N blocks of cout * 9 * cin floats (bytes into the workspace)
     bool stage_train;                            // (round 6) ... and the TRAINING forward / backward can run it as one launch per direction (stage_train.hip): every
@@ -544,7 +546,24 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
     if (getenv("CLHIP_PLAN_DEBUG"))
         for (int i = 0; i < n_units; ++i) fprintf(stderr, "plan: unit %d stage_len %d src %d res %d k %d s %d C %d->%d H %d\n", i, p->units[i].stage_len, p->units[i].d.src, p->units[i].d.res,
                                                   p->units[i].d.ksize, p->units[i].d.stride, p->units[i].d.cin, p->units[i].d.cout, p->units[i].H);
-    for (Unit& u : p->units) { u.run_first = -1; u.st_slab = 0; }
+    for (Unit& u : p->units) { u.run_first = -1; u.st_slab = 0; u.entry_first = -1; }
+    // the down-sampling block in front of a run: a = 3x3 / s2 (C / 2 -> C) on activation s, b = 1x1 / s2 shortcut on the same activation (conv -> BN, no ReLU), c = the
+    // block's second convolution (src a, res b), and the run opens on c's output
+    for (int f = 3; f < n_units; ++f) {
+        Unit& uf = p->units[f];
+        if (!uf.stage_train || uf.d.cout < 32) continue;
+        const Unit &a = p->units[f - 3], &b = p->units[f - 2], &c = p->units[f - 1];
+        const int C = uf.d.cout;
+        // (branch-stream roles -- forks / joins / branch -- only matter in plans that can have extra streams: branch_stream_on)
+        auto plain = [&](const Unit& q) { return !q.pre_res && !q.raw_src && !q.no_bn && !q.has_dzr && q.rep_fwd > 0 && q.rep_bwd > 0 && ((q.joins < 0 && q.forks < 0 && q.branch < 0) || !p->side_ok); };
+        if (!(plain(a) && plain(b) && plain(c))) continue;
+        if (!(a.d.ksize == 3 && a.d.stride == 2 && a.d.pad == 1 && a.d.cin == C / 2 && a.cin_pad == C / 2 && a.d.cout == C && a.relu && a.d.res < 0 && a.H == 2 * uf.H && a.W == 2 * uf.W)) continue;
+        if (!(b.d.ksize == 1 && b.d.stride == 2 && b.d.pad == 0 && b.d.src == a.d.src && b.d.cin == C / 2 && b.cin_pad == C / 2 && b.d.cout == C && !b.relu && b.d.res < 0)) continue;
+        if (!(c.d.ksize == 3 && c.d.stride == 1 && c.d.pad == 1 && c.d.cin == C && c.d.cout == C && c.relu && c.d.src == f - 2 && c.d.res == f - 1 && c.mask_off != 0 && uf.d.src == f)) continue;
+        if (a.d.src < 1 || uf.stage_len + 1 > 16) continue;
+        // a's activation must reach c the way the per-unit backward expects it: lazily (its only consumer) -- otherwise the launch writes it
+        uf.entry_first = f - 3;
+    }
     if (any_train) {
         size_t off2 = p->ws_bytes;
         for (int i = 0; i < n_units; ++i) {
@@ -919,6 +938,30 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
         }
         if (use_acc && u.rep_fwd > 0) {
             // conv epilogue adds the per-channel sums into the fp64 accumulator; BN-apply derives scale / shift on the fly
+            static const bool entry_off = clhip_cfg("STAGE_ENTRY") != nullptr && atoi(clhip_cfg("STAGE_ENTRY")) == 0;
+            if (strain_on && !entry_off && i + 3 < p->units.size() && p->units[i + 3].stage_train && p->units[i + 3].entry_first == (int)i) {
+                // the stage's down-sampling block AND the run behind it as one launch (stage_train.hip, ENTRY): units i (3x3 / s2), i + 1 (shortcut), i + 2, then the run
+                const Unit& uf = p->units[i + 3];
+                const int len = uf.stage_len + 3;
+                const void* wv[20]; const float *gv[20], *bv[20]; float *rmv[20], *rvv[20], *mev[20], *isv[20], *cov[20]; void *zv[20], *yv[20], *mkv[20];
+                for (int k = 0; k < len; ++k) {
+                    const Unit& q = p->units[i + k];
+                    wv[k] = sh + q.sh_fwd; gv[k] = params + q.d.gamma_off; bv[k] = params + q.d.beta_off; rmv[k] = bn_stats + q.d.rm_off; rvv[k] = bn_stats + q.d.rv_off;
+                    mev[k] = fr + q.f_mean; isv[k] = fr + q.f_invstd; cov[k] = fr + q.f_scale; zv[k] = ws + q.z_off; mkv[k] = nullptr;
+                    // block outputs and the shortcut's BatchNorm output are written; a first convolution's activation only where its consumer does not take it lazily
+                    const bool first = k == 0 || (k >= 3 && ((k - 3) & 1) == 0);
+                    const bool lazy = first && q.lazy_to == (int)i + k + (k == 0 ? 2 : 1);
+                    yv[k] = lazy ? nullptr : ws + p->acts[i + k + 1].y_off;
+                    p->lazy_live[i + k] = lazy ? 1 : 0;
+                    p->mask_stale[i + k] = (k == 2 || (k >= 3 && ((k - 3) & 1) == 1)) ? 1 : 0;
+                }
+                TRY(stage_train_serialize(p, (hipStream_t)stream));
+                TRY(clhip_stage_train_fwd_launch(ws + src.y_off, p->N, uf.H, uf.W, uf.d.cout, uf.stage_len + 1, wv, gv, bv, rmv, rvv, mev, isv, cov, zv, yv, mkv, kBnMomentum, kBnEps,
+                                                 p->xch, stage_trace_cfg(uf.d.cout), 1, p->dtype, (hipStream_t)stream));
+                ++p->st_fwd_launches;
+                i += len - 1;
+                continue;
+            }
             if (strain_on && u.stage_train) {
                 // a run of BasicBlocks as ONE launch: one workgroup per image, the activation resident in LDS, the batch statistics of every convolution through the
                 // in-launch all-reduce (stage_train.hip).  Leaves what the per-unit launches leave: z, saved + running statistics, the block outputs with their masks;
@@ -934,7 +977,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 }
                 TRY(stage_train_serialize(p, (hipStream_t)stream));
                 TRY(clhip_stage_train_fwd_launch(ws + src.y_off, p->N, u.H, u.W, u.d.cout, u.stage_len, wv, gv, bv, rmv, rvv, mev, isv, cov, zv, yv, mkv, kBnMomentum, kBnEps,
-                                                 p->xch, stage_trace_cfg(u.d.cout), p->dtype, (hipStream_t)stream));
+                                                 p->xch, stage_trace_cfg(u.d.cout), 0, p->dtype, (hipStream_t)stream));
                 ++p->st_fwd_launches;
                 i += u.stage_len - 1;
                 continue;

@@ -48,6 +48,7 @@ struct StFwdParams {
     double invM, unbias;      // 1 / (N HW HW), M / (M - 1)
     int trace;                // > 0: workgroup 0 stamps the phases of convolution `trace` into the exchange buffer's spare words (clhip_stage_train_trace)
     XchBuf xb;
+    StConv ea, ed;            // (entry block) its 3x3 / stride-2 convolution and its 1x1 / stride-2 shortcut convolution; x is then the block's INPUT [N][2 HW][2 HW][C / 2]
     StConv c[kMaxConvT];
 };
 
@@ -69,15 +70,22 @@ struct StGeo {
     static constexpr int LDS_FWD = 2 * BUF + AUX;
 };
 
-template <int C, int HW>
+// ENTRY: the launch starts with the stage's DOWN-SAMPLING block (resnet.py:289-316 with stride 2 and the 1x1 / stride-2 shortcut of :299-305, built at :383 / :386):
+// the input image (2 HW x 2 HW pixels, C / 2 channels) lands in a third LDS buffer, the block's first convolution (3x3 / stride 2) and the shortcut convolution read it
+// at strided pixel positions with the output tiling of every other convolution of the run, each with its own statistics exchange; the block's second convolution is
+// then an ordinary "second" convolution.  p.c[] = [second convolution of the entry block, first / second convolutions of the following blocks ...] (nconv odd).
+template <int C, int HW, bool ENTRY>
 __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams p) {
     using G = StGeo<C, HW>;
     constexpr int P = G::P, PB = G::PB, BUF = G::BUF, PTW = G::PTW, KTW = G::KTW, KS = G::KS, WK = G::WK;
     constexpr int LOGC = C == 16 ? 4 : (C == 32 ? 5 : 6);
+    constexpr int CI = C / 2, HWI = 2 * HW, PI = HWI + 2, PBI = CI == 16 ? 32 : 2 * CI + 16, INB = ENTRY ? PI * PI * PBI : 0;      // the entry block's input image
+    constexpr int KSA = (9 * CI + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* X = smem;
-    char* Y = smem + BUF;
-    float* tab = reinterpret_cast<float*>(smem + 2 * BUF);        // [C][2]: scale, shift of the convolution in flight
+    char* IN = smem;
+    char* X = smem + INB;
+    char* Y = X + BUF;
+    float* tab = reinterpret_cast<float*>(Y + BUF);               // [C][2]: scale, shift of the convolution in flight
     float* red = tab + 2 * C;                                      // [4 waves][2][C]
     float* vals = red + 8 * C;                                     // [2][C]: this image's sums
     double* tot = reinterpret_cast<double*>(vals + 2 * C);         // [2][C]: the batch's sums
@@ -88,10 +96,18 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
     const int img = blockIdx.x;
     const unsigned base = xch_base(p.xb);
 
-    // ---- zero both buffers (the halo rings stay zero for the whole run), land the image in X
-    for (int o = tid * 16; o < 2 * BUF; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
+    // ---- zero the buffers (the halo rings stay zero for the whole run), land the input image
+    for (int o = tid * 16; o < INB + 2 * BUF; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    {
+    if constexpr (ENTRY) {
+        constexpr int CPP = CI / 8;
+        const uint4* src = reinterpret_cast<const uint4*>(p.x + (size_t)img * HWI * HWI * CI);
+        for (int i = tid; i < HWI * HWI * CPP; i += 256) {
+            const int q = i / CPP, cc = i - q * CPP;
+            const int yy = q / HWI, xx = q - yy * HWI;
+            *reinterpret_cast<uint4*>(IN + ((yy + 1) * PI + xx + 1) * PBI + cc * 16) = src[i];
+        }
+    } else {
         constexpr int CPP = C / 8;                                  // 16-byte chunks per pixel
         const uint4* src = reinterpret_cast<const uint4*>(p.x + (size_t)img * HW * HW * C);
         for (int i = tid; i < HW * HW * CPP; i += 256) {
@@ -133,46 +149,11 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
             }
         }
     };
-    auto conv = [&](int cv, const bf16x8_t (&wf)[KTW][KS]) {
-        const bool second = cv & 1;                                 // second convolution of a block: reads Y, adds the block input from X, writes X
-        const char* S = second ? Y : X;
-        char* D = second ? X : Y;
-        const StConv& cc = p.c[cv];
-        const bool tr = p.trace > 0 && cv == p.trace && img == 0;
-        st_stamp(p.xb, tr, 0);
-        // (this channel's parameters -- workgroup 0: the running statistics too -- are requested before the MFMA loop: behind the exchange they would be an L2
-        //  round trip on every workgroup's critical path, and workgroup 0's read-modify-write one on everybody's)
-        float c_gamma = 0.f, c_beta = 0.f, c_rm = 0.f, c_rv = 0.f;
-        if (tid < C) {
-            c_gamma = cc.gamma[tid]; c_beta = cc.beta[tid];
-            if (img == 0) { c_rm = cc.rm[tid]; c_rv = cc.rv[tid]; }
-        }
-        f32x4 acc[PTW][KTW];
-#pragma unroll
-        for (int t = 0; t < PTW; ++t)
-#pragma unroll
-            for (int kt = 0; kt < KTW; ++kt) acc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        constexpr int SLOTS = KS * PTW;
-        auto xread = [&](int n) {
-            const int s_ = n / PTW, t_ = n - s_ * PTW;
-            const int a = koff[s_] >= 0 ? pbase[t_] + koff[s_] : 0;
-            return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(S + a));
-        };
-        // (pixel fragments RING - 1 slots ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency)
-        constexpr int RING = 8;
-        bf16x8_t xr[RING];
-#pragma unroll
-        for (int n = 0; n < RING - 1; ++n) if (n < SLOTS) xr[n] = xread(n);
-#pragma unroll
-        for (int n = 0; n < SLOTS; ++n) {
-            const int s_ = n / PTW, t_ = n - s_ * PTW;
-            if (n + RING - 1 < SLOTS) xr[(n + RING - 1) % RING] = xread(n + RING - 1);
-#pragma unroll
-            for (int kt = 0; kt < KTW; ++kt) acc[t_][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt][s_], xr[n % RING], acc[t_][kt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    // everything behind a convolution's MFMA loop: z to global memory, the image's channel sums, the batch's sums (exchange `xi` of the launch), scale / shift, then
+    // the BatchNorm [+ block input] [+ ReLU] of the accumulators into LDS buffer D.  mode 0: first convolution of a block (ReLU); 1: second (adds what D holds -- the
+    // block input -- and writes the block output to global memory too); 2: the shortcut convolution of an entry block (no ReLU, into the block-input buffer)
+    auto finish = [&](const StConv& cc, f32x4 (&acc)[PTW][KTW], float c_gamma, float c_beta, float c_rm, float c_rv, int xi, int mode, char* D, bool tr) {
         st_stamp(p.xb, tr, 1);
-        // ---- z (bf16) to global memory for the backward; per-image channel sums of the fp32 accumulators
         unsigned zp[PTW][KTW][2];
         float sv[KTW * 8];
 #pragma unroll
@@ -212,7 +193,7 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
         __syncthreads();
         st_stamp(p.xb, tr, 2);
         // ---- the batch's sums: identical fp64 totals in every workgroup
-        const unsigned tag = base + (unsigned)cv + 1u;
+        const unsigned tag = base + (unsigned)xi + 1u;
         xch_begin(p.xb, img, p.N, 2 * C, tag, vals, scratch);
         st_stamp(p.xb, tr, 3);
         xch_end(p.xb, p.N, 2 * C, tag, tot, scratch);
@@ -238,7 +219,6 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
         }
         __syncthreads();
         st_stamp(p.xb, tr, 5);
-        // ---- BatchNorm (+ block input) + ReLU on the bf16-rounded z, into the other LDS buffer; block outputs also go to global memory with their packed mask
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) {
             const int ch = (wk * KTW + kt) * 16 + 4 * g;
@@ -252,62 +232,145 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
                 v[1] = fmaf(__uint_as_float(zp[t][kt][0] & 0xffff0000u), s01.z, s01.w);
                 v[2] = fmaf(__uint_as_float(zp[t][kt][1] << 16), s23.x, s23.y);
                 v[3] = fmaf(__uint_as_float(zp[t][kt][1] & 0xffff0000u), s23.z, s23.w);
-                if (second) {
+                if (mode == 1) {
                     const uint2 r = *reinterpret_cast<const uint2*>(D + o + ch * 2);
                     v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
                     v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
                 }
+                if (mode != 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
                 const uint2 out = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 *reinterpret_cast<uint2*>(D + o + ch * 2) = out;
-                if (cc.y != nullptr) {
-                    const size_t at = ((size_t)img * HW * HW + pixq[t]) * C + ch;
-                    *reinterpret_cast<uint2*>(cc.y + at) = out;
-                    if (cc.mask != nullptr) {
-                        unsigned nib = 0;
-                        nib |= ((out.x & 0x7fffu) != 0u && (out.x & 0x8000u) == 0u) ? 1u : 0u;
-                        nib |= ((out.x & 0x7fff0000u) != 0u && (out.x & 0x80000000u) == 0u) ? 2u : 0u;
-                        nib |= ((out.y & 0x7fffu) != 0u && (out.y & 0x8000u) == 0u) ? 4u : 0u;
-                        nib |= ((out.y & 0x7fff0000u) != 0u && (out.y & 0x80000000u) == 0u) ? 8u : 0u;
-                        const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);      // the lane with the neighbouring four channels
-                        if ((g & 1) == 0) cc.mask[at >> 3] = (unsigned char)(nib | (other << 4));
-                    }
-                }
+                if (cc.y != nullptr) *reinterpret_cast<uint2*>(cc.y + ((size_t)img * HW * HW + pixq[t]) * C + ch) = out;
             }
         }
         __syncthreads();
         st_stamp(p.xb, tr, 6);
     };
+    auto conv = [&](int cv, const bf16x8_t (&wf)[KTW][KS]) {
+        const bool second = ENTRY ? !(cv & 1) : (cv & 1);           // second convolution of a block: reads Y, adds the block input from X, writes X
+        const char* S = second ? Y : X;
+        char* D = second ? X : Y;
+        const StConv& cc = p.c[cv];
+        const bool tr = p.trace > 0 && cv == p.trace && img == 0;
+        st_stamp(p.xb, tr, 0);
+        // (this channel's parameters -- workgroup 0: the running statistics too -- are requested before the MFMA loop: behind the exchange they would be an L2
+        //  round trip on every workgroup's critical path, and workgroup 0's read-modify-write one on everybody's)
+        float c_gamma = 0.f, c_beta = 0.f, c_rm = 0.f, c_rv = 0.f;
+        if (tid < C) {
+            c_gamma = cc.gamma[tid]; c_beta = cc.beta[tid];
+            if (img == 0) { c_rm = cc.rm[tid]; c_rv = cc.rv[tid]; }
+        }
+        f32x4 acc[PTW][KTW];
+#pragma unroll
+        for (int t = 0; t < PTW; ++t)
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) acc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int SLOTS = KS * PTW;
+        auto xread = [&](int n) {
+            const int s_ = n / PTW, t_ = n - s_ * PTW;
+            const int a = koff[s_] >= 0 ? pbase[t_] + koff[s_] : 0;
+            return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(S + a));
+        };
+        // (pixel fragments RING - 1 slots ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency)
+        constexpr int RING = 8;
+        bf16x8_t xr[RING];
+#pragma unroll
+        for (int n = 0; n < RING - 1; ++n) if (n < SLOTS) xr[n] = xread(n);
+#pragma unroll
+        for (int n = 0; n < SLOTS; ++n) {
+            const int s_ = n / PTW, t_ = n - s_ * PTW;
+            if (n + RING - 1 < SLOTS) xr[(n + RING - 1) % RING] = xread(n + RING - 1);
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) acc[t_][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt][s_], xr[n % RING], acc[t_][kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        finish(cc, acc, c_gamma, c_beta, c_rm, c_rv, (ENTRY ? 2 : 0) + cv, second ? 1 : 0, D, tr);
+    };
+    // the two strided convolutions of an entry block: output pixel (y, x) reads the input at (2 y + dy - 1, 2 x + dx - 1) = padded (2 y + dy, 2 x + dx) [3x3, pad 1] or
+    // at (2 y, 2 x) = padded (2 y + 1, 2 x + 1) [1x1, pad 0]; K = tap * CI + channel
+    auto entry_conv = [&](const StConv& cc, bool shortcut, int xi, char* D) {
+        constexpr int KSE = KSA;                                    // (the 1x1 uses its first K step only)
+        float c_gamma = 0.f, c_beta = 0.f, c_rm = 0.f, c_rv = 0.f;
+        if (tid < C) {
+            c_gamma = cc.gamma[tid]; c_beta = cc.beta[tid];
+            if (img == 0) { c_rm = cc.rm[tid]; c_rv = cc.rv[tid]; }
+        }
+        const int ks = shortcut ? 1 : KSE, kmax = shortcut ? CI : 9 * CI;
+        f32x4 acc[PTW][KTW];
+#pragma unroll
+        for (int t = 0; t < PTW; ++t)
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) acc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ks; ++s) {
+            const int kk = 32 * s + 8 * g;
+            const int tap = kk / CI, c0 = kk - tap * CI;
+            const int dy = shortcut ? 1 : tap / 3, dx = shortcut ? 1 : tap - 3 * (tap / 3);
+            const bool live = kk < kmax;
+            bf16x8_t wf[KTW];
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (live) v = *reinterpret_cast<const uint4*>(cc.w + (size_t)((wk * KTW + kt) * 16 + l15) * (shortcut ? CI : 9 * CI) + kk);
+                wf[kt] = __builtin_bit_cast(bf16x8_t, v);
+            }
+            const int ko = (dy * PI + dx) * PBI + c0 * 2;
+#pragma unroll
+            for (int t = 0; t < PTW; ++t) {
+                const int q = pixq[t], yy = q / HW, xx = q - yy * HW;
+                uint4 xv = make_uint4(0u, 0u, 0u, 0u);
+                if (live) xv = *reinterpret_cast<const uint4*>(IN + (2 * yy * PI + 2 * xx) * PBI + ko);
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt], __builtin_bit_cast(bf16x8_t, xv), acc[t][kt], 0, 0, 0);
+            }
+        }
+        finish(cc, acc, c_gamma, c_beta, c_rm, c_rv, xi, shortcut ? 2 : 0, D, false);
+    };
     bf16x8_t wa[KTW][KS], wb[KTW][KS];
-    load_filters(0, wa);
-    for (int cv = 0; cv < p.nconv; cv += 2) {                       // (nconv is even: pairs of convolutions = BasicBlocks)
-        load_filters(cv + 1, wb);
-        conv(cv, wa);
-        if (cv + 2 < p.nconv) load_filters(cv + 2, wa);
-        conv(cv + 1, wb);
+    if constexpr (ENTRY) {
+        load_filters(0, wa);
+        entry_conv(p.ea, false, 0, Y);                              // conv -> BN -> ReLU into Y
+        entry_conv(p.ed, true, 1, X);                               // shortcut conv -> BN into X: the "block input" the second convolution adds
+        conv(0, wa);
+        for (int cv = 1; cv + 1 < p.nconv; cv += 2) {               // (nconv is odd: the entry block's second convolution, then pairs)
+            load_filters(cv, wb);
+            load_filters(cv + 1, wa);
+            conv(cv, wb);
+            conv(cv + 1, wa);
+        }
+        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv + 2u);
+    } else {
+        load_filters(0, wa);
+        for (int cv = 0; cv < p.nconv; cv += 2) {                   // (nconv is even: pairs of convolutions = BasicBlocks)
+            load_filters(cv + 1, wb);
+            conv(cv, wa);
+            if (cv + 2 < p.nconv) load_filters(cv + 2, wa);
+            conv(cv + 1, wb);
+        }
+        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
     }
-    if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
 }
 
-template <int C, int HW>
+template <int C, int HW, bool ENTRY>
 int launch_fwd(const StFwdParams& p, hipStream_t st) {
-    constexpr int lds = StGeo<C, HW>::LDS_FWD;
+    constexpr int CI = C / 2, PI = 2 * HW + 2, PBI = CI == 16 ? 32 : 2 * CI + 16;
+    constexpr int lds = StGeo<C, HW>::LDS_FWD + (ENTRY ? PI * PI * PBI : 0);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr[16] = {};
     if (dev < 0 || dev >= 16 || !attr[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stage_train_fwd_kernel<C, HW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stage_train_fwd_kernel<C, HW, ENTRY>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             clhip_set_error("stage_train_fwd: cannot reserve %d bytes of LDS", lds);
             return CLHIP_EHIP;
         }
         if (dev >= 0 && dev < 16) attr[dev] = true;
     }
-    hipLaunchKernelGGL((stage_train_fwd_kernel<C, HW>), dim3(p.N), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((stage_train_fwd_kernel<C, HW, ENTRY>), dim3(p.N), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
-
 
 // =============================================================================================== backward
 // One workgroup per image again.  Per unit cv (last to first), with `acc` = the gradient of the unit's output in registers (the MFMA result layout: lane (l15, g) holds
@@ -1062,24 +1125,34 @@ static bool stage_train_group(int N, int C) { return C == 64 && N >= 128; }
 int clhip_stage_train_slab_blocks(int N, int C) { const int ipg = (C / 16) * (C / 16); return stage_train_group(N, C) ? (N + ipg - 1) / ipg : N; }
 
 // One entry per convolution of the run (C ABI of the plan: plain arrays of pointers).  x: the run's input activation [N][H][W][C] bf16.
+// entry != 0: the launch starts with the stage's down-sampling block -- the arrays then hold nconv + 2 entries, [0] = that block's 3x3 / stride-2 convolution,
+// [1] = its 1x1 / stride-2 shortcut convolution (w: [C][9][C / 2] and [C][1][C / 2]), [2] = its second convolution, [3 ...] = the blocks behind it (nconv odd), and x
+// is the block's input [N][2 H][2 W][C / 2].
 int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
                                  float* const* rm, float* const* rv, float* const* mean, float* const* invstd, float* const* coef, void* const* z, void* const* y,
-                                 void* const* mask, float momentum, float eps, void* xch, int trace, int dtype, hipStream_t st) {
-    if (!clhip_stage_train_supported(N, H, W, C, nconv, dtype) || xch == nullptr) { clhip_set_error("stage_train_fwd: unsupported geometry"); return CLHIP_EINVAL; }
+                                 void* const* mask, float momentum, float eps, void* xch, int trace, int entry, int dtype, hipStream_t st) {
+    const bool ok = entry ? (clhip_stage_train_supported(N, H, W, C, nconv + 1, dtype) && (nconv & 1) && C >= 32) : clhip_stage_train_supported(N, H, W, C, nconv, dtype);
+    if (!ok || xch == nullptr) { clhip_set_error("stage_train_fwd: unsupported geometry"); return CLHIP_EINVAL; }
     StFwdParams p;
     p.x = static_cast<const bf16_t*>(x); p.N = N; p.nconv = nconv; p.eps = eps; p.momentum = momentum; p.trace = trace;
     const double M = (double)N * H * W;
     p.invM = 1.0 / M; p.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
     p.xb = xch_carve(xch, N, 128);
-    for (int i = 0; i < nconv; ++i) {
-        StConv& c = p.c[i];
+    auto fill = [&](StConv& c, int i) {
         c.w = static_cast<const bf16_t*>(w[i]); c.wd = nullptr; c.gamma = gamma[i]; c.beta = beta[i]; c.rm = rm[i]; c.rv = rv[i];
         c.mean = mean[i]; c.invstd = invstd[i]; c.coef = coef[i]; c.z = static_cast<bf16_t*>(z[i]);
         c.y = static_cast<bf16_t*>(y[i]); c.mask = static_cast<unsigned char*>(mask[i]);
+    };
+    const int o = entry ? 2 : 0;
+    if (entry) { fill(p.ea, 0); fill(p.ed, 1); }
+    for (int i = 0; i < nconv; ++i) fill(p.c[i], o + i);
+    if (entry) {
+        if (C == 32) return launch_fwd<32, 16, true>(p, st);
+        return launch_fwd<64, 8, true>(p, st);
     }
-    if (C == 16) return launch_fwd<16, 32>(p, st);
-    if (C == 32) return launch_fwd<32, 16>(p, st);
-    return launch_fwd<64, 8>(p, st);
+    if (C == 16) return launch_fwd<16, 32, false>(p, st);
+    if (C == 32) return launch_fwd<32, 16, false>(p, st);
+    return launch_fwd<64, 8, false>(p, st);
 }
 
 // The backward of the same run.  dy: gradient of the run's output activation, dx: gradient of its input activation (accumulated into when dx_accumulate), slab[i]:

@@ -162,3 +162,22 @@ def test_vit_methods_train_end_to_end(method, dtype):
     if method == "InfLoRA_OPT":
         assert len(tr.model.feature_list) == 2 and all(a.apply_lora is False for a in tr.model.attention_modules)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("method,extra", [
+    ("EWC", {}),
+    ("ICarl", {"buffer": {"name": "LinearHerdingBuffer", "kwargs": {"buffer_size": 60, "batch_size": 32}}}),
+])
+def test_the_trainers_own_batch_32_epochs_replay_from_a_graph(method, extra, recwarn):
+    """the step bench.py replays at batch 32 is what the Trainer itself runs -- its EWC and iCaRL epochs at 32 images per step
+    (CifarResNet-32, bf16, fused SGD) are captured and replayed, task >= 1 included (penalty term / frozen teacher on its side stream), with no
+    "could not be captured" warning; the aborted captures of tests/test_trainer_trace_gpu.py come from that test's host-reading observe() wrapper"""
+    tr = Trainer(0, cfg_for(method, "cifar_resnet32", "bf16", batch_size=32, epoch=3, init_epoch=3, task_num=2, **extra), log=lambda *a, **k: None)
+    out = tr.train_loop()
+    assert np.isfinite(out["acc_table"]).all()
+    gs = getattr(tr.model, "_graphed_step", None)
+    assert gs is not None and not gs.disabled, "the Trainer's step loop never built a GraphedStep / gave the capture up"
+    assert len(gs.graphs) >= 1 and (any(g is not None for g in gs.graphs.values()) or "eager" in gs.choice.values())
+    bad = [str(w.message) for w in recwarn.list if "could not be captured" in str(w.message)]
+    assert not bad, bad
+    torch.cuda.synchronize()
