@@ -48,7 +48,7 @@ int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int 
                                  void* const* mask, float momentum, float eps, void* xch, int trace, int entry, int dtype, hipStream_t st);
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
-                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int dtype, hipStream_t st);
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int entry, int dtype, hipStream_t st);
 int clhip_stage_train_slab_blocks(int N, int C);
 int clhip_stage_train_trace(void* xch, unsigned long long* out24);
 int clhip_stage_train_status(void* xch);
@@ -573,6 +573,14 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
                 q.run_first = i;
                 q.st_slab = off2;
                 off2 = align_up(off2 + (size_t)N * q.d.cout * 9 * q.cin_pad * sizeof(float));
+            }
+        }
+        for (int f = 0; f < n_units; ++f) {                          // ... and of the down-sampling block a launch can take along (one block per image each)
+            if (p->units[f].entry_first < 0) continue;
+            for (int k = 0; k < 3; ++k) {                           // (3x3 / s2, shortcut, and the block's second convolution)
+                Unit& q = p->units[p->units[f].entry_first + k];
+                q.st_slab = off2;
+                off2 = align_up(off2 + (size_t)N * q.d.cout * q.d.ksize * q.d.ksize * q.cin_pad * sizeof(float));
             }
         }
         p->ws_bytes = off2;
@@ -1249,6 +1257,35 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
             const Unit& uf = p->units[f];
             if (i == f + uf.stage_len - 1 && f >= unit_lo) {
                 const int len = uf.stage_len;
+                static const bool entry_off = clhip_cfg("STAGE_ENTRY") != nullptr && atoi(clhip_cfg("STAGE_ENTRY")) == 0;
+                const bool entry_bwd_off = clhip_cfg("STAGE_ENTRY_BWD") != nullptr && atoi(clhip_cfg("STAGE_ENTRY_BWD")) == 0;
+                const int entry_sel = clhip_cfg("STAGE_ENTRY_BWD") != nullptr ? atoi(clhip_cfg("STAGE_ENTRY_BWD")) : 1;      // (2 / 3: only the 32- / 64-channel stage: debugging)
+                if (!entry_off && !entry_bwd_off && uf.entry_first >= 0 && uf.entry_first >= unit_lo && (entry_sel == 1 || (entry_sel == 2 && uf.d.cout == 32) || (entry_sel == 3 && uf.d.cout == 64))) {
+                    // the launch takes the stage's down-sampling block along: units e (3x3 / s2), e + 1 (shortcut), e + 2 (second convolution), then the run
+                    const int e0 = uf.entry_first, n = len + 3;
+                    const Unit& ua = p->units[e0];
+                    const void* wdv[20]; const float *gv[20], *bv[20], *mev[20], *isv[20]; const void *zv[20], *yv[20]; float *dgv[20], *dbv[20], *slv[20]; void* dzv[20];
+                    for (int q = 0; q < n; ++q) {
+                        const Unit& uq = p->units[e0 + q];
+                        wdv[q] = sh + uq.sh_dg; gv[q] = params + uq.d.gamma_off; bv[q] = params + uq.d.beta_off; mev[q] = fr + uq.f_mean; isv[q] = fr + uq.f_invstd;
+                        zv[q] = ws + uq.z_off; yv[q] = (q == 2 || (q >= 3 && ((q - 3) & 1))) ? ws + p->acts[e0 + q + 1].y_off : nullptr;
+                        dgv[q] = grads + uq.d.gamma_off; dbv[q] = grads + uq.d.beta_off; slv[q] = reinterpret_cast<float*>(ws + uq.st_slab);
+                        dzv[q] = ws + p->acts[e0 + q + 1].dy_off;
+                    }
+                    if (p->br_act >= 0) join_branch();
+                    TRY(stage_train_serialize(p, main_s));
+                    TRY(clhip_stage_train_bwd_launch(ws + p->acts[ua.d.src].y_off, ws + p->acts[f + len].dy_off, ws + p->acts[ua.d.src].dy_off, p->units[e0 + 1].dx_acc, p->N, uf.H,
+                                                     uf.W, uf.d.cout, len + 1, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), 1, p->dtype, main_s));
+                    ++p->st_bwd_launches;
+                    for (int q = n - 1; q >= 0; --q) {
+                        const Unit& uq = p->units[e0 + q];
+                        const int blocks = q < 2 ? p->N : clhip_stage_train_slab_blocks(p->N, uq.d.cout);
+                        TRY(clhip_wgrad_reduce_launch(reinterpret_cast<const float*>(ws + uq.st_slab), grads + uq.d.w_off, (int64_t)uq.d.cout * uq.d.ksize * uq.d.ksize * uq.cin_pad / 4,
+                                                      blocks, main_s));
+                    }
+                    i = e0;
+                    continue;
+                }
                 const void* wdv[16]; const float *gv[16], *bv[16], *mev[16], *isv[16]; const void *zv[16], *yv[16]; float *dgv[16], *dbv[16], *slv[16]; void* dzv[16];
                 for (int q = 0; q < len; ++q) {
                     const Unit& uq = p->units[f + q];
@@ -1260,7 +1297,7 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                 if (p->br_act >= 0) join_branch();
                 TRY(stage_train_serialize(p, main_s));
                 TRY(clhip_stage_train_bwd_launch(ws + p->acts[uf.d.src].y_off, ws + p->acts[f + len].dy_off, ws + p->acts[uf.d.src].dy_off, p->units[f + 1].dres_acc, p->N, uf.H,
-                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), p->dtype, main_s));
+                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), 0, p->dtype, main_s));
                 ++p->st_bwd_launches;
                 for (int q = len - 1; q >= 0; --q) {
                     const Unit& uq = p->units[f + q];

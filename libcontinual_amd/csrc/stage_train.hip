@@ -405,6 +405,8 @@ struct StBwdParams {
     double invM;
     int trace;
     XchBuf xb;
+    StConvB ea, ed;           // (entry block) its 3x3 / stride-2 convolution and its shortcut convolution: wd = [C / 2][9][C] / [C / 2][1][C], slab = [N][C][9][C / 2] / [N][C][C / 2];
+                              // x is then the block's INPUT [N][2 HW][2 HW][C / 2] and dx its gradient
     StConvB c[kMaxConvT];
 };
 
@@ -419,6 +421,13 @@ struct StGrp {
     static constexpr int IMG = XS + ZS;
     static constexpr int KPI = HW * HW / 32;                         // K steps (32 pixels) per image: 8 / 2
     static constexpr int BYTES = IPG * IMG + 2 * 5 * 64 * 16;        // staging + the K halves' hand-over
+};
+
+template <int C, int HW>
+struct StEnt {                                                     // the input image of an entry block and the shortcut's dz, behind everything else in LDS
+    static constexpr int CI = C / 2, HWI = 2 * HW, PI = HWI + 2, PBI = CI == 16 ? 32 : 2 * CI + 16;
+    static constexpr int INB = PI * PI * PBI;
+    static constexpr int BYTES = INB + StGeo<C, HW>::BUF;
 };
 
 template <int C, int HW, bool GRP>
@@ -681,10 +690,181 @@ __device__ __forceinline__ void st_grp_run(const StGrpRegs<C, HW>& r, char* stg,
     __syncthreads();
 }
 
-template <int C, int HW, bool GRP>
+// ---- the backward of an entry block's two strided convolutions (ENTRY), everything from this workgroup's LDS: D / Dds = dz of the 3x3 / stride-2 convolution and of
+// the 1x1 / stride-2 shortcut (HW x HW x C, zero-haloed), IN = the block's input image (2 HW x 2 HW x C / 2, zero-haloed).
+// Weight gradients: dw[k][tap][ci] = sum over output pixels (y, x) of dz[y][x][k] * in[2 y + dy - 1][2 x + dx - 1][ci]  (padded coordinates (2 y + dy, 2 x + dx)); the
+// shortcut's single tap reads in[2 y][2 x].  Transposing reads as in the other weight gradients; a lane's four-pixel stride in the input image is eight pixels.
+template <int C, int HW>
+__device__ __forceinline__ void st_wgrad_entry(const char* D, const char* Dds, const char* IN, float* slab_a, float* slab_d) {
+    using G = StGeo<C, HW>;
+    using E = StEnt<C, HW>;
+    constexpr int P = G::P, PB = G::PB, CI = E::CI, PI = E::PI, PBI = E::PBI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int seg = (fr & 3) * 8;
+    if constexpr (C == 32) {
+        // K step = two output rows of 16 pixels; wave = (output-channel tile, tap half); one input-channel tile
+        const int ot = wave & 1, th = wave >> 1, t0 = th * 5, nt = th == 0 ? 5 : 4;
+        const int prow = fg >> 1, pcol = (fg & 1) * 8 + (fr >> 2);
+        f32x4 acc[5], accd = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int h0 = 0; h0 < HW; h0 += 2) {
+            const int pd = ((h0 + prow + 1) * P + pcol + 1) * PB + ot * 32 + seg;
+            const int pi = (2 * (h0 + prow) * PI + 2 * pcol) * PBI + seg;
+            const uint4 zf = st_tr8(D, pd, 4 * PB);
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (q < nt) {
+                    const int t = t0 + q, dy = t / 3, dx = t - 3 * dy;
+                    const uint4 xf = st_tr8(IN, pi + (dy * PI + dx) * PBI, 8 * PBI);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[q], 0, 0, 0);
+                }
+            if (th == 0) {                                          // (the shortcut's weight gradient rides on the tap-half-0 waves)
+                const uint4 zd = st_tr8(Dds, pd, 4 * PB);
+                const uint4 xf = st_tr8(IN, pi + (PI + 1) * PBI, 8 * PBI);
+                accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zd), __builtin_bit_cast(bf16x8_t, xf), accd, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (q < nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slab_a[((ot * 16 + fg * 4 + e) * 9 + t0 + q) * CI + fr] = acc[q][e];
+        if (th == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab_d[(ot * 16 + fg * 4 + e) * CI + fr] = accd[e];
+        }
+    } else {
+        // K step = four output rows of 8 pixels (two per image); wave = output-channel tile, both input-channel tiles, nine taps + the shortcut's
+        const int ot = wave, prow = fg, pcol = fr >> 2;
+        f32x4 acc[2][9], accd[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int h0 = 0; h0 < HW; h0 += 4) {
+            const int pd = ((h0 + prow + 1) * P + pcol + 1) * PB + ot * 32 + seg;
+            const int pi = (2 * (h0 + prow) * PI + 2 * pcol) * PBI + seg;
+            const uint4 zf = st_tr8(D, pd, 4 * PB), zd = st_tr8(Dds, pd, 4 * PB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3, dx = t - 3 * dy;
+                    const uint4 xf = st_tr8(IN, pi + (dy * PI + dx) * PBI + i * 32, 8 * PBI);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf), __builtin_bit_cast(bf16x8_t, xf), acc[i][t], 0, 0, 0);
+                    if (t == 4) accd[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zd), __builtin_bit_cast(bf16x8_t, xf), accd[i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slab_a[((ot * 16 + fg * 4 + e) * 9 + t) * CI + i * 16 + fr] = acc[i][t][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab_d[(ot * 16 + fg * 4 + e) * CI + i * 16 + fr] = accd[i][e];
+        }
+    }
+}
+
+// Input gradient of the entry block: in[i][j] receives, from the 3x3 / stride-2 convolution, the taps (dy, dx) with i + 1 - dy and j + 1 - dx even,
+//     dz[(i + 1 - dy) / 2][(j + 1 - dx) / 2] . w[dy][dx],
+// and at even (i, j) the shortcut's dz_ds[i / 2][j / 2] . w_ds.  Sorted by the parity of (i, j) that is four small convolutions over the HW x HW grids of D / Dds (1 + 1,
+// 2, 2 and 4 taps -- a zero-stuffed 3x3 would run 9 taps on four times the pixels), each writing one pixel of every 2 x 2 cell of dx.  wa = [C / 2][9][C], wd = [C / 2][C].
+template <int C, int HW>
+__device__ __forceinline__ void st_dgrad_entry(const char* D, const char* Dds, const bf16_t* wa, const bf16_t* wd, bf16_t* dx_img, int dx_acc) {
+    using G = StGeo<C, HW>;
+    using E = StEnt<C, HW>;
+    constexpr int P = G::P, PB = G::PB, CI = E::CI, HWI = E::HWI;
+    constexpr int KTC = CI / 16;                                    // output (input-channel) tiles: 1 / 2
+    constexpr int PTC = (HW * HW / 16) / 4;                         // pixel tiles per wave: 4 / 1
+    constexpr int KSC = C / 32;                                     // K steps per tap: 1 / 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        const int pi = cls >> 1, pj = cls & 1;
+        f32x4 acc[PTC][KTC];
+#pragma unroll
+        for (int t = 0; t < PTC; ++t)
+#pragma unroll
+            for (int kt = 0; kt < KTC; ++kt) acc[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // taps of this class: dy in {1} (pi = 0) or {0, 2} (pi = 1), likewise dx; source pixel offset (pi + 1 - dy) / 2
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (pi == 0 && a == 1) continue;
+            const int dy = pi == 0 ? 1 : 2 * a, oy = (pi + 1 - dy) / 2;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (pj == 0 && b == 1) continue;
+                const int dx = pj == 0 ? 1 : 2 * b, ox = (pj + 1 - dx) / 2;
+                const int tap = dy * 3 + dx;
+#pragma unroll
+                for (int s = 0; s < KSC; ++s) {
+                    const int kk = 32 * s + 8 * g;
+                    bf16x8_t wf[KTC];
+#pragma unroll
+                    for (int kt = 0; kt < KTC; ++kt) wf[kt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wa + ((size_t)(kt * 16 + l15) * 9 + tap) * C + kk));
+#pragma unroll
+                    for (int t = 0; t < PTC; ++t) {
+                        const int q = (wave * PTC + t) * 16 + l15, yy = q / HW, xx = q - yy * HW;
+                        const uint4 xv = *reinterpret_cast<const uint4*>(D + ((yy + oy + 1) * P + xx + ox + 1) * PB + kk * 2);
+#pragma unroll
+                        for (int kt = 0; kt < KTC; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt], __builtin_bit_cast(bf16x8_t, xv), acc[t][kt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (cls == 0) {                                             // the shortcut's input gradient lands on the even pixels
+#pragma unroll
+            for (int s = 0; s < KSC; ++s) {
+                const int kk = 32 * s + 8 * g;
+                bf16x8_t wf[KTC];
+#pragma unroll
+                for (int kt = 0; kt < KTC; ++kt) wf[kt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wd + (size_t)(kt * 16 + l15) * C + kk));
+#pragma unroll
+                for (int t = 0; t < PTC; ++t) {
+                    const int q = (wave * PTC + t) * 16 + l15, yy = q / HW, xx = q - yy * HW;
+                    const uint4 xv = *reinterpret_cast<const uint4*>(Dds + ((yy + 1) * P + xx + 1) * PB + kk * 2);
+#pragma unroll
+                    for (int kt = 0; kt < KTC; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kt], __builtin_bit_cast(bf16x8_t, xv), acc[t][kt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PTC; ++t) {
+            const int q = (wave * PTC + t) * 16 + l15, yy = q / HW, xx = q - yy * HW;
+#pragma unroll
+            for (int kt = 0; kt < KTC; ++kt) {
+                bf16_t* o = dx_img + ((size_t)(2 * yy + pi) * HWI + 2 * xx + pj) * CI + kt * 16 + 4 * g;
+                float v0 = acc[t][kt][0], v1 = acc[t][kt][1], v2 = acc[t][kt][2], v3 = acc[t][kt][3];
+                if (dx_acc) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(o);
+                    v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+                    v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+                }
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+        }
+    }
+}
+
+// ENTRY: p.c[] = [second convolution of the stage's down-sampling block, first / second convolutions of the blocks behind it ...] (nconv odd), and behind unit 0 the
+// launch runs that block's 3x3 / stride-2 convolution (p.ea) and shortcut (p.ed) as well: BatchNorm backward of both (two more exchanges, the pending weight gradients in
+// their shadow), the input gradient by pixel parity (st_dgrad_entry) and the two strided weight gradients (st_wgrad_entry).
+template <int C, int HW, bool GRP, bool ENTRY>
 __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams p) {
     using G = StGeo<C, HW>;
     using GB = StGeoB<C, HW, GRP>;
+    constexpr int LDS_ALL = GB::LDS + (ENTRY ? StEnt<C, HW>::BYTES : 0);
+    auto is_second = [](int cv) { return ENTRY ? !(cv & 1) : (cv & 1) != 0; };      // second convolution of a block (block output, residual add)
     constexpr int P = G::P, PB = G::PB, BUF = G::BUF, PTW = G::PTW, KTW = G::KTW, KS = G::KS, WK = G::WK;
     constexpr int LOGC = C == 16 ? 4 : (C == 32 ? 5 : 6);
     constexpr int CPP = C / 8;
@@ -707,8 +887,10 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     const unsigned base = xch_base(p.xb);
     const size_t ibase = (size_t)img * HW * HW;
 
-    for (int o = tid * 16; o < GB::LDS; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
+    for (int o = tid * 16; o < LDS_ALL; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
+    // the convolution whose output feeds unit cv (its z is the lazy input of a block's second convolution; its y the input of a block's first one)
+    auto prevc = [&](int cv) -> const StConvB& { return (ENTRY && cv == 0) ? p.ea : p.c[cv > 0 ? cv - 1 : 0]; };
 
     // the group weight gradient of unit u (32 / 64 channels): this workgroup's work items -- (out tile, in tile) pair x group of images -- from global memory.  The first
     // item's operands are REQUESTED (grp_issue) a stage before they are used (grp_finish): a batch of sixteen 16-byte loads per thread, a quarter of them write-through
@@ -719,11 +901,11 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     auto grp_issue = [&](int u, int item) __attribute__((always_inline)) {
         if constexpr (GRP) {
             using Q = StGrp<C, HW>;
-            const bool lazy = u & 1;
-            const bf16_t* xsrc = lazy ? p.c[u - 1].z : (u == 0 ? p.x : p.c[u - 1].y);
+            const bool lazy = is_second(u);
+            const bf16_t* xsrc = lazy ? prevc(u).z : (u == 0 ? p.x : p.c[u - 1].y);
             const __amdgpu_buffer_rsrc_t dzrs = __builtin_amdgcn_make_buffer_rsrc(p.c[u].dzg, 0, p.N * HW * HW * C * 2, 0x00020000);
             if (lazy) {
-                const StConvB& a = p.c[u - 1];
+                const StConvB& a = prevc(u);
                 const int c0 = ((item % Q::IPG) % (C / 16)) * 16 + (tid & 1) * 8;
                 grp_raw[0] = *reinterpret_cast<const float4*>(a.gamma + c0); grp_raw[1] = *reinterpret_cast<const float4*>(a.gamma + c0 + 4);
                 grp_raw[2] = *reinterpret_cast<const float4*>(a.invstd + c0); grp_raw[3] = *reinterpret_cast<const float4*>(a.invstd + c0 + 4);
@@ -748,7 +930,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { coef[e] = ga[e] * is[e]; coef[8 + e] = be[e] - mu[e] * coef[e]; }
                 }
-                st_grp_run<C, HW>(grp_regs, stg, reinterpret_cast<float*>(stg + Q::IPG * Q::IMG), coef, (u & 1) != 0, item, p.c[u].slab, p.xb, tr);
+                st_grp_run<C, HW>(grp_regs, stg, reinterpret_cast<float*>(stg + Q::IPG * Q::IMG), coef, is_second(u), item, p.c[u].slab, p.xb, tr);
             }
         }
     };
@@ -761,6 +943,33 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     unsigned zq[PTW][KTW][2], yq[PTW][KTW][2];
     float4 mu4[KTW], is4[KTW], ga4[KTW], be4[KTW];
     float c_gamma = 0.f, c_invstd = 0.f, c_dg = 0.f, c_db = 0.f;    // thread c < C: its channel's parameters; workgroup 0: the old dgamma / dbeta
+    float4 md4[KTW], id4[KTW];                                      // (ENTRY) the shortcut BatchNorm's saved statistics at this lane's channels
+    float d_gamma = 0.f, d_invstd = 0.f, d_dg = 0.f, d_db = 0.f;
+    // (ENTRY) behind unit 0: z of the block's 3x3 / stride-2 convolution into zq, z of its shortcut into yq, the statistics of both
+    auto prefetch_entry = [&](int l15) __attribute__((always_inline)) {
+        if constexpr (ENTRY) {
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+                const int ch = (wk * KTW + kt) * 16 + 4 * g;
+                mu4[kt] = *reinterpret_cast<const float4*>(p.ea.mean + ch);
+                is4[kt] = *reinterpret_cast<const float4*>(p.ea.invstd + ch);
+                ga4[kt] = *reinterpret_cast<const float4*>(p.ea.gamma + ch);
+                be4[kt] = *reinterpret_cast<const float4*>(p.ea.beta + ch);
+                md4[kt] = *reinterpret_cast<const float4*>(p.ed.mean + ch);
+                id4[kt] = *reinterpret_cast<const float4*>(p.ed.invstd + ch);
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) {
+                    const size_t at = (ibase + (wp * PTW + t) * 16 + l15) * C + ch;
+                    const uint2 za = *reinterpret_cast<const uint2*>(p.ea.z + at), zd = *reinterpret_cast<const uint2*>(p.ed.z + at);
+                    zq[t][kt][0] = za.x; zq[t][kt][1] = za.y; yq[t][kt][0] = zd.x; yq[t][kt][1] = zd.y;
+                }
+            }
+            if (tid < C) {
+                c_gamma = p.ea.gamma[tid]; c_invstd = p.ea.invstd[tid]; d_gamma = p.ed.gamma[tid]; d_invstd = p.ed.invstd[tid];
+                if (img == 0) { c_dg = p.ea.dgamma[tid]; c_db = p.ea.dbeta[tid]; d_dg = p.ed.dgamma[tid]; d_db = p.ed.dbeta[tid]; }
+            }
+        }
+    };
 
     auto prefetch = [&](int cv, int l15) __attribute__((always_inline)) {
         const StConvB& cc = p.c[cv];
@@ -776,7 +985,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
                 const size_t at = (ibase + (wp * PTW + t) * 16 + l15) * C + ch;
                 const uint2 zz = *reinterpret_cast<const uint2*>(cc.z + at);
                 zq[t][kt][0] = zz.x; zq[t][kt][1] = zz.y;
-                if (cv & 1) { const uint2 yy = *reinterpret_cast<const uint2*>(cc.y + at); yq[t][kt][0] = yy.x; yq[t][kt][1] = yy.y; }
+                if (is_second(cv)) { const uint2 yy = *reinterpret_cast<const uint2*>(cc.y + at); yq[t][kt][0] = yy.x; yq[t][kt][1] = yy.y; }
             }
         }
         if (tid < C) {
@@ -786,7 +995,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     };
 
     auto unit = [&](int cv) __attribute__((always_inline)) {
-        const bool second = cv & 1;
+        const bool second = is_second(cv);
         const StConvB& cc = p.c[cv];
         const bool tr = p.trace > 0 && cv == p.trace && img == 0;
         st_stamp(p.xb, tr, 8);
@@ -878,12 +1087,12 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             uint4 xin[NCH];
             float xsc[8], xsh[8];
             {
-                const bf16_t* src = second ? p.c[cv - 1].z : (cv == 0 ? p.x : p.c[cv - 1].y);
+                const bf16_t* src = second ? prevc(cv).z : (cv == 0 ? p.x : p.c[cv - 1].y);
                 const uint4* s4 = reinterpret_cast<const uint4*>(src + ibase * C);
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) xin[k] = s4[tid + k * 256];
                 if (second) {
-                    const StConvB& a = p.c[cv - 1];
+                    const StConvB& a = prevc(cv);
                     const int c0 = (tid & (CPP - 1)) * 8;
                     const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gamma + c0 + 4);
                     const float4 i0 = *reinterpret_cast<const float4*>(a.invstd + c0), i1 = *reinterpret_cast<const float4*>(a.invstd + c0 + 4);
@@ -970,6 +1179,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         st_stamp(p.xb, tr, 15);
         // ---- E: the gradient of this unit's input; the operands of the unit below are requested first
         if (cv > 0) prefetch(cv - 1, l15);
+        else prefetch_entry(l15);
         int koff[KS];                                               // mirrored taps: filter tap (r, s) reads the gradient at (y + 1 - r, x + 1 - s) = padded (y + 2 - r, x + 2 - s)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -1034,63 +1244,204 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         }
     }
 #pragma unroll 1
-    for (int cv = p.nconv - 1; cv > 0; cv -= 2) {                  // (nconv is even: odd positions = second convolution of a block)
+    for (int cv = p.nconv - 1; cv > 0; cv -= 2) {                  // (pairs from the top; ENTRY: nconv is odd and unit 0 -- the entry block's second convolution -- is left)
         unit(cv);
         unit(cv - 1);
     }
-    // ---- the gradient of the run's input
-    {
-        const int l15 = lane & 15;
+    if constexpr (ENTRY) {
+        unit(0);
+        // ================= the entry block's two strided convolutions (acc = gradient of the 3x3 / stride-2 convolution's activation, gres = gradient of the
+        // shortcut's BatchNorm output -- what went around the block -- zq / yq = their z)
+        using E = StEnt<C, HW>;
+        constexpr int CI = E::CI, HWI = E::HWI, PI = E::PI, PBI = E::PBI;
+        char* INB = smem + GB::LDS;
+        char* Dds = INB + E::INB;
+        float* vals2 = ctab + 5 * C;                                // the shortcut's sums (ctab uses [0, 5 C) of its 8 C floats)
+        int l15 = lane & 15;
+        asm volatile("" : "+v"(l15));
+        int pbase[PTW];
+#pragma unroll
+        for (int t = 0; t < PTW; ++t) {
+            const int q = (wp * PTW + t) * 16 + l15;
+            const int yy = q / HW, xx = q - yy * HW;
+            pbase[t] = (yy * P + xx) * PB;
+        }
+        unsigned gqa[PTW][KTW][2];
+        float sva[KTW * 8], svd[KTW * 8];
+#pragma unroll
+        for (int q = 0; q < KTW * 8; ++q) { sva[q] = 0.f; svd[q] = 0.f; }
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) {
-            const int ch = (wk * KTW + kt) * 16 + 4 * g;
+            const float mu[4] = {mu4[kt].x, mu4[kt].y, mu4[kt].z, mu4[kt].w}, is[4] = {is4[kt].x, is4[kt].y, is4[kt].z, is4[kt].w};
+            const float mud[4] = {md4[kt].x, md4[kt].y, md4[kt].z, md4[kt].w}, isd[4] = {id4[kt].x, id4[kt].y, id4[kt].z, id4[kt].w};
+            float sc[4], sh[4];
+            {
+                const float ga[4] = {ga4[kt].x, ga4[kt].y, ga4[kt].z, ga4[kt].w}, be[4] = {be4[kt].x, be4[kt].y, be4[kt].z, be4[kt].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[e] = ga[e] * is[e]; sh[e] = be[e] - mu[e] * sc[e]; }
+            }
 #pragma unroll
             for (int t = 0; t < PTW; ++t) {
-                bf16_t* o = p.dx + (ibase + (wp * PTW + t) * 16 + l15) * C + ch;
-                float v0 = acc[t][kt][0], v1 = acc[t][kt][1], v2 = acc[t][kt][2], v3 = acc[t][kt][3];
-                if (p.dx_acc) {
-                    const uint2 old = *reinterpret_cast<const uint2*>(o);
-                    v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
-                    v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+                const unsigned z0 = zq[t][kt][0], z1 = zq[t][kt][1], y0 = yq[t][kt][0], y1 = yq[t][kt][1];
+                const float zf[4] = {__uint_as_float(z0 << 16), __uint_as_float(z0 & 0xffff0000u), __uint_as_float(z1 << 16), __uint_as_float(z1 & 0xffff0000u)};
+                const float zd[4] = {__uint_as_float(y0 << 16), __uint_as_float(y0 & 0xffff0000u), __uint_as_float(y1 << 16), __uint_as_float(y1 & 0xffff0000u)};
+                const unsigned d0 = pack_bf16x2(acc[t][kt][0], acc[t][kt][1]), d1 = pack_bf16x2(acc[t][kt][2], acc[t][kt][3]);
+                float gg[4] = {__uint_as_float(d0 << 16), __uint_as_float(d0 & 0xffff0000u), __uint_as_float(d1 << 16), __uint_as_float(d1 & 0xffff0000u)};
+                const float gd[4] = {__uint_as_float(gres[t][kt][0] << 16), __uint_as_float(gres[t][kt][0] & 0xffff0000u), __uint_as_float(gres[t][kt][1] << 16),
+                                     __uint_as_float(gres[t][kt][1] & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gg[e] = fmaf(zf[e], sc[e], sh[e]) > 0.f ? gg[e] : 0.f;
+                    sva[kt * 8 + e] += gg[e];
+                    sva[kt * 8 + 4 + e] = fmaf(gg[e], (zf[e] - mu[e]) * is[e], sva[kt * 8 + 4 + e]);
+                    svd[kt * 8 + e] += gd[e];                      // (no ReLU behind the shortcut's BatchNorm: its gradient is what the block's last BatchNorm backward left)
+                    svd[kt * 8 + 4 + e] = fmaf(gd[e], (zd[e] - mud[e]) * isd[e], svd[kt * 8 + 4 + e]);
                 }
-                *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                gqa[t][kt][0] = pack_bf16x2(gg[0], gg[1]); gqa[t][kt][1] = pack_bf16x2(gg[2], gg[3]);
             }
         }
-    }
-    // ---- the weight gradients still owed
-    if constexpr (!GRP) {
-        if constexpr (C == 16) st_wgrad16<HW>(D, XA, wred, p.c[0].slab + (size_t)img * (9 * C * C));
-        else st_wgrad_wide<C, HW>(D, XA, p.c[0].slab + (size_t)img * (9 * C * C));
-        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
-    } else {
-        // unit 1's dz is in memory everywhere (the exchange of unit 0 has completed); unit 0's needs one more grid-wide hand-shake, taken around unit 1's work
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto reduce_to = [&](float (&sv)[KTW * 8], float* out) {
+            row16_sum_n(sv);
+            if (l15 == 0) {
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) {
+                    const int ch = (wk * KTW + kt) * 16 + 4 * g;
+                    *reinterpret_cast<float4*>(red + (wave * 2 + 0) * C + ch) = make_float4(sv[kt * 8], sv[kt * 8 + 1], sv[kt * 8 + 2], sv[kt * 8 + 3]);
+                    *reinterpret_cast<float4*>(red + (wave * 2 + 1) * C + ch) = make_float4(sv[kt * 8 + 4], sv[kt * 8 + 5], sv[kt * 8 + 6], sv[kt * 8 + 7]);
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * C) {
+                const int stat = tid / C, ch = tid - stat * C;
+                float v;
+                if (WK == 1) v = ((red[(0 * 2 + stat) * C + ch] + red[(1 * 2 + stat) * C + ch]) + red[(2 * 2 + stat) * C + ch]) + red[(3 * 2 + stat) * C + ch];
+                else v = red[((ch >> 4) * 2 + stat) * C + ch];
+                out[tid] = v;
+            }
+            __syncthreads();
+        };
+        reduce_to(sva, vals);
+        reduce_to(svd, vals2);
+        if constexpr (GRP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        const unsigned tagA = base + (unsigned)p.nconv + 1u, tagD = tagA + 1u;
+        // ---- exchange A (the 3x3 / stride-2 convolution's sums), the pending weight gradient of unit 0 (own-image) / unit 1 (group) in its shadow
+        if (GRP && p.nconv > 1) grp_issue(1, img);
+        xch_begin(p.xb, img, p.N, 2 * C, tagA, vals, scratch);
+        if constexpr (!GRP) { st_wgrad_wide<C, HW>(D, XA, p.c[0].slab + (size_t)img * (9 * C * C)); __syncthreads(); }
+        else if (p.nconv > 1) grp_finish(1, false);
+        xch_end(p.xb, p.N, 2 * C, tagA, tot, scratch);
+        if (tid < C) {
+            const double s1 = tot[tid], s2 = tot[C + tid];
+            ctab[tid] = (float)(s1 * p.invM);
+            ctab[C + tid] = (float)(s2 * p.invM);
+            ctab[4 * C + tid] = c_gamma * c_invstd;
+            if (img == 0) { p.ea.dbeta[tid] = c_db + (float)s1; p.ea.dgamma[tid] = c_dg + (float)s2; }
+        }
         __syncthreads();
-        const unsigned tag = base + (unsigned)p.nconv + 1u;
-        if (p.nconv > 1) grp_issue(1, img);
-        xch_begin(p.xb, img, p.N, 2 * C, tag, vals, scratch);
-        if (p.nconv > 1) grp_finish(1, false);
-        xch_end(p.xb, p.N, 2 * C, tag, tot, scratch);
-        grp_issue(0, img);
-        grp_finish(0, false);
-        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv + 1u);
+        auto write_dz = [&](char* dst, const unsigned (&gq)[PTW][KTW][2], const unsigned (&zz)[PTW][KTW][2], const float4 (&m4)[KTW], const float4 (&i4)[KTW]) {
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+                const int ch = (wk * KTW + kt) * 16 + 4 * g;
+                const float4 k04 = *reinterpret_cast<const float4*>(ctab + ch), k14 = *reinterpret_cast<const float4*>(ctab + C + ch);
+                const float4 gi4 = *reinterpret_cast<const float4*>(ctab + 4 * C + ch);
+                const float k0[4] = {k04.x, k04.y, k04.z, k04.w}, k1[4] = {k14.x, k14.y, k14.z, k14.w}, gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w};
+                const float mu[4] = {m4[kt].x, m4[kt].y, m4[kt].z, m4[kt].w}, is[4] = {i4[kt].x, i4[kt].y, i4[kt].z, i4[kt].w};
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) {
+                    const float zf[4] = {__uint_as_float(zz[t][kt][0] << 16), __uint_as_float(zz[t][kt][0] & 0xffff0000u), __uint_as_float(zz[t][kt][1] << 16),
+                                         __uint_as_float(zz[t][kt][1] & 0xffff0000u)};
+                    const float gg[4] = {__uint_as_float(gq[t][kt][0] << 16), __uint_as_float(gq[t][kt][0] & 0xffff0000u), __uint_as_float(gq[t][kt][1] << 16),
+                                         __uint_as_float(gq[t][kt][1] & 0xffff0000u)};
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = gi[e] * (gg[e] - k0[e] - (zf[e] - mu[e]) * is[e] * k1[e]);
+                    *reinterpret_cast<uint2*>(dst + pbase[t] + (P + 1) * PB + ch * 2) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                }
+            }
+        };
+        write_dz(D, gqa, zq, mu4, is4);
+        // ---- exchange D (the shortcut's sums); the block's input image comes into LDS -- and the group weight gradient of unit 0 runs -- in its shadow
+        if constexpr (GRP) grp_issue(0, img);                       // (every workgroup's dz of unit 0 was in memory before it published exchange A)
+        xch_begin(p.xb, img, p.N, 2 * C, tagD, vals2, scratch);
+        {
+            constexpr int CPPI = CI / 8;
+            const uint4* src = reinterpret_cast<const uint4*>(p.x + (size_t)img * HWI * HWI * CI);
+            for (int i = tid; i < HWI * HWI * CPPI; i += 256) {
+                const int q = i / CPPI, c8 = i - q * CPPI;
+                const int yy = q / HWI, xx = q - yy * HWI;
+                *reinterpret_cast<uint4*>(INB + ((yy + 1) * PI + xx + 1) * PBI + c8 * 16) = src[i];
+            }
+        }
+        if constexpr (GRP) grp_finish(0, false);
+        xch_end(p.xb, p.N, 2 * C, tagD, tot, scratch);
+        if (tid < C) {
+            const double s1 = tot[tid], s2 = tot[C + tid];
+            ctab[tid] = (float)(s1 * p.invM);
+            ctab[C + tid] = (float)(s2 * p.invM);
+            ctab[4 * C + tid] = d_gamma * d_invstd;
+            if (img == 0) { p.ed.dbeta[tid] = d_db + (float)s1; p.ed.dgamma[tid] = d_dg + (float)s2; }
+        }
+        __syncthreads();
+        write_dz(Dds, gres, yq, md4, id4);
+        __syncthreads();
+        st_dgrad_entry<C, HW>(D, Dds, p.ea.wd, p.ed.wd, p.dx + (size_t)img * HWI * HWI * CI, p.dx_acc);
+        st_wgrad_entry<C, HW>(D, Dds, INB, p.ea.slab + (size_t)img * (9 * C * CI), p.ed.slab + (size_t)img * (C * CI));
+        if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv + 2u);
+    } else {
+        // ---- the gradient of the run's input
+        {
+            const int l15 = lane & 15;
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+                const int ch = (wk * KTW + kt) * 16 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) {
+                    bf16_t* o = p.dx + (ibase + (wp * PTW + t) * 16 + l15) * C + ch;
+                    float v0 = acc[t][kt][0], v1 = acc[t][kt][1], v2 = acc[t][kt][2], v3 = acc[t][kt][3];
+                    if (p.dx_acc) {
+                        const uint2 old = *reinterpret_cast<const uint2*>(o);
+                        v0 += __uint_as_float(old.x << 16); v1 += __uint_as_float(old.x & 0xffff0000u);
+                        v2 += __uint_as_float(old.y << 16); v3 += __uint_as_float(old.y & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+        }
+        // ---- the weight gradients still owed
+        if constexpr (!GRP) {
+            if constexpr (C == 16) st_wgrad16<HW>(D, XA, wred, p.c[0].slab + (size_t)img * (9 * C * C));
+            else st_wgrad_wide<C, HW>(D, XA, p.c[0].slab + (size_t)img * (9 * C * C));
+            if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
+        } else {
+            // unit 1's dz is in memory everywhere (the exchange of unit 0 has completed); unit 0's needs one more grid-wide hand-shake, taken around unit 1's work
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned tag = base + (unsigned)p.nconv + 1u;
+            if (p.nconv > 1) grp_issue(1, img);
+            xch_begin(p.xb, img, p.N, 2 * C, tag, vals, scratch);
+            if (p.nconv > 1) grp_finish(1, false);
+            xch_end(p.xb, p.N, 2 * C, tag, tot, scratch);
+            grp_issue(0, img);
+            grp_finish(0, false);
+            if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv + 1u);
+        }
     }
 }
 
-template <int C, int HW, bool GRP>
+template <int C, int HW, bool GRP, bool ENTRY>
 int launch_bwd(const StBwdParams& p, hipStream_t st) {
-    constexpr int lds = StGeoB<C, HW, GRP>::LDS;
+    constexpr int lds = StGeoB<C, HW, GRP>::LDS + (ENTRY ? StEnt<C, HW>::BYTES : 0);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr[16] = {};
     if (dev < 0 || dev >= 16 || !attr[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stage_train_bwd_kernel<C, HW, GRP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stage_train_bwd_kernel<C, HW, GRP, ENTRY>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             clhip_set_error("stage_train_bwd: cannot reserve %d bytes of LDS", lds);
             return CLHIP_EHIP;
         }
         if (dev >= 0 && dev < 16) attr[dev] = true;
     }
-    hipLaunchKernelGGL((stage_train_bwd_kernel<C, HW, GRP>), dim3(p.N), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((stage_train_bwd_kernel<C, HW, GRP, ENTRY>), dim3(p.N), dim3(256), lds, st, p);
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -1156,25 +1507,35 @@ int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int 
 }
 
 // The backward of the same run.  dy: gradient of the run's output activation, dx: gradient of its input activation (accumulated into when dx_accumulate), slab[i]:
-// N x (C * 9 * C) floats of scratch per convolution -- the caller adds the N blocks to the weight gradient in a fixed order (clhip_wgrad_reduce_launch).
+// scratch for the weight gradient's partial blocks -- the caller adds clhip_stage_train_slab_blocks() of them to the weight gradient in a fixed order
+// (clhip_wgrad_reduce_launch).  entry != 0: as in the forward -- nconv + 2 array entries, [0] = the 3x3 / stride-2 convolution (wd [C / 2][9][C], slab N x C x 9 x C / 2
+// floats), [1] = the shortcut (wd [C / 2][1][C], slab N x C x C / 2), x / dx = the block's input [N][2 H][2 W][C / 2] and its gradient.
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
-                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int dtype, hipStream_t st) {
-    if (!clhip_stage_train_supported(N, H, W, C, nconv, dtype) || xch == nullptr) { clhip_set_error("stage_train_bwd: unsupported geometry"); return CLHIP_EINVAL; }
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int entry, int dtype, hipStream_t st) {
+    const bool ok = entry ? (clhip_stage_train_supported(N, H, W, C, nconv + 1, dtype) && (nconv & 1) && C >= 32) : clhip_stage_train_supported(N, H, W, C, nconv, dtype);
+    if (!ok || xch == nullptr) { clhip_set_error("stage_train_bwd: unsupported geometry"); return CLHIP_EINVAL; }
     StBwdParams p;
     p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.dx = static_cast<bf16_t*>(dx); p.dx_acc = dx_accumulate;
     p.N = N; p.nconv = nconv; p.invM = 1.0 / ((double)N * H * W); p.trace = trace;
     p.xb = xch_carve(xch, N, 128);
-    for (int i = 0; i < nconv; ++i) {
-        StConvB& c = p.c[i];
+    auto fill = [&](StConvB& c, int i) {
         c.wd = static_cast<const bf16_t*>(wd[i]); c.gamma = gamma[i]; c.beta = beta[i]; c.mean = mean[i]; c.invstd = invstd[i];
         c.z = static_cast<const bf16_t*>(z[i]); c.y = static_cast<const bf16_t*>(y[i]); c.dgamma = dgamma[i]; c.dbeta = dbeta[i]; c.slab = slab[i];
         c.dzg = static_cast<bf16_t*>(dzg[i]);
+    };
+    const int o = entry ? 2 : 0;
+    if (entry) { fill(p.ea, 0); fill(p.ed, 1); }
+    for (int i = 0; i < nconv; ++i) fill(p.c[i], o + i);
+    if (entry) {
+        if (C == 32) return launch_bwd<32, 16, false, true>(p, st);
+        if (stage_train_group(N, C)) return launch_bwd<64, 8, true, true>(p, st);
+        return launch_bwd<64, 8, false, true>(p, st);
     }
-    if (C == 16) return launch_bwd<16, 32, false>(p, st);
-    if (C == 32) return launch_bwd<32, 16, false>(p, st);
-    if (stage_train_group(N, C)) return launch_bwd<64, 8, true>(p, st);
-    return launch_bwd<64, 8, false>(p, st);
+    if (C == 16) return launch_bwd<16, 32, false, false>(p, st);
+    if (C == 32) return launch_bwd<32, 16, false, false>(p, st);
+    if (stage_train_group(N, C)) return launch_bwd<64, 8, true, false>(p, st);
+    return launch_bwd<64, 8, false, false>(p, st);
 }
 
 // the sticky error word of an exchange buffer (non-zero: a bounded spin ran out -- the grid was not co-resident); synchronises the device
