@@ -502,6 +502,15 @@ class HipResNet(nn.Module):
                 hi = lo
         self.attach_grads()
 
+    def stage_status(self):
+        """0 unless an in-launch wait of a stage-level training launch (csrc/stage_train.hip) ran out -- its grid was not co-resident: two such launches on two
+        streams, or several processes on one GPU.  Synchronises the device: call at task / epoch boundaries."""
+        L = _lib.lib()
+        bad = 0
+        for p, _ in self._handle.plans.values():
+            bad |= int(L.clhip_plan_stage_status(p))
+        return bad
+
     def grad_cut_for_fraction(self, frac=0.5):
         """unit index k such that the parameters of units >= k (the tail of the flat buffer, whose gradients the backward
         produces first) hold at least `frac` of all parameter elements, k as large as possible"""

@@ -214,6 +214,18 @@ def attach(model, optimizer, reducer):
                 _lib.lib().clhip_config(b"BRANCH_STREAM", b"0")
             except Exception:
                 pass                                          # CPU-only processes (gloo tests) have no library to steer
+        if reducer.world > 1 and os.environ.get("CLHIP_STAGE_TRAIN") is None:
+            # the stage-level training launches (stage_train.hip) need every workgroup of a launch resident at once: ranks that SHARE a GPU (tests, oversubscribed
+            # nodes) would hold each other's compute units -- such a process keeps the per-unit launches
+            try:
+                import torch
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+                shared = bool(os.environ.get("CLHIP_SHARED_GPU")) or (torch.cuda.is_available() and local_world > torch.cuda.device_count())
+                if shared:
+                    from . import _lib
+                    _lib.lib().clhip_config(b"STAGE_TRAIN", b"0")
+            except Exception:
+                pass
     if hasattr(model, "grad_reducer") or own:
         model.grad_reducer = reducer if own else None
     if hasattr(optimizer, "grad_scale"):

@@ -513,6 +513,12 @@ class Trainer:
                 # batches).  Before anything is DERIVED from the model -- herding picks, class means, Fisher, evaluation -- every
                 # rank takes rank 0's buffers (what DDP's broadcast_buffers does on every forward), so the replicas stay one model
                 parallel.broadcast_module_state(model)
+            # a stage-level training launch whose workgroups were not all resident leaves wrong numbers and a sticky error word, not a hung GPU: say so here
+            for mod in getattr(model, "modules", lambda: [])():
+                if hasattr(mod, "stage_status") and mod.stage_status():
+                    raise RuntimeError("libcontinual_amd: a stage-level training launch (csrc/stage_train.hip) ran out of its bounded in-launch wait during task "
+                                       f"{task_idx}: its workgroups were not all resident (several processes on one GPU, or two training passes on two streams). "
+                                       "Set CLHIP_STAGE_TRAIN=0 for such runs.")
             if hasattr(model, "after_task"):
                 self.hook_trace.append(("after_task", task_idx, -1))
                 model.after_task(task_idx, self.buffer, self.train_loader.get_loader(task_idx), self.test_loader.get_loader(task_idx))
