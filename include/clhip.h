@@ -247,7 +247,13 @@ int clhip_plan_backward(clhip_plan*, const float* dfeat, const float* params, co
 int clhip_plan_num_units(const clhip_plan* p);
 int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, const float* params, const void* shadow, void* workspace,
                               float* grads, int unit_hi, int unit_lo, void* stream);
-/* debugging / tests: copy activation `idx` (0=input) as fp32 NCHW; which: 0 = y, 1 = pre-BN z (idx>=1), 2 = dy */
+/* debugging / tests: copy activation `idx` (0=input) as fp32 NCHW; which: 0 = y, 1 = pre-BN z (idx>=1), 2 = dy.
+ * Not every intermediate is written by the fast paths.  An activation whose BatchNorm the consumer applies on its operand load (training: the first convolution
+ * of a block, also inside a stage-level run of stage_train.hip; eval: EVAL_LAZY) is REBUILT here from its z and coefficients by the apply launch the eager path
+ * would have made -- which is why `workspace` is written to despite the const, and why the call must not be made between a forward and its backward on another
+ * stream.  An activation INSIDE a run the eval forward executed as one launch (stage.hip) was never produced: CLHIP_EINVAL (clhip_config("STAGE_EVAL", "0") keeps
+ * one launch per unit).  dy (which = 2) exists for the per-unit backward only: inside a stage-level training run the gradient of an activation never leaves LDS
+ * (clhip_config("STAGE_TRAIN", "0") before the forward keeps the per-unit backward). */
 int clhip_plan_read_act(clhip_plan*, const void* workspace, int idx, int which, float* out_nchw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
