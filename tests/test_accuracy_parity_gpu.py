@@ -18,12 +18,13 @@ by one part in 10^6) so that the reference's own run-to-run spread is part of th
     oracle/trainer_scenarios.py: every sample blends its class pattern with its partner class's, blend weight uniform in [0, 0.58)): the
     reference's own twenty-four runs end at 85.4 +- 0.56 % (overall 85.3 +- 0.28; the distribution has a lower tail -- 83.8 at worst -- that
     twelve runs did not show and the product's runs do too) -- far from saturation, and the samples near a blend weight of 0.5 are decided
-    by the details of the trained network.  Sixteen product runs per mode in the DEFAULT suite, twenty-four with CLHIP_ACC_RUNS=full.
+    by the details of the trained network.  Sixteen bf16 / eight f32 product runs in the DEFAULT suite, twenty-four with CLHIP_ACC_RUNS=full.
+    Since round 6 its three quantities are gated on the mean alone: |mean(product) - mean(reference)| <= 0.3, the standard error reported beside it.
 The gate, two-sided, in BOTH arithmetic modes (f32 = like for like with the reference, bf16 = the benchmarked mode):
       |mean(product) - mean(reference)| <= 0.3 + 2 SE,   SE = sqrt(var_ref / 10 + var_prod / 10),
 and a quantity only counts as a gate if the runs can resolve the band: SE <= 0.15 (asserted -- a quantity that cannot is a finding, not
 a pass).  The hook sequence and the first optimisation steps (2e-4 f32 / 3e-2 bf16) are checked on the unperturbed run as well.
-Every run's figures go to gpurun_out/accuracy_parity_r03.json (copied to profiles/)."""
+Every run's figures go to gpurun_out/accuracy_parity_r06[_quick].json (copied to profiles/)."""
 import json
 import os
 
@@ -45,7 +46,9 @@ RUN_CAP = {"acc_lwf": 40, "acc_icarl11": 10, "acc_icarl11_hard": 24, "acc_icarl1
 # ... with CLHIP_ACC_RUNS=full (the evidence run behind profiles/r04_accuracy_parity.json: 16 minutes of GPU time for the three scenarios).  The default
 # suite keeps the same gates (bands are 0.3 + 2 SE of the runs actually made) on fewer product runs so that `pytest -m gpu` stays a quarter of an hour.
 if os.environ.get("CLHIP_ACC_RUNS", "") != "full":
-    RUN_CAP = {"acc_lwf": 10, "acc_icarl11": 6, "acc_icarl11_hard": 4, "acc_icarl11_overlap": 16}      # (the 70-90 % scenario keeps most of its runs: it is the gate that bites)
+    RUN_CAP = {"acc_lwf": 10, "acc_icarl11": 4, "acc_icarl11_hard": 4, "acc_icarl11_overlap": 16}      # (the 70-90 % scenario keeps most of its runs: it is the gate that bites)
+# round 6: the f32 MODE of the overlap scenario -- not the product's default arithmetic -- makes half of them in the default suite
+RUN_CAP_F32 = {"acc_icarl11_overlap": 8} if os.environ.get("CLHIP_ACC_RUNS", "") != "full" else {}
 # first optimisation steps of the unperturbed run: these scenarios step at lr 0.05 (the short ones at 0.02), so the chaotic amplification
 # sets in one step earlier -- f32 mode observed 1.5e-7, 1.8e-5, then 9e-4 at the third step
 FIRST_STEPS_ACC = {"f32": (2, 2e-4), "bf16": (2, 3e-2)}
@@ -60,10 +63,10 @@ def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
     ref = np.load(path)
     ref_final, ref_overall = ref["runs_final_avg_acc"], ref["runs_overall_avg_acc"]
     assert len(ref_final) >= N_RUNS
-    n_runs = min(len(ref_final), RUN_CAP[name])
+    n_runs = min(len(ref_final), RUN_CAP_F32.get(name, RUN_CAP[name]) if dtype == "f32" else RUN_CAP[name])
     prod_final, prod_overall, prod_task0 = [], [], []
     for q in range(n_runs):
-        got, _ = run_product(name, dtype, str(tmp_path / f"r{q}"), perturb=q)
+        got, _ = run_product(name, dtype, str(tmp_path / "data"), perturb=q)            # (one data root: the scenario's files do not depend on the perturbation)
         if q == 0:
             assert got["trace"].tolist() == ref["trace"].tolist()
             n0 = int(ref["trace"][2][2])
@@ -87,7 +90,7 @@ def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
                            product_mean=float(pr.mean()), product_std=float(pr.std(ddof=1)))
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    jp = os.path.join(out, "accuracy_parity_r05.json" if os.environ.get("CLHIP_ACC_RUNS", "") == "full" else "accuracy_parity_r05_quick.json")
+    jp = os.path.join(out, "accuracy_parity_r06.json" if os.environ.get("CLHIP_ACC_RUNS", "") == "full" else "accuracy_parity_r06_quick.json")
     prev = json.load(open(jp)) if os.path.exists(jp) else {}
     prev[f"{name}/{dtype}"] = report
     json.dump(prev, open(jp, "w"), indent=1)
@@ -97,10 +100,18 @@ def test_final_average_accuracy_within_the_band(name, dtype, tmp_path):
              "acc_icarl11_overlap": ("final_avg_acc", "overall_avg_acc", "task0_avg_acc")}[name]
     # (the unsaturated scenario: 24 + 24 runs of a std-0.6 quantity; the overlap scenario: 24 + 16..24 runs of a quantity whose std is 0.56 in the reference
     #  and up to 1.0 in the product's f32 runs: SE 0.2-0.3)
-    se_cap = 0.2 if name == "acc_icarl11_hard" else (0.3 if name == "acc_icarl11_overlap" else 0.15)
+    se_cap = 0.2 if name == "acc_icarl11_hard" else (0.35 if name == "acc_icarl11_overlap" else 0.15)
     for key in gated:
         r = report[key]
         assert r["se"] <= se_cap, (key, r)                                 # the runs resolve the band
+        if name == "acc_icarl11_overlap":
+            # round 6: the scenario that bites is gated on the MEAN alone -- BASELINE.json's +-0.3 points, no allowance for the standard
+            # error, which is recorded beside it (`se`, `mean_gate`).  The runs are deterministic (bit-reproducible steps, fixed perturbations), so the gate
+            # does not flicker; measured: final -0.13 / -0.19, overall +0.15 / +0.06, first task 0.00 / -0.17 points (f32 / bf16, 16 runs), and -0.22 /
+            # +0.08 / +0.09 on the eight f32 runs of the default suite
+            r["mean_gate"] = 0.3
+            assert abs(r["gap_points"]) <= 0.3 + 1e-9, (key, r)
+            continue
         assert abs(r["gap_points"]) <= r["band"] + 1e-9, (key, r)          # BASELINE.json: within +-0.3 points of the CPU reference
     if name == "acc_lwf":
         # the after-one-increment figure with 40 + 40 runs: a gate if they resolve it (SE <= 0.5), the measured bias with its interval otherwise
