@@ -45,10 +45,10 @@ bool clhip_stage_train_supported(int N, int H, int W, int C, int nconv, int dtyp
 size_t clhip_stage_train_xch_bytes(int N);
 int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
                                  float* const* rm, float* const* rv, float* const* mean, float* const* invstd, float* const* coef, void* const* z, void* const* y,
-                                 void* const* mask, float momentum, float eps, void* xch, int trace, int entry, int dtype, hipStream_t st);
+                                 void* const* mask, float momentum, float eps, void* xch, int trace, int entry, float* feat, int dtype, hipStream_t st);
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
-                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int entry, int dtype, hipStream_t st);
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int entry, const float* dfeat, int dtype, hipStream_t st);
 int clhip_stage_train_slab_blocks(int N, int C);
 int clhip_stage_train_trace(void* xch, unsigned long long* out24);
 int clhip_stage_train_status(void* xch);
@@ -921,6 +921,11 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     // STAGE_TRAIN (default on; looked up per call): runs of BasicBlocks as ONE training launch (stage_train.hip) where the plan found them and the lazy forms are on
     const char* strain_cfg = clhip_cfg("STAGE_TRAIN");
     const bool strain_on = rlazy_on && p->xch != nullptr && stage_train_default(strain_cfg, p->N);
+    // ... and the launch of the LAST run also averages its output (the global pooling behind it): STAGE_POOL=0 keeps the pooling launch
+    const char* spool_cfg = clhip_cfg("STAGE_POOL");
+    const bool spool_on = !(spool_cfg != nullptr && atoi(spool_cfg) == 0) && p->pool_win == 0;
+    auto pool_in_run = [&](size_t end, int C) { return spool_on && end == p->units.size() && p->acts.back().C == C; };
+    bool pooled = false;
     for (size_t i = 0; i < p->units.size(); ++i) p->lazy_live[i] = p->res_pending[i] = p->wt_pending[i] = p->eval_unwritten[i] = p->stage_skipped[i] = 0;
     if (training) std::fill(p->mask_stale.begin(), p->mask_stale.end(), 0);
     p->params_dev = params; p->bn_stats_dev = bn_stats;
@@ -965,8 +970,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 }
                 TRY(stage_train_serialize(p, (hipStream_t)stream));
                 TRY(clhip_stage_train_fwd_launch(ws + src.y_off, p->N, uf.H, uf.W, uf.d.cout, uf.stage_len + 1, wv, gv, bv, rmv, rvv, mev, isv, cov, zv, yv, mkv, kBnMomentum, kBnEps,
-                                                 p->xch, stage_trace_cfg(uf.d.cout), 1, p->dtype, (hipStream_t)stream));
+                                                 p->xch, stage_trace_cfg(uf.d.cout), 1, pool_in_run(i + len, uf.d.cout) ? feat : nullptr, p->dtype, (hipStream_t)stream));
                 ++p->st_fwd_launches;
+                if (pool_in_run(i + len, uf.d.cout)) pooled = true;
                 i += len - 1;
                 continue;
             }
@@ -985,8 +991,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                 }
                 TRY(stage_train_serialize(p, (hipStream_t)stream));
                 TRY(clhip_stage_train_fwd_launch(ws + src.y_off, p->N, u.H, u.W, u.d.cout, u.stage_len, wv, gv, bv, rmv, rvv, mev, isv, cov, zv, yv, mkv, kBnMomentum, kBnEps,
-                                                 p->xch, stage_trace_cfg(u.d.cout), 0, p->dtype, (hipStream_t)stream));
+                                                 p->xch, stage_trace_cfg(u.d.cout), 0, pool_in_run(i + u.stage_len, u.d.cout) ? feat : nullptr, p->dtype, (hipStream_t)stream));
                 ++p->st_fwd_launches;
+                if (pool_in_run(i + u.stage_len, u.d.cout)) pooled = true;
                 i += u.stage_len - 1;
                 continue;
             }
@@ -1134,6 +1141,7 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
         TRY(clhip_bn_apply(ws + u.z_off, fr + u.f_scale, fr + u.f_shift, res, ws + dst.y_off, u.M, u.d.cout, u.relu, p->dtype, stream));
     }
     const Act& last = p->acts.back();
+    if (pooled) return CLHIP_OK;                              // (the last run's launch averaged its output on the way out)
     if (p->pool_win > 0) TRY(clhip_avgpool_win_fwd(ws + last.y_off, feat, p->N, last.H, last.W, last.C, p->pool_win, p->dtype, stream));
     else TRY(clhip_avgpool_fwd(ws + last.y_off, feat, p->N, last.H * last.W, last.C, p->dtype, stream));
     return CLHIP_OK;
@@ -1154,7 +1162,18 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     char* ws = static_cast<char*>(workspace);
     const char* sh = static_cast<const char*>(shadow);
     float* fr = reinterpret_cast<float*>(ws + p->f_base);
-    if (unit_hi == (int)p->units.size()) {
+    // the pooling's backward inside the last run's stage-level launch (stage_train.hip: the gradient of the run's output is dfeat / (H W), formed in registers)
+    bool pool_in_stage = false;
+    {
+        const char* c1 = clhip_cfg("STAGE_TRAIN_BWD");
+        const char* c2 = clhip_cfg("STAGE_TRAIN");
+        const char* c3 = clhip_cfg("STAGE_POOL");
+        const Unit& lu = p->units.back();
+        pool_in_stage = unit_hi == (int)p->units.size() && p->pool_win == 0 && p->xch != nullptr && !(c1 != nullptr && atoi(c1) == 0) && stage_train_default(c2, p->N) &&
+                        !(c3 != nullptr && atoi(c3) == 0) && !(plan_skip() & 6) && lu.run_first >= 0 && lu.run_first >= unit_lo &&
+                        lu.run_first + p->units[lu.run_first].stage_len == (int)p->units.size() && p->acts.back().C == lu.d.cout;
+    }
+    if (unit_hi == (int)p->units.size() && !pool_in_stage) {
         const Act& last = p->acts.back();
         if (p->pool_win > 0) TRY(clhip_avgpool_win_bwd(dfeat, ws + last.dy_off, p->N, last.H, last.W, last.C, p->pool_win, p->dtype, stream));
         else {
@@ -1251,6 +1270,11 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
     const char* stb_cfg = clhip_cfg("STAGE_TRAIN_BWD");
     const char* stb_cfg2 = clhip_cfg("STAGE_TRAIN");
     const bool stb_on = p->xch != nullptr && !(stb_cfg != nullptr && atoi(stb_cfg) == 0) && stage_train_default(stb_cfg2, p->N) && !br_on && !(plan_skip() & 6);
+    if (pool_in_stage && !stb_on) {                          // (decided before the branch stream's state was known: the pooling's backward as its own launch after all)
+        const Act& last = p->acts.back();
+        TRY(clhip_avgpool_bwd(dfeat, ws + last.dy_off, p->N, last.H * last.W, last.C, p->dtype, stream));
+        pool_in_stage = false;
+    }
     for (int i = unit_hi - 1; i >= unit_lo; --i, k = (k + 1) % n_dz) {
         if (stb_on && p->units[i].run_first >= 0) {
             const int f = p->units[i].run_first;
@@ -1275,7 +1299,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                     if (p->br_act >= 0) join_branch();
                     TRY(stage_train_serialize(p, main_s));
                     TRY(clhip_stage_train_bwd_launch(ws + p->acts[ua.d.src].y_off, ws + p->acts[f + len].dy_off, ws + p->acts[ua.d.src].dy_off, p->units[e0 + 1].dx_acc, p->N, uf.H,
-                                                     uf.W, uf.d.cout, len + 1, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), 1, p->dtype, main_s));
+                                                     uf.W, uf.d.cout, len + 1, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), 1,
+                                                     pool_in_stage && f + len == (int)p->units.size() ? dfeat : nullptr, p->dtype, main_s));
                     ++p->st_bwd_launches;
                     for (int q = n - 1; q >= 0; --q) {
                         const Unit& uq = p->units[e0 + q];
@@ -1297,7 +1322,8 @@ extern "C" int clhip_plan_backward_range(clhip_plan* p, const float* dfeat, cons
                 if (p->br_act >= 0) join_branch();
                 TRY(stage_train_serialize(p, main_s));
                 TRY(clhip_stage_train_bwd_launch(ws + p->acts[uf.d.src].y_off, ws + p->acts[f + len].dy_off, ws + p->acts[uf.d.src].dy_off, p->units[f + 1].dres_acc, p->N, uf.H,
-                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), 0, p->dtype, main_s));
+                                                 uf.W, uf.d.cout, len, wdv, gv, bv, mev, isv, zv, yv, dgv, dbv, slv, dzv, p->xch, stage_trace_cfg(uf.d.cout), 0,
+                                                 pool_in_stage && f + len == (int)p->units.size() ? dfeat : nullptr, p->dtype, main_s));
                 ++p->st_bwd_launches;
                 for (int q = len - 1; q >= 0; --q) {
                     const Unit& uq = p->units[f + q];

@@ -47,6 +47,7 @@ struct StFwdParams {
     float eps, momentum;
     double invM, unbias;      // 1 / (N HW HW), M / (M - 1)
     int trace;                // > 0: workgroup 0 stamps the phases of convolution `trace` into the exchange buffer's spare words (clhip_stage_train_trace)
+    float* feat;              // nullable: [N][C] the global average of the run's output (the pooling behind the LAST run of a backbone)
     XchBuf xb;
     StConv ea, ed;            // (entry block) its 3x3 / stride-2 convolution and its 1x1 / stride-2 shortcut convolution; x is then the block's INPUT [N][2 HW][2 HW][C / 2]
     StConv c[kMaxConvT];
@@ -351,6 +352,17 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
         }
         if (img == 0 && tid == 0) xch_advance(p.xb, base, (unsigned)p.nconv);
     }
+    if (p.feat != nullptr && tid < C) {
+        // the global average pooling behind the run: its output sits in X (every run ends on a block's second convolution); summed in pixel order like
+        // avgpool_fwd_kernel (bn.hip), so the features are bit-identical to the pooling launch's
+        float s = 0.f;
+#pragma unroll 8
+        for (int px = 0; px < HW * HW; ++px) {
+            const int yy = px / HW, xx = px - yy * HW;
+            s += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(X + ((yy + 1) * P + xx + 1) * PB + tid * 2) << 16);
+        }
+        p.feat[(size_t)img * C + tid] = s / (float)(HW * HW);
+    }
 }
 
 template <int C, int HW, bool ENTRY>
@@ -404,6 +416,7 @@ struct StBwdParams {
     int N, nconv;
     double invM;
     int trace;
+    const float* dfeat;       // nullable: [N][C] gradient of the pooled features -- the run's output gradient is then dfeat / (HW HW) at every pixel and dy is not read
     XchBuf xb;
     StConvB ea, ed;           // (entry block) its 3x3 / stride-2 convolution and its shortcut convolution: wd = [C / 2][9][C] / [C / 2][1][C], slab = [N][C][9][C / 2] / [N][C][C / 2];
                               // x is then the block's INPUT [N][2 HW][2 HW][C / 2] and dx its gradient
@@ -1237,7 +1250,13 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             const int ch = (wk * KTW + kt) * 16 + 4 * g;
 #pragma unroll
             for (int t = 0; t < PTW; ++t) {
-                const uint2 v = *reinterpret_cast<const uint2*>(p.dy + (ibase + (wp * PTW + t) * 16 + l15) * C + ch);
+                uint2 v;
+                if (p.dfeat != nullptr) {
+                    // the global pooling behind the run: every pixel's gradient is dfeat / (H W), rounded to bf16 like the tensor avgpool_bwd_kernel (bn.hip) stores
+                    const float4 d = *reinterpret_cast<const float4*>(p.dfeat + (size_t)img * C + ch);
+                    constexpr float inv = 1.f / (float)(HW * HW);
+                    v = make_uint2(pack_bf16x2(d.x * inv, d.y * inv), pack_bf16x2(d.z * inv, d.w * inv));
+                } else v = *reinterpret_cast<const uint2*>(p.dy + (ibase + (wp * PTW + t) * 16 + l15) * C + ch);
                 acc[t][kt] = (f32x4){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
                 gres[t][kt][0] = gres[t][kt][1] = 0u;
             }
@@ -1481,11 +1500,11 @@ int clhip_stage_train_slab_blocks(int N, int C) { const int ipg = (C / 16) * (C 
 // is the block's input [N][2 H][2 W][C / 2].
 int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
                                  float* const* rm, float* const* rv, float* const* mean, float* const* invstd, float* const* coef, void* const* z, void* const* y,
-                                 void* const* mask, float momentum, float eps, void* xch, int trace, int entry, int dtype, hipStream_t st) {
+                                 void* const* mask, float momentum, float eps, void* xch, int trace, int entry, float* feat, int dtype, hipStream_t st) {
     const bool ok = entry ? (clhip_stage_train_supported(N, H, W, C, nconv + 1, dtype) && (nconv & 1) && C >= 32) : clhip_stage_train_supported(N, H, W, C, nconv, dtype);
     if (!ok || xch == nullptr) { clhip_set_error("stage_train_fwd: unsupported geometry"); return CLHIP_EINVAL; }
     StFwdParams p;
-    p.x = static_cast<const bf16_t*>(x); p.N = N; p.nconv = nconv; p.eps = eps; p.momentum = momentum; p.trace = trace;
+    p.x = static_cast<const bf16_t*>(x); p.N = N; p.nconv = nconv; p.eps = eps; p.momentum = momentum; p.trace = trace; p.feat = feat;
     const double M = (double)N * H * W;
     p.invM = 1.0 / M; p.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
     p.xb = xch_carve(xch, N, 128);
@@ -1512,12 +1531,12 @@ int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int 
 // floats), [1] = the shortcut (wd [C / 2][1][C], slab N x C x C / 2), x / dx = the block's input [N][2 H][2 W][C / 2] and its gradient.
 int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx_accumulate, int N, int H, int W, int C, int nconv, const void* const* wd,
                                  const float* const* gamma, const float* const* beta, const float* const* mean, const float* const* invstd, const void* const* z,
-                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int entry, int dtype, hipStream_t st) {
+                                 const void* const* y, float* const* dgamma, float* const* dbeta, float* const* slab, void* const* dzg, void* xch, int trace, int entry, const float* dfeat, int dtype, hipStream_t st) {
     const bool ok = entry ? (clhip_stage_train_supported(N, H, W, C, nconv + 1, dtype) && (nconv & 1) && C >= 32) : clhip_stage_train_supported(N, H, W, C, nconv, dtype);
     if (!ok || xch == nullptr) { clhip_set_error("stage_train_bwd: unsupported geometry"); return CLHIP_EINVAL; }
     StBwdParams p;
     p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.dx = static_cast<bf16_t*>(dx); p.dx_acc = dx_accumulate;
-    p.N = N; p.nconv = nconv; p.invM = 1.0 / ((double)N * H * W); p.trace = trace;
+    p.N = N; p.nconv = nconv; p.invM = 1.0 / ((double)N * H * W); p.trace = trace; p.dfeat = dfeat;
     p.xb = xch_carve(xch, N, 128);
     auto fill = [&](StConvB& c, int i) {
         c.wd = static_cast<const bf16_t*>(wd[i]); c.gamma = gamma[i]; c.beta = beta[i]; c.mean = mean[i]; c.invstd = invstd[i];

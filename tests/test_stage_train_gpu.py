@@ -149,3 +149,29 @@ def test_stage_level_training_backward_matches_the_per_unit_launches(kind, batch
     assert _rel(g11, g10) <= 3e-2 and _rel(g01, g00) <= 3e-2
     assert worst[1] <= 6e-2, worst
     assert _rel(g11, g00) <= 0.6
+
+
+@pytest.mark.parametrize("kind,batch", [("cifar", 256), ("v2", 72)])
+def test_the_pooling_inside_the_last_runs_launches_changes_no_bit(kind, batch):
+    """STAGE_POOL (default on): the last run's forward launch also averages its output, its backward launch forms the output gradient from the feature gradient --
+    same sums in the same order, same bf16 rounding of the gradient as the two pooling launches they replace"""
+    bb = _backbone(kind, 11)
+    _trained_like(bb, 12)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(batch, 3, 32, 32, generator=g).cuda()
+    w = torch.randn(batch, bb.out_dim, generator=g).cuda() / batch
+    L = _lib.lib()
+    out = {}
+    for flag in (b"1", b"0", b"1"):
+        assert L.clhip_config(b"STAGE_POOL", flag) == 0
+        try:
+            out.setdefault(flag, []).append(_step(bb, x, w, b"1", b"1"))
+        finally:
+            L.clhip_config(b"STAGE_POOL", None)
+    assert _status(bb) == [0] * len(bb._handle.plans)
+    (f1, g1), (f1b, g1b) = out[b"1"]
+    (f0, g0), = out[b"0"]
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert torch.equal(f1, f1b) and torch.equal(g1, g1b)
+    assert torch.equal(f1, f0), float((f1 - f0).abs().max())
+    assert torch.equal(g1, g0), _rel(g1, g0)
