@@ -29,7 +29,7 @@ extern "C" int clhip_version(void) { return 103; }
 namespace {
 const char* const kKeys[] = {
     // dispatch switches (A/B runs, tests that pin a code path)
-    "ATTN_GENERIC", "BN_FUSE", "BN_FUSE_MAX_M", "BN_MASK_BITS", "BN_MASK_FROM_Y", "BN_PARTIALS", "CE_ROWS", "CE_ONE_WG", "LINEAR_BWD_SPLIT", "CONV3G", "CONV4", "CONV_V1",
+    "ATTN_GENERIC", "ATTN_BWD", "BN_FUSE", "BN_FUSE_MAX_M", "BN_MASK_BITS", "BN_MASK_FROM_Y", "BN_PARTIALS", "CE_ROWS", "CE_ONE_WG", "LINEAR_BWD_SPLIT", "CONV3G", "CONV4", "CONV_V1",
     "GEMM_NO_SPLIT", "GEMM_TAIL", "NO_CONV16", "NO_CONV3", "NO_PARITY_DGRAD", "NO_SHORTCUT", "NO_STEM", "PREP_NARROW", "WGRAD4",
     "WGRAD_NO_TR", "WGRAD2_ATOMIC", "WGRAD_DEFER", "WGRAD_DEFER_SIDE", "BWD_FUSED", "WGRAD_STREAM", "BRANCH_STREAM", "WGRAD_ALWAYS_QUEUE", "SIDE_PRIO", "EVENT_FLAGS", "EVENT_RECORD", "CONV5", "CONV6", "WGRAD16_PARTS", "WGRAD32_IPG", "WGRAD64_IPG", "WGRAD64_IPI2", "CONV64", "CONV64_BM", "CONV64_FWD", "CONV6_PAIR", "CONV7", "CONV7_TPW", "WGRAD7", "FWD7", "PAIR_BN_FUSE", "POOL_BN_FUSE", "BN_INPUT", "BN_INPUT_WT", "BN_RES_INPUT", "BN_GRAD", "BN_GRAD_MINC", "BN_GRAD_RES", "CONV6_DEBUG", "BN_ONEPASS", "WGRAD5", "WGRAD32",
     // tuning values

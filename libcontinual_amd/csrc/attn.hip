@@ -283,6 +283,193 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParam
     }
 }
 
+// The same backward with TWO tiles per wave (round 6).  The kernel above is LDS-bandwidth bound: every operand fragment it reads (1 KB per wave) feeds ONE MFMA, and
+// 128 B/clk of LDS serve one such read per 8 cycles where the matrix pipes retire an MFMA per 4.  Here a wave owns a PAIR of query tiles in phase A and a pair of key
+// tiles in phase B, so every K / V (phase A) or Q / dO (phase B) fragment -- and every transposing read -- feeds two MFMAs: half the LDS bytes per MFMA.  Eight waves
+// (seven busy at 197 tokens), two per SIMD with up to 256 registers each.  Same MFMAs on the same operands in the same order per output tile: bit-identical results.
+constexpr int BWD2_WAVES = 8;
+
+__global__ __launch_bounds__(64 * BWD2_WAVES) void attn_bwd_mfma2_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int N = p.N, D = p.D, nKT = (N + 15) >> 4, NP2 = ((nKT + 1) & ~1) * 16, nPair = NP2 >> 5;
+    const size_t ld = 3 * (size_t)D;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (size_t)b * N * ld + h * 64;
+    const bf16_t* dob = static_cast<const bf16_t*>(p.dout) + (size_t)b * N * D + h * 64;
+    const bf16_t* ob = static_cast<const bf16_t*>(p.out) + (size_t)b * N * D + h * 64;
+    bf16_t* dqb = static_cast<bf16_t*>(p.dqkv) + (size_t)b * N * ld + h * 64;
+    char* Qs = smem;
+    char* Ks = Qs + NP2 * KP;
+    char* Vs = Ks + NP2 * KP;
+    char* Gs = Vs + NP2 * KP;                                  // dO
+    float* lse_s = reinterpret_cast<float*>(Gs + NP2 * KP);    // [NP2]  lse * log2(e)  (+inf beyond N -> P = 0)
+    float* dq_s = lse_s + NP2;                                 // [NP2]  rowsum(dO * O)
+    stage_rows(Qs, base, ld, N, NP2);
+    stage_rows(Ks, base + D, ld, N, NP2);
+    stage_rows(Vs, base + 2 * D, ld, N, NP2);
+    stage_rows(Gs, dob, D, N, NP2);
+    for (int q = tid; q < NP2; q += 64 * BWD2_WAVES) {
+        float dsum = 0.f, l = INFINITY;
+        if (q < N) {
+            l = p.lse[((size_t)b * p.H + h) * N + q];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float x[8], y[8];
+                load8<bf16_t>(dob + (size_t)q * D + c * 8, x);
+                load8<bf16_t>(ob + (size_t)q * D + c * 8, y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum += x[j] * y[j];
+            }
+        }
+        lse_s[q] = l * 1.4426950408889634f;
+        dq_s[q] = dsum;
+    }
+    __syncthreads();
+    const float c = p.scale * 1.4426950408889634f;          // scores -> exp2 domain
+
+    // ---- phase A: dQ of query tiles 2 w, 2 w + 1
+    for (int qp = wave; qp < nPair; qp += BWD2_WAVES) {
+        uint4 qf[2][2], gf[2][2];
+        float lq[2], dq[2];
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int qrow = (2 * qp + j) * 16 + l15;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                qf[j][kk] = ldsq(Qs, qrow * KP + (g + 4 * kk) * 16);
+                gf[j][kk] = ldsq(Gs, qrow * KP + (g + 4 * kk) * 16);
+            }
+            lq[j] = lse_s[qrow]; dq[j] = dq_s[qrow];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int ks = 0; ks < nPair; ++ks) {
+            f32x4 ds[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int krow = (2 * ks + t) * 16 + l15;
+                uint4 kfr[2], vfr[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    kfr[kk] = ldsq(Ks, krow * KP + (g + 4 * kk) * 16);
+                    vfr[kk] = ldsq(Vs, krow * KP + (g + 4 * kk) * 16);
+                }
+                const bool tail = (2 * ks + t) >= nKT - 1;               // only the last key tile(s) hold keys >= N
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        s = mfma_bf16(kfr[kk], qf[j][kk], s);
+                        dp = mfma_bf16(vfr[kk], gf[j][kk], dp);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pr = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lq[j]));
+                        if (tail && (2 * ks + t) * 16 + g * 4 + e >= N) pr = 0.f;
+                        ds[j][t][e] = pr * (dp[e] - dq[j]);
+                    }
+                }
+            }
+            const uint4 db0 = pack8(ds[0][0], ds[0][1]), db1 = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 kt_ = tr8(Ks, (2 * ks * 16 + g * 4 + (l15 >> 2)) * KP + (dt * 16 + (l15 & 3) * 4) * 2, 16 * KP);
+                acc[0][dt] = mfma_bf16(kt_, db0, acc[0][dt]);
+                acc[1][dt] = mfma_bf16(kt_, db1, acc[1][dt]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int qrow = (2 * qp + j) * 16 + l15;
+            if (qrow < N) {
+                bf16_t* r = dqb + (size_t)qrow * ld + g * 4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<uint2*>(r + dt * 16) = make_uint2(pack_bf16x2(acc[j][dt][0] * p.scale, acc[j][dt][1] * p.scale),
+                                                                        pack_bf16x2(acc[j][dt][2] * p.scale, acc[j][dt][3] * p.scale));
+            }
+        }
+    }
+
+    // ---- phase B: dK, dV of key tiles 2 w, 2 w + 1
+    for (int kp = wave; kp < nPair; kp += BWD2_WAVES) {
+        uint4 kf[2][2], vf[2][2];
+        bool kok[2];
+        f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int krow = (2 * kp + j) * 16 + l15;
+            kok[j] = krow < N;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                kf[j][kk] = ldsq(Ks, krow * KP + (g + 4 * kk) * 16);
+                vf[j][kk] = ldsq(Vs, krow * KP + (g + 4 * kk) * 16);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+        for (int qs = 0; qs < nPair; ++qs) {
+            f32x4 pr[2][2], ds[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qr = (2 * qs + t) * 16 + l15;
+                uint4 qfr[2], gfr[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    qfr[kk] = ldsq(Qs, qr * KP + (g + 4 * kk) * 16);
+                    gfr[kk] = ldsq(Gs, qr * KP + (g + 4 * kk) * 16);
+                }
+                const int q0 = (2 * qs + t) * 16 + g * 4;
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);
+                const float4 d4 = *reinterpret_cast<const float4*>(dq_s + q0);
+                const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        s = mfma_bf16(qfr[kk], kf[j][kk], s);
+                        dp = mfma_bf16(gfr[kk], vf[j][kk], dp);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = kok[j] ? __builtin_amdgcn_exp2f(fmaf(s[e], c, -le[e])) : 0.f;      // lse = +inf beyond N -> 0
+                        pr[j][t][e] = pe;
+                        ds[j][t][e] = pe * (dp[e] - de[e]);
+                    }
+                }
+            }
+            const uint4 pb0 = pack8(pr[0][0], pr[0][1]), db0 = pack8(ds[0][0], ds[0][1]);
+            const uint4 pb1 = pack8(pr[1][0], pr[1][1]), db1 = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int a = (2 * qs * 16 + g * 4 + (l15 >> 2)) * KP + (dt * 16 + (l15 & 3) * 4) * 2;
+                const uint4 gt = tr8(Gs, a, 16 * KP), qt = tr8(Qs, a, 16 * KP);
+                dv[0][dt] = mfma_bf16(gt, pb0, dv[0][dt]);
+                dk[0][dt] = mfma_bf16(qt, db0, dk[0][dt]);
+                dv[1][dt] = mfma_bf16(gt, pb1, dv[1][dt]);
+                dk[1][dt] = mfma_bf16(qt, db1, dk[1][dt]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int krow = (2 * kp + j) * 16 + l15;
+            if (kok[j]) {
+                bf16_t* r = dqb + (size_t)krow * ld + g * 4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<uint2*>(r + D + dt * 16) = make_uint2(pack_bf16x2(dk[j][dt][0] * p.scale, dk[j][dt][1] * p.scale),
+                                                                            pack_bf16x2(dk[j][dt][2] * p.scale, dk[j][dt][3] * p.scale));
+                    *reinterpret_cast<uint2*>(r + 2 * D + dt * 16) = make_uint2(pack_bf16x2(dv[j][dt][0], dv[j][dt][1]), pack_bf16x2(dv[j][dt][2], dv[j][dt][3]));
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ generic path
 // One wave per (batch, head, row); lane = key while scoring, lane = d while accumulating.  Used for fp32 (parity mode)
 // and head sizes other than 64.  N <= 256, head dim <= 64.
@@ -452,9 +639,12 @@ extern "C" int clhip_attn_bwd(const void* qkv, const void* out, const float* lse
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
             done = true;
         }
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(64 * BWD_WAVES), smem, s, p);
+        const char* v = clhip_cfg("ATTN_BWD");                 // 1: one tile per wave (rounds 2-5), 2: two (default); looked up per call: the tests compare the two
+        if (v != nullptr && atoi(v) == 1) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(64 * BWD_WAVES), smem, s, p);
+        else hipLaunchKernelGGL(attn_bwd_mfma2_kernel, dim3(B * H), dim3(64 * BWD2_WAVES), smem, s, p);
     } else {
         CLHIP_CHECK_ARG(dsum_ws != nullptr);
         const int rows = B * H * N;

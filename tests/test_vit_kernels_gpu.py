@@ -299,6 +299,31 @@ def test_attention_fwd_bwd(dt, B, N, H, hd):
         assert relerr(dqkv[:, i * D:(i + 1) * D], g[:, i * D:(i + 1) * D]) < (4e-2 if dt == "bf16" else 5e-5), nm
 
 
+@pytest.mark.parametrize("B,N,H", [(5, 197, 12), (2, 222, 3), (3, 17, 2), (2, 240, 1), (2, 33, 2)])
+def test_attention_bwd_two_tiles_per_wave_is_bit_identical(B, N, H):
+    """attn_bwd_mfma2_kernel (two query / key tiles per wave: half the LDS bytes per MFMA) issues the MFMAs of every output tile on the same operands in the same
+    order as the one-tile kernel it replaces (ATTN_BWD=1)"""
+    D = H * 64
+    qkv = (rnd(B * N, 3 * D, seed=17) * 1.5).to(torch.bfloat16)
+    dout = rnd(B * N, D, seed=18).to(torch.bfloat16)
+    out = torch.empty(B * N, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device=DEV)
+    dsum = torch.empty(B, H, N, device=DEV)
+    call("clhip_attn_fwd", p(qkv), p(out), p(lse), B, N, H, D, CODE["bf16"], st())
+    got = {}
+    for v in (b"1", b"2"):
+        dqkv = torch.full((B * N, 3 * D), 3.0, device=DEV).to(torch.bfloat16)
+        assert _lib.lib().clhip_config(b"ATTN_BWD", v) == 0
+        try:
+            call("clhip_attn_bwd", p(qkv), p(out), p(lse), p(dout), p(dqkv), p(dsum), B, N, H, D, CODE["bf16"], st())
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().clhip_config(b"ATTN_BWD", None)
+        got[v] = dqkv
+    assert torch.isfinite(got[b"2"].float()).all() and float(got[b"2"].float().abs().max()) > 0
+    assert torch.equal(got[b"1"], got[b"2"])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("M,D", [(197 * 3, 768), (50, 128), (7, 64), (33, 2048)])
 def test_layernorm(dt, M, D):

@@ -2,7 +2,7 @@
 
     python tools/bench_profile.py [workload ...]
 
-* `rocprofv3 --kernel-trace --stats -- python bench.py --workload W --no-cpu-baseline` -> gpurun_out/bench_kernel_stats_<W>.txt (the
+* `rocprofv3 --kernel-trace --stats -- python bench.py --workload W --no-cpu-baseline --no-secondary` -> gpurun_out/bench_kernel_stats_<W>.txt (the
   per-symbol table) and gpurun_out/bench_kernel_stats.json {W: {steps, ms_per_step, kernels: {symbol: {calls, avg_us, pct}}}} -- the
   in-step average durations bench.py reports next to its stand-alone measurements;
 * `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains) over `bench.py --roofline-only` ->
@@ -39,7 +39,7 @@ def prof(args, tag, extra):
 
 
 def kernel_stats(workload):
-    d, bench = prof(["--workload", workload, "--no-cpu-baseline"], "kt", ["--kernel-trace", "--stats"])
+    d, bench = prof(["--workload", workload, "--no-cpu-baseline", "--no-secondary"], "kt", ["--kernel-trace", "--stats"])
     rows = list(csv.DictReader(open(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True)[0])))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     ks, lines = {}, []
@@ -48,7 +48,7 @@ def kernel_stats(workload):
         ks[n] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, pct=100.0 * float(r["TotalDurationNs"]) / tot)
         lines.append(f"{n[:100]:100s} calls {int(r['Calls']):7d}  avg {float(r['AverageNs']) / 1e3:9.2f} us  total {float(r['TotalDurationNs']) / 1e6:9.2f} ms  {ks[n]['pct']:5.1f} %")
     nsteps = bench["steps"] + bench["warmup"]
-    head = (f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {workload} --no-cpu-baseline\n"
+    head = (f"rocprofv3 --kernel-trace --stats -- python bench.py --workload {workload} --no-cpu-baseline --no-secondary\n"
             f"bench line under the profiler: {bench['value']:.0f} img/s, {bench['ms_per_step']:.3f} ms/step, {bench['steps']} timed + {bench['warmup']} warm-up steps\n"
             f"kernel time in the whole run {tot / 1e6:.1f} ms (includes the roofline block's stand-alone launches and start-up)\n")
     open(os.path.join(OUT, f"bench_kernel_stats_{workload}.txt"), "w").write(head + "\n".join(lines) + "\n")

@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 python tools/bench_profile.py lwf_resnet18_b50_task0 lwf_resnet18_b50_task1 ewc_resnet32_b50_task1 icarl_resnet32_b50_task1 lucir_resnet32_b50_task1 ewc_fisher_pass herding_b50 inflora_vitb16_b20_task1 l2p_vitb16_b10_task1 2>&1 | tail -12
 python tools/layer_roofline.py 30 > gpurun_out/layer_roofline.md 2>gpurun_out/layer_roofline.err
 for w in lwf_resnet18_b50_task0 lwf_resnet18_b50_task1 ewc_resnet32_b50_task1 icarl_resnet32_b50_task1 lucir_resnet32_b50_task1 ewc_fisher_pass herding_b50 inflora_vitb16_b20_task1 l2p_vitb16_b10_task1; do
-  python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_$w.json
+  python bench.py --workload $w --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > gpurun_out/bench_$w.json
 done
 python bench.py --workload ewc_resnet32_b50_task1 --batch 32 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_ewc_resnet32_b32.json
 # the ViT-B/16 forward + backward at batch 256 (north_star's second roofline target; SURVEY section 8(d) row 4 "+ scale-up run at 256")
