@@ -283,17 +283,23 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma_kernel(AttnParam
     }
 }
 
-// The same backward with TWO tiles per wave (round 6).  The kernel above is LDS-bandwidth bound: every operand fragment it reads (1 KB per wave) feeds ONE MFMA, and
-// 128 B/clk of LDS serve one such read per 8 cycles where the matrix pipes retire an MFMA per 4.  Here a wave owns a PAIR of query tiles in phase A and a pair of key
-// tiles in phase B, so every K / V (phase A) or Q / dO (phase B) fragment -- and every transposing read -- feeds two MFMAs: half the LDS bytes per MFMA.  Eight waves
-// (seven busy at 197 tokens), two per SIMD with up to 256 registers each.  Same MFMAs on the same operands in the same order per output tile: bit-identical results.
-constexpr int BWD2_WAVES = 8;
 
-__global__ __launch_bounds__(64 * BWD2_WAVES) void attn_bwd_mfma2_kernel(AttnParams p) {
+// Round 6, 197 / 222 tokens (NPAIR = 7).  Where the kernel above spends a 128 x 12-head launch (ablation: prologue alone 31 us -- it reads q, k, v, dO, O = 194 MB, HBM
+// rate, but in TEN dependent round trips with one workgroup per CU and nothing beside it; + phase A 41 us; + phase B 63 us; PMC: matrix pipes 18 % busy, 59 % of the wave
+// cycles parked in s_waitcnt, no bank conflicts; both phases sit at ~64 B/clk of LDS operand reads).  This form
+//   * makes every global read of the prologue in ONE round trip (151 -> 137 us on the evidence box);
+//   * drops the masks of keys >= N: a padded key's K and V rows are zero in LDS, so whatever finite dS it gets multiplies zeros in dQ (phase A), and in phase B it only
+//     feeds its own output column, which is never stored (14 + 8 compare / select instructions per tile pair).  Padded QUERIES still vanish through lse = +inf;
+//   * requests the next tile's fragments before this tile's arithmetic.
+// The last two measure nothing by themselves (the phases are LDS-bandwidth bound: a two-tiles-per-wave variant that halves the LDS bytes per MFMA needs > 128 registers,
+// i.e. eight waves instead of sixteen, and ran 167 us).  Same MFMAs on the same operands for every stored element: bit-identical to the kernel above (tests).
+template <int NPAIR>
+__global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_mfma3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const int N = p.N, D = p.D, nKT = (N + 15) >> 4, NP2 = ((nKT + 1) & ~1) * 16, nPair = NP2 >> 5;
+    const int N = p.N, D = p.D, nKT = (N + 15) >> 4;
+    constexpr int NP2 = NPAIR * 32, nPair = NPAIR;
     const size_t ld = 3 * (size_t)D;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (size_t)b * N * ld + h * 64;
     const bf16_t* dob = static_cast<const bf16_t*>(p.dout) + (size_t)b * N * D + h * 64;
@@ -305,166 +311,175 @@ __global__ __launch_bounds__(64 * BWD2_WAVES) void attn_bwd_mfma2_kernel(AttnPar
     char* Gs = Vs + NP2 * KP;                                  // dO
     float* lse_s = reinterpret_cast<float*>(Gs + NP2 * KP);    // [NP2]  lse * log2(e)  (+inf beyond N -> P = 0)
     float* dq_s = lse_s + NP2;                                 // [NP2]  rowsum(dO * O)
-    stage_rows(Qs, base, ld, N, NP2);
-    stage_rows(Ks, base + D, ld, N, NP2);
-    stage_rows(Vs, base + 2 * D, ld, N, NP2);
-    stage_rows(Gs, dob, D, N, NP2);
-    for (int q = tid; q < NP2; q += 64 * BWD2_WAVES) {
-        float dsum = 0.f, l = INFINITY;
-        if (q < N) {
-            l = p.lse[((size_t)b * p.H + h) * N + q];
+    // every global read of the prologue in ONE round trip (the kernel above makes ten: four staging loops of two trips each, then the lse / dO / O rows; with one
+    // workgroup per CU nothing overlaps them): the four tiles' chunks and, for the thread that owns a query row, its lse and O row
+    constexpr int CH = (NP2 * 8 + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);
+    uint4 sq[CH], sk[CH], sv[CH], sg[CH], orow[8];
+    float lraw = INFINITY;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float x[8], y[8];
-                load8<bf16_t>(dob + (size_t)q * D + c * 8, x);
-                load8<bf16_t>(ob + (size_t)q * D + c * 8, y);
+    for (int i = 0; i < CH; ++i) {
+        const int idx = tid + i * 64 * BWD_WAVES, row = idx >> 3, cc = idx & 7;
+        sq[i] = sk[i] = sv[i] = sg[i] = make_uint4(0, 0, 0, 0);
+        if (idx < NP2 * 8 && row < N) {
+            sq[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + cc * 8);
+            sk[i] = *reinterpret_cast<const uint4*>(base + D + (size_t)row * ld + cc * 8);
+            sv[i] = *reinterpret_cast<const uint4*>(base + 2 * D + (size_t)row * ld + cc * 8);
+            sg[i] = *reinterpret_cast<const uint4*>(dob + (size_t)row * D + cc * 8);
+        }
+    }
+    if (tid < N) {
+        lraw = p.lse[((size_t)b * p.H + h) * N + tid];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dsum += x[j] * y[j];
+        for (int cc = 0; cc < 8; ++cc) orow[cc] = *reinterpret_cast<const uint4*>(ob + (size_t)tid * D + cc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int idx = tid + i * 64 * BWD_WAVES, row = idx >> 3, cc = idx & 7;
+        if (idx < NP2 * 8) {
+            *reinterpret_cast<uint4*>(Qs + row * KP + cc * 16) = sq[i];
+            *reinterpret_cast<uint4*>(Ks + row * KP + cc * 16) = sk[i];
+            *reinterpret_cast<uint4*>(Vs + row * KP + cc * 16) = sv[i];
+            *reinterpret_cast<uint4*>(Gs + row * KP + cc * 16) = sg[i];
+        }
+    }
+    __syncthreads();
+    if (tid < NP2) {
+        float dsum = 0.f;
+        if (tid < N) {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {                     // (the element order of the kernel above: the sums agree bit for bit)
+                const uint4 xg = ldsq(Gs, tid * KP + cc * 16);
+                const unsigned xw[4] = {xg.x, xg.y, xg.z, xg.w}, yw[4] = {orow[cc].x, orow[cc].y, orow[cc].z, orow[cc].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dsum += __uint_as_float(xw[j] << 16) * __uint_as_float(yw[j] << 16);
+                    dsum += __uint_as_float(xw[j] & 0xffff0000u) * __uint_as_float(yw[j] & 0xffff0000u);
+                }
             }
         }
-        lse_s[q] = l * 1.4426950408889634f;
-        dq_s[q] = dsum;
+        lse_s[tid] = lraw * 1.4426950408889634f;
+        dq_s[tid] = dsum;
     }
     __syncthreads();
     const float c = p.scale * 1.4426950408889634f;          // scores -> exp2 domain
 
-    // ---- phase A: dQ of query tiles 2 w, 2 w + 1
-    for (int qp = wave; qp < nPair; qp += BWD2_WAVES) {
-        uint4 qf[2][2], gf[2][2];
-        float lq[2], dq[2];
-        f32x4 acc[2][4];
+    // ---- phase A: dQ.  wave <- query tile; per key-tile pair: S^T, dP^T (D layout: rows key g*4+e, col q l15).  The K / V fragments of the NEXT key tile and the
+    //      transposed K fragments of this pair are requested before this tile's arithmetic (the rounds 2-5 loop waited for each small group of reads where it used it:
+    //      nine LDS round trips per pair)
+    auto frag = [&](const char* A, const char* B, int row, uint4 (&fa)[2], uint4 (&fb)[2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int qrow = (2 * qp + j) * 16 + l15;
+        for (int kk = 0; kk < 2; ++kk) {
+            fa[kk] = ldsq(A, row * KP + (g + 4 * kk) * 16);
+            fb[kk] = ldsq(B, row * KP + (g + 4 * kk) * 16);
+        }
+    };
+    for (int qt = wave; qt < nKT; qt += BWD_WAVES) {
+        const int qrow = qt * 16 + l15;
+        uint4 qf[2], gf[2];
+        frag(Qs, Gs, qrow, qf, gf);
+        const float lq = lse_s[qrow], dq = dq_s[qrow];
+        f32x4 acc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        uint4 k0[2], v0[2], k1[2], v1[2];
+        frag(Ks, Vs, l15, k0, v0);
+        auto tileA = [&](const uint4 (&kf)[2], const uint4 (&vf)[2], f32x4& ds) {
+            f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                qf[j][kk] = ldsq(Qs, qrow * KP + (g + 4 * kk) * 16);
-                gf[j][kk] = ldsq(Gs, qrow * KP + (g + 4 * kk) * 16);
+                s = mfma_bf16(kf[kk], qf[kk], s);
+                dp = mfma_bf16(vf[kk], gf[kk], dp);
             }
-            lq[j] = lse_s[qrow]; dq[j] = dq_s[qrow];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+            for (int e = 0; e < 4; ++e) ds[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lq)) * (dp[e] - dq);
+        };
+#pragma unroll 1
         for (int ks = 0; ks < nPair; ++ks) {
-            f32x4 ds[2][2];
+            uint4 kt_[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int krow = (2 * ks + t) * 16 + l15;
-                uint4 kfr[2], vfr[2];
+            for (int dt = 0; dt < 4; ++dt) kt_[dt] = tr8(Ks, (2 * ks * 16 + g * 4 + (l15 >> 2)) * KP + (dt * 16 + (l15 & 3) * 4) * 2, 16 * KP);
+            frag(Ks, Vs, (2 * ks + 1) * 16 + l15, k1, v1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 ds[2];
+            tileA(k0, v0, ds[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < nPair) frag(Ks, Vs, (2 * ks + 2) * 16 + l15, k0, v0);
+            __builtin_amdgcn_sched_barrier(0);
+            tileA(k1, v1, ds[1]);
+            const uint4 db = pack8(ds[0], ds[1]);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    kfr[kk] = ldsq(Ks, krow * KP + (g + 4 * kk) * 16);
-                    vfr[kk] = ldsq(Vs, krow * KP + (g + 4 * kk) * 16);
-                }
-                const bool tail = (2 * ks + t) >= nKT - 1;               // only the last key tile(s) hold keys >= N
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        s = mfma_bf16(kfr[kk], qf[j][kk], s);
-                        dp = mfma_bf16(vfr[kk], gf[j][kk], dp);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float pr = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lq[j]));
-                        if (tail && (2 * ks + t) * 16 + g * 4 + e >= N) pr = 0.f;
-                        ds[j][t][e] = pr * (dp[e] - dq[j]);
-                    }
-                }
-            }
-            const uint4 db0 = pack8(ds[0][0], ds[0][1]), db1 = pack8(ds[1][0], ds[1][1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint4 kt_ = tr8(Ks, (2 * ks * 16 + g * 4 + (l15 >> 2)) * KP + (dt * 16 + (l15 & 3) * 4) * 2, 16 * KP);
-                acc[0][dt] = mfma_bf16(kt_, db0, acc[0][dt]);
-                acc[1][dt] = mfma_bf16(kt_, db1, acc[1][dt]);
-            }
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma_bf16(kt_[dt], db, acc[dt]);
         }
+        if (qrow < N) {
+            bf16_t* r = dqb + (size_t)qrow * ld + g * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int qrow = (2 * qp + j) * 16 + l15;
-            if (qrow < N) {
-                bf16_t* r = dqb + (size_t)qrow * ld + g * 4;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    *reinterpret_cast<uint2*>(r + dt * 16) = make_uint2(pack_bf16x2(acc[j][dt][0] * p.scale, acc[j][dt][1] * p.scale),
-                                                                        pack_bf16x2(acc[j][dt][2] * p.scale, acc[j][dt][3] * p.scale));
-            }
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(r + dt * 16) = make_uint2(pack_bf16x2(acc[dt][0] * p.scale, acc[dt][1] * p.scale),
+                                                                    pack_bf16x2(acc[dt][2] * p.scale, acc[dt][3] * p.scale));
         }
     }
 
-    // ---- phase B: dK, dV of key tiles 2 w, 2 w + 1
-    for (int kp = wave; kp < nPair; kp += BWD2_WAVES) {
-        uint4 kf[2][2], vf[2][2];
-        bool kok[2];
-        f32x4 dk[2][4], dv[2][4];
+    // ---- phase B: dK, dV.  wave <- key tile; per query-tile pair: S, dP (D layout: rows q g*4+e, col key l15); the same read-ahead
+    for (int kt = wave; kt < nKT; kt += BWD_WAVES) {
+        const int krow = kt * 16 + l15;
+        const bool kok = krow < N;
+        uint4 kf[2], vf[2];
+        frag(Ks, Vs, krow, kf, vf);
+        f32x4 dk[4], dv[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int krow = (2 * kp + j) * 16 + l15;
-            kok[j] = krow < N;
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        uint4 q0[2], g0[2], q1[2], g1[2];
+        frag(Qs, Gs, l15, q0, g0);
+        auto tileB = [&](const uint4 (&qfr)[2], const uint4 (&gfr)[2], int qtile, f32x4& pr, f32x4& ds) {
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qtile * 16 + g * 4);
+            const float4 d4 = *reinterpret_cast<const float4*>(dq_s + qtile * 16 + g * 4);
+            f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                kf[j][kk] = ldsq(Ks, krow * KP + (g + 4 * kk) * 16);
-                vf[j][kk] = ldsq(Vs, krow * KP + (g + 4 * kk) * 16);
+                s = mfma_bf16(qfr[kk], kf[kk], s);
+                dp = mfma_bf16(gfr[kk], vf[kk], dp);
             }
+            const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        }
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], c, -le[e]));                  // lse = +inf beyond N -> 0
+                pr[e] = pe;
+                ds[e] = pe * (dp[e] - de[e]);
+            }
+        };
+#pragma unroll 1
         for (int qs = 0; qs < nPair; ++qs) {
-            f32x4 pr[2][2], ds[2][2];
+            const int a = (2 * qs * 16 + g * 4 + (l15 >> 2)) * KP + (l15 & 3) * 8;
+            frag(Qs, Gs, (2 * qs + 1) * 16 + l15, q1, g1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 pr[2], ds[2];
+            tileB(q0, g0, 2 * qs, pr[0], ds[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (qs + 1 < nPair) frag(Qs, Gs, (2 * qs + 2) * 16 + l15, q0, g0);
+            uint4 gt[2], qt_[2];                                    // (the first half of the pair's transposed dO / Q fragments: requested behind the read-ahead, used last)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int qr = (2 * qs + t) * 16 + l15;
-                uint4 qfr[2], gfr[2];
+            for (int dt = 0; dt < 2; ++dt) { gt[dt] = tr8(Gs, a + dt * 32, 16 * KP); qt_[dt] = tr8(Qs, a + dt * 32, 16 * KP); }
+            __builtin_amdgcn_sched_barrier(0);
+            tileB(q1, g1, 2 * qs + 1, pr[1], ds[1]);
+            const uint4 pb = pack8(pr[0], pr[1]), db = pack8(ds[0], ds[1]);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    qfr[kk] = ldsq(Qs, qr * KP + (g + 4 * kk) * 16);
-                    gfr[kk] = ldsq(Gs, qr * KP + (g + 4 * kk) * 16);
-                }
-                const int q0 = (2 * qs + t) * 16 + g * 4;
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);
-                const float4 d4 = *reinterpret_cast<const float4*>(dq_s + q0);
-                const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        s = mfma_bf16(qfr[kk], kf[j][kk], s);
-                        dp = mfma_bf16(gfr[kk], vf[j][kk], dp);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pe = kok[j] ? __builtin_amdgcn_exp2f(fmaf(s[e], c, -le[e])) : 0.f;      // lse = +inf beyond N -> 0
-                        pr[j][t][e] = pe;
-                        ds[j][t][e] = pe * (dp[e] - de[e]);
-                    }
-                }
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = mfma_bf16(gt[dt], pb, dv[dt]);
+                dk[dt] = mfma_bf16(qt_[dt], db, dk[dt]);
             }
-            const uint4 pb0 = pack8(pr[0][0], pr[0][1]), db0 = pack8(ds[0][0], ds[0][1]);
-            const uint4 pb1 = pack8(pr[1][0], pr[1][1]), db1 = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+            for (int dt = 2; dt < 4; ++dt) {
+                dv[dt] = mfma_bf16(tr8(Gs, a + dt * 32, 16 * KP), pb, dv[dt]);
+                dk[dt] = mfma_bf16(tr8(Qs, a + dt * 32, 16 * KP), db, dk[dt]);
+            }
+        }
+        if (kok) {
+            bf16_t* r = dqb + (size_t)krow * ld + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int a = (2 * qs * 16 + g * 4 + (l15 >> 2)) * KP + (dt * 16 + (l15 & 3) * 4) * 2;
-                const uint4 gt = tr8(Gs, a, 16 * KP), qt = tr8(Qs, a, 16 * KP);
-                dv[0][dt] = mfma_bf16(gt, pb0, dv[0][dt]);
-                dk[0][dt] = mfma_bf16(qt, db0, dk[0][dt]);
-                dv[1][dt] = mfma_bf16(gt, pb1, dv[1][dt]);
-                dk[1][dt] = mfma_bf16(qt, db1, dk[1][dt]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int krow = (2 * kp + j) * 16 + l15;
-            if (kok[j]) {
-                bf16_t* r = dqb + (size_t)krow * ld + g * 4;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    *reinterpret_cast<uint2*>(r + D + dt * 16) = make_uint2(pack_bf16x2(dk[j][dt][0] * p.scale, dk[j][dt][1] * p.scale),
-                                                                            pack_bf16x2(dk[j][dt][2] * p.scale, dk[j][dt][3] * p.scale));
-                    *reinterpret_cast<uint2*>(r + 2 * D + dt * 16) = make_uint2(pack_bf16x2(dv[j][dt][0], dv[j][dt][1]), pack_bf16x2(dv[j][dt][2], dv[j][dt][3]));
-                }
+                *reinterpret_cast<uint2*>(r + D + dt * 16) = make_uint2(pack_bf16x2(dk[dt][0] * p.scale, dk[dt][1] * p.scale),
+                                                                        pack_bf16x2(dk[dt][2] * p.scale, dk[dt][3] * p.scale));
+                *reinterpret_cast<uint2*>(r + 2 * D + dt * 16) = make_uint2(pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3]));
             }
         }
     }
@@ -639,12 +654,13 @@ extern "C" int clhip_attn_bwd(const void* qkv, const void* out, const float* lse
         static bool done = false;
         if (!done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
             done = true;
         }
-        const char* v = clhip_cfg("ATTN_BWD");                 // 1: one tile per wave (rounds 2-5), 2: two (default); looked up per call: the tests compare the two
-        if (v != nullptr && atoi(v) == 1) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(64 * BWD_WAVES), smem, s, p);
-        else hipLaunchKernelGGL(attn_bwd_mfma2_kernel, dim3(B * H), dim3(64 * BWD2_WAVES), smem, s, p);
+        // ATTN_BWD=1: the rounds 2-5 kernel at every token count (looked up per call: the tests compare the two bit for bit); default: the round-6 form at 197 / 222 tokens
+        const char* v = clhip_cfg("ATTN_BWD");
+        if ((v != nullptr && atoi(v) == 1) || NP2 != 224) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(64 * BWD_WAVES), smem, s, p);
+        else hipLaunchKernelGGL(attn_bwd_mfma3_kernel<7>, dim3(B * H), dim3(64 * BWD_WAVES), smem, s, p);
     } else {
         CLHIP_CHECK_ARG(dsum_ws != nullptr);
         const int rows = B * H * N;
