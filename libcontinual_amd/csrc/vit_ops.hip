@@ -16,28 +16,35 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// one wave per row; a lane owns chunks lane, lane+64, ... of 8 elements (D % 8 == 0, D <= 2048)
-template <typename T>
+// one wave per row; a lane owns chunks lane, lane+64, ... of 8 elements (D % 8 == 0, D <= 512 NC: NC = 2 keeps ViT-B's 768 columns at half the registers)
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nch = D >> 3;
-    float v[4][8];
+    float v[NC][8], gm[NC][8], bt[NC][8];
     float s = 0.f;
+    // (every global read of the row's lifetime is requested up front: gamma / beta behind the two reductions were a second dependent round trip per wave)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             load8<T>(x + (size_t)row * D + c * 8, v[i]);
+            load8<float>(gamma + c * 8, gm[i]);
+            load8<float>(beta + c * 8, bt[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+        if (lane + 64 * i < nch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[i][j];
         }
-    }
     const float mu = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NC; ++i)
         if (lane + 64 * i < nch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
@@ -45,37 +52,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const float rs = rsqrtf(wave_sum(q) / D + eps);
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
-            float gm[8], bt[8], o[8];
-            load8<float>(gamma + c * 8, gm);
-            load8<float>(beta + c * 8, bt);
+            float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * gm[j] + bt[j];
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * gm[i][j] + bt[i][j];
             store8<T>(y + (size_t)row * D + c * 8, o);
         }
     }
 }
 
 // g[row] += LN'(x[row])^T dy[row]   (input gradient only; gamma frozen)
-template <typename T>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ g, int M, int D) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nch = D >> 3;
     const float mu = mean[row], rs = rstd[row];
-    float dg[4][8], xh[4][8];
+    float dg[NC][8], xh[NC][8], go[NC][8];
     float s1 = 0.f, s2 = 0.f;
+    // (the accumulated-into gradient row is requested with dy and x: behind the two reductions it was a second dependent round trip per wave)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             float d[8], xv[8], gm[8];
             load8<T>(dy + (size_t)row * D + c * 8, d);
             load8<T>(x + (size_t)row * D + c * 8, xv);
             load8<float>(gamma + c * 8, gm);
+            load8<T>(g + (size_t)row * D + c * 8, go[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 dg[i][j] = d[j] * gm[j];
@@ -88,13 +95,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             float o[8];
-            load8<T>(g + (size_t)row * D + c * 8, o);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += rs * (dg[i][j] - s1 - xh[i][j] * s2);
+            for (int j = 0; j < 8; ++j) o[j] = go[i][j] + rs * (dg[i][j] - s1 - xh[i][j] * s2);
             store8<T>(g + (size_t)row * D + c * 8, o);
         }
     }
@@ -684,9 +690,14 @@ extern "C" int clhip_ln_fwd(const void* x, const float* gamma, const float* beta
                             void* stream) {
     CLHIP_CHECK_ARG(x && gamma && beta && y && M > 0 && D % 8 == 0 && D <= 2048 && (mean == nullptr) == (rstd == nullptr));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DT_DISPATCH(dtype,
-                hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps),
-                hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps));
+    if (D <= 1024)
+        DT_DISPATCH(dtype,
+                    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 2>), dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps),
+                    hipLaunchKernelGGL((ln_fwd_kernel<float, 2>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps));
+    else
+        DT_DISPATCH(dtype,
+                    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 4>), dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps),
+                    hipLaunchKernelGGL((ln_fwd_kernel<float, 4>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps));
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
@@ -695,9 +706,14 @@ extern "C" int clhip_ln_bwd(const void* dy, const void* x, const float* gamma, c
                             void* stream) {
     CLHIP_CHECK_ARG(dy && x && gamma && mean && rstd && g && M > 0 && D % 8 == 0 && D <= 2048);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DT_DISPATCH(dtype,
-                hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)g, M, D),
-                hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)g, M, D));
+    if (D <= 1024)
+        DT_DISPATCH(dtype,
+                    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 2>), dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)g, M, D),
+                    hipLaunchKernelGGL((ln_bwd_kernel<float, 2>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)g, M, D));
+    else
+        DT_DISPATCH(dtype,
+                    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 4>), dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)g, M, D),
+                    hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)g, M, D));
     CLHIP_LAUNCH_CHECK();
     return CLHIP_OK;
 }
