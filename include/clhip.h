@@ -511,9 +511,6 @@ const char* clhip_config_get(const char* key);
  * supported (tests); -1 = from $CLHIP_GEMM8.  Same epilogues as clhip_gemm_nt's other kernels
  * (core/model/backbone/transformer.py:172, 194, 1259-1271). */
 void clhip_gemm8_config(int mode);
-/* stream-K last round of gemm8.hip ($CLHIP_GEMM8_SK=1; off by default: measured slower than the whole-rounds + tail split, profiles/r05_gemm8_notes.md section 7): 1 if a launch on the current device ever gave up waiting for another workgroup's span (a bounded wait: a wrong
- * tile instead of a hang; never observed), else 0.  Synchronises the device.  Test / diagnostics hook. */
-int clhip_gemm8_sk_status(void);
 /* workgroups the LDS-DMA weight-gradient kernel (wgrad4.hip) aims for: 0 = the default (160 -- 128 until round 4 --, chosen for the training step, where the
  * launch shares the chip with the dgrad / BatchNorm chain of the caller's stream; $CLHIP_WGRAD_TARGET), 256 = one per CU (the kernel
  * alone: bench.py's `full_chip` figures).  The scratch size (clhip_conv_wgrad_ws_bytes) follows the setting. */

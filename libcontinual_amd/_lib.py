@@ -161,7 +161,6 @@ _PROTOS = {
     "clhip_conv_fwd_acc_bn_input_wt": (_i, [_p, _p, _p, _p, _p, _p, _i] + [_i] * 9 + [_p]),
     "clhip_gram_accum_batched": (_i, [_p, C.c_size_t, _i, _p, _i, _i, _i, _p]),
     "clhip_gemm8_config": (None, [_i]),
-    "clhip_gemm8_sk_status": (_i, []),
     "clhip_wgrad4_config": (None, [_i]),
     "clhip_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clhip_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -31,9 +31,6 @@ struct GemmParams {
     // in part[y][M][N]; splitk_epilogue_kernel sums the slices in index order and applies the epilogue -- bitwise reproducible
     int ksplit = 1;
     float* part = nullptr;
-    // round 5, opt-in (CLHIP_GEMM_SPLITK_FUSED=1; measured slower, see launch_mt): with `tickets` (one zeroed int per output tile) the LAST of a tile's K slices to finish
-    // sums the slices -- all of them, from memory, in index order: still bitwise reproducible -- and runs the epilogue itself: no second launch
-    int* tickets = nullptr;
 };
 
 template <typename T> struct Chunk;
@@ -300,43 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && WM * WN == 4) ? 2 
                 if (n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = acc[i][j];
             }
         }
-        if (p.tickets == nullptr) return;
-        // publish the slice, draw a ticket (cdna_hip_programming.md section 5: plain stores -> every wave waits -> barrier -> ONE agent-scope release, then the counter)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int t = __hip_atomic_fetch_add(p.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = t == p.ksplit - 1;
-            if (last) {
-                __hip_atomic_store(p.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm * 16 * MT + i * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * 16 * NT + j * 16 + g * 4;
-                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (m < p.M && n < p.N) {
-                    const float* src = p.part + (size_t)m * p.N + n;
-                    a = *reinterpret_cast<const f32x4*>(src);
-                    for (int y = 1; y < p.ksplit; ++y) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)y * p.M * p.N);
-                        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
-                    }
-                }
-                acc[i][j] = a;
-            }
-        }
-        __syncthreads();                                             // the flag word is LDS the epilogue stages through
+        return;
     }
     // 256 x 256 bf16 tile: the results leave through LDS.  A lane's accumulators are 4 columns of 16 different rows, so direct
     // stores (and the H loads of the x H epilogue) touch 16 cache lines per instruction with 32 bytes each -- the GELU epilogue
@@ -463,7 +424,7 @@ template <typename T, int EPI, int MT, int NT, int WM = 2, int WN = 2> int launc
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, MT, NT, WM, WN>), dim3(tiles, p.ksplit), dim3(64 * WM * WN), smem, s, p);
     CLHIP_LAUNCH_CHECK();
-    if (p.ksplit > 1 && p.tickets == nullptr) {
+    if (p.ksplit > 1) {
         const long long n = (long long)p.M * (p.N >> 2);
         hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
         CLHIP_LAUNCH_CHECK();
@@ -483,7 +444,7 @@ float* splitk_scratch(hipStream_t s, size_t bytes) {
     (void)hipGetDevice(&dev);
     Slot* sl = nullptr;
     for (int i = 0; i < nslots; ++i) if (slots[i].s == s && slots[i].dev == dev) sl = &slots[i];
-    bytes += 4096;                                            // the first 4 KB: 1024 tile tickets, zeroed here once and left at zero by every launch
+    bytes += 4096;                                            // (the first 4 KB stay unused: round 5's fused variant kept its tile tickets there)
     if (sl != nullptr && sl->n >= bytes) return sl->p;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
@@ -548,11 +509,8 @@ template <typename T, int EPI> int launch_mt(const GemmParams& p, hipStream_t s,
                     if (ws != nullptr) {
                         GemmParams q = p;
                         q.ksplit = ks; q.part = ws + 1024; q.group_m = 1;
-                        // CLHIP_GEMM_SPLITK_FUSED=1: the last slice of a tile to finish reduces and stores it (one launch instead of two).  Measured SLOWER and therefore off:
-                        // [3552 x 768 x 3072] 34.7 -> 54.7 us, the L2P batch-16 step 5.05 -> 5.75 ms -- three 64-KB slices per tile read behind agent-scope release /
-                        // acquire fences cost the reducer more than the second launch does (the guide's price list says as much: "a few tens of KB" per tile at most)
-                        static const bool fused = clhip_cfg("GEMM_SPLITK_FUSED") != nullptr && atoi(clhip_cfg("GEMM_SPLITK_FUSED")) != 0;
-                        if (fused && t128 <= 1024) q.tickets = reinterpret_cast<int*>(ws);
+                        // (round 5 also had the LAST slice of a tile reduce and store it -- one launch instead of two; measured slower, [3552 x 768 x 3072] 34.7 -> 54.7 us:
+                        //  three 64-KB slices per tile read behind agent-scope fences cost the reducer more than the second launch does; removed in round 6)
                         return launch<T, EPI, 4, 4>(q, s);
                     }
                 }

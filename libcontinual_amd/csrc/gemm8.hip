@@ -29,7 +29,6 @@
 //
 // Epilogues as gemm.hip / gemm5.hip.  Replaces F.linear on the ViT path (core/model/backbone/transformer.py:172, 194, 1259-1271).
 #include <stdlib.h>
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -50,10 +49,6 @@ struct Gemm8Params {
     int nt, items, ipx;          // n tiles, tiles, tiles per XCD
     int group_m, panels;         // rasterisation: tiles are numbered column-major inside groups of group_m row panels (1: row-major)
     int max_nmy, shift;          // tiles of the busiest workgroup; start delay (shader cycles) of the workgroups that walk fewer tiles (see the kernel)
-    // stream-K last round (sk_tiles > 0): the tiles behind the last whole round, ids [sk_first, sk_first + sk_tiles), are cut along K into spans of sk_L K tiles over
-    // all workgroups; partial accumulators go through sk_ws ([tile][contributor <= sk_cap][8 blocks][512 threads][16 floats]), sk_cnt[tile] counts the published ones
-    int sk_tiles, sk_first, sk_L, sk_cap;
-    float* sk_ws; int* sk_cnt; int* sk_err;
     int opt;                     // experiments (CLHIP_GEMM8_OPT): bit 0 = the two wave halves realign at a tile's end and store at the same time (measured: no gain, qkv 101 -> 107 us)
 };
 
@@ -136,18 +131,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int t_lo = xcd * p.ipx, t_hi = min(p.items, t_lo + p.ipx);
     const int ndp = t_lo + slot0 < t_hi ? (t_hi - t_lo - slot0 + per_xcd - 1) / per_xcd : 0;      // whole tiles of the data-parallel rounds
-    // stream-K spans: workgroup wq (numbered so that an XCD's workgroups are neighbours) owns K-tile iterations [wq * L, (wq + 1) * L) of the left-over tiles: at most
-    // the end of one tile and the beginning of the next (L < K tiles per tile; L, the K tiles per tile and therefore every cut are even)
-    int sk_tile[2] = {0, 0}, sk_kb[2] = {0, 0}, sk_kc[2] = {0, 0}, nsk = 0;
-    const int wq = xcd * per_xcd + slot0;
-    if (p.sk_tiles > 0) {
-        const int q0 = wq * p.sk_L, q1 = min(q0 + p.sk_L, p.sk_tiles * nkt);
-        if (q0 < q1) {
-            sk_tile[0] = q0 / nkt; sk_kb[0] = q0 - sk_tile[0] * nkt; sk_kc[0] = min(nkt - sk_kb[0], q1 - q0); nsk = 1;
-            if (q0 + sk_kc[0] < q1) { sk_tile[1] = sk_tile[0] + 1; sk_kb[1] = 0; sk_kc[1] = q1 - q0 - sk_kc[0]; nsk = 2; }
-        }
-    }
-    const int nmy = ndp + nsk;
+    const int nmy = ndp;
     if (nmy == 0) return;
     // All workgroups start together and stay in lockstep from tile to tile: the chip alternates between "every CU multiplies" and "every CU stores its tile"
     // (fc1 + GELU + GELU': 62 MB per round, the HBM write rate fully exposed).  A workgroup that walks FEWER tiles than the busiest one has the time of a tile to
@@ -172,13 +156,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
         }
     };
 
-    // segment k of this workgroup: a whole tile of the data-parallel rounds (k < ndp) or a stream-K span
-    auto seg_of = [&](int k, int& m0, int& n0, int& kb, int& kc) {
-        if (k < ndp) { tile_of(k, m0, n0); kb = 0; kc = nkt; return; }
-        const int t = p.sk_first + sk_tile[k - ndp];
-        const int mt = t / p.nt;
-        m0 = mt * BM; n0 = (t - mt * p.nt) * BN; kb = sk_kb[k - ndp]; kc = sk_kc[k - ndp];
-    };
+    // segment k of this workgroup: a whole tile (all of K).  (Round 5's opt-in stream-K last round cut the left-over tiles into K spans here; it measured slower than
+    // whole rounds + a tail launch -- profiles/r05_gemm8_notes.md section 7 -- and was removed in round 6.)
+    auto seg_of = [&](int k, int& m0, int& n0, int& kb, int& kc) { tile_of(k, m0, n0); kb = 0; kc = nkt; };
 
     // ---- DMA cursor: half tiles are issued in the order W0 X0 W1 X1 of K tile 0, 1, ... of tile 0, 1, ...; it advances behind every X1
     // (at most two K tiles ahead of the multiplying phases and K >= 256, so it enters tile k + 1 while tile k is being multiplied: the bases of the
@@ -379,32 +359,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
         }
 #undef KTILE8
 #undef MFMA8
-        if (k == nmy - 1 || k >= ndp || (p.opt & 1)) { if (!lag) __builtin_amdgcn_s_barrier(); aligned = true; }      // the barrier waves 4-7 still owe
-
-        if (k >= ndp) {
-            // ---- stream-K span: the raw accumulators of this span go to the workspace (every thread its 8 blocks of 16 floats, 64 contiguous bytes each) and are
-            //      published; NOTHING is waited for here (a wait between a workgroup's two spans would chain the tiles one behind the other) -- see "phase 2" below
-            const int sk = sk_tile[k - ndp];
-            const int wf = (sk * nkt) / p.sk_L;              // first contributor of the tile
-            float* slab = p.sk_ws + ((size_t)(sk * p.sk_cap + (wq - wf)) * 8) * (512 * 16) + (size_t)tid * 16;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float* d = slab + (size_t)(i * 2 + j) * (512 * 16);
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        *reinterpret_cast<f32x4*>(d + 4 * q4) = (f32x4){acc[j][i][4 * q4], acc[j][i][4 * q4 + 1], acc[j][i][4 * q4 + 2], acc[j][i][4 * q4 + 3]};
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(p.sk_cnt + sk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            continue;
-        }
+        if (k == nmy - 1 || (p.opt & 1)) { if (!lag) __builtin_amdgcn_s_barrier(); aligned = true; }      // the barrier waves 4-7 still owe
 
         // ---- epilogue of a whole tile
 #pragma unroll
@@ -413,43 +368,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const Gemm8Params p) {
             for (int j = 0; j < 2; ++j) epi_block(acc[j][i], m0, n0, i, j);
     }
 
-    // ---- stream-K, phase 2: every span of the launch has been published or will be without waiting for anything (above), so waiting here cannot deadlock while
-    //      all workgroups are resident (one per CU, grid <= 256).  A tile's contributors are the workgroups whose spans meet it, numbered in K order; contributor jc
-    //      reduces the blocks b with b % c == jc: it sums the c partial blocks in contributor order (a fixed order: the result does not depend on who arrives when)
-    //      and runs the block's epilogue.
-    for (int e = 0; e < nsk; ++e) {
-        const int sk = sk_tile[e];
-        const int wf = (sk * nkt) / p.sk_L;
-        const int wl = min((sk * nkt + nkt - 1) / p.sk_L, (p.sk_tiles * nkt - 1) / p.sk_L);
-        const int c = wl - wf + 1, jc = wq - wf;
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(p.sk_cnt + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 22)) { __hip_atomic_store(p.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // never in a correct launch: no hang
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        const int t = p.sk_first + sk, mt = t / p.nt;
-        const int m0 = mt * BM, n0 = (t - mt * p.nt) * BN;
-        const float* tile_ws = p.sk_ws + (size_t)sk * p.sk_cap * 8 * (512 * 16) + (size_t)tid * 16;
-#pragma unroll 1
-        for (int b = jc; b < 8; b += c) {
-            f32x16 v;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = 0.f;
-            for (int jj = 0; jj < c; ++jj) {
-                const float* src = tile_ws + (size_t)(jj * 8 + b) * (512 * 16);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * q4);
-                    v[4 * q4] += x[0]; v[4 * q4 + 1] += x[1]; v[4 * q4 + 2] += x[2]; v[4 * q4 + 3] += x[3];
-                }
-            }
-            epi_block(v, m0, n0, b >> 1, b & 1);
-        }
-    }
     wait_vm8<0>();                                           // the zero-fill requests behind the last tile write LDS too: nothing may be in flight when the wave ends
 #undef IC
 }
@@ -505,68 +423,15 @@ int clhip_gemm8_rows(int M, int N, int K, int lda, int ldb, int ldc, int ldr, in
     if (tiles * 100 >= rounds * 256 * min_fill) return rounds * (K / 64) >= min_work ? M : 0;           // the last round is (nearly) full
     if (!split || tiles < 256) return 0;
     if ((tiles / 256) * (K / 64) < min_work) return 0;
-    const int sk = clhip_cfg("GEMM8_SK") ? atoi(clhip_cfg("GEMM8_SK")) : 0;
-    if (sk) return M;                                                      // the left-over tiles run as a stream-K round inside the launch (sk_setup)
     const int full_panels = (int)((tiles / 256) * 256 / nt);               // whole rounds (the last panel of a round may leave a few tiles unused)
     return full_panels * 256;
 }
 extern "C" void clhip_gemm8_config(int mode) { g_mode8 = mode; }
 
-// ---- stream-K last round (CLHIP_GEMM8_SK=1).  With T tiles and 256 workgroups the first 256 * (T / 256) tiles run as whole rounds; the R left-over tiles are cut
-// along K into spans of L K tiles (even; at least R * nkt / 256 so that 256 spans cover them, at least nkt / 7 so that a tile has at most 8 contributors), one span
-// per workgroup.  Workspace and counters are per device, allocated on first use (never inside a stream capture: such a launch runs without the stream-K round).
-namespace {
-struct SkState { float* ws = nullptr; size_t ws_bytes = 0; int* cnt = nullptr; };       // cnt[0 .. 255] published spans per tile, cnt[256] the time-out flag
-SkState g_sk[16];
-
-int sk_setup(Gemm8Params& p, hipStream_t st) {
-    const int sk_mode = clhip_cfg("GEMM8_SK") ? atoi(clhip_cfg("GEMM8_SK")) : 0;         // (looked up per launch: tests flip it with clhip_config)
-    const int T = p.items, F = T / 256, R = T - 256 * F;
-    if (sk_mode == 0 || F < 1 || R == 0) return CLHIP_OK;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return CLHIP_OK;
-    const int nkt = p.K / 64;
-    int L = 2 * ((R * nkt + 511) / 512);
-    if (L < 2 * ((nkt + 13) / 14)) L = 2 * ((nkt + 13) / 14);
-    const int cap = (nkt + L - 1) / L + 1 < 8 ? (nkt + L - 1) / L + 1 : 8;
-    const size_t need = (size_t)R * cap * 8 * 512 * 16 * sizeof(float);
-    static std::mutex mu;                                    // (launches of several host threads on one device: one of them allocates)
-    std::lock_guard<std::mutex> lk(mu);
-    SkState& S = g_sk[dev];
-    if (S.cnt == nullptr || S.ws_bytes < need) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return CLHIP_OK;      // no allocation inside a capture
-        (void)hipDeviceSynchronize();                        // an older launch may still use the smaller workspace
-        if (S.ws) (void)hipFree(S.ws);
-        S.ws = nullptr; S.ws_bytes = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&S.ws), need) != hipSuccess) { (void)hipGetLastError(); return CLHIP_OK; }      // no memory: the plain rounds
-        S.ws_bytes = need;
-        if (S.cnt == nullptr) {
-            if (hipMalloc(reinterpret_cast<void**>(&S.cnt), 257 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); S.cnt = nullptr; return CLHIP_OK; }
-            (void)hipMemset(S.cnt, 0, 257 * sizeof(int));
-        }
-    }
-    if (hipMemsetAsync(S.cnt, 0, 256 * sizeof(int), st) != hipSuccess) { clhip_set_error("gemm8: cannot reset the stream-K counters"); return CLHIP_EHIP; }
-    p.sk_tiles = R; p.sk_first = 256 * F; p.sk_L = L; p.sk_cap = cap;
-    p.sk_ws = S.ws; p.sk_cnt = S.cnt; p.sk_err = S.cnt + 256;
-    p.items = 256 * F; p.ipx = 32 * F; p.max_nmy = F; p.shift = 0; p.group_m = 1;
-    return CLHIP_OK;
-}
-}  // namespace
-
-// 1 if a stream-K launch on the current device ever gave up waiting for a span (it then stored a wrong tile instead of hanging); tests assert 0.  Synchronises.
-extern "C" int clhip_gemm8_sk_status(void) {
-    int dev = 0, flag = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || g_sk[dev].cnt == nullptr) return 0;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&flag, g_sk[dev].cnt + 256, sizeof(int), hipMemcpyDeviceToHost);
-    return flag;
-}
-
 int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias, const void* R, void* H, int M, int N, int K,
                        int lda, int ldb, int ldc, int ldr, int ldh, int epilogue, hipStream_t st) {
     Gemm8Params p{static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), static_cast<bf16_t*>(C), bias, static_cast<const bf16_t*>(R),
-                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+                  static_cast<bf16_t*>(H), M, N, K, lda, ldb, ldc, ldr, ldh, 0, 0, 0, 1, 0, 0, 0, 0};
     static const int opt = clhip_cfg("GEMM8_OPT") ? atoi(clhip_cfg("GEMM8_OPT")) : 0;
     p.opt = opt;
     p.nt = N / 256;
@@ -583,7 +448,6 @@ int clhip_gemm8_launch(const void* A, const void* B, void* C, const float* bias,
         static const int shift_kt = clhip_cfg("GEMM8_SHIFT") ? atoi(clhip_cfg("GEMM8_SHIFT")) : 2000;      // shader cycles per K tile: about half of what a K tile takes
         p.shift = p.max_nmy > 1 ? (K / 64) * shift_kt : 0;
     }
-    if (int rc = sk_setup(p, st)) return rc;
     switch (epilogue) {
         case EPI_NONE: return launch8<EPI_NONE>(p, st);
         case EPI_BIAS: return launch8<EPI_BIAS>(p, st);

@@ -149,56 +149,6 @@ def test_gemm8_whole_rounds_and_a_register_staged_tail(M, N, K, epi):
         _lib.lib().clhip_gemm8_config(-1)
 
 
-@pytest.mark.parametrize("M,N,K", [(8960, 3072, 768), (256 * 86 + 100, 768, 512), (256 * 70 + 131, 1024, 512), (25216, 768, 3072), (256 * 197, 768, 768)])
-@pytest.mark.parametrize("epi", [0, 2, 3, 4])
-def test_gemm8_stream_k_last_round(M, N, K, epi):
-    """CLHIP_GEMM8_SK=1: the tiles behind the last whole round are cut along K over all workgroups (spans of 2-8 K tiles that end inside a tile and go on in the next:
-    420 tiles -> 164 left over, 8-K-tile spans against 12 per tile; 261 -> 5 left over, four contributors each; 297 -> 41, six contributors of 8 of 48; 591 -> 79),
-    partial accumulators through the workspace, every contributor reducing its share of the 32 x 32 blocks in contributor order: same results as the plain rounds to
-    fp32 summation order, twice the same bits, no wait ever timed out"""
-    L = _lib.lib()
-    L.clhip_gemm8_config(2)
-    L.clhip_config(b"GEMM8_SK", b"1")
-    try:
-        A = rnd(M, K, seed=21).to(torch.bfloat16)
-        B = rnd(N, K, scale=1 / math.sqrt(K), seed=22).to(torch.bfloat16)
-        bias = rnd(N, seed=23)
-        R = rnd(M, N, seed=24).to(torch.bfloat16)
-        Hin = rnd(M, N, seed=25).to(torch.bfloat16)
-        outs = []
-        for rep in range(2):
-            Cc = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            Hout = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            Hp = Hout if epi == 3 else (Hin if epi == 4 else None)
-            call("clhip_gemm_nt", p(A), p(B), p(Cc), p(bias) if epi in (1, 2, 3) else None, p(R) if epi == 2 else None, p(Hp), M, N, K, K, K, N, N, N, epi, CODE["bf16"], st())
-            torch.cuda.synchronize()
-            outs.append((Cc, Hout))
-        assert L.clhip_gemm8_sk_status() == 0
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])           # fixed reduction order
-        Cc, Hout = outs[0]
-        ref = A.double() @ B.double().T
-        if epi in (1, 2, 3):
-            ref = ref + bias.double()
-        if epi == 2:
-            ref = ref + R.double()
-        pre = ref.clone()
-        if epi == 3:
-            ref = F.gelu(ref)
-            pre = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
-        if epi == 4:
-            ref = ref * Hin.double()
-        for lo in range(0, M, 2048):                          # row blocks: a wrong stream-K tile would hide in the norm of the whole
-            assert relerr(Cc[lo:min(M, lo + 2048)], ref[lo:min(M, lo + 2048)]) < TOL["bf16"], lo
-        assert float((Cc[M].float() - 7.0).abs().max()) == 0.0
-        if epi == 3:
-            for lo in range(0, M, 2048):
-                assert relerr(Hout[lo:min(M, lo + 2048)], pre[lo:min(M, lo + 2048)]) < TOL["bf16"], lo
-            assert float((Hout[M].float() - 7.0).abs().max()) == 0.0
-    finally:
-        L.clhip_gemm8_config(-1)
-        L.clhip_config(b"GEMM8_SK", b"0")
-
-
 @pytest.mark.parametrize("M,N,K", [(3552, 768, 3072), (3552, 768, 2304), (777, 768, 1536), (130, 256, 4096)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
 def test_gemm_nt_split_k(M, N, K, epi):
