@@ -194,6 +194,7 @@ class GraphedStep:
                 torch.cuda.synchronize()
                 self.disabled = True
                 if self.reducer is not None and hasattr(self.reducer, "_early"):
+                    self.reducer._rest = {}
                     self.reducer._early.clear()   # (segment hooks that fired inside the dropped capture left offsets and Work objects of an invalidated capture)
                 for o in self.owners:             # launches "made" during the dropped capture never ran: the weight copies they were to refresh are stale
                     o.mark_params_modified()

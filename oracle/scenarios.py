@@ -41,6 +41,24 @@ class ListLoader:
         return len(self.batches)
 
 
+_PNG_CACHE = {}
+
+
+def _decoded(path):
+    """the decoded image of a scenario file (the files of a data root never change; an accuracy scenario reads each of its 6 000 files ~12 times per run and the
+    GPU suite makes up to 16 runs per scenario: half of a run's wall-clock was PNG decoding).  Transforms get the cached PIL image and must not modify it."""
+    st = os.stat(path)
+    key = (path, st.st_mtime_ns, st.st_size)                # (a rewritten file is a different entry)
+    img = _PNG_CACHE.get(key)
+    if img is None:
+        from PIL import Image
+        img = Image.open(path).convert("RGB")
+        img.load()
+        if len(_PNG_CACHE) < 20000:
+            _PNG_CACHE[key] = img
+    return img
+
+
 class PngDataset(torch.utils.data.Dataset):
     """Class-folder style dataset over PNG files (reference layout docs/tutorials/en/data_module_en.md:15-39):
     `images` are paths relative to data_root/mode, `trfms` maps a PIL image to a tensor."""
@@ -53,9 +71,7 @@ class PngDataset(torch.utils.data.Dataset):
         return len(self.labels)
 
     def __getitem__(self, i):
-        from PIL import Image
-        img = Image.open(os.path.join(self.data_root, self.mode, self.images[i])).convert("RGB")
-        return {"image": self.trfms(img), "label": int(self.labels[i])}
+        return {"image": self.trfms(_decoded(os.path.join(self.data_root, self.mode, self.images[i]))), "label": int(self.labels[i])}
 
 
 def png_transform(img):

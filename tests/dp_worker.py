@@ -45,7 +45,9 @@ def main(out_dir, steps):
     st = opt.state[m.backbone._params[0]]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=flat.cpu().numpy(), head=m.classifier.weight.detach().cpu().numpy(),
              rm=rm, rm_synced=m.backbone._stats.cpu().numpy(), momentum_elems=np.array(sum(v.numel() for k, v in st.items() if k.startswith("flat_momentum"))),
-             nflat=np.array(flat.numel()))
+             nflat=np.array(flat.numel()),
+             head_grad_in_bucket=np.array(int(red._rest.get("flat") is not None and m.classifier.weight.grad is not None and
+                                              red._rest["flat"].data_ptr() <= m.classifier.weight.grad.data_ptr() < red._rest["flat"].data_ptr() + 4 * red._rest["flat"].numel())))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -97,7 +97,8 @@ def test_reduced_step_does_not_stall_under_the_queue_cap():
     streams must neither re-create the multi-stream stall of profiles/r04_stream_stall.md (4.2 ms at a cap of 6) nor push the weight-gradient stream
     onto a shared hardware queue (2.6 ms in some stream-creation orders at a cap of 2 or 3, plain steps included: round 5, profiles/r05_notes.md).
     Runs tools/dp_step_micro.py in a process of its own (the cap is read when the HIP runtime starts): several models one after the other, so that
-    later plans' streams land on every queue; every reduced step stays within 12 % of the fastest plain step and plain steps within 5 % of each other."""
+    later plans' streams land on every queue; every reduced step stays within 15 % of the fastest plain step and plain steps within 8 % of each other
+    (the stalls this guards against are +27 % and +100 %; a busy box moved a plain step by 5 % once)."""
     import os
     import re
     import subprocess
@@ -114,8 +115,8 @@ def test_reduced_step_does_not_stall_under_the_queue_cap():
     tail = [float(v) for k, v in rows if k == "tail"]
     print(f"batch-256 ResNet-18 LwF step in a rank's configuration (GPU_MAX_HW_QUEUES=4, 1-rank RCCL group): plain {plain} ms, with the overlapped all-reduce {tail} ms")
     assert len(plain) == 3 and len(tail) == 4
-    assert max(plain) < 1.05 * min(plain), plain
-    assert max(tail) < 1.12 * min(plain), (plain, tail)
+    assert max(plain) < 1.08 * min(plain), plain
+    assert max(tail) < 1.15 * min(plain), (plain, tail)
 
 
 def _make_r32(seed):

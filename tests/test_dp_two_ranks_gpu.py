@@ -51,6 +51,8 @@ def test_two_ranks_train_in_lockstep_and_match_the_emulation(tmp_path):
     assert np.abs(a["rm"] - b["rm"]).max() > 0          # ... but per-rank BatchNorm statistics (DDP-faithful)
     np.testing.assert_array_equal(a["rm_synced"], b["rm_synced"])      # until the end-of-task broadcast makes the replicas one model
     np.testing.assert_array_equal(a["rm_synced"], a["rm"])             # (rank 0's statistics)
+    # the head's bucket: the reduced bucket IS the gradient afterwards (views of it: no copy_ per tensor behind the collective)
+    assert int(a["head_grad_in_bucket"]) == 1
 
     # single-process emulation: two replicas, each on its rank's batches, gradients averaged by hand, same optimizer
     sys.path.insert(0, os.path.join(ROOT, "tests"))
