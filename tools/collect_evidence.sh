@@ -4,6 +4,7 @@
 # Outputs land in gpurun_out/; copy the ones to keep into profiles/.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export PYTHONPATH=$GRAFT_REPO_ROOT
 python tools/bench_profile.py lwf_resnet18_b50_task0 lwf_resnet18_b50_task1 ewc_resnet32_b50_task1 icarl_resnet32_b50_task1 lucir_resnet32_b50_task1 ewc_fisher_pass herding_b50 inflora_vitb16_b20_task1 l2p_vitb16_b10_task1 2>&1 | tail -12
 python tools/layer_roofline.py 30 > gpurun_out/layer_roofline.md 2>gpurun_out/layer_roofline.err
 for w in lwf_resnet18_b50_task0 lwf_resnet18_b50_task1 ewc_resnet32_b50_task1 icarl_resnet32_b50_task1 lucir_resnet32_b50_task1 ewc_fisher_pass herding_b50 inflora_vitb16_b20_task1 l2p_vitb16_b10_task1; do
@@ -25,4 +26,11 @@ python tools/gemm_vs_blas.py 30 > gpurun_out/gemm_vs_blas.txt 2>&1
 for sk in 0 1 2 4 7; do
   echo "PLAN_SKIP=$sk $(CLHIP_PLAN_SKIP=$sk python bench.py --workload ewc_resnet32_b50_task1 --batch 32 --no-cpu-baseline 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*')"
 done > gpurun_out/b32_ablation.txt
+# every dispatch of ONE step: the headline and the stage-level CifarResNet-32 step
+bash tools/step_timeline.sh "A=1" --no-secondary > gpurun_out/step_timeline.txt 2>&1
+bash tools/step_timeline.sh "A=1" --workload ewc_resnet32_b50_task1 --no-secondary > gpurun_out/step_timeline_ewc_resnet32.txt 2>&1
+python tools/attn_bwd_micro.py 128 50 > gpurun_out/attn_bwd_micro.txt 2>&1
+CLHIP_ATTN_BWD=1 python tools/attn_bwd_micro.py 128 50 >> gpurun_out/attn_bwd_micro.txt 2>&1
+python tools/ln_micro.py 25216 200 > gpurun_out/ln_micro.txt 2>&1
+python tools/bn_micro.py 64 32 256 > gpurun_out/bn_micro.txt 2>&1
 ls -la gpurun_out | tail -30

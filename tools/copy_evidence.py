@@ -7,7 +7,8 @@ for fn in glob.glob(os.path.join(G, "bench_kernel_stats_*.txt")):
     shutil.copy(fn, os.path.join(P, f"{pre}_" + os.path.basename(fn)))
 for a, b in (("bench_kernel_stats.json", "bench_kernel_stats.json"), ("roofline_pmc.json", "roofline_pmc.json"), ("layer_roofline.md", "layer_roofline.md"),
              ("gemm_vs_blas.txt", "gemm_vs_blas.txt"), ("small_kernels.txt", "small_kernels.txt"), ("inflora_task_boundary.md", "inflora_task_boundary.md"),
-             ("b32_ablation.txt", "b32_ablation.txt"), ("step_timeline.txt", "step_timeline.txt")):
+             ("b32_ablation.txt", "b32_ablation.txt"), ("step_timeline.txt", "step_timeline.txt"), ("step_timeline_ewc_resnet32.txt", "step_timeline_ewc_resnet32.txt"),
+             ("attn_bwd_micro.txt", "attn_bwd_micro.txt"), ("ln_micro.txt", "ln_micro.txt"), ("bn_micro.txt", "bn_micro.txt")):
     if os.path.exists(os.path.join(G, a)):
         shutil.copy(os.path.join(G, a), os.path.join(P, f"{pre}_{b}"))
 lines = {}
