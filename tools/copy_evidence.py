@@ -11,6 +11,17 @@ for a, b in (("bench_kernel_stats.json", "bench_kernel_stats.json"), ("roofline_
              ("attn_bwd_micro.txt", "attn_bwd_micro.txt"), ("ln_micro.txt", "ln_micro.txt"), ("bn_micro.txt", "bn_micro.txt")):
     if os.path.exists(os.path.join(G, a)):
         shutil.copy(os.path.join(G, a), os.path.join(P, f"{pre}_{b}"))
+# the GPU box has no .git: stamp the commit of the kernel sources the in-step tables were taken at (the last commit that touched csrc/ or the header -- the
+# tables' own `src_hash` says whether they still match) where bench_profile.py could not
+import subprocess
+ks = os.path.join(P, f"{pre}_bench_kernel_stats.json")
+if os.path.exists(ks):
+    d = json.load(open(ks))
+    head = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "libcontinual_amd/csrc", "include"], capture_output=True, text=True).stdout.strip() or None
+    for k, v in d.items():
+        if isinstance(v, dict) and v.get("head") is None:
+            v["head"] = head
+    json.dump(d, open(ks, "w"), indent=1)
 lines = {}
 for fn in sorted(glob.glob(os.path.join(G, "bench_*.json"))):
     key = os.path.basename(fn)[len("bench_"):-len(".json")]
