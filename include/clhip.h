@@ -222,11 +222,14 @@ int clhip_plan_feat_dim(const clhip_plan*);
  * Those launches need every workgroup resident at once, so: (1) a plan's training passes must not run on two streams concurrently, nor beside the training
  * passes of another plan of the same device on another stream (the library serialises stream switches outside a capture; inside a capture the caller must);
  * (2) several PROCESSES sharing one GPU must switch STAGE_TRAIN off.  Every in-launch wait is bounded: a violation ends in wrong results plus a sticky error
- * word, not a hung device.  clhip_plan_stage_status returns that word (0 = clean; synchronises the device -- call it at epoch / task boundaries). */
+ * word, not a hung device.  clhip_plan_stage_status returns that word (0 = clean; synchronises the device -- call it at epoch / task boundaries).
+ * The batch statistics of grids of 64+ workgroups are exchanged XCD-first (xch.h: plain stores inside an XCD's L2, the XCDs' partial sums across): that form is used
+ * only on a device where a probe at plan creation found workgroup w on the XCD of workgroup w % 8 for every grid size it tries; clhip_config("STAGE_XCH3", "0")
+ * keeps the two-hop form (another fixed summation order: the two forms agree to fp64 rounding, not bit for bit). */
 int clhip_plan_stage_status(clhip_plan*);
 /* what: 0 = units of the plan that run inside stage-level training launches, 1 / 2 = such forward / backward launches made so far (tests, diagnostics) */
 long long clhip_plan_stage_info(const clhip_plan*, int what);
-/* diagnostic (clhip_config("STAGE_TRACE", "<channels>:<convolution>")): 24 phase stamps (100-MHz ticks) of workgroup 0's last traced forward [0..7] / backward [8..23] unit */
+/* diagnostic (clhip_config("STAGE_TRACE", "<channels>:<convolution>")): 24 phase stamps (s_memtime ticks: shader cycles on this part) of workgroup 0's last traced forward [0..7] / backward [8..23] unit */
 int clhip_plan_stage_trace(clhip_plan*, unsigned long long* out24);
 /* refresh the `dtype` weight shadows from the fp32 masters (call after every optimizer step) */
 int clhip_plan_prep_weights(clhip_plan*, const float* params, void* shadow, void* stream);

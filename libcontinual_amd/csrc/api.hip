@@ -35,7 +35,7 @@ const char* const kKeys[] = {
     // tuning values
     "BN_ACC_CPT", "BN_BWD_ITERS", "CONV3_CFG", "CONV4_CFG", "CONV4_GRID", "GEMM_GROUP_M", "GEMM_MT", "IGEMM_TILE",
     "SHORTCUT_MIN_PIXELS", "STEM_GRID", "STEM_WGRAD_GRID", "WGRAD4_MIN_STEPS", "WGRAD4_MIN_TOTAL", "WGRAD_NET_GFLOP", "WGRAD_TARGET",
-    "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "DZ_BUFFERS", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "CONV9", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK", "STREAM_PROBE", "STAGE_EVAL", "STAGE_TRAIN", "STAGE_TRAIN_BWD", "STAGE_TRACE", "STAGE_ENTRY", "STAGE_ENTRY_BWD", "STAGE_POOL",
+    "CONV5_MIN_TILES", "CONV5_GRID", "CONV64_MAX_W", "CONV64_MAX_M", "CONV8", "CONV8_MIN_TILES", "DZ_BUFFERS", "CONV8_GRID", "CONV8_OPT", "CONV8_BNR", "CONV9", "PLAN_SKIP", "WT_DEBUG", "EVAL_LAZY", "GEMM_SPLITK", "STREAM_PROBE", "STAGE_EVAL", "STAGE_TRAIN", "STAGE_TRAIN_BWD", "STAGE_TRACE", "STAGE_ENTRY", "STAGE_ENTRY_BWD", "STAGE_POOL", "STAGE_XCH3",
     // micro-benchmark / ablation hooks (tools/ubench): applied immediately, not cached
     "CONV3_DEBUG", "WGRAD_DEBUG", "CONV4_FORCE_CFG", "CONV4_ENABLE", "CONV4_DEBUG", "CONV4_TRACE", "WGRAD4_TRACE", "CONV6_TRACE", "CONV8_TRACE", "CONV9_TRACE",
 };

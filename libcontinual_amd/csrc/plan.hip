@@ -43,6 +43,7 @@ int clhip_stage_eval_launch(const void* x, void* y, int N, int H, int W, int C, 
                             const float* const* mean, const float* const* var, float eps, int dtype, hipStream_t st);
 bool clhip_stage_train_supported(int N, int H, int W, int C, int nconv, int dtype);                                            // stage_train.hip
 size_t clhip_stage_train_xch_bytes(int N);
+bool clhip_stage_train_xcd_rule(bool probe);
 int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int nconv, const void* const* w, const float* const* gamma, const float* const* beta,
                                  float* const* rm, float* const* rv, float* const* mean, float* const* invstd, float* const* coef, void* const* z, void* const* y,
                                  void* const* mask, float momentum, float eps, void* xch, int trace, int entry, float* feat, int dtype, hipStream_t st);
@@ -586,6 +587,7 @@ extern "C" clhip_plan* clhip_plan_create_ex(const clhip_unit_desc* units, int n_
         p->ws_bytes = off2;
     }
     if (any_train) {
+        (void)clhip_stage_train_xcd_rule(true);                      // (once per device: may the exchange take its three-level form?  stage_train.hip)
         const size_t xb = clhip_stage_train_xch_bytes(N);
         if (hipMalloc(&p->xch, xb) != hipSuccess || hipMemset(p->xch, 0, xb) != hipSuccess) {
             (void)hipGetLastError();

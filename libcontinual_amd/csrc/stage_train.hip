@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         st_stamp(p.xb, tr, 10);
         // ---- B: the batch's sums are on their way ...
         const unsigned tag = base + (unsigned)(p.nconv - 1 - cv) + 1u;
-        xch_begin(p.xb, img, p.N, 2 * C, tag, vals, scratch);
+        xch_begin<4>(p.xb, img, p.N, 2 * C, tag, vals, scratch);
         st_stamp(p.xb, tr, 11);
         // ---- C: ... while this unit's input image is requested (the block input -- a written activation -- for the first convolution of a block; z of the first
         //      convolution for the second one, turned into relu(scale z + shift) with the forward's expressions on its way into LDS) and the weight gradient of
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         const unsigned tagA = base + (unsigned)p.nconv + 1u, tagD = tagA + 1u;
         // ---- exchange A (the 3x3 / stride-2 convolution's sums), the pending weight gradient of unit 0 (own-image) / unit 1 (group) in its shadow
         if (GRP && p.nconv > 1) grp_issue(1, img);
-        xch_begin(p.xb, img, p.N, 2 * C, tagA, vals, scratch);
+        xch_begin<4>(p.xb, img, p.N, 2 * C, tagA, vals, scratch);
         if constexpr (!GRP) { st_wgrad_wide<C, HW>(D, XA, p.c[0].slab + (size_t)img * (9 * C * C)); __syncthreads(); }
         else if (p.nconv > 1) grp_finish(1, false);
         xch_end(p.xb, p.N, 2 * C, tagA, tot, scratch);
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
         write_dz(D, gqa, zq, mu4, is4);
         // ---- exchange D (the shortcut's sums); the block's input image comes into LDS -- and the group weight gradient of unit 0 runs -- in its shadow
         if constexpr (GRP) grp_issue(0, img);                       // (every workgroup's dz of unit 0 was in memory before it published exchange A)
-        xch_begin(p.xb, img, p.N, 2 * C, tagD, vals2, scratch);
+        xch_begin<4>(p.xb, img, p.N, 2 * C, tagD, vals2, scratch);
         {
             constexpr int CPPI = CI / 8;
             const uint4* src = reinterpret_cast<const uint4*>(p.x + (size_t)img * HWI * HWI * CI);
@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             __syncthreads();
             const unsigned tag = base + (unsigned)p.nconv + 1u;
             if (p.nconv > 1) grp_issue(1, img);
-            xch_begin(p.xb, img, p.N, 2 * C, tag, vals, scratch);
+            xch_begin<4>(p.xb, img, p.N, 2 * C, tag, vals, scratch);
             if (p.nconv > 1) grp_finish(1, false);
             xch_end(p.xb, p.N, 2 * C, tag, tot, scratch);
             grp_issue(0, img);
@@ -1486,6 +1486,44 @@ bool clhip_stage_train_supported(int N, int H, int W, int C, int nconv, int dtyp
 }
 
 size_t clhip_stage_train_xch_bytes(int N) { return xch_bytes(N, 128); }
+
+// The three-level exchange of xch.h is correct only where every workgroup w of a grid runs on XCD w % 8 -- more precisely, where workgroups with equal w % 8 share an
+// L2.  Checked ONCE per device (a probe launch per grid size + a read-back: plan.hip calls this when it creates a plan, never inside a stream capture); launches
+// consult the cached answer and keep the two-hop form where the rule does not hold, was never checked, or STAGE_XCH3=0.
+namespace {
+__global__ void xcd_probe_kernel(unsigned* out) {
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = v & 0xfu;
+    }
+}
+int g_xcd_rule[16] = {};          // per device: 0 unknown, 1 holds, -1 does not
+}  // namespace
+bool clhip_stage_train_xcd_rule(bool probe) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    if (g_xcd_rule[dev] == 0 && probe) {
+        int rule = -1;
+        unsigned* d = nullptr;
+        if (hipMalloc(&d, 256 * sizeof(unsigned)) == hipSuccess) {
+            bool ok = true;
+            for (int G : {256, 200, 128, 100, 72, 64}) {
+                unsigned h[256];
+                hipLaunchKernelGGL(xcd_probe_kernel, dim3(G), dim3(64), 0, nullptr, d);
+                if (hipMemcpy(h, d, G * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+                for (int i = kXchXcds; i < G && ok; ++i) ok = h[i] == h[i & (kXchXcds - 1)];
+                if (!ok) break;
+            }
+            (void)hipFree(d);
+            if (ok) rule = 1;
+        }
+        (void)hipGetLastError();
+        g_xcd_rule[dev] = rule;
+    }
+    const char* sw = clhip_cfg("STAGE_XCH3");
+    return g_xcd_rule[dev] == 1 && !(sw != nullptr && atoi(sw) == 0);
+}
 // The weight gradient of a run's backward: per image out of the workgroup's own LDS (partial blocks of 9 / 36 / 147 KB per image and convolution), or -- 64 channels at
 // 128 images or more, where those blocks would be 300 MB per run -- per (channel-tile pair, group of 16 images) from global memory (StGrp).  Measured at batch 256 /
 // 32 (profiles/r06_stage_train_notes.md): the gather of 16-channel slices out of 64- / 128-byte pixels costs 2.4 / 5.8 us of load issue per unit at 64 / 32 channels,
@@ -1508,6 +1546,7 @@ int clhip_stage_train_fwd_launch(const void* x, int N, int H, int W, int C, int 
     const double M = (double)N * H * W;
     p.invM = 1.0 / M; p.unbias = M > 1.0 ? M / (M - 1.0) : 1.0;
     p.xb = xch_carve(xch, N, 128);
+    if (!clhip_stage_train_xcd_rule(false)) p.xb.gx = nullptr;       // (two hops instead of three levels)
     auto fill = [&](StConv& c, int i) {
         c.w = static_cast<const bf16_t*>(w[i]); c.wd = nullptr; c.gamma = gamma[i]; c.beta = beta[i]; c.rm = rm[i]; c.rv = rv[i];
         c.mean = mean[i]; c.invstd = invstd[i]; c.coef = coef[i]; c.z = static_cast<bf16_t*>(z[i]);
@@ -1538,6 +1577,7 @@ int clhip_stage_train_bwd_launch(const void* x, const void* dy, void* dx, int dx
     p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.dx = static_cast<bf16_t*>(dx); p.dx_acc = dx_accumulate;
     p.N = N; p.nconv = nconv; p.invM = 1.0 / ((double)N * H * W); p.trace = trace; p.dfeat = dfeat;
     p.xb = xch_carve(xch, N, 128);
+    if (!clhip_stage_train_xcd_rule(false)) p.xb.gx = nullptr;       // (two hops instead of three levels)
     auto fill = [&](StConvB& c, int i) {
         c.wd = static_cast<const bf16_t*>(wd[i]); c.gamma = gamma[i]; c.beta = beta[i]; c.mean = mean[i]; c.invstd = invstd[i];
         c.z = static_cast<const bf16_t*>(z[i]); c.y = static_cast<const bf16_t*>(y[i]); c.dgamma = dgamma[i]; c.dbeta = dbeta[i]; c.slab = slab[i];

@@ -28,6 +28,7 @@ typedef __attribute__((address_space(1))) unsigned xch_gu32;
 struct XchBuf {
     unsigned long long* g1;   // [2 parities][G][NVmax]
     unsigned long long* g2;   // [NVmax][2]
+    unsigned long long* gx;   // [2 parities][8 XCDs][NVmax][2]  (three-level form: the XCDs' partial sums)
     unsigned* ctl;            // [0] tag base (advanced by the launch), [1] error word (sticky), [2..3] spare
     int NVmax;
     int G;                    // workgroups of the grid this buffer was carved for (the parity stride of g1)
@@ -170,26 +171,140 @@ __device__ __forceinline__ void xch_sweep(const XchBuf& b, int G, int NV, unsign
 }
 __device__ __forceinline__ bool xch_one_hop(int G, int NV) { return G * NV <= kXchOneHop; }
 
+// THREE levels for big grids (round 6, late): a granule that only has to reach the OTHER workgroups of the same XCD need not be written through to memory -- they
+// share the L2.  Measured (tools/ubench/xcd_local.hip): a workgroup of a grid of any size lands on XCD blockIdx % 8; a round trip between two workgroups of one XCD
+// costs 1 270 shader cycles with plain stores + agent-scope polls against 2 500-2 600 with write-through stores; a sweep over an XCD's 32 workgroups 2 700 against 4 450.
+//   level 1  workgroup w publishes its values with PLAIN stores; ONE of the <= 32 workgroups of its XCD (w % 8) -- member (tag mod members), another one every phase --
+//            sweeps the members' granules and holds the XCD's partial sums (member order)
+//   level 2  ... and publishes them -- fp64 as two granules -- with write-through stores into gx[parity][xcd]
+//   level 3  every workgroup polls the <= 8 XCDs' partial sums and adds them in XCD order
+// Same totals in every workgroup, one fixed order.  gx is double-buffered by phase parity like g1 (a leader publishes phase p + 2 only after every member of its XCD
+// has finished phase p + 1, which needed every workgroup's phase-p + 1 contribution, i.e. everybody had finished reading phase p).  The form RELIES on the
+// placement rule above: a workgroup whose XCD is not blockIdx % 8 would poll an L2 its partners never write -- the bounded spins turn that into the error word, and
+// stage_train.hip checks the rule once per device before it lets a plan use this form (clhip_stage_train_xcd_rule).
+constexpr int kXchXcds = 8;
+__device__ __forceinline__ bool xch_hier(int G, int NV) { return G * NV > kXchOneHop && G >= 64; }
+__device__ __forceinline__ void xch_store_local(unsigned long long* p, unsigned tag, unsigned value) {
+    __hip_atomic_store((xch_gu64*)p, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // no cache bits: stays in the XCD's L2
+}
+// levels 1 + 2 (contains workgroup barriers; `part` = NV LDS doubles that receive the XCD's partial sums, scratch >= 256 doubles)
+template <int W = 16>      // polls in flight per trip of the sweep: 16 where registers are free (forward), 4 in the backward kernels
+__device__ __forceinline__ void xch_hier_begin(const XchBuf& b, int wg, int G, int NV, unsigned tag, const float* vals, double* part, double* scratch) {
+    const int t = threadIdx.x;
+    unsigned long long* g1 = xch_g1(b, tag);
+    if (t < NV) xch_store_local(g1 + (size_t)wg * b.NVmax + t, tag, __float_as_uint(vals[t]));
+    const int x = wg & (kXchXcds - 1), members = (G - x + kXchXcds - 1) / kXchXcds;      // <= 32
+    // only ONE member of the XCD sums it, and a different one every phase: a workgroup that sweeps waits for its slowest partner before it gets to the work the caller
+    // puts between begin and end (the weight gradient of the backward) -- with every member sweeping, the exchange was a barrier in front of that work (the backward
+    // launches ran 8-15 % longer); the others publish and move on, like the workgroups of the two-hop form that own no value
+    if ((wg >> 3) != (int)(tag % (unsigned)members)) return;      // (uniform per workgroup)
+    const int groups = 256 / NV, v = t & (NV - 1), grp = t / NV;
+    // (W polls in flight per trip, 16 / W trips: sixteen at once -- as xch_sweep does -- cost the backward kernels 32 more live registers at their tightest
+    //  point: 70 -> 119 spilled in the 16-channel one; four trips of four cost the 64-channel forward, whose sweep has all sixteen contributors, 9 us per launch)
+    double s = 0.0;
+#pragma unroll 1
+    for (int k0 = 0; k0 < 16; k0 += W) {
+        if (k0 * groups >= members) break;                              // (uniform)
+        unsigned long long q[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) q[k] = 0ull;
+        bool ok = t >= 256;
+        for (unsigned spins = 0; !ok; ++spins) {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const int src = grp + (k0 + k) * groups;
+                q[k] = src < members ? xch_load(g1 + (size_t)(x + kXchXcds * src) * b.NVmax + v) : ((unsigned long long)tag << 32);
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) ok &= (unsigned)(q[k] >> 32) == tag;
+            ok = __all(ok);
+            if (!ok) {
+                if (spins >= kXchSpinLimit) { xch_fail(b, 8u); break; }
+                if ((spins & 1023u) == 1023u && __hip_atomic_load((xch_gu32*)(b.ctl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) s += (grp + (k0 + k) * groups < members) ? (double)__uint_as_float((unsigned)q[k]) : 0.0;
+    }
+    if (t < 256) scratch[t] = s;
+    __syncthreads();
+    if (t < NV) {
+        double a = 0.0;
+        for (int g = 0; g < groups; ++g) a += scratch[g * NV + t];
+        part[t] = a;
+    }
+    __syncthreads();
+    if (t < 2 * NV) {
+        const unsigned long long u = __double_as_longlong(part[t >> 1]);
+        xch_store(b.gx + (((size_t)(tag & 1u) * kXchXcds + x) * b.NVmax + (t >> 1)) * 2 + (t & 1), tag, (t & 1) ? (unsigned)(u >> 32) : (unsigned)u);
+    }
+}
+// level 3: the totals into out[NV] (LDS doubles; may be the `part` of xch_hier_begin); ends with a workgroup barrier
+__device__ __forceinline__ void xch_hier_end(const XchBuf& b, int G, int NV, unsigned tag, double* out, double* scratch) {
+    const int t = threadIdx.x;
+    const int nx = G < kXchXcds ? G : kXchXcds;
+    const int groups = 256 / NV, v = t & (NV - 1), grp = t / NV, per = kXchXcds / groups;      // NV = 32 / 64 / 128: 1 / 2 / 4 XCDs per thread
+    const unsigned long long* gx = b.gx + (size_t)(tag & 1u) * kXchXcds * b.NVmax * 2;
+    unsigned long long q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = 0ull;
+    bool ok = t >= 256;
+    for (unsigned spins = 0; !ok; ++spins) {
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int xi = grp * per + (k >> 1);
+            q[k] = ((k >> 1) < per && xi < nx) ? xch_load(gx + ((size_t)xi * b.NVmax + v) * 2 + (k & 1)) : ((unsigned long long)tag << 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ok &= (unsigned)(q[k] >> 32) == tag;
+        ok = __all(ok);
+        if (!ok) {
+            if (spins >= kXchSpinLimit) { xch_fail(b, 16u); break; }
+            if ((spins & 1023u) == 1023u && __hip_atomic_load((xch_gu32*)(b.ctl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < per && grp * per + k < nx) s += __longlong_as_double(((unsigned long long)(unsigned)q[2 * k + 1] << 32) | (unsigned)q[2 * k]);
+    if (t < 256) scratch[t] = s;
+    __syncthreads();
+    if (t < NV) {
+        double a = 0.0;
+        for (int g = 0; g < groups; ++g) a += scratch[g * NV + t];
+        out[t] = a;
+    }
+    __syncthreads();
+}
+
 // the whole exchange in two calls, so that work which does not need the totals can sit between them:
 //   xch_begin  publishes this workgroup's values and (two-hop form) plays its reducer role
 //   xch_end    leaves the totals in out[NV]
+template <int W = 16>
 __device__ __forceinline__ void xch_begin(const XchBuf& b, int wg, int G, int NV, unsigned tag, const float* vals, double* scratch) {
+    if (b.gx != nullptr && xch_hier(G, NV)) { xch_hier_begin<W>(b, wg, G, NV, tag, vals, scratch + 256, scratch); return; }
     xch_publish(b, wg, NV, tag, vals);
     if (!xch_one_hop(G, NV)) xch_reduce(b, wg, G, NV, tag, scratch);
 }
 __device__ __forceinline__ void xch_end(const XchBuf& b, int G, int NV, unsigned tag, double* out, double* scratch) {
-    if (xch_one_hop(G, NV)) xch_sweep(b, G, NV, tag, out, scratch);
+    if (b.gx != nullptr && xch_hier(G, NV)) xch_hier_end(b, G, NV, tag, out, scratch);
+    else if (xch_one_hop(G, NV)) xch_sweep(b, G, NV, tag, out, scratch);
     else xch_collect(b, NV, tag, out, scratch);
 }
 
 // bytes of the three arrays for a grid of up to G workgroups and NVmax values, and their carving from one zeroed allocation
-static inline size_t xch_bytes(int G, int NVmax) { return 256 + 2 * (size_t)G * NVmax * 8 + (size_t)NVmax * 16; }
+static inline size_t xch_bytes(int G, int NVmax) { return 256 + 2 * (size_t)G * NVmax * 8 + (size_t)NVmax * 16 + 2 * (size_t)kXchXcds * NVmax * 16; }
 static inline XchBuf xch_carve(void* base, int G, int NVmax) {
     XchBuf b;
     char* p = static_cast<char*>(base);
     b.ctl = reinterpret_cast<unsigned*>(p);
     b.g1 = reinterpret_cast<unsigned long long*>(p + 256);
     b.g2 = reinterpret_cast<unsigned long long*>(p + 256 + 2 * (size_t)G * NVmax * 8);
+    b.gx = reinterpret_cast<unsigned long long*>(p + 256 + 2 * (size_t)G * NVmax * 8 + (size_t)NVmax * 16);      // (nullptr: the three-level form is off)
     b.NVmax = NVmax; b.G = G;
     return b;
 }

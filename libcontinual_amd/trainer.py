@@ -69,7 +69,7 @@ class GraphedStep:
     WARM, KEEP = 2, 4
     PROBE = 12                      # auto mode: steps of each kind timed per key before the faster one is kept (see _pick)
     _PLAN_SWITCHES = (b"BN_INPUT", b"BN_INPUT_WT", b"BN_RES_INPUT", b"BN_GRAD", b"BN_GRAD_RES", b"BN_FUSE", b"BRANCH_STREAM", b"WGRAD_STREAM", b"CONV6_PAIR",
-                      b"STAGE_EVAL", b"EVAL_LAZY", b"STAGE_TRAIN", b"STAGE_TRAIN_BWD", b"GEMM8", b"GEMM_TAIL")
+                      b"STAGE_EVAL", b"EVAL_LAZY", b"STAGE_TRAIN", b"STAGE_TRAIN_BWD", b"STAGE_ENTRY", b"STAGE_POOL", b"STAGE_XCH3", b"GEMM8", b"GEMM_TAIL", b"ATTN_BWD")
 
     def __init__(self, model, optimizer, method_name, reducer=None):
         self.model, self.optimizer, self.method_name = model, optimizer, method_name

@@ -29,13 +29,15 @@ __global__ __launch_bounds__(256) void xch_kernel(XchBuf b, int G, int NV, int p
         if (t < NV) vals[t] = val_of(wg, t, p);
         __syncthreads();
         const unsigned tag = base + p + 1;
-        xch_publish(b, wg, NV, tag, vals);
+        if (MODE == 2) xch_hier_begin(b, wg, G, NV, tag, vals, scratch + 256, scratch);
+        else xch_publish(b, wg, NV, tag, vals);
         if (MODE == 0) xch_reduce(b, wg, G, NV, tag, scratch);
         if (work > 0) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while ((long long)(__builtin_amdgcn_s_memtime() - t0) < work) {}
         }
         if (MODE == 0) xch_collect(b, NV, tag, tot, scratch);
+        else if (MODE == 2) xch_hier_end(b, G, NV, tag, tot, scratch);
         else xch_sweep(b, G, NV, tag, tot, scratch);
         if (t < NV) {
             const double e = (double)G * (G - 1) * 0.5 + (double)G * (t + (p & 1023));
@@ -64,7 +66,7 @@ static void run(int G, int NV, int skew, int work, void* buf, unsigned* derr) {
     unsigned herr[2] = {0, 0}, hctl[4];
     CK(hipMemcpy(herr, derr, 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hctl, b.ctl, 16, hipMemcpyDeviceToHost));
-    printf("%s G=%3d NV=%3d skew=%4d work=%5d ticks : %7.2f us per phase   mismatches %u  timeout-word %u\n", MODE == 0 ? "two-hop" : "one-hop", G, NV, skew, work,
+    printf("%s G=%3d NV=%3d skew=%4d work=%5d ticks : %7.2f us per phase   mismatches %u  timeout-word %u\n", MODE == 0 ? "two-hop" : (MODE == 1 ? "one-hop" : "3-level"), G, NV, skew, work,
            best * 1000.f / phases, herr[0], hctl[1]);
     CK(hipMemset(derr, 0, 4));
 }
@@ -74,7 +76,7 @@ int main() {
     const size_t bytes = xch_bytes(256, 128);
     CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
     CK(hipMalloc(&derr, 64)); CK(hipMemset(derr, 0, 64));
-    const int Gs[] = {8, 32, 64, 128, 256};
+    const int Gs[] = {8, 32, 64, 72, 100, 128, 200, 256};
     const int NVs[] = {32, 64, 128};
     // s_memtime ticks at 100 MHz: work = 250 ticks = 2.5 us of independent work between publish and collect (the weight gradient of the backward)
     for (int work : {0, 250})
@@ -84,6 +86,7 @@ int main() {
                     if (work && skew) continue;
                     run<0>(G, NV, skew, work, buf, derr);
                     if (G * NV <= kXchOneHop) run<1>(G, NV, skew, work, buf, derr);
+                    if (G >= 32) run<2>(G, NV, skew, work, buf, derr);
                 }
     return 0;
 }
