@@ -198,9 +198,13 @@ class _BackboneFn(torch.autograd.Function):
         return None, None, None, None
 
 
+_LIVE = weakref.WeakSet()        # every HipResNet of the process (ops.TeacherPass asks the training ones whether they take stage-level launches)
+
+
 class HipResNet(nn.Module):
     def __init__(self, kind, depth=None, layers=None, dtype=None, init="normal_fan_out"):
         super().__init__()
+        _LIVE.add(self)
         self._units, self.out_dim, extra, self._stages = _topology(kind, depth, layers)
         self.feat_dim = self.out_dim
         self._dtype = _dtype_code(dtype)
@@ -501,6 +505,20 @@ class HipResNet(nn.Module):
                 hook(self, self._unit_off[lo], end)
                 hi = lo
         self.attach_grads()
+
+    def takes_stage_launches(self, x):
+        """True when this backbone's TRAINING passes at x's shape run as stage-level launches (csrc/stage_train.hip: one workgroup per image on every compute unit,
+        waiting on in-launch exchanges) -- a second network's forward then gains nothing on a side stream (its kernels find no free compute unit) and pays the fork / join"""
+        if x.dim() != 4:
+            return False
+        ent = self._handle.plans.get((x.shape[0], x.shape[2], x.shape[3], self._dtype))
+        if ent is None:
+            return False
+        L = _lib.lib()
+        if int(L.clhip_plan_stage_info(ent[0], 0)) == 0:
+            return False
+        sw = L.clhip_config_get(b"STAGE_TRAIN")
+        return int(sw) != 0 if sw not in (None, b"") else x.shape[0] > 64
 
     def stage_status(self):
         """0 unless an in-launch wait of a stage-level training launch (csrc/stage_train.hip) ran out -- its grid was not co-resident: two such launches on two
