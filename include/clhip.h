@@ -234,7 +234,9 @@ int clhip_plan_stage_trace(clhip_plan*, unsigned long long* out24);
 /* refresh the `dtype` weight shadows from the fp32 masters (call after every optimizer step) */
 int clhip_plan_prep_weights(clhip_plan*, const float* params, void* shadow, void* stream);
 /* x: fp32 NCHW input; feat: fp32 [N, feat_dim].  training!=0: batch statistics, running stats updated,
- * activations saved in `workspace` for clhip_plan_backward.                                           */
+ * activations saved in `workspace` for clhip_plan_backward.  training == 2: the same forward with the promise that NO backward (and no clhip_plan_read_act)
+ * follows -- a frozen teacher that runs on batch statistics: the stage-level launches then skip the stores of z and of the activations inside a run
+ * (same features, same statistics); launches that do not know the hint ignore it.                      */
 int clhip_plan_forward(clhip_plan*, const float* x, const float* params, float* bn_stats, const void* shadow,
                        void* workspace, float* feat, int training, void* stream);
 /* the same with nn.BatchNorm2d's `num_batches_tracked += 1` (torch/nn/modules/batchnorm.py, one int64 counter per unit, slot i = unit i;

@@ -923,6 +923,9 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
     // STAGE_TRAIN (default on; looked up per call): runs of BasicBlocks as ONE training launch (stage_train.hip) where the plan found them and the lazy forms are on
     const char* strain_cfg = clhip_cfg("STAGE_TRAIN");
     const bool strain_on = rlazy_on && p->xch != nullptr && stage_train_default(strain_cfg, p->N);
+    // training == 2: batch-statistics forward that no backward will follow (a teacher under torch.no_grad()): the stage-level launches skip the z / activation
+    // stores of everything inside a run (per convolution 32 KB per image written for nobody); the per-unit launches ignore the hint
+    const bool nosave = training == 2;
     // ... and the launch of the LAST run also averages its output (the global pooling behind it): STAGE_POOL=0 keeps the pooling launch
     const char* spool_cfg = clhip_cfg("STAGE_POOL");
     const bool spool_on = !(spool_cfg != nullptr && atoi(spool_cfg) == 0) && p->pool_win == 0;
@@ -967,6 +970,8 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                     const bool first = k == 0 || (k >= 3 && ((k - 3) & 1) == 0);
                     const bool lazy = first && q.lazy_to == (int)i + k + (k == 0 ? 2 : 1);
                     yv[k] = lazy ? nullptr : ws + p->acts[i + k + 1].y_off;
+                    // (no-save: only what a LATER launch of this forward reads survives -- the launch's output, unless it is the network's and the pooling rides along)
+                    if (nosave) { zv[k] = nullptr; if (!(k == len - 1 && !pool_in_run(i + len, uf.d.cout))) yv[k] = nullptr; }
                     p->lazy_live[i + k] = lazy ? 1 : 0;
                     p->mask_stale[i + k] = (k == 2 || (k >= 3 && ((k - 3) & 1) == 1)) ? 1 : 0;
                 }
@@ -988,6 +993,8 @@ extern "C" int clhip_plan_forward_ex(clhip_plan* p, const float* x, const float*
                     wv[k] = sh + q.sh_fwd; gv[k] = params + q.d.gamma_off; bv[k] = params + q.d.beta_off; rmv[k] = bn_stats + q.d.rm_off; rvv[k] = bn_stats + q.d.rv_off;
                     mev[k] = fr + q.f_mean; isv[k] = fr + q.f_invstd; cov[k] = fr + q.f_scale; zv[k] = ws + q.z_off;
                     yv[k] = (k & 1) ? ws + p->acts[i + k + 1].y_off : nullptr; mkv[k] = nullptr;
+                    // (no-save: only what a LATER launch of this forward reads survives -- the run's output, unless the pooling rides in this launch too)
+                    if (nosave) { zv[k] = nullptr; if (!(k == u.stage_len - 1 && !pool_in_run(i + u.stage_len, u.d.cout))) yv[k] = nullptr; }
                     p->lazy_live[i + k] = (k & 1) ? 0 : 1;
                     p->mask_stale[i + k] = (k & 1) ? 1 : 0;
                 }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void stage_train_fwd_kernel(const StFwdParams 
             for (int t = 0; t < PTW; ++t) {
                 zp[t][kt][0] = pack_bf16x2(acc[t][kt][0], acc[t][kt][1]);
                 zp[t][kt][1] = pack_bf16x2(acc[t][kt][2], acc[t][kt][3]);
-                *reinterpret_cast<uint2*>(cc.z + ((size_t)img * HW * HW + pixq[t]) * C + ch) = make_uint2(zp[t][kt][0], zp[t][kt][1]);
+                if (cc.z != nullptr) *reinterpret_cast<uint2*>(cc.z + ((size_t)img * HW * HW + pixq[t]) * C + ch) = make_uint2(zp[t][kt][0], zp[t][kt][1]);      // (nullptr: a forward no backward follows)
             }
         }
         row16_sum_n(sv);

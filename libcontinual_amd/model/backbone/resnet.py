@@ -198,6 +198,22 @@ class _BackboneFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _NoSave:
+    """`with resnet.no_backward_follows():` -- forwards made inside it under torch.no_grad() tell the library that nothing they compute is needed by a backward
+    (ops.TeacherPass: a teacher that runs on batch statistics): the stage-level launches then skip the stores of z and of the activations inside a run"""
+    depth = 0
+
+    def __enter__(self):
+        _NoSave.depth += 1
+
+    def __exit__(self, *a):
+        _NoSave.depth -= 1
+
+
+def no_backward_follows():
+    return _NoSave()
+
+
 _LIVE = weakref.WeakSet()        # every HipResNet of the process (ops.TeacherPass asks the training ones whether they take stage-level launches)
 
 
@@ -477,7 +493,7 @@ class HipResNet(nn.Module):
         feat = torch.empty(x.shape[0], state["feat_dim"], device=x.device, dtype=torch.float32)
         # num_batches_tracked += 1 rides on the forward's first launch (it was a torch add kernel per step)
         call("clhip_plan_forward_ex", plan, x.data_ptr(), self._flat.data_ptr(), self._stats.data_ptr(), self._shadow.data_ptr(),
-             ws.data_ptr(), feat.data_ptr(), int(training), self._nbt.data_ptr() if training else None,
+             ws.data_ptr(), feat.data_ptr(), int(state.get("mode", training)), self._nbt.data_ptr() if training else None,
              torch.cuda.current_stream().cuda_stream)
         return feat
 
@@ -551,6 +567,8 @@ class HipResNet(nn.Module):
         self._generation += 1
         need_grad = torch.is_grad_enabled() and self._params[0].requires_grad
         state = dict(plan=plan, ws=self._ws, training=self.training, gen=self._generation, shape=tuple(x.shape), feat_dim=feat_dim)
+        if self.training and not need_grad and _NoSave.depth > 0:
+            state["mode"] = 2                                         # (clhip_plan_forward_ex: batch statistics, nothing kept for a backward)
         self._last_state = state
         if need_grad:
             self.flat_parameters()

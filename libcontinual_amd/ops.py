@@ -487,7 +487,8 @@ class TeacherPass:
             st_prev = _lib.lib().clhip_config_get(b"STAGE_TRAIN")
             _lib.lib().clhip_config(b"STAGE_TRAIN", b"0")
             try:
-                with torch.cuda.stream(side), torch.no_grad():
+                from .model.backbone import resnet as _resnet
+                with torch.cuda.stream(side), torch.no_grad(), _resnet.no_backward_follows():
                     self._out = fn()
             finally:
                 _lib.lib().clhip_config(b"STAGE_TRAIN", st_prev)
@@ -495,7 +496,8 @@ class TeacherPass:
 
     def result(self):
         if self._side is None:
-            with torch.no_grad():
+            from .model.backbone import resnet as _resnet
+            with torch.no_grad(), _resnet.no_backward_follows():
                 return self._fn()
         main = torch.cuda.current_stream()
         main.wait_stream(self._side)

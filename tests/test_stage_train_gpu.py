@@ -206,3 +206,37 @@ def test_the_three_level_exchange_agrees_with_the_two_hop_form(kind, batch):
         assert l2 <= (1e-4 if a <= 4 else 6e-2), f"unit {a}: {l2:.2e}"
     assert float((s1 - s0).abs().max()) / float(s0.abs().max()) <= 2e-3
     assert torch.isfinite(g1).all() and _rel(g1, g0) <= 0.6
+
+
+@pytest.mark.parametrize("kind,batch", [("cifar", 256), ("v2", 96)])
+def test_a_forward_no_backward_follows_leaves_the_same_features_and_statistics(kind, batch):
+    """clhip_plan_forward_ex(training = 2) -- what ops.TeacherPass asks for around a teacher that runs on batch statistics: the stage-level launches skip the z /
+    activation stores inside a run; features and running statistics are bit-identical to the saving forward's"""
+    from libcontinual_amd.model.backbone import resnet as R
+    bb = _backbone(kind, 31)
+    _trained_like(bb, 32)
+    x = torch.randn(batch, 3, 32, 32, generator=torch.Generator().manual_seed(33)).cuda()
+    stats0 = bb._stats.clone()
+    with torch.no_grad():
+        f_save = bb(x)["features"].clone()
+    s_save = bb._stats.clone()
+    bb._stats.copy_(stats0)
+    n0 = _launches(bb)
+    with torch.no_grad(), R.no_backward_follows():
+        f_ns = bb(x)["features"].clone()
+    s_ns = bb._stats.clone()
+    n1 = _launches(bb)
+    torch.cuda.synchronize()
+    assert n1[1] - n0[1] == 3                              # still the three stage-level launches
+    assert _status(bb) == [0] * len(bb._handle.plans)
+    assert torch.isfinite(f_ns).all() and float(f_ns.abs().max()) > 0
+    assert torch.equal(f_save, f_ns) and torch.equal(s_save, s_ns)
+    # and a training step right after it is unaffected (the workspace holds nothing of the no-save forward that the step would read)
+    w = torch.randn(batch, bb.out_dim, generator=torch.Generator().manual_seed(34)).cuda() / batch
+    bb._stats.copy_(stats0)
+    fa, ga = _step(bb, x, w, b"1", b"1")
+    with torch.no_grad(), R.no_backward_follows():
+        bb(x)
+    bb._stats.copy_(stats0)
+    fb, gb = _step(bb, x, w, b"1", b"1")
+    assert torch.equal(fa, fb) and torch.equal(ga, gb)
