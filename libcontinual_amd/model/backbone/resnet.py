@@ -631,6 +631,7 @@ class HipResNet(nn.Module):
         named = dict(new.named_parameters())
         new._params = [named[nm] for nm, *_ in new._layout]
         new._tag_params()
+        _LIVE.add(new)
         return new
 
 
