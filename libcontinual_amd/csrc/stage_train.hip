@@ -449,7 +449,7 @@ struct StGeoB {
     static constexpr int AUX = 8 * C * 4 + 8 * C * 4 + 2 * C * 4 + 2 * C * 8 + kXchScratchDoubles * 8;      // ctab, red, vals, tot, scratch
     // own-image weight gradient: dz + the input image of the unit whose weight gradient is pending (+ the cross-wave sum of the 16-channel form); group form: dz +
     // the staging area
-    static constexpr int LDS = GRP ? G::BUF + AUX + StGrp<C, HW>::BYTES : 2 * G::BUF + AUX + (C == 16 ? 4 * 2304 * 4 : 0);
+    static constexpr int LDS = GRP ? G::BUF + AUX + StGrp<C, HW>::BYTES : 2 * G::BUF + AUX + (C == 16 ? 4 * 2304 * 4 + HW * HW * 32 : 0);      // (16 channels: + the residual gradient of the block in flight, parked in LDS)
 };
 
 __device__ __forceinline__ uint4 st_tr8(const char* base, int addr, int second) {
@@ -952,7 +952,12 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
     //   zq / yq / mu4 .. : z, the block output and the saved statistics of the NEXT unit to process at this lane's positions -- requested before the dgrad of the
     //                      unit above it multiplies;  xin: the unit's input image -- requested before the weight gradient of the unit above runs
     f32x4 acc[PTW][KTW];
-    unsigned gres[PTW][KTW][2];                                     // the residual gradient of the block in flight (bf16 pairs)
+    // the residual gradient of the block in flight (bf16 pairs): registers -- except at 16 channels, where those 32 registers are the difference between a kernel that
+    // fits its 256 + 256 and one that shuffles ~1 300 accumulator-register copies and 127 scratch accesses per pair of units: there it is parked in LDS (GR, same
+    // lane -> pixel mapping on the way in and out: 512 contiguous bytes per wave and store)
+    constexpr bool GRES_LDS = C == 16 && !ENTRY && !GRP;
+    unsigned gres[GRES_LDS ? 1 : PTW][KTW][2];
+    char* GR = stg + 4 * 2304 * 4;
     unsigned zq[PTW][KTW][2], yq[PTW][KTW][2];
     float4 mu4[KTW], is4[KTW], ga4[KTW], be4[KTW];
     float c_gamma = 0.f, c_invstd = 0.f, c_dg = 0.f, c_db = 0.f;    // thread c < C: its channel's parameters; workgroup 0: the old dgamma / dbeta
@@ -1064,7 +1069,10 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
                     sv[kt * 8 + 4 + e] = fmaf(gg[e], xh, sv[kt * 8 + 4 + e]);
                 }
                 gq[t][kt][0] = pack_bf16x2(gg[0], gg[1]); gq[t][kt][1] = pack_bf16x2(gg[2], gg[3]);      // (exact)
-                if (second) { gres[t][kt][0] = gq[t][kt][0]; gres[t][kt][1] = gq[t][kt][1]; }
+                if (second) {
+                    if constexpr (GRES_LDS) *reinterpret_cast<uint2*>(GR + (((wp * PTW + t) * 16 + l15) * C + (wk * KTW + kt) * 16 + 4 * g) * 2) = make_uint2(gq[t][kt][0], gq[t][kt][1]);
+                    else { gres[t][kt][0] = gq[t][kt][0]; gres[t][kt][1] = gq[t][kt][1]; }
+                }
             }
         }
         st_stamp(p.xb, tr, 9);
@@ -1233,10 +1241,15 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
                 for (int kt = 0; kt < KTW; ++kt) {
                     // (the per-unit path rounds the dgrad result to bf16 before the residual gradient is added to it)
                     const unsigned d0 = pack_bf16x2(acc[t][kt][0], acc[t][kt][1]), d1 = pack_bf16x2(acc[t][kt][2], acc[t][kt][3]);
-                    acc[t][kt][0] = __uint_as_float(d0 << 16) + __uint_as_float(gres[t][kt][0] << 16);
-                    acc[t][kt][1] = __uint_as_float(d0 & 0xffff0000u) + __uint_as_float(gres[t][kt][0] & 0xffff0000u);
-                    acc[t][kt][2] = __uint_as_float(d1 << 16) + __uint_as_float(gres[t][kt][1] << 16);
-                    acc[t][kt][3] = __uint_as_float(d1 & 0xffff0000u) + __uint_as_float(gres[t][kt][1] & 0xffff0000u);
+                    unsigned r0, r1;
+                    if constexpr (GRES_LDS) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(GR + (((wp * PTW + t) * 16 + l15) * C + (wk * KTW + kt) * 16 + 4 * g) * 2);
+                        r0 = rr.x; r1 = rr.y;
+                    } else { r0 = gres[t][kt][0]; r1 = gres[t][kt][1]; }
+                    acc[t][kt][0] = __uint_as_float(d0 << 16) + __uint_as_float(r0 << 16);
+                    acc[t][kt][1] = __uint_as_float(d0 & 0xffff0000u) + __uint_as_float(r0 & 0xffff0000u);
+                    acc[t][kt][2] = __uint_as_float(d1 << 16) + __uint_as_float(r1 << 16);
+                    acc[t][kt][3] = __uint_as_float(d1 & 0xffff0000u) + __uint_as_float(r1 & 0xffff0000u);
                 }
         }
     };
@@ -1258,7 +1271,7 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
                     v = make_uint2(pack_bf16x2(d.x * inv, d.y * inv), pack_bf16x2(d.z * inv, d.w * inv));
                 } else v = *reinterpret_cast<const uint2*>(p.dy + (ibase + (wp * PTW + t) * 16 + l15) * C + ch);
                 acc[t][kt] = (f32x4){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
-                gres[t][kt][0] = gres[t][kt][1] = 0u;
+                if constexpr (!GRES_LDS) gres[t][kt][0] = gres[t][kt][1] = 0u;
             }
         }
     }
