@@ -1108,10 +1108,8 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
             uint4 xin[NCH];
             float xsc[8], xsh[8];
             {
-                const bf16_t* src = second ? prevc(cv).z : (cv == 0 ? p.x : p.c[cv - 1].y);
-                const uint4* s4 = reinterpret_cast<const uint4*>(src + ibase * C);
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) xin[k] = s4[tid + k * 256];
+                // (the lazy input's coefficients are requested -- and consumed -- BEFORE the image: vector loads retire in order, so waiting for coefficients that were
+                //  issued behind the image meant waiting for the image, ~2 us in front of the weight gradient that was to hide it)
                 if (second) {
                     const StConvB& a = prevc(cv);
                     const int c0 = (tid & (CPP - 1)) * 8;
@@ -1124,6 +1122,11 @@ __global__ __launch_bounds__(256) void stage_train_bwd_kernel(const StBwdParams 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { xsc[e] = ga[e] * is[e]; xsh[e] = be[e] - mu[e] * xsc[e]; }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16_t* src = second ? prevc(cv).z : (cv == 0 ? p.x : p.c[cv - 1].y);
+                const uint4* s4 = reinterpret_cast<const uint4*>(src + ibase * C);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) xin[k] = s4[tid + k * 256];
             }
             if (cv + 1 < p.nconv) {
                 if constexpr (C == 16) st_wgrad16<HW>(D, XA, wred, p.c[cv + 1].slab + (size_t)img * (9 * C * C));
